@@ -1,0 +1,313 @@
+"""CPU ORACLE bindings (test infrastructure -- NOT product code).
+
+ctypes wrappers over ``oracle/liboracle.so`` (plain C, see ``rsqp_oracle.h``) plus a
+restatement of the dispatch logic of ``qpOASESInterface`` (reference
+``src/qpOASESInterface.cpp:137-224, 686-758, 817-833``).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this package. ``restartsqp_amd`` never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+INFTY = 1.0e20
+c_int_p = C.POINTER(C.c_int)
+c_dbl_p = C.POINTER(C.c_double)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("sphb_oracle.c", "kkt_oracle.c", "qp_oracle.c", "rsqp_oracle.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    return so
+
+
+class OptimalityStatus(C.Structure):
+    _fields_ = [("primal_violation", C.c_double), ("dual_violation", C.c_double),
+                ("compl_violation", C.c_double), ("stationarity_violation", C.c_double),
+                ("KKT_error", C.c_double)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.orc_qp_create.restype = C.c_void_p
+        L.orc_qp_create.argtypes = [C.c_int, C.c_int]
+        L.orc_qp_destroy.argtypes = [C.c_void_p]
+        L.orc_qp_set_A_csc.argtypes = [C.c_void_p, c_int_p, c_int_p, c_dbl_p]
+        L.orc_qp_set_H_csc.argtypes = [C.c_void_p, c_int_p, c_int_p, c_dbl_p]
+        L.orc_qp_init.argtypes = [C.c_void_p] + [c_dbl_p] * 5 + [c_int_p, c_dbl_p, c_dbl_p, c_int_p]
+        L.orc_qp_hotstart.argtypes = [C.c_void_p] + [c_dbl_p] * 5 + [c_int_p]
+        L.orc_qp_hotstart_matrices.argtypes = [C.c_void_p] + [c_dbl_p] * 5 + [c_int_p]
+        L.orc_qp_get_primal.argtypes = [C.c_void_p, c_dbl_p]
+        L.orc_qp_get_dual.argtypes = [C.c_void_p, c_dbl_p]
+        L.orc_qp_get_objective.restype = C.c_double
+        L.orc_qp_get_objective.argtypes = [C.c_void_p]
+        L.orc_qp_get_working_set_bounds.argtypes = [C.c_void_p, c_int_p]
+        L.orc_qp_get_working_set_constraints.argtypes = [C.c_void_p, c_int_p]
+        for f in ("orc_qp_status", "orc_qp_is_solved", "orc_qp_is_infeasible", "orc_qp_is_unbounded",
+                  "orc_qp_nflips", "orc_exitflag"):
+            getattr(L, f).argtypes = [C.c_void_p]
+            getattr(L, f).restype = C.c_int
+        L.orc_one_norm.restype = C.c_double
+        L.orc_inf_norm.restype = C.c_double
+        _LIB = L
+    return _LIB
+
+
+def _d(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(c_dbl_p)
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(c_int_p)
+
+
+# --------------------------------------------------------------------------
+# containers
+# --------------------------------------------------------------------------
+def sphb_set_structure(nrow, ncol, irow, jcol, val, ident=None, compressed_row=False):
+    """SpHbMat::setStructure(rhs, I_info). ``ident`` = list of (irow, jcol, size, value), 1-based."""
+    irow, jcol, val = _i(irow), _i(jcol), _d(val)
+    ident = ident or []
+    ii = _i([b[0] for b in ident]); ij = _i([b[1] for b in ident])
+    isz = _i([b[2] for b in ident]); iv = _d([b[3] for b in ident])
+    nnz = len(val) + int(sum(b[2] for b in ident))
+    nmaj = nrow if compressed_row else ncol
+    ptr = np.zeros(nmaj + 1, np.int32); idx = np.zeros(nnz, np.int32)
+    out = np.zeros(nnz); order = np.zeros(nnz, np.int32)
+    lib().orc_sphb_set_structure(C.c_int(nrow), C.c_int(ncol), C.c_int(len(val)), _ip(irow), _ip(jcol), _dp(val),
+                                 C.c_int(len(ident)), _ip(ii), _ip(ij), _ip(isz), _dp(iv),
+                                 C.c_int(int(compressed_row)), _ip(ptr), _ip(idx), _dp(out), _ip(order))
+    return ptr, idx, out, order
+
+
+def sphb_set_structure_sym(nrow, ncol, irow, jcol, val, is_symmetric=True, compressed_row=False):
+    """SpHbMat::setStructure(rhs) -- mirrors off-diagonals of a one-triangle symmetric triplet."""
+    irow, jcol, val = _i(irow), _i(jcol), _d(val)
+    nnz = lib().orc_sphb_sym_nnz(C.c_int(len(val)), _ip(irow), _ip(jcol), C.c_int(int(is_symmetric)))
+    nmaj = nrow if compressed_row else ncol
+    ptr = np.zeros(nmaj + 1, np.int32); idx = np.zeros(nnz, np.int32)
+    out = np.zeros(nnz); order = np.zeros(nnz, np.int32)
+    lib().orc_sphb_set_structure_sym(C.c_int(nrow), C.c_int(ncol), C.c_int(len(val)), _ip(irow), _ip(jcol),
+                                     _dp(val), C.c_int(int(is_symmetric)), C.c_int(int(compressed_row)),
+                                     _ip(ptr), _ip(idx), _dp(out), _ip(order))
+    return ptr, idx, out, order
+
+
+def sphb_set_matval(order, triplet_val, matval, n_ident_entries):
+    order, tv = _i(order), _d(triplet_val)
+    lib().orc_sphb_set_matval(C.c_int(len(order)), C.c_int(n_ident_entries), _ip(order), _dp(tv), _dp(matval))
+    return matval
+
+
+def sphb_set_matval_sym(irow, jcol, is_symmetric, order, triplet_val, matval):
+    irow, jcol, order, tv = _i(irow), _i(jcol), _i(order), _d(triplet_val)
+    lib().orc_sphb_set_matval_sym(C.c_int(len(tv)), _ip(irow), _ip(jcol), C.c_int(int(is_symmetric)), _ip(order),
+                                  _dp(tv), _dp(matval))
+    return matval
+
+
+def sphb_times(nrow, ncol, ptr, idx, val, p, compressed_row=False):
+    ptr, idx, val, p = _i(ptr), _i(idx), _d(val), _d(p)
+    out = np.zeros(nrow)
+    lib().orc_sphb_times(C.c_int(nrow), C.c_int(ncol), C.c_int(int(compressed_row)), _ip(ptr), _ip(idx), _dp(val),
+                         _dp(p), _dp(out))
+    return out
+
+
+def sphb_transposed_times(nrow, ncol, ptr, idx, val, p, compressed_row=False):
+    ptr, idx, val, p = _i(ptr), _i(idx), _d(val), _d(p)
+    out = np.zeros(ncol)
+    lib().orc_sphb_transposed_times(C.c_int(nrow), C.c_int(ncol), C.c_int(int(compressed_row)), _ip(ptr), _ip(idx),
+                                    _dp(val), _dp(p), _dp(out))
+    return out
+
+
+def sphb_from_dense(dense, compressed_row=False):
+    """SpHbMat dense ctor (row-oriented input)."""
+    dense = np.ascontiguousarray(dense, dtype=np.float64)
+    nrow, ncol = dense.shape
+    nmaj = nrow if compressed_row else ncol
+    ptr = np.zeros(nmaj + 1, np.int32); idx = np.zeros(nrow * ncol, np.int32); val = np.zeros(nrow * ncol)
+    n = lib().orc_sphb_from_dense(_dp(dense), C.c_int(nrow), C.c_int(ncol), C.c_int(1), C.c_int(int(compressed_row)),
+                                  _ip(ptr), _ip(idx), _dp(val))
+    return ptr, idx[:n].copy(), val[:n].copy()
+
+
+def sphb_to_dense(nrow, ncol, ptr, idx, val, compressed_row=False):
+    ptr, idx, val = _i(ptr), _i(idx), _d(val)
+    out = np.zeros((nrow, ncol))
+    lib().orc_sphb_to_dense(C.c_int(nrow), C.c_int(ncol), C.c_int(int(compressed_row)), _ip(ptr), _ip(idx), _dp(val),
+                            _dp(out))
+    return out
+
+
+def triplet_times(nrow, ncol, irow, jcol, val, p, is_symmetric=False, transposed=False):
+    irow, jcol, val, p = _i(irow), _i(jcol), _d(val), _d(p)
+    out = np.zeros(ncol if (transposed and not is_symmetric) else nrow)
+    f = lib().orc_triplet_transposed_times if transposed else lib().orc_triplet_times
+    f(C.c_int(nrow), C.c_int(ncol), C.c_int(len(val)), _ip(irow), _ip(jcol), _dp(val), C.c_int(int(is_symmetric)),
+      _dp(p), _dp(out))
+    return out
+
+
+def handler_set_bounds(delta, x_l, x_u, x_k, c_l, c_u, c_k):
+    n, m = len(x_k), len(c_k)
+    lb = np.zeros(n + 2 * m); ub = np.zeros(n + 2 * m); lbA = np.zeros(m); ubA = np.zeros(m)
+    a = [_d(v) for v in (x_l, x_u, x_k, c_l, c_u, c_k)]
+    lib().orc_handler_set_bounds(C.c_int(n), C.c_int(m), C.c_double(delta), *[_dp(v) for v in a], _dp(lb), _dp(ub),
+                                 _dp(lbA), _dp(ubA))
+    return lb, ub, lbA, ubA
+
+
+def handler_update_bounds(delta, x_l, x_u, x_k, c_l, c_k, lb, ub, lbA):
+    n, m = len(x_k), len(c_k)
+    a = [_d(v) for v in (x_l, x_u, x_k, c_l, c_k)]
+    lib().orc_handler_update_bounds(C.c_int(n), C.c_int(m), C.c_double(delta), *[_dp(v) for v in a], _dp(lb), _dp(ub),
+                                    _dp(lbA))
+
+
+def handler_set_g(grad, rho, m):
+    n = len(grad)
+    g = np.zeros(n + 2 * m)
+    gr = _d(grad)
+    lib().orc_handler_set_g(C.c_int(n), C.c_int(m), _dp(gr), C.c_double(rho), _dp(g))
+    return g
+
+
+# --------------------------------------------------------------------------
+# KKT certificate
+# --------------------------------------------------------------------------
+def kkt_get_working_set(nV, nC, A, x, lb, ub, lbA, ubA, ws_b, ws_c):
+    Ajc, Air, Aval = _i(A[0]), _i(A[1]), _d(A[2])
+    W_b = np.zeros(nV, np.int32); W_c = np.zeros(nC, np.int32)
+    v = [_d(t) for t in (x, lb, ub, lbA, ubA)]
+    wb, wc = _i(ws_b), _i(ws_c)
+    rc = lib().orc_kkt_get_working_set(C.c_int(nV), C.c_int(nC), _ip(Ajc), _ip(Air), _dp(Aval), *[_dp(t) for t in v],
+                                       _ip(wb), _ip(wc), _ip(W_b), _ip(W_c))
+    if rc != 0:
+        raise ValueError("INVALID_WORKING_SET")
+    return W_b, W_c
+
+
+def kkt_test_optimality(nV, nC, A, H, g, lb, ub, lbA, ubA, x, y, W_b, W_c):
+    Ajc, Air, Aval = _i(A[0]), _i(A[1]), _d(A[2])
+    if H is None:
+        Hjc = Hir = Hval = None
+    else:
+        Hjc, Hir, Hval = _i(H[0]), _i(H[1]), _d(H[2])
+    v = [_d(t) for t in (g, lb, ub, lbA, ubA, x, y)]
+    wb, wc = _i(W_b), _i(W_c)
+    st = OptimalityStatus()
+    rc = lib().orc_kkt_test_optimality(C.c_int(nV), C.c_int(nC), _ip(Ajc), _ip(Air), _dp(Aval), _ip(Hjc), _ip(Hir),
+                                       _dp(Hval), *[_dp(t) for t in v], _ip(wb), _ip(wc), C.byref(st))
+    if rc < 0:
+        raise ValueError("INVALID_WORKING_SET")
+    return bool(rc), st
+
+
+# --------------------------------------------------------------------------
+# active-set solver
+# --------------------------------------------------------------------------
+class OracleQP:
+    """Stand-in for ``qpOASES::SQProblem`` (see qp_oracle.c)."""
+
+    def __init__(self, nV, nC):
+        self.nV, self.nC = nV, nC
+        self._h = lib().orc_qp_create(nV, nC)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_qp_destroy(self._h)
+            self._h = None
+
+    def set_A_csc(self, jc, ir, val):
+        jc, ir, val = _i(jc), _i(ir), _d(val)
+        lib().orc_qp_set_A_csc(self._h, _ip(jc), _ip(ir), _dp(val))
+
+    def set_H_csc(self, jc, ir, val):
+        if jc is None:
+            lib().orc_qp_set_H_csc(self._h, None, None, None)
+            return
+        jc, ir, val = _i(jc), _i(ir), _d(val)
+        lib().orc_qp_set_H_csc(self._h, _ip(jc), _ip(ir), _dp(val))
+
+    def _vecs(self, g, lb, ub, lbA, ubA):
+        self._keep = [_d(g), _d(lb), _d(ub), _d(lbA), _d(ubA)]
+        return [_dp(v) for v in self._keep]
+
+    def init(self, g, lb, ub, lbA, ubA, nWSR, x0=None, y0=None, guess_b=None):
+        n = C.c_int(nWSR)
+        x0, y0, gb = _d(x0), _d(y0), _i(guess_b)
+        rc = lib().orc_qp_init(self._h, *self._vecs(g, lb, ub, lbA, ubA), C.byref(n), _dp(x0), _dp(y0), _ip(gb))
+        return rc, n.value
+
+    def hotstart(self, g, lb, ub, lbA, ubA, nWSR):
+        n = C.c_int(nWSR)
+        rc = lib().orc_qp_hotstart(self._h, *self._vecs(g, lb, ub, lbA, ubA), C.byref(n))
+        return rc, n.value
+
+    def hotstart_matrices(self, g, lb, ub, lbA, ubA, nWSR):
+        n = C.c_int(nWSR)
+        rc = lib().orc_qp_hotstart_matrices(self._h, *self._vecs(g, lb, ub, lbA, ubA), C.byref(n))
+        return rc, n.value
+
+    @property
+    def x(self):
+        out = np.zeros(self.nV)
+        lib().orc_qp_get_primal(self._h, _dp(out))
+        return out
+
+    @property
+    def y(self):
+        out = np.zeros(self.nV + self.nC)
+        lib().orc_qp_get_dual(self._h, _dp(out))
+        return out
+
+    @property
+    def objective(self):
+        return lib().orc_qp_get_objective(self._h)
+
+    @property
+    def ws_bounds(self):
+        out = np.zeros(self.nV, np.int32)
+        lib().orc_qp_get_working_set_bounds(self._h, _ip(out))
+        return out
+
+    @property
+    def ws_constraints(self):
+        out = np.zeros(self.nC, np.int32)
+        lib().orc_qp_get_working_set_constraints(self._h, _ip(out))
+        return out
+
+    def is_solved(self):
+        return bool(lib().orc_qp_is_solved(self._h))
+
+    def is_infeasible(self):
+        return bool(lib().orc_qp_is_infeasible(self._h))
+
+    def is_unbounded(self):
+        return bool(lib().orc_qp_is_unbounded(self._h))
+
+    def nflips(self):
+        return lib().orc_qp_nflips(self._h)
+
+    def exitflag(self):
+        return lib().orc_exitflag(self._h)
