@@ -1,0 +1,190 @@
+/*
+ * rsqp_hip.h -- C ABI of the MI355X-native QP-subproblem engine (librsqp_hip.so).
+ *
+ * Drop-in boundary for lanl-ansi/RestartSQP: these are the entry points a
+ * `QPSolverInterface` subclass (include/sqphot/QPsolverInterface.hpp:43-194) binds in place
+ * of its qpOASES calls. Plain pointers and sizes only; every pointer is a HOST pointer
+ * unless the name says `_dev`. All floating point data is fp64, indices are 32-bit int.
+ *
+ * QP convention (QPsolverInterface.hpp:37-41):
+ *      min 1/2 x'Hx + g'x   s.t.  lbA <= Ax <= ubA,  lb <= x <= ub
+ * Multipliers: y[0..nV) for the bounds, y[nV..nV+nC) for the constraints
+ * (qpOASESInterface.cpp:290-305); y >= 0 at a lower side, y <= 0 at an upper side.
+ *
+ * Return value of every int function: RSQP_OK (0) or a negative RSQP_ERR_* code; solver
+ * outcomes (infeasible, iteration limit ...) are NOT errors -- read rsqp_get_status().
+ * The host adapter turns them into the reference's exceptions.
+ */
+#ifndef RSQP_HIP_H
+#define RSQP_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSQP_OK 0
+#define RSQP_ERR_ARG (-1)       /* bad argument / call order                         */
+#define RSQP_ERR_DEVICE (-2)    /* HIP runtime failure (no GPU, launch error, OOM)    */
+#define RSQP_ERR_TOO_LARGE (-3) /* problem does not fit the selected engine           */
+#define RSQP_ERR_WORKING_SET (-4) /* INVALID_WORKING_SET (qpOASESInterface.cpp:552,866) */
+
+/* include/sqphot/Types.hpp:51-73 (subset produced on this path) */
+#define RSQP_QP_OPTIMAL 20
+#define RSQP_QPERROR_INTERNAL_ERROR 21
+#define RSQP_QPERROR_INFEASIBLE 22
+#define RSQP_QPERROR_UNBOUNDED 23
+#define RSQP_QPERROR_EXCEED_MAX_ITER 24
+#define RSQP_QPERROR_NOTINITIALISED 25
+#define RSQP_QPERROR_PREPARINGAUXILIARYQP 26
+#define RSQP_QPERROR_AUXILIARYQPSOLVED 27
+#define RSQP_QPERROR_PERFORMINGHOMOTOPY 28
+#define RSQP_QPERROR_HOMOTOPYQPSOLVED 29
+#define RSQP_QPERROR_UNKNOWN 30
+
+/* include/sqphot/Types.hpp:84-89 */
+#define RSQP_ACTIVE_ABOVE 1
+#define RSQP_ACTIVE_BELOW (-1)
+#define RSQP_ACTIVE_BOTH_SIDE (-99)
+#define RSQP_INACTIVE 0
+
+/* which vector (setters of QPsolverInterface.hpp:144-173) */
+enum { RSQP_VEC_G = 0, RSQP_VEC_LB = 1, RSQP_VEC_UB = 2, RSQP_VEC_LBA = 3, RSQP_VEC_UBA = 4 };
+
+/* how a solve starts -- the four qpOASES call shapes of qpOASESInterface.cpp:137-224 */
+enum {
+    RSQP_MODE_COLD = 0,         /* init(H,g,A,lb,ub,lbA,ubA,nWSR)                :155       */
+    RSQP_MODE_HOT_VECTORS = 1,  /* hotstart(g,lb,ub,lbA,ubA,nWSR)                :180,191   */
+    RSQP_MODE_HOT_MATRICES = 2, /* hotstart(H,g,A,lb,ub,lbA,ubA,nWSR)            :184,197   */
+    RSQP_MODE_WARM_REINIT = 3   /* init(..., nWSR,0,x_qp,y_qp,&bounds)           :204-206   */
+};
+
+/* include/sqphot/Types.hpp:107-119 (the numeric part) */
+typedef struct {
+    double primal_violation, dual_violation, compl_violation, stationarity_violation, KKT_error;
+} rsqp_optimality_status;
+
+typedef struct rsqp_solver rsqp_solver;
+typedef struct rsqp_batch rsqp_batch;
+
+/* ------------------------------------------------------------------------------------ */
+/* library                                                                               */
+/* ------------------------------------------------------------------------------------ */
+const char *rsqp_version(void);
+/* number of visible HIP devices (0 when there is none); never initialises a context */
+int rsqp_device_count(void);
+const char *rsqp_last_error(void);
+
+/* ------------------------------------------------------------------------------------ */
+/* one QP: replaces qpOASESInterface (+ the SQProblem object it owns)                    */
+/* ------------------------------------------------------------------------------------ */
+/* qpOASESInterface ctor + allocate_memory (qpOASESInterface.cpp:35-50, 106-128) and the
+ * plain-QP ctor (:54-94). device < 0 selects the current device. */
+int rsqp_create(int nV, int nC, int device, rsqp_solver **out);
+void rsqp_destroy(rsqp_solver *s);
+/* Options fields the adapter reads: qp_maxiter, lp_maxiter (Options.cpp:45,54) */
+int rsqp_set_options(rsqp_solver *s, int qp_maxiter, int lp_maxiter);
+
+/* set_A (qpOASESInterface.cpp:426-442): first call = SpHbMat::setStructure(rhs, I_info)
+ * (SpHbMat.cpp:196-268) -- 1-based COO + identity blocks -> CSC on the device; later
+ * calls = SpHbMat::setMatVal (:368-380), a device scatter through `order`. */
+int rsqp_set_A_triplet(rsqp_solver *s, int nnz, const int *irow, const int *jcol, const double *val,
+                       int n_ident, const int *id_irow, const int *id_jcol, const int *id_size,
+                       const double *id_value);
+/* set_H (qpOASESInterface.cpp:400-423): SpHbMat::setStructure(rhs) (:284-355, symmetric
+ * triangle mirrored) on the first call, setMatVal (:383-393) afterwards. */
+int rsqp_set_H_triplet(rsqp_solver *s, int nnz, const int *irow, const int *jcol, const double *val,
+                       int is_symmetric);
+/* plain-QP ctor path (qpOASESInterface.cpp:54-94): matrices arrive as CSC (0-based).
+ * H is the full symmetric matrix. A second call with the same pattern refreshes values. */
+int rsqp_set_A_csc(rsqp_solver *s, const int *jc, const int *ir, const double *val);
+int rsqp_set_H_csc(rsqp_solver *s, const int *jc, const int *ir, const double *val);
+/* read the device CSC back (getA()/getH() of QPsolverInterface.hpp:47-59); any output
+ * pointer may be NULL. `order` is SpHbMat::order_. */
+int rsqp_get_A_nnz(const rsqp_solver *s);
+int rsqp_get_H_nnz(const rsqp_solver *s);
+int rsqp_get_A_csc(const rsqp_solver *s, int *jc, int *ir, double *val, int *order);
+int rsqp_get_H_csc(const rsqp_solver *s, int *jc, int *ir, double *val, int *order);
+
+/* vector setters (qpOASESInterface.cpp:361-395, 445-484). Scalar setters are staged on
+ * the host and flushed to the device by the next solve / product / certificate call. */
+int rsqp_set_vector(rsqp_solver *s, int which, const double *v);
+int rsqp_set_entry(rsqp_solver *s, int which, int location, double value);
+int rsqp_get_vector(const rsqp_solver *s, int which, double *v);
+/* reset_constraints (qpOASESInterface.cpp:897-902) */
+int rsqp_reset_constraints(rsqp_solver *s);
+
+/* optimizeQP (qpOASESInterface.cpp:137-224) including the FIXED/VARIED dispatch of
+ * get_Matrix_change_status (:817-833), reset_flags (:488-496) and handle_error
+ * (:686-758). *nWSR_used receives what the adapter adds to Stats::qp_iter. */
+int rsqp_optimize_qp(rsqp_solver *s, int *nWSR_used);
+/* low-level: one SQProblem::init / hotstart call. nWSR: in = limit, out = used.
+ * x0, y0, guess_b (qpOASES convention -1/0/+1) may be NULL. */
+int rsqp_solve(rsqp_solver *s, int mode, int *nWSR, const double *x0, const double *y0,
+               const int *guess_b);
+
+/* getters (qpOASESInterface.cpp:290-357) */
+int rsqp_get_primal(const rsqp_solver *s, double *x);            /* nV            */
+int rsqp_get_dual(const rsqp_solver *s, double *y);              /* nV + nC       */
+double rsqp_get_objective(const rsqp_solver *s);
+int rsqp_get_status(const rsqp_solver *s);                       /* Exitflag      */
+int rsqp_is_solved(const rsqp_solver *s);
+/* solver convention -1 lower / 0 / +1 upper (getWorkingSetBounds/Constraints) */
+int rsqp_get_working_set_raw(const rsqp_solver *s, int *ws_b, int *ws_c);
+/* get_working_set (qpOASESInterface.cpp:835-895): ActiveType per bound / constraint,
+ * computed on the device (A*x product + mapping), reference quirks preserved. */
+int rsqp_get_working_set(rsqp_solver *s, int *W_c, int *W_b);
+/* test_optimality (qpOASESInterface.cpp:498-684): fused device certificate. Returns 1
+ * (KKT_error <= 1e-6), 0, or RSQP_ERR_WORKING_SET. W_c / W_b may be NULL. */
+int rsqp_test_optimality(rsqp_solver *s, int *W_c, int *W_b, rsqp_optimality_status *out);
+
+/* SpHbMat::times / transposed_times on the device copy (SpHbMat.cpp:659-737) */
+int rsqp_A_times(rsqp_solver *s, const double *p, double *result);            /* nC <- nV */
+int rsqp_A_transposed_times(rsqp_solver *s, const double *p, double *result); /* nV <- nC */
+int rsqp_H_times(rsqp_solver *s, const double *p, double *result);
+
+/* ------------------------------------------------------------------------------------ */
+/* a batch of independent QPs (north_star: CUTEst sweeps / parameter scans)              */
+/* ------------------------------------------------------------------------------------ */
+/* nq problems of individual size; nV[q], nC[q], and per problem CSC matrices given as
+ * concatenated arrays with offsets: Ajc_off[q] indexes into Ajc (length sum(nV+1)),
+ * Annz_off[q] into Air/Aval; likewise H. Everything is copied to the device once. */
+int rsqp_batch_create(int nq, const int *nV, const int *nC, const int *Ajc, const int *Air,
+                      const double *Aval, const int *Hjc, const int *Hir, const double *Hval,
+                      int device, rsqp_batch **out);
+void rsqp_batch_destroy(rsqp_batch *b);
+/* vectors concatenated over the batch: g, lb, ub have sum(nV) entries; lbA, ubA sum(nC) */
+int rsqp_batch_set_vectors(rsqp_batch *b, const double *g, const double *lb, const double *ub,
+                           const double *lbA, const double *ubA);
+/* refresh the matrix values (same patterns) */
+int rsqp_batch_set_matrix_values(rsqp_batch *b, const double *Aval, const double *Hval);
+/* solve all problems with one launch; data already resident on the device.
+ * mode as above (WARM_REINIT not available for batches). Asynchronous on the batch's
+ * stream; rsqp_batch_sync() waits. */
+int rsqp_batch_solve(rsqp_batch *b, int mode, int max_nWSR);
+int rsqp_batch_sync(rsqp_batch *b);
+/* device time of the last rsqp_batch_solve in milliseconds (HIP events on its stream) */
+float rsqp_batch_last_solve_ms(rsqp_batch *b);
+/* results, concatenated like the inputs; any pointer may be NULL */
+int rsqp_batch_get_results(rsqp_batch *b, double *x, double *y, int *ws_b, int *ws_c, int *status,
+                           int *nWSR, double *obj);
+/* fused KKT certificate for every problem of the batch (one launch) */
+int rsqp_batch_test_optimality(rsqp_batch *b, rsqp_optimality_status *out /* nq */, int *ok /* nq */);
+
+/* ------------------------------------------------------------------------------------ */
+/* batched sparse products, device resident -- the SpMV the roofline target names        */
+/* ------------------------------------------------------------------------------------ */
+/* y_k = A_k x_k (transposed == 0) or x_k = A_k' y_k for nbatch matrices that share one
+ * CSC pattern (jc, ir) and have their own values / vectors, all in device memory. */
+typedef struct rsqp_spmv_plan rsqp_spmv_plan;
+int rsqp_spmv_plan_create(int nrow, int ncol, const int *jc, const int *ir, int nbatch, int device,
+                          rsqp_spmv_plan **out);
+void rsqp_spmv_plan_destroy(rsqp_spmv_plan *p);
+/* host -> device staging of values (nbatch*nnz) and input vectors */
+int rsqp_spmv_plan_upload(rsqp_spmv_plan *p, const double *vals, const double *xin, int transposed);
+int rsqp_spmv_plan_run(rsqp_spmv_plan *p, int transposed, int repeats, float *ms_per_launch);
+int rsqp_spmv_plan_download(rsqp_spmv_plan *p, double *out, int transposed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,929 @@
+// qp_small.hip -- batched online active-set QP engine for gfx950: ONE QP PER WORKGROUP,
+// the whole solver state (Q, T, R, iterate, working set) resident in LDS.
+//
+// Replaces, for hs0xx-scale problems, the qpOASES 3.2.1 SQProblem::init / hotstart calls
+// made at reference src/qpOASESInterface.cpp:155,180,184,191,197,204. Algorithm = dense
+// null-space online active-set strategy (see DESIGN.md section "Algorithm"):
+//   A_AC,FR * Q = [0 T]  (T reverse triangular),  R'R = Z'HZ,  Givens up/down-dates,
+//   primal + dual ratio tests with lowest-candidate-id tie break, exchange on linear
+//   dependence, bound flipping when Z'HZ would lose definiteness.
+//
+// MI355X mapping:
+//   * grid = number of QPs; workgroup = NT threads (one wave for NT = 64) -- a batch
+//     fills the 256 CUs with independent problems; no inter-workgroup communication.
+//   * LDS image per problem (rsqp_image_bytes): Q and R column-major with an ODD leading
+//     dimension so that the lane<->row and lane<->column access patterns below are both
+//     bank-conflict free for ds_read_b64; T row-major with the same stride.
+//   * sparse H / A stay in global memory in CSC (+ a CSR copy of A): they are read-only
+//     and L2-resident; lane-per-row / lane-per-column products, no atomics.
+//   * reductions are wave butterflies (__shfl_xor, identical result in every lane) so
+//     all control flow stays wave-uniform; argmin carries the candidate id for the
+//     deterministic tie break.
+//   * the image is written back to HBM at the end of a solve and reloaded by the next
+//     hot start (qpOASES keeps the same data inside the SQProblem object).
+#include "rsqp_internal.h"
+
+#define SYNC() __syncthreads()
+#define PFOR(i, n) for (int i = threadIdx.x; i < (n); i += NT)
+
+namespace {
+
+struct Blocking {
+    double tau;
+    int kind;  // 0 none, 1 remove constraint, 2 remove bound, 3 add constraint, 4 add bound
+    int idx, side;
+};
+
+template <int NT>
+struct Engine {
+    // problem
+    int nV, nC, ld, sizeT, haveH;
+    const int *Ajc, *Air; const double *Aval;
+    const int *Arp, *Aci; const double *Arv;
+    const int *Hjc, *Hir; const double *Hval;
+    // LDS image
+    double *Q, *R, *T;
+    double *x, *g, *lb, *ub, *gN, *lbN, *ubN, *dx, *wq, *wv1, *wv2, *wv3, *wv4, *rc, *rs;
+    double *Ax, *lbA, *ubA, *lbAN, *ubAN, *dAx, *wc1, *wc2;
+    double *y, *dy;
+    double *scal;  // 8 scalars for broadcasts
+    int *Sb, *Sc, *AC, *posAC;
+    int *iscal;    // 8 ints
+    double *red;   // cross-wave reduction scratch (outside the image)
+    // uniform registers
+    int nFR, nAC, status, infeasible, unbounded, nflips;
+
+    // ------------------------------------------------------------------ carve
+    __device__ void carve(char *base, int nV_, int nC_) {
+        nV = nV_; nC = nC_; ld = rsqp_ld(nV); sizeT = nV < nC ? nV : nC;
+        double *p = reinterpret_cast<double *>(base);
+        Q = p; p += (size_t)ld * nV;
+        R = p; p += (size_t)ld * nV;
+        T = p; p += (size_t)sizeT * ld;
+#define CARVE_V(name) name = p; p += nV
+        CARVE_V(x); CARVE_V(g); CARVE_V(lb); CARVE_V(ub); CARVE_V(gN); CARVE_V(lbN); CARVE_V(ubN);
+        CARVE_V(dx); CARVE_V(wq); CARVE_V(wv1); CARVE_V(wv2); CARVE_V(wv3); CARVE_V(wv4); CARVE_V(rc); CARVE_V(rs);
+#undef CARVE_V
+        p += 3 * nV;  // reserve (the image holds 18 vectors of nV)
+#define CARVE_C(name) name = p; p += nC
+        CARVE_C(Ax); CARVE_C(lbA); CARVE_C(ubA); CARVE_C(lbAN); CARVE_C(ubAN); CARVE_C(dAx); CARVE_C(wc1); CARVE_C(wc2);
+#undef CARVE_C
+        p += nC;
+        y = p; p += nV + nC;
+        dy = p; p += nV + nC;
+        scal = p; p += 8;
+        int *ip = reinterpret_cast<int *>(p);
+        Sb = ip; ip += nV;
+        Sc = ip; ip += nC;
+        AC = ip; ip += nC;
+        posAC = ip; ip += nC;
+        iscal = ip; ip += 8;
+    }
+
+    // ------------------------------------------------------------------ reductions
+    __device__ double wave_sum(double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    }
+    __device__ double block_sum(double v) {
+        v = wave_sum(v);
+        if constexpr (NT > 64) {
+            SYNC();
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+            SYNC();
+            v = 0.0;
+            for (int w = 0; w < NT / 64; w++) v += red[w];
+        }
+        return v;
+    }
+    // lexicographic min of (t, id)
+    __device__ void block_argmin(double &t, int &id) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            double t2 = __shfl_xor(t, o);
+            int id2 = __shfl_xor(id, o);
+            if (t2 < t || (t2 == t && id2 < id)) { t = t2; id = id2; }
+        }
+        if constexpr (NT > 64) {
+            SYNC();
+            if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = t; red[8 + (threadIdx.x >> 6)] = (double)id; }
+            SYNC();
+            t = red[0]; id = (int)red[8];
+            for (int w = 1; w < NT / 64; w++) {
+                double t2 = red[w]; int id2 = (int)red[8 + w];
+                if (t2 < t || (t2 == t && id2 < id)) { t = t2; id = id2; }
+            }
+        }
+    }
+    __device__ double dot(const double *a, const double *b, int n) {
+        double s = 0.0;
+        PFOR(i, n) s += a[i] * b[i];
+        return block_sum(s);
+    }
+
+    // ------------------------------------------------------------------ sparse products
+    __device__ void A_times(const double *v, double *out) {
+        PFOR(r, nC) {
+            double s = 0.0;
+            for (int k = Arp[r]; k < Arp[r + 1]; k++) s += Arv[k] * v[Aci[k]];
+            out[r] = s;
+        }
+        SYNC();
+    }
+    __device__ void AT_times(const double *yc, double *out) {
+        PFOR(c, nV) {
+            double s = 0.0;
+            for (int k = Ajc[c]; k < Ajc[c + 1]; k++) s += Aval[k] * yc[Air[k]];
+            out[c] = s;
+        }
+        SYNC();
+    }
+    __device__ void H_times(const double *v, double *out) {
+        PFOR(c, nV) {
+            double s = 0.0;
+            if (haveH)
+                for (int k = Hjc[c]; k < Hjc[c + 1]; k++) s += Hval[k] * v[Hir[k]];
+            out[c] = s;
+        }
+        SYNC();
+    }
+    // a[v] = A[i][v] for free v, 0 otherwise (all==true: every variable)
+    __device__ void row_of_A(int i, double *a, bool all) {
+        PFOR(v, nV) a[v] = 0.0;
+        SYNC();
+        for (int k = Arp[i] + threadIdx.x; k < Arp[i + 1]; k += NT) {
+            int c = Aci[k];
+            if (all || Sb[c] == 0) a[c] = Arv[k];
+        }
+        SYNC();
+    }
+    // w[c] = Q[:,c] . a   for c < nFR
+    __device__ void QT_times(const double *a, double *w) {
+        PFOR(c, nFR) {
+            const double *qc = Q + (size_t)c * ld;
+            double s = 0.0;
+            for (int v = 0; v < nV; v++) s += qc[v] * a[v];
+            w[c] = s;
+        }
+        SYNC();
+    }
+
+    // ------------------------------------------------------------------ Givens helpers
+    __device__ static void givens(double a_elim, double b_keep, double &c, double &s) {
+        if (a_elim == 0.0) { c = 1.0; s = 0.0; return; }
+        double r = hypot(a_elim, b_keep);
+        c = b_keep / r;
+        s = a_elim / r;
+    }
+    // rotations (j, j+1), j = j0 .. j1-1, left to right, coefficients rc/rs[j], applied
+    // to the vector w (thread 0 computes them: the chain is sequential)
+    __device__ void plan_sweep(double *w, int j0, int j1, int jskip_below) {
+        if (threadIdx.x == 0) {
+            for (int j = j0; j < j1; j++) {
+                double c = 1.0, s = 0.0;
+                if (j >= jskip_below) givens(w[j], w[j + 1], c, s);
+                double a = w[j], b = w[j + 1];
+                w[j] = c * a - s * b;
+                w[j + 1] = s * a + c * b;
+                rc[j] = c; rs[j] = s;
+            }
+        }
+        SYNC();
+    }
+    // apply the planned sweep to the columns of Q (lane per variable, value carried)
+    __device__ void sweep_Q(int j0, int j1) {
+        if (j1 <= j0) return;
+        PFOR(v, nV) {
+            double carry = Q[(size_t)j0 * ld + v];
+            for (int j = j0; j < j1; j++) {
+                double b = Q[(size_t)(j + 1) * ld + v], c = rc[j], s = rs[j];
+                Q[(size_t)j * ld + v] = c * carry - s * b;
+                carry = s * carry + c * b;
+            }
+            Q[(size_t)j1 * ld + v] = carry;
+        }
+        SYNC();
+    }
+    // same sweep on the columns of T (lane per active row)
+    __device__ void sweep_T(int j0, int j1) {
+        if (j1 <= j0) return;
+        PFOR(i, nAC) {
+            double *row = T + (size_t)i * ld;
+            double carry = row[j0];
+            for (int j = j0; j < j1; j++) {
+                double b = row[j + 1], c = rc[j], s = rs[j];
+                row[j] = c * carry - s * b;
+                carry = s * carry + c * b;
+            }
+            row[j1] = carry;
+        }
+        SYNC();
+    }
+    // column sweep (j, j+1), j = 0..nZ-2, on R followed by the row rotations that make
+    // it upper triangular again
+    __device__ void sweep_R(int nZ) {
+        if (nZ < 2) return;
+        PFOR(r, nZ) {
+            int j0 = r > 0 ? r - 1 : 0;
+            double carry = R[(size_t)j0 * ld + r];
+            for (int j = j0; j + 1 < nZ; j++) {
+                double b = R[(size_t)(j + 1) * ld + r], c = rc[j], s = rs[j];
+                R[(size_t)j * ld + r] = c * carry - s * b;
+                carry = s * carry + c * b;
+            }
+            R[(size_t)(nZ - 1) * ld + r] = carry;
+        }
+        SYNC();
+        for (int j = 0; j + 1 < nZ; j++) {
+            double diag = R[(size_t)j * ld + j], sub = R[(size_t)j * ld + j + 1];
+            if (sub != 0.0) {  // uniform: every lane read the same LDS words
+                double r = hypot(diag, sub), cc = diag / r, ss = sub / r;
+                SYNC();
+                for (int col = j + threadIdx.x; col < nZ; col += NT) {
+                    double *pc = R + (size_t)col * ld;
+                    double a = pc[j], b = pc[j + 1];
+                    pc[j] = cc * a + ss * b;
+                    pc[j + 1] = col == j ? 0.0 : -ss * a + cc * b;
+                }
+                SYNC();
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ independence tests
+    __device__ bool constraint_is_LI(int i) {
+        int nZ = nFR - nAC;
+        if (nZ <= 0) return false;
+        row_of_A(i, wv1, false);
+        double na2 = dot(wv1, wv1, nV);
+        if (na2 == 0.0) return false;
+        double s = 0.0;
+        PFOR(c, nZ) {
+            const double *qc = Q + (size_t)c * ld;
+            double d = 0.0;
+            for (int v = 0; v < nV; v++) d += qc[v] * wv1[v];
+            s += d * d;
+        }
+        s = block_sum(s);
+        return sqrt(s) > RSQP_EPS_LI * sqrt(na2);
+    }
+    __device__ bool bound_is_LI(int v) {
+        int nZ = nFR - nAC;
+        if (nZ <= 0) return false;
+        double s = 0.0;
+        PFOR(c, nZ) { double d = Q[(size_t)c * ld + v]; s += d * d; }
+        s = block_sum(s);
+        return sqrt(s) > RSQP_EPS_LI;
+    }
+
+    // ------------------------------------------------------------------ working-set updates
+    __device__ void add_constraint(int i, int st, bool upd_chol, bool skipZ) {
+        int nZ = nFR - nAC;
+        row_of_A(i, wv1, false);
+        QT_times(wv1, wq);
+        int j1 = nZ - 1 > 0 ? nZ - 1 : 0;
+        plan_sweep(wq, 0, j1, skipZ ? j1 : 0);
+        if (!skipZ) {
+            sweep_Q(0, j1);
+            if (upd_chol) sweep_R(nZ);
+        }
+        double *row = T + (size_t)nAC * ld;
+        PFOR(c, nV) row[c] = (c >= nZ - 1 && c < nFR) ? wq[c] : 0.0;
+        if (threadIdx.x == 0) { AC[nAC] = i; posAC[i] = nAC; Sc[i] = st; }
+        nAC++;
+        SYNC();
+    }
+
+    __device__ void add_bound(int v, int st, bool upd_chol, bool skipZ) {
+        int nZ = nFR - nAC;
+        PFOR(c, nFR) wq[c] = Q[(size_t)c * ld + v];
+        SYNC();
+        int jz = nZ - 1 > 0 ? nZ - 1 : 0;
+        plan_sweep(wq, 0, nFR - 1, skipZ ? jz : 0);
+        sweep_Q(skipZ ? jz : 0, nFR - 1);
+        if (!skipZ && upd_chol) sweep_R(nZ);
+        sweep_T(jz, nFR - 1);
+        // row v is now +-e_{nFR-1}: drop that row and column
+        PFOR(c, nFR) Q[(size_t)c * ld + v] = 0.0;
+        PFOR(u, nV) Q[(size_t)(nFR - 1) * ld + u] = 0.0;
+        PFOR(i, nAC) T[(size_t)i * ld + nFR - 1] = 0.0;
+        if (threadIdx.x == 0) Sb[v] = st;
+        nFR--;
+        SYNC();
+    }
+
+    // append the Cholesky column of the new null-space column zc; false = not pos. def.
+    __device__ bool chol_append(int zc) {
+        const double *z = Q + (size_t)zc * ld;
+        H_times(z, wv2);
+        double zHz = dot(z, wv2, nV);
+        PFOR(j, zc) {
+            const double *qj = Q + (size_t)j * ld;
+            double s = 0.0;
+            for (int v = 0; v < nV; v++) s += qj[v] * wv2[v];
+            wv3[j] = s;
+        }
+        SYNC();
+        // R' r = rhs, column oriented
+        for (int j = 0; j < zc; j++) {
+            double rj = wv3[j] / R[(size_t)j * ld + j];
+            SYNC();
+            if (threadIdx.x == 0) wv3[j] = rj;
+            for (int k = j + 1 + threadIdx.x; k < zc; k += NT) wv3[k] -= R[(size_t)k * ld + j] * rj;
+            SYNC();
+        }
+        double rr = dot(wv3, wv3, zc);
+        double rho2 = zHz - rr;
+        if (!(rho2 > RSQP_EPS_PD_REL * (fabs(zHz) + rr) + RSQP_EPS_PD_ABS)) return false;
+        PFOR(j, nV) R[(size_t)zc * ld + j] = j < zc ? wv3[j] : (j == zc ? sqrt(rho2) : 0.0);
+        SYNC();
+        return true;
+    }
+
+    // right-to-left sweep used by the two removals: rotation t acts on columns
+    // (cfirst - t, cfirst - t + 1) and is fixed by row (row0 + t) of T
+    __device__ void removal_sweep(int row0, int nrot, int cfirst) {
+        for (int t = 0; t < nrot; t++) {
+            int i = row0 + t, c0 = cfirst - t;
+            double *ri = T + (size_t)i * ld;
+            double c, s;
+            givens(ri[c0], ri[c0 + 1], c, s);  // uniform
+            SYNC();
+            if (threadIdx.x == 0) { rc[t] = c; rs[t] = s; }
+            if (s != 0.0) {
+                for (int ii = i + threadIdx.x; ii < nAC; ii += NT) {
+                    double *row = T + (size_t)ii * ld;
+                    double a = row[c0], b = row[c0 + 1];
+                    row[c0] = ii == i ? 0.0 : c * a - s * b;
+                    row[c0 + 1] = s * a + c * b;
+                }
+            }
+            SYNC();
+        }
+        if (nrot <= 0) return;
+        PFOR(v, nV) {
+            double keep = Q[(size_t)(cfirst + 1) * ld + v];
+            for (int t = 0; t < nrot; t++) {
+                int c0 = cfirst - t;
+                double a = Q[(size_t)c0 * ld + v], c = rc[t], s = rs[t];
+                Q[(size_t)(c0 + 1) * ld + v] = s * a + c * keep;
+                keep = c * a - s * keep;
+            }
+            Q[(size_t)(cfirst - nrot + 1) * ld + v] = keep;
+        }
+        SYNC();
+    }
+
+    __device__ int remove_constraint_tq(int k) {
+        int cons = AC[k];
+        SYNC();
+        PFOR(c, nV)
+            for (int i = k; i + 1 < nAC; i++) T[(size_t)i * ld + c] = T[(size_t)(i + 1) * ld + c];
+        if (threadIdx.x == 0) {
+            for (int i = k; i + 1 < nAC; i++) { AC[i] = AC[i + 1]; posAC[AC[i]] = i; }
+            posAC[cons] = -1;
+            Sc[cons] = 0;
+        }
+        nAC--;
+        SYNC();
+        PFOR(c, nV) T[(size_t)nAC * ld + c] = 0.0;
+        SYNC();
+        removal_sweep(k, nAC - k, nFR - 2 - k);
+        return nFR - nAC - 1;
+    }
+
+    __device__ int remove_bound_tq(int v) {
+        int cn = nFR;
+        nFR++;
+        PFOR(u, nV) Q[(size_t)cn * ld + u] = u == v ? 1.0 : 0.0;
+        PFOR(c, cn) Q[(size_t)c * ld + v] = 0.0;
+        PFOR(i, nAC) T[(size_t)i * ld + cn] = 0.0;
+        if (threadIdx.x == 0) Sb[v] = 0;
+        SYNC();
+        for (int k = Ajc[v] + threadIdx.x; k < Ajc[v + 1]; k += NT) {
+            int r = Air[k];
+            if (Sc[r] != 0) T[(size_t)posAC[r] * ld + cn] = Aval[k];
+        }
+        SYNC();
+        removal_sweep(0, nAC, cn - 1);
+        return nFR - nAC - 1;
+    }
+
+    __device__ bool chol_setup() {
+        int nZ = nFR - nAC;
+        for (int c = 0; c < nZ; c++)
+            if (!chol_append(c)) return false;
+        return true;
+    }
+
+    // ------------------------------------------------------------------ auxiliary QP
+    __device__ static double clampinf(double v) {
+        return v > RSQP_INFTY ? RSQP_INFTY : (v < -RSQP_INFTY ? -RSQP_INFTY : v);
+    }
+    __device__ void store_targets(const double *g_, const double *lb_, const double *ub_,
+                                  const double *lbA_, const double *ubA_) {
+        PFOR(v, nV) { gN[v] = g_[v]; lbN[v] = clampinf(lb_[v]); ubN[v] = clampinf(ub_[v]); }
+        PFOR(i, nC) { lbAN[i] = clampinf(lbA_[i]); ubAN[i] = clampinf(ubA_[i]); }
+        SYNC();
+    }
+
+    // x0 / y0 / guess_b / guess_c: global or LDS pointers, may be null
+    __device__ int setup_aux(const double *x0, const double *y0, const int *guess_b, const int *guess_c) {
+        status = QPS_PREPARINGAUXILIARYQP;
+        infeasible = unbounded = 0;
+        PFOR(v, nV) {
+            double xv = x0 ? x0[v] : 0.0;
+            int s;
+            if (guess_b) s = guess_b[v];
+            else if (x0) s = xv <= lbN[v] + RSQP_BOUND_TOLERANCE ? -1 : (xv >= ubN[v] - RSQP_BOUND_TOLERANCE ? 1 : 0);
+            else if (y0) s = y0[v] > RSQP_EPS ? -1 : (y0[v] < -RSQP_EPS ? 1 : 0);
+            else s = -1;
+            if (s == -1 && lbN[v] <= -RSQP_INFTY) s = (ubN[v] < RSQP_INFTY && !x0 && !guess_b) ? 1 : 0;
+            if (s == 1 && ubN[v] >= RSQP_INFTY) s = 0;
+            wv4[v] = xv;          // staged: x0 may alias x (hot start with new matrices)
+            wq[v] = (double)s;
+        }
+        PFOR(i, nV + nC) dy[i] = y0 ? y0[i] : 0.0;
+        PFOR(i, nC) wc1[i] = guess_c ? (double)guess_c[i] : 0.0;
+        SYNC();
+        PFOR(v, nV) { x[v] = wv4[v]; Sb[v] = (int)wq[v]; }
+        PFOR(i, nV + nC) y[i] = dy[i];
+        for (int k = threadIdx.x; k < ld * nV; k += NT) { Q[k] = 0.0; R[k] = 0.0; }
+        for (int k = threadIdx.x; k < sizeT * ld; k += NT) T[k] = 0.0;
+        PFOR(i, nC) { Sc[i] = 0; posAC[i] = -1; }
+        SYNC();
+        if (threadIdx.x == 0) {
+            int n = 0;
+            for (int v = 0; v < nV; v++)
+                if (Sb[v] == 0) Q[(size_t)(n++) * ld + v] = 1.0;
+            iscal[0] = n;
+        }
+        SYNC();
+        nFR = iscal[0];
+        nAC = 0;
+        A_times(x, Ax);
+        for (int i = 0; i < nC; i++) {
+            int s = 0;
+            if (guess_c) s = (int)wc1[i];
+            else if (x0) s = Ax[i] <= lbAN[i] + RSQP_BOUND_TOLERANCE ? -1 : (Ax[i] >= ubAN[i] - RSQP_BOUND_TOLERANCE ? 1 : 0);
+            else if (y0) s = y[nV + i] > RSQP_EPS ? -1 : (y[nV + i] < -RSQP_EPS ? 1 : 0);
+            if (s == -1 && lbAN[i] <= -RSQP_INFTY) s = 0;
+            if (s == 1 && ubAN[i] >= RSQP_INFTY) s = 0;
+            if (s != 0 && constraint_is_LI(i)) add_constraint(i, s, false, false);
+        }
+        PFOR(v, nV) {
+            double yv = y[v];
+            if (Sb[v] == 0 || (Sb[v] == -1 && yv < 0.0) || (Sb[v] == 1 && yv > 0.0)) y[v] = 0.0;
+        }
+        PFOR(i, nC) {
+            double yi = y[nV + i];
+            if (Sc[i] == 0 || (Sc[i] == -1 && yi < 0.0) || (Sc[i] == 1 && yi > 0.0)) y[nV + i] = 0.0;
+        }
+        SYNC();
+        AT_times(y + nV, wv1);
+        H_times(x, wv2);
+        PFOR(v, nV) {
+            double xv = x[v];
+            g[v] = wv1[v] + y[v] - wv2[v];
+            lb[v] = Sb[v] == -1 ? xv : fmin(lbN[v], xv - RSQP_BOUND_RELAXATION);
+            ub[v] = Sb[v] == 1 ? xv : fmax(ubN[v], xv + RSQP_BOUND_RELAXATION);
+        }
+        PFOR(i, nC) {
+            double ax = Ax[i];
+            lbA[i] = Sc[i] == -1 ? ax : fmin(lbAN[i], ax - RSQP_BOUND_RELAXATION);
+            ubA[i] = Sc[i] == 1 ? ax : fmax(ubAN[i], ax + RSQP_BOUND_RELAXATION);
+        }
+        SYNC();
+        if (!chol_setup()) return RET_SETUP_FAILED;
+        status = QPS_AUXILIARYQPSOLVED;
+        return RET_OK;
+    }
+
+    // ------------------------------------------------------------------ step direction
+    __device__ static double delta_of(double target, double cur) {
+        return (fabs(target) >= RSQP_INFTY && fabs(cur) >= RSQP_INFTY) ? 0.0 : target - cur;
+    }
+
+    __device__ void step_direction() {
+        int nZ = nFR - nAC;
+        PFOR(v, nV) dx[v] = Sb[v] == -1 ? delta_of(lbN[v], lb[v]) : (Sb[v] == 1 ? delta_of(ubN[v], ub[v]) : 0.0);
+        PFOR(i, nV + nC) dy[i] = 0.0;
+        SYNC();
+        A_times(dx, wc2);
+        H_times(dx, wv2);
+        PFOR(i, nAC) {
+            int r = AC[i];
+            wc1[i] = (Sc[r] == -1 ? delta_of(lbAN[r], lbA[r]) : delta_of(ubAN[r], ubA[r])) - wc2[r];
+        }
+        PFOR(v, nV) wv1[v] = (gN[v] - g[v]) + wv2[v];  // tmpg
+        PFOR(c, nFR) wq[c] = 0.0;
+        SYNC();
+        // range space: T wY = bA (column oriented)
+        for (int i = 0; i < nAC; i++) {
+            int c = nFR - 1 - i;
+            double w = wc1[i] / T[(size_t)i * ld + c];
+            SYNC();
+            if (threadIdx.x == 0) wq[c] = w;
+            for (int ii = i + 1 + threadIdx.x; ii < nAC; ii += NT) wc1[ii] -= T[(size_t)ii * ld + c] * w;
+            SYNC();
+        }
+        PFOR(v, nV) {
+            double s = 0.0;
+            for (int c = nZ; c < nFR; c++) s += Q[(size_t)c * ld + v] * wq[c];
+            wv3[v] = s;  // xY
+        }
+        SYNC();
+        // null space: R'R wZ = -Z'(tmpg + H xY)
+        H_times(wv3, wv2);
+        PFOR(v, nV) wv2[v] += wv1[v];
+        SYNC();
+        PFOR(j, nZ) {
+            const double *qj = Q + (size_t)j * ld;
+            double s = 0.0;
+            for (int v = 0; v < nV; v++) s += qj[v] * wv2[v];
+            wq[j] = -s;
+        }
+        SYNC();
+        for (int j = 0; j < nZ; j++) {
+            double u = wq[j] / R[(size_t)j * ld + j];
+            SYNC();
+            if (threadIdx.x == 0) wq[j] = u;
+            for (int k = j + 1 + threadIdx.x; k < nZ; k += NT) wq[k] -= R[(size_t)k * ld + j] * u;
+            SYNC();
+        }
+        for (int j = nZ - 1; j >= 0; j--) {
+            double w = wq[j] / R[(size_t)j * ld + j];
+            SYNC();
+            if (threadIdx.x == 0) wq[j] = w;
+            for (int k = threadIdx.x; k < j; k += NT) wq[k] -= R[(size_t)j * ld + k] * w;
+            SYNC();
+        }
+        PFOR(v, nV) {
+            if (Sb[v] == 0) {
+                double s = wv3[v];
+                for (int j = 0; j < nZ; j++) s += Q[(size_t)j * ld + v] * wq[j];
+                dx[v] = s;
+            }
+        }
+        SYNC();
+        // multipliers of the active constraints: T' dyAC = Y'(H dx + dg)
+        H_times(dx, wv2);
+        PFOR(v, nV) wv2[v] += gN[v] - g[v];
+        SYNC();
+        for (int c = nZ + threadIdx.x; c < nFR; c += NT) {
+            const double *qc = Q + (size_t)c * ld;
+            double s = 0.0;
+            for (int v = 0; v < nV; v++) s += qc[v] * wv2[v];
+            wq[c] = s;
+        }
+        SYNC();
+        for (int m = 0; m < nAC; m++) {
+            int i = nAC - 1 - m, c = nZ + m;
+            const double *ri = T + (size_t)i * ld;
+            double d = wq[c] / ri[c];
+            SYNC();
+            if (threadIdx.x == 0) dy[nV + AC[i]] = d;
+            for (int cc = c + 1 + threadIdx.x; cc < nFR; cc += NT) wq[cc] -= ri[cc] * d;
+            SYNC();
+        }
+        AT_times(dy + nV, wv3);
+        PFOR(v, nV) dy[v] = Sb[v] != 0 ? wv2[v] - wv3[v] : 0.0;
+        A_times(dx, dAx);
+    }
+
+    // ------------------------------------------------------------------ ratio tests
+    __device__ static void cand(double num, double den, int id, double &bt, int &bid) {
+        if (den >= RSQP_EPS_DEN) {
+            double t = (num > 0.0 ? num : 0.0) / den;
+            if (t < bt || (t == bt && id < bid)) { bt = t; bid = id; }
+        }
+    }
+    // candidate ids: [0,nC) active constr. duals, [nC,nC+nV) fixed-variable duals,
+    // then inactive constr. lower / upper, then free variables lower / upper
+    __device__ Blocking ratio_tests() {
+        double bt = 1.0;
+        int bid = 0x7fffffff;
+        PFOR(i, nC) {
+            double Axi = Ax[i], dA = dAx[i];
+            if (Sc[i] != 0) {
+                double yi = y[nV + i], d = dy[nV + i];
+                if (Sc[i] == -1) cand(yi, -d, i, bt, bid); else cand(-yi, d, i, bt, bid);
+            } else {
+                if (lbAN[i] > -RSQP_INFTY) cand(Axi - lbA[i], delta_of(lbAN[i], lbA[i]) - dA, nC + nV + i, bt, bid);
+                if (ubAN[i] < RSQP_INFTY) cand(ubA[i] - Axi, dA - delta_of(ubAN[i], ubA[i]), 2 * nC + nV + i, bt, bid);
+            }
+        }
+        PFOR(v, nV) {
+            if (Sb[v] != 0) {
+                double yi = y[v], d = dy[v];
+                if (Sb[v] == -1) cand(yi, -d, nC + v, bt, bid); else cand(-yi, d, nC + v, bt, bid);
+            } else {
+                if (lbN[v] > -RSQP_INFTY) cand(x[v] - lb[v], delta_of(lbN[v], lb[v]) - dx[v], 3 * nC + nV + v, bt, bid);
+                if (ubN[v] < RSQP_INFTY) cand(ub[v] - x[v], dx[v] - delta_of(ubN[v], ub[v]), 3 * nC + 2 * nV + v, bt, bid);
+            }
+        }
+        // a candidate only blocks if it is strictly inside the step (t < 1)
+        if (!(bt < 1.0)) { bt = 1.0; bid = 0x7fffffff; }
+        block_argmin(bt, bid);
+        Blocking b;
+        b.tau = bt; b.kind = 0; b.idx = -1; b.side = 0;
+        if (bid != 0x7fffffff) {
+            if (bid < nC) { b.kind = 1; b.idx = bid; }
+            else if (bid < nC + nV) { b.kind = 2; b.idx = bid - nC; }
+            else if (bid < 2 * nC + nV) { b.kind = 3; b.idx = bid - nC - nV; b.side = -1; }
+            else if (bid < 3 * nC + nV) { b.kind = 3; b.idx = bid - 2 * nC - nV; b.side = 1; }
+            else if (bid < 3 * nC + 2 * nV) { b.kind = 4; b.idx = bid - 3 * nC - nV; b.side = -1; }
+            else { b.kind = 4; b.idx = bid - 3 * nC - 2 * nV; b.side = 1; }
+        }
+        return b;
+    }
+
+    // ------------------------------------------------------------------ removal with guard
+    __device__ int remove_with_guard(bool is_bound, int idx) {
+        if (is_bound) {
+            int old = Sb[idx];
+            SYNC();
+            int zc = remove_bound_tq(idx);
+            if (threadIdx.x == 0) y[idx] = 0.0;
+            SYNC();
+            if (chol_append(zc)) return RET_OK;
+            if ((old == -1 && ubN[idx] >= RSQP_INFTY) || (old == 1 && lbN[idx] <= -RSQP_INFTY)) {
+                add_bound(idx, old, false, true);
+                return RET_UNBOUNDED;
+            }
+            add_bound(idx, -old, false, true);
+            if (threadIdx.x == 0) { if (old == -1) ub[idx] = x[idx]; else lb[idx] = x[idx]; }
+            nflips++;
+            SYNC();
+            return RET_OK;
+        } else {
+            int old = Sc[idx], k = posAC[idx];
+            SYNC();
+            int zc = remove_constraint_tq(k);
+            if (threadIdx.x == 0) y[nV + idx] = 0.0;
+            SYNC();
+            if (chol_append(zc)) return RET_OK;
+            if ((old == -1 && ubAN[idx] >= RSQP_INFTY) || (old == 1 && lbAN[idx] <= -RSQP_INFTY)) {
+                add_constraint(idx, old, false, true);
+                return RET_UNBOUNDED;
+            }
+            add_constraint(idx, -old, false, true);
+            if (threadIdx.x == 0) { if (old == -1) ubA[idx] = Ax[idx]; else lbA[idx] = Ax[idx]; }
+            nflips++;
+            SYNC();
+            return RET_OK;
+        }
+    }
+
+    // ------------------------------------------------------------------ exchange
+    // a_full in wv4. Shifts the multipliers; returns partner in (pkind, pidx)
+    __device__ int ensure_LI(int side, double &y_new, int &pkind, int &pidx) {
+        int nZ = nFR - nAC;
+        PFOR(v, nV) wv1[v] = Sb[v] == 0 ? wv4[v] : 0.0;
+        PFOR(i, nC) wc2[i] = 0.0;
+        SYNC();
+        QT_times(wv1, wq);
+        for (int m = 0; m < nAC; m++) {
+            int i = nAC - 1 - m, c = nZ + m;
+            const double *ri = T + (size_t)i * ld;
+            double d = wq[c] / ri[c];
+            SYNC();
+            if (threadIdx.x == 0) wc2[AC[i]] = d;
+            for (int cc = c + 1 + threadIdx.x; cc < nFR; cc += NT) wq[cc] -= ri[cc] * d;
+            SYNC();
+        }
+        AT_times(wc2, wv2);
+        PFOR(v, nV) wv2[v] = Sb[v] != 0 ? wv4[v] - wv2[v] : 0.0;  // xiB
+        SYNC();
+        double sgn = side == 1 ? -1.0 : 1.0;
+        double bt = RSQP_INFTY;
+        int bid = 0x7fffffff;
+        PFOR(i, nC) {
+            if (Sc[i] != 0) {
+                double xi = sgn * wc2[i], yi = y[nV + i];
+                double num = Sc[i] == -1 ? yi : -yi, den = Sc[i] == -1 ? xi : -xi;
+                if (den > RSQP_EPS_DEN) {
+                    double t = (num > 0.0 ? num : 0.0) / den;
+                    if (t < bt || (t == bt && i < bid)) { bt = t; bid = i; }
+                }
+            }
+        }
+        PFOR(v, nV) {
+            if (Sb[v] != 0) {
+                double xi = sgn * wv2[v], yi = y[v];
+                double num = Sb[v] == -1 ? yi : -yi, den = Sb[v] == -1 ? xi : -xi;
+                if (den > RSQP_EPS_DEN) {
+                    double t = (num > 0.0 ? num : 0.0) / den;
+                    if (t < bt || (t == bt && nC + v < bid)) { bt = t; bid = nC + v; }
+                }
+            }
+        }
+        block_argmin(bt, bid);
+        if (bid == 0x7fffffff) return RET_INFEASIBLE;
+        PFOR(i, nC) if (Sc[i] != 0) y[nV + i] -= bt * sgn * wc2[i];
+        PFOR(v, nV) if (Sb[v] != 0) y[v] -= bt * sgn * wv2[v];
+        SYNC();
+        y_new = sgn * bt;
+        pkind = bid < nC ? 1 : 2;
+        pidx = bid < nC ? bid : bid - nC;
+        return RET_OK;
+    }
+
+    __device__ bool remove_partner(int pkind, int pidx) {
+        int zc;
+        if (pkind == 1) {
+            int k = posAC[pidx];
+            SYNC();
+            zc = remove_constraint_tq(k);
+            if (threadIdx.x == 0) y[nV + pidx] = 0.0;
+        } else {
+            zc = remove_bound_tq(pidx);
+            if (threadIdx.x == 0) y[pidx] = 0.0;
+        }
+        SYNC();
+        return chol_append(zc);
+    }
+
+    __device__ int change_active_set(const Blocking &b) {
+        if (b.kind == 1) return remove_with_guard(false, b.idx);
+        if (b.kind == 2) return remove_with_guard(true, b.idx);
+        if (b.kind == 3 || b.kind == 4) {
+            double ynew = 0.0;
+            bool full = true;
+            bool li = b.kind == 3 ? constraint_is_LI(b.idx) : bound_is_LI(b.idx);
+            if (!li) {
+                int pkind = 0, pidx = -1;
+                if (b.kind == 3) row_of_A(b.idx, wv4, true);
+                else { PFOR(v, nV) wv4[v] = v == b.idx ? 1.0 : 0.0; SYNC(); }
+                int rc_ = ensure_LI(b.side, ynew, pkind, pidx);
+                if (rc_ != RET_OK) return rc_;
+                full = remove_partner(pkind, pidx);
+            }
+            if (b.kind == 3) {
+                add_constraint(b.idx, b.side, full, !full);
+                if (threadIdx.x == 0) y[nV + b.idx] = ynew;
+            } else {
+                add_bound(b.idx, b.side, full, !full);
+                if (threadIdx.x == 0) y[b.idx] = ynew;
+            }
+            SYNC();
+        }
+        return RET_OK;
+    }
+
+    // ------------------------------------------------------------------ homotopy
+    __device__ void drift_correction() {
+        PFOR(v, nV) if (Sb[v] != 0) x[v] = Sb[v] == -1 ? lb[v] : ub[v];
+        SYNC();
+        A_times(x, Ax);
+        PFOR(i, nC) { if (Sc[i] == -1) lbA[i] = Ax[i]; else if (Sc[i] == 1) ubA[i] = Ax[i]; }
+        AT_times(y + nV, wv1);
+        H_times(x, wv2);
+        PFOR(v, nV) g[v] = wv1[v] + y[v] - wv2[v];
+        SYNC();
+    }
+
+    __device__ int homotopy(int maxit, int &nWSR) {
+        int iter = 0, rcode = RET_OK;
+        status = QPS_PERFORMINGHOMOTOPY;
+        PFOR(v, nV) {
+            if (Sb[v] != -1 && lb[v] <= -RSQP_INFTY && lbN[v] > -RSQP_INFTY) lb[v] = fmin(lbN[v], x[v] - RSQP_BOUND_RELAXATION);
+            if (Sb[v] != 1 && ub[v] >= RSQP_INFTY && ubN[v] < RSQP_INFTY) ub[v] = fmax(ubN[v], x[v] + RSQP_BOUND_RELAXATION);
+        }
+        PFOR(i, nC) {
+            if (Sc[i] != -1 && lbA[i] <= -RSQP_INFTY && lbAN[i] > -RSQP_INFTY) lbA[i] = fmin(lbAN[i], Ax[i] - RSQP_BOUND_RELAXATION);
+            if (Sc[i] != 1 && ubA[i] >= RSQP_INFTY && ubAN[i] < RSQP_INFTY) ubA[i] = fmax(ubAN[i], Ax[i] + RSQP_BOUND_RELAXATION);
+        }
+        SYNC();
+        for (;;) {
+            step_direction();
+            Blocking b = ratio_tests();
+            double tau = b.tau;
+            bool done = b.kind == 0;
+            PFOR(v, nV) {
+                if (done) {
+                    g[v] = gN[v]; lb[v] = lbN[v]; ub[v] = ubN[v];
+                    x[v] = Sb[v] == -1 ? lb[v] : (Sb[v] == 1 ? ub[v] : x[v] + tau * dx[v]);
+                } else {
+                    x[v] += tau * dx[v];
+                    g[v] += tau * (gN[v] - g[v]);
+                    lb[v] += tau * delta_of(lbN[v], lb[v]);
+                    ub[v] += tau * delta_of(ubN[v], ub[v]);
+                }
+            }
+            PFOR(i, nV + nC) y[i] += tau * dy[i];
+            PFOR(i, nC) {
+                if (done) { lbA[i] = lbAN[i]; ubA[i] = ubAN[i]; }
+                else { lbA[i] += tau * delta_of(lbAN[i], lbA[i]); ubA[i] += tau * delta_of(ubAN[i], ubA[i]); }
+            }
+            SYNC();
+            A_times(x, Ax);
+            if (done) { status = QPS_SOLVED; break; }
+            if (iter >= maxit) { rcode = RET_MAX_NWSR; break; }
+            if (threadIdx.x == 0) {
+                if (b.kind == 3) { if (b.side == -1) lbA[b.idx] = Ax[b.idx]; else ubA[b.idx] = Ax[b.idx]; }
+                else if (b.kind == 4) { if (b.side == -1) lb[b.idx] = x[b.idx]; else ub[b.idx] = x[b.idx]; }
+            }
+            SYNC();
+            rcode = change_active_set(b);
+            if (rcode == RET_INFEASIBLE) { infeasible = 1; break; }
+            if (rcode == RET_UNBOUNDED) { unbounded = 1; break; }
+            iter++;
+            drift_correction();
+        }
+        nWSR = iter;
+        return rcode;
+    }
+
+    __device__ double objective() {
+        H_times(x, wv2);
+        double a = dot(x, wv2, nV), b = dot(gN, x, nV);
+        return 0.5 * a + b;
+    }
+};
+
+// ------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(NT)
+small_qp_kernel(QPPools P, int mode, int maxWSR) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const QPDesc d = P.desc[blockIdx.x];
+    Engine<NT> E;
+    E.carve(smem, d.nV, d.nC);
+    const long long nd = rsqp_image_doubles(d.nV, d.nC), ni = rsqp_image_ints(d.nV, d.nC);
+    E.red = reinterpret_cast<double *>(smem + ((nd * 8 + ni * 4 + 15) & ~15LL));
+    E.haveH = d.haveH;
+    E.Ajc = P.Ajc + d.offAjc; E.Air = P.Air + d.offAnz; E.Aval = P.Aval + d.offAnz;
+    E.Arp = P.Arp + d.offArp; E.Aci = P.Aci + d.offAnz; E.Arv = P.Arv + d.offAnz;
+    E.Hjc = P.Hjc + d.offHjc; E.Hir = P.Hir + d.offHnz; E.Hval = P.Hval + d.offHnz;
+    E.nflips = 0; E.infeasible = E.unbounded = 0; E.status = QPS_NOTINITIALISED; E.nFR = E.nAC = 0;
+    double *img = P.state + d.offState;
+    int *iimg = reinterpret_cast<int *>(img + nd);
+    double *simg = reinterpret_cast<double *>(smem);
+    int *siimg = reinterpret_cast<int *>(simg + nd);
+
+    int rcode = RET_OK, nWSR = 0;
+    if (mode != 0) {  // reload the image of the previous solve
+        for (long long k = threadIdx.x; k < nd; k += NT) simg[k] = img[k];
+        for (long long k = threadIdx.x; k < ni; k += NT) siimg[k] = iimg[k];
+        SYNC();
+        E.nFR = E.iscal[1]; E.nAC = E.iscal[2]; E.status = E.iscal[3];
+        SYNC();
+        if (E.status == QPS_NOTINITIALISED) mode = 0;
+    }
+    E.store_targets(P.g + d.offV, P.lb + d.offV, P.ub + d.offV, P.lbA + d.offC, P.ubA + d.offC);
+    if (mode == 0) {
+        rcode = E.setup_aux(nullptr, nullptr, nullptr, nullptr);
+    } else if (mode == 2) {  // hot start with new matrices: keep x, y and the working set
+        rcode = E.setup_aux(E.x, E.y, E.Sb, E.Sc);
+        if (rcode != RET_OK) rcode = E.setup_aux(nullptr, nullptr, nullptr, nullptr);
+    } else if (mode == 3) {  // warm re-initialisation from (x0, y0, guessed bounds)
+        rcode = E.setup_aux(P.x0 ? P.x0 + d.offV : nullptr, P.y0 ? P.y0 + d.offV + d.offC : nullptr,
+                            P.guess_b ? P.guess_b + d.offV : nullptr, nullptr);
+        if (rcode != RET_OK) rcode = E.setup_aux(nullptr, nullptr, nullptr, nullptr);
+    } else {
+        E.infeasible = E.unbounded = 0;
+    }
+    if (rcode == RET_OK) rcode = E.homotopy(maxWSR, nWSR);
+    double obj = E.objective();
+
+    // results
+    for (int v = threadIdx.x; v < d.nV; v += NT) { P.x[d.offV + v] = E.x[v]; P.ws_b[d.offV + v] = E.Sb[v]; }
+    for (int i = threadIdx.x; i < d.nV + d.nC; i += NT) P.y[d.offV + d.offC + i] = E.y[i];
+    for (int i = threadIdx.x; i < d.nC; i += NT) P.ws_c[d.offC + i] = E.Sc[i];
+    if (threadIdx.x == 0) {
+        int st = E.status;
+        P.status[blockIdx.x] = E.infeasible ? 100 + st : (E.unbounded ? 200 + st : st);
+        P.ret[blockIdx.x] = rcode;
+        P.nwsr[blockIdx.x] = nWSR;
+        P.nflips[blockIdx.x] = E.nflips;
+        P.obj[blockIdx.x] = obj;
+        E.iscal[1] = E.nFR; E.iscal[2] = E.nAC; E.iscal[3] = E.status;
+    }
+    SYNC();
+    for (long long k = threadIdx.x; k < nd; k += NT) img[k] = simg[k];
+    for (long long k = threadIdx.x; k < ni; k += NT) iimg[k] = siimg[k];
+}
+
+}  // namespace
+
+static const long long kMaxLds = 160 * 1024;
+
+int rsqp_small_qp_fits(int nVmax, int nCmax) {
+    return rsqp_image_bytes(nVmax, nCmax) + 256 <= kMaxLds;
+}
+
+hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, int mode, int maxWSR,
+                                hipStream_t stream) {
+    size_t lds = (size_t)rsqp_image_bytes(nVmax, nCmax) + 256;
+    if ((long long)lds > kMaxLds) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&small_qp_kernel<64>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(small_qp_kernel<64>, dim3(nq), dim3(64), lds, stream, p, mode, maxWSR);
+    return hipGetLastError();
+}

@@ -1,0 +1,1013 @@
+// rsqp_api.hip -- the C ABI of include/rsqp_hip.h (host side of librsqp_hip.so).
+//
+// Host logic restated from the reference adapter src/qpOASESInterface.cpp: the
+// FIXED/VARIED warm-start dispatch (:137-224, :817-833), dirty flags (:361-496),
+// handle_error (:686-758), status mapping (:332-357). Structure analysis of
+// SpHbMat::setStructure (src/SpHbMat.cpp:196-355) runs once on the host (a sort); every
+// per-iteration operation (value refresh, products, certificate, QP solve) is a kernel.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/rsqp_hip.h"
+#include "rsqp_sparse.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(RSQP_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count, bool zero = true) {
+        release();
+        n = count;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; return e; }
+        if (zero) e = hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T));
+        return e;
+    }
+    hipError_t upload(const T *h, size_t count) {
+        if (count == 0) return hipSuccess;
+        return hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice);
+    }
+    hipError_t from(const std::vector<T> &h) {
+        hipError_t e = alloc(h.size(), false);
+        if (e != hipSuccess) return e;
+        return upload(h.data(), h.size());
+    }
+    hipError_t download(T *h, size_t count) const {
+        if (count == 0) return hipSuccess;
+        return hipMemcpy(h, p, count * sizeof(T), hipMemcpyDeviceToHost);
+    }
+};
+
+// ---------------------------------------------------------------------------------
+// structure analysis (host, one-off)
+// ---------------------------------------------------------------------------------
+struct Compressed {
+    int nrow = 0, ncol = 0;
+    std::vector<int> jc, ir, order, tmap;  // CSC; order[ext] = position; tmap[ext] = triplet index
+    std::vector<double> val;
+    int nnz() const { return (int)ir.size(); }
+};
+
+// SpHbMat::setStructure: sort the (extended) triplet list by (col,row); ties by position.
+void csc_from_entries(int nrow, int ncol, const std::vector<int> &row1, const std::vector<int> &col1,
+                      const std::vector<double> &v, Compressed &out) {
+    const int n = (int)v.size();
+    std::vector<int> perm(n);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) {
+        if (col1[a] != col1[b]) return col1[a] < col1[b];
+        return row1[a] < row1[b];
+    });
+    out.nrow = nrow; out.ncol = ncol;
+    out.jc.assign(ncol + 1, 0); out.ir.resize(n); out.val.resize(n); out.order.resize(n);
+    for (int p = 0; p < n; p++) {
+        int e = perm[p];
+        out.ir[p] = row1[e] - 1;
+        out.val[p] = v[e];
+        out.order[e] = p;
+        out.jc[col1[e]]++;  // 1-based col -> slot col (= 0-based col + 1)
+    }
+    for (int c = 0; c < ncol; c++) out.jc[c + 1] += out.jc[c];
+}
+
+struct CsrCopy {
+    std::vector<int> rp, ci, perm;  // perm[p] = CSC position of CSR entry p
+};
+void csr_from_csc(int nrow, int ncol, const int *jc, const int *ir, CsrCopy &out) {
+    const int nnz = jc[ncol];
+    out.rp.assign(nrow + 1, 0); out.ci.resize(nnz); out.perm.resize(nnz);
+    for (int k = 0; k < nnz; k++) out.rp[ir[k] + 1]++;
+    for (int r = 0; r < nrow; r++) out.rp[r + 1] += out.rp[r];
+    std::vector<int> fill(nrow, 0);
+    for (int c = 0; c < ncol; c++)
+        for (int k = jc[c]; k < jc[c + 1]; k++) {
+            int r = ir[k], p = out.rp[r] + fill[r]++;
+            out.ci[p] = c;
+            out.perm[p] = k;
+        }
+}
+
+// blocks of consecutive majors with at most `chunk` entries; a longer major stands alone
+std::vector<int> build_blocks(int nmajor, const int *ptr, int chunk) {
+    std::vector<int> blk;
+    blk.push_back(0);
+    int start = 0;
+    while (start < nmajor) {
+        int end = start + 1;
+        while (end < nmajor && ptr[end + 1] - ptr[start] <= chunk && end - start < 4096) end++;
+        blk.push_back(end);
+        start = end;
+    }
+    return blk;
+}
+
+int exitflag_of(int status_word, int ret) {
+    // qpOASESInterface::get_status (src/qpOASESInterface.cpp:332-357)
+    if (status_word >= 200) return RSQP_QPERROR_UNBOUNDED;
+    if (status_word >= 100) return RSQP_QPERROR_INFEASIBLE;
+    if (status_word == QPS_SOLVED) return RSQP_QP_OPTIMAL;
+    (void)ret;
+    switch (status_word) {
+    case QPS_NOTINITIALISED: return RSQP_QPERROR_NOTINITIALISED;
+    case QPS_PREPARINGAUXILIARYQP: return RSQP_QPERROR_PREPARINGAUXILIARYQP;
+    case QPS_AUXILIARYQPSOLVED: return RSQP_QPERROR_AUXILIARYQPSOLVED;
+    case QPS_PERFORMINGHOMOTOPY: return RSQP_QPERROR_PERFORMINGHOMOTOPY;
+    case QPS_HOMOTOPYQPSOLVED: return RSQP_QPERROR_HOMOTOPYQPSOLVED;
+    }
+    return RSQP_QPERROR_UNKNOWN;
+}
+
+}  // namespace
+
+// =====================================================================================
+// one matrix on the device (CSC + optional CSR copy + spmv blocks)
+// =====================================================================================
+struct DevMatrix {
+    int nrow = 0, ncol = 0, nnz = 0;
+    bool initialised = false, symmetric = false, from_triplet = false;
+    int n_ident_entries = 0, n_triplet = 0;
+    std::vector<int> h_jc, h_ir, h_order;  // host mirror of the pattern
+    DevBuf<int> jc, ir, order, tmap, blk_c;          // CSC
+    DevBuf<double> val, tv;                          // tv: staging for triplet values
+    DevBuf<int> rp, ci, perm, blk_r;                 // CSR copy (A only)
+    DevBuf<double> rval;
+    int nblk_c = 0, nblk_r = 0;
+    bool have_csr = false;
+};
+
+struct rsqp_solver {
+    int nV = 0, nC = 0, device = 0;
+    int qp_maxiter = 1000, lp_maxiter = 100;
+    hipStream_t stream = nullptr;
+    DevMatrix A, H;
+    // host staging of the vectors (scalar setter storm of QPhandler::update_bounds)
+    std::vector<double> h_vec[5];
+    bool vec_dirty = true;
+    DevBuf<double> d_vec[5];
+    // engine pools (batch of one)
+    DevBuf<QPDesc> d_desc;
+    DevBuf<double> d_x, d_y, d_obj, d_state, d_x0, d_y0;
+    DevBuf<int> d_wsb, d_wsc, d_status, d_ret, d_nwsr, d_nflips, d_guess;
+    DevBuf<int> d_dummy_i; DevBuf<double> d_dummy_d;
+    // certificate scratch
+    DevBuf<double> d_Ax, d_ATy, d_Hx, d_kkt, d_in, d_out;
+    DevBuf<int> d_Wb, d_Wc;
+    // results mirrored on the host
+    std::vector<double> h_x, h_y;
+    std::vector<int> h_wsb, h_wsc;
+    int status_word = QPS_NOTINITIALISED, last_ret = 0, last_nflips = 0;
+    double obj = 0.0;
+    // dispatch state (qpOASESInterface.hpp:225-250)
+    bool firstQPsolved = false;
+    bool upd_A = false, upd_H = false, upd_bounds = false, upd_g = false;
+    int old_status = 0, new_status = 0;  // 0 UNDEFINED, 1 FIXED, 2 VARIED
+    bool desc_ready = false;
+};
+
+namespace {
+
+int upload_matrix(DevMatrix &M, const Compressed &c, bool want_csr) {
+    M.nrow = c.nrow; M.ncol = c.ncol; M.nnz = c.nnz();
+    M.h_jc = c.jc; M.h_ir = c.ir; M.h_order = c.order;
+    HIPCHK(M.jc.from(c.jc));
+    HIPCHK(M.ir.alloc(std::max(M.nnz, 1), true)); HIPCHK(M.ir.upload(c.ir.data(), c.ir.size()));
+    HIPCHK(M.val.alloc(std::max(M.nnz, 1), true)); HIPCHK(M.val.upload(c.val.data(), c.val.size()));
+    HIPCHK(M.order.alloc(std::max(M.nnz, 1), true)); HIPCHK(M.order.upload(c.order.data(), c.order.size()));
+    if (!c.tmap.empty()) { HIPCHK(M.tmap.from(c.tmap)); }
+    HIPCHK(M.tv.alloc(std::max(M.nnz, 1), true));
+    std::vector<int> blk = build_blocks(M.ncol, c.jc.data(), rsqp_spmv_chunk());
+    M.nblk_c = (int)blk.size() - 1;
+    HIPCHK(M.blk_c.from(blk));
+    M.have_csr = want_csr;
+    if (want_csr) {
+        CsrCopy r;
+        csr_from_csc(M.nrow, M.ncol, c.jc.data(), c.ir.data(), r);
+        HIPCHK(M.rp.from(r.rp));
+        HIPCHK(M.ci.alloc(std::max(M.nnz, 1), true)); HIPCHK(M.ci.upload(r.ci.data(), r.ci.size()));
+        HIPCHK(M.perm.alloc(std::max(M.nnz, 1), true)); HIPCHK(M.perm.upload(r.perm.data(), r.perm.size()));
+        HIPCHK(M.rval.alloc(std::max(M.nnz, 1), true));
+        std::vector<int> blr = build_blocks(M.nrow, r.rp.data(), rsqp_spmv_chunk());
+        M.nblk_r = (int)blr.size() - 1;
+        HIPCHK(M.blk_r.from(blr));
+        if (rsqp_launch_gather(M.nnz, M.perm.p, M.val.p, M.rval.p, nullptr) != hipSuccess)
+            return fail(RSQP_ERR_DEVICE, "gather launch failed");
+    }
+    M.initialised = true;
+    return RSQP_OK;
+}
+
+int flush_vectors(rsqp_solver *s) {
+    if (!s->vec_dirty) return RSQP_OK;
+    for (int k = 0; k < 5; k++) HIPCHK(s->d_vec[k].upload(s->h_vec[k].data(), s->h_vec[k].size()));
+    s->vec_dirty = false;
+    return RSQP_OK;
+}
+
+int ensure_desc(rsqp_solver *s) {
+    if (s->desc_ready) return RSQP_OK;
+    QPDesc d;
+    std::memset(&d, 0, sizeof(d));
+    d.nV = s->nV; d.nC = s->nC; d.haveH = s->H.initialised ? 1 : 0;
+    std::vector<QPDesc> hd(1, d);
+    HIPCHK(s->d_desc.from(hd));
+    s->desc_ready = true;
+    return RSQP_OK;
+}
+
+QPPools pools_of(rsqp_solver *s) {
+    QPPools p;
+    std::memset(&p, 0, sizeof(p));
+    p.desc = s->d_desc.p;
+    p.Ajc = s->A.initialised ? s->A.jc.p : s->d_dummy_i.p;
+    p.Air = s->A.initialised ? s->A.ir.p : s->d_dummy_i.p;
+    p.Aval = s->A.initialised ? s->A.val.p : s->d_dummy_d.p;
+    p.Arp = s->A.initialised ? s->A.rp.p : s->d_dummy_i.p;
+    p.Aci = s->A.initialised ? s->A.ci.p : s->d_dummy_i.p;
+    p.Arv = s->A.initialised ? s->A.rval.p : s->d_dummy_d.p;
+    p.Hjc = s->H.initialised ? s->H.jc.p : s->d_dummy_i.p;
+    p.Hir = s->H.initialised ? s->H.ir.p : s->d_dummy_i.p;
+    p.Hval = s->H.initialised ? s->H.val.p : s->d_dummy_d.p;
+    p.g = s->d_vec[RSQP_VEC_G].p; p.lb = s->d_vec[RSQP_VEC_LB].p; p.ub = s->d_vec[RSQP_VEC_UB].p;
+    p.lbA = s->d_vec[RSQP_VEC_LBA].p; p.ubA = s->d_vec[RSQP_VEC_UBA].p;
+    p.x = s->d_x.p; p.y = s->d_y.p; p.ws_b = s->d_wsb.p; p.ws_c = s->d_wsc.p;
+    p.status = s->d_status.p; p.ret = s->d_ret.p; p.nwsr = s->d_nwsr.p; p.nflips = s->d_nflips.p;
+    p.obj = s->d_obj.p; p.state = s->d_state.p;
+    return p;
+}
+
+int fetch_results(rsqp_solver *s) {
+    HIPCHK(s->d_x.download(s->h_x.data(), s->nV));
+    HIPCHK(s->d_y.download(s->h_y.data(), s->nV + s->nC));
+    HIPCHK(s->d_wsb.download(s->h_wsb.data(), s->nV));
+    HIPCHK(s->d_wsc.download(s->h_wsc.data(), s->nC));
+    HIPCHK(s->d_status.download(&s->status_word, 1));
+    HIPCHK(s->d_ret.download(&s->last_ret, 1));
+    HIPCHK(s->d_nflips.download(&s->last_nflips, 1));
+    HIPCHK(s->d_obj.download(&s->obj, 1));
+    return RSQP_OK;
+}
+
+bool solved(const rsqp_solver *s) { return s->status_word == QPS_SOLVED; }
+bool infeasible(const rsqp_solver *s) { return s->status_word >= 100 && s->status_word < 200; }
+
+}  // namespace
+
+// =====================================================================================
+// library
+// =====================================================================================
+extern "C" const char *rsqp_version(void) { return "restartsqp_amd 0.1 (gfx950)"; }
+extern "C" const char *rsqp_last_error(void) { return g_err.c_str(); }
+extern "C" int rsqp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// =====================================================================================
+// one QP
+// =====================================================================================
+extern "C" int rsqp_create(int nV, int nC, int device, rsqp_solver **out) {
+    if (!out || nV <= 0 || nC < 0) return fail(RSQP_ERR_ARG, "rsqp_create: bad sizes");
+    if (rsqp_device_count() <= 0) return fail(RSQP_ERR_DEVICE, "rsqp_create: no HIP device visible");
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    if (!rsqp_small_qp_fits(nV, nC))
+        return fail(RSQP_ERR_TOO_LARGE, "rsqp_create: problem exceeds the LDS-resident engine (160 KiB image)");
+    rsqp_solver *s = new rsqp_solver();
+    s->nV = nV; s->nC = nC;
+    HIPCHK(hipGetDevice(&s->device));
+    for (int k = 0; k < 5; k++) {
+        size_t n = (k <= RSQP_VEC_UB) ? nV : nC;
+        s->h_vec[k].assign(n, 0.0);
+        HIPCHK(s->d_vec[k].alloc(n));
+    }
+    HIPCHK(s->d_x.alloc(nV)); HIPCHK(s->d_y.alloc(nV + nC)); HIPCHK(s->d_obj.alloc(1));
+    HIPCHK(s->d_wsb.alloc(nV)); HIPCHK(s->d_wsc.alloc(nC));
+    HIPCHK(s->d_status.alloc(1)); HIPCHK(s->d_ret.alloc(1)); HIPCHK(s->d_nwsr.alloc(1)); HIPCHK(s->d_nflips.alloc(1));
+    HIPCHK(s->d_state.alloc((size_t)rsqp_image_bytes(nV, nC) / 8));
+    HIPCHK(s->d_x0.alloc(nV)); HIPCHK(s->d_y0.alloc(nV + nC)); HIPCHK(s->d_guess.alloc(nV));
+    HIPCHK(s->d_dummy_i.alloc(std::max(nV, nC) + 2)); HIPCHK(s->d_dummy_d.alloc(4));
+    HIPCHK(s->d_Ax.alloc(nC)); HIPCHK(s->d_ATy.alloc(nV)); HIPCHK(s->d_Hx.alloc(nV)); HIPCHK(s->d_kkt.alloc(6));
+    HIPCHK(s->d_in.alloc(std::max(nV, nC))); HIPCHK(s->d_out.alloc(std::max(nV, nC)));
+    HIPCHK(s->d_Wb.alloc(nV)); HIPCHK(s->d_Wc.alloc(nC));
+    s->h_x.assign(nV, 0.0); s->h_y.assign(nV + nC, 0.0); s->h_wsb.assign(nV, 0); s->h_wsc.assign(nC, 0);
+    *out = s;
+    return RSQP_OK;
+}
+
+extern "C" void rsqp_destroy(rsqp_solver *s) { delete s; }
+
+extern "C" int rsqp_set_options(rsqp_solver *s, int qp_maxiter, int lp_maxiter) {
+    if (!s || qp_maxiter < 0 || lp_maxiter < 0) return fail(RSQP_ERR_ARG, "rsqp_set_options");
+    s->qp_maxiter = qp_maxiter; s->lp_maxiter = lp_maxiter;
+    return RSQP_OK;
+}
+
+extern "C" int rsqp_set_A_triplet(rsqp_solver *s, int nnz, const int *irow, const int *jcol, const double *val,
+                                  int n_ident, const int *id_irow, const int *id_jcol, const int *id_size,
+                                  const double *id_value) {
+    if (!s || nnz < 0 || (nnz > 0 && (!irow || !jcol || !val))) return fail(RSQP_ERR_ARG, "rsqp_set_A_triplet");
+    if (s->firstQPsolved && !s->upd_A) s->upd_A = true;  // qpOASESInterface.cpp:427-429
+    DevMatrix &M = s->A;
+    if (!M.initialised) {
+        std::vector<int> r(irow, irow + nnz), c(jcol, jcol + nnz);
+        std::vector<double> v(val, val + nnz);
+        int nid = 0;
+        for (int b = 0; b < n_ident; b++)
+            for (int j = 0; j < id_size[b]; j++) {
+                r.push_back(id_irow[b] + j); c.push_back(id_jcol[b] + j); v.push_back(id_value[b]);
+                nid++;
+            }
+        for (size_t k = 0; k < r.size(); k++)
+            if (r[k] < 1 || r[k] > s->nC || c[k] < 1 || c[k] > s->nV)
+                return fail(RSQP_ERR_ARG, "rsqp_set_A_triplet: index out of range (indices are 1-based)");
+        Compressed cs;
+        csc_from_entries(s->nC, s->nV, r, c, v, cs);
+        M.from_triplet = true; M.n_triplet = nnz; M.n_ident_entries = nid;
+        int rc = upload_matrix(M, cs, true);
+        if (rc != RSQP_OK) return rc;
+        s->desc_ready = false;
+        return RSQP_OK;
+    }
+    if (!M.from_triplet || nnz != M.n_triplet) return fail(RSQP_ERR_ARG, "rsqp_set_A_triplet: pattern changed");
+    // SpHbMat::setMatVal(rhs, I_info): only the first nnz(J) entries are rewritten
+    HIPCHK(M.tv.upload(val, nnz));
+    if (rsqp_launch_scatter(nnz, M.order.p, nullptr, M.tv.p, M.val.p, s->stream) != hipSuccess ||
+        rsqp_launch_gather(M.nnz, M.perm.p, M.val.p, M.rval.p, s->stream) != hipSuccess)
+        return fail(RSQP_ERR_DEVICE, "value refresh launch failed");
+    return RSQP_OK;
+}
+
+extern "C" int rsqp_set_H_triplet(rsqp_solver *s, int nnz, const int *irow, const int *jcol, const double *val,
+                                  int is_symmetric) {
+    if (!s || nnz < 0 || (nnz > 0 && (!irow || !jcol || !val))) return fail(RSQP_ERR_ARG, "rsqp_set_H_triplet");
+    if (s->firstQPsolved && !s->upd_H) s->upd_H = true;  // :407-409
+    DevMatrix &M = s->H;
+    if (!M.initialised) {
+        std::vector<int> r, c, tmap;
+        std::vector<double> v;
+        for (int i = 0; i < nnz; i++) {
+            if (irow[i] < 1 || irow[i] > s->nV || jcol[i] < 1 || jcol[i] > s->nV)
+                return fail(RSQP_ERR_ARG, "rsqp_set_H_triplet: index out of range (indices are 1-based)");
+            r.push_back(irow[i]); c.push_back(jcol[i]); v.push_back(val[i]); tmap.push_back(i);
+            if (is_symmetric && irow[i] != jcol[i]) {  // mirror right behind (SpHbMat.cpp:302-308)
+                r.push_back(jcol[i]); c.push_back(irow[i]); v.push_back(val[i]); tmap.push_back(i);
+            }
+        }
+        Compressed cs;
+        csc_from_entries(s->nV, s->nV, r, c, v, cs);
+        cs.tmap = tmap;
+        M.from_triplet = true; M.n_triplet = nnz; M.symmetric = is_symmetric != 0;
+        int rc = upload_matrix(M, cs, false);
+        if (rc != RSQP_OK) return rc;
+        s->desc_ready = false;
+        return RSQP_OK;
+    }
+    if (!M.from_triplet || nnz != M.n_triplet) return fail(RSQP_ERR_ARG, "rsqp_set_H_triplet: pattern changed");
+    HIPCHK(M.tv.upload(val, nnz));
+    if (rsqp_launch_scatter(M.nnz, M.order.p, M.tmap.p, M.tv.p, M.val.p, s->stream) != hipSuccess)
+        return fail(RSQP_ERR_DEVICE, "value refresh launch failed");
+    return RSQP_OK;
+}
+
+namespace {
+int set_csc(rsqp_solver *s, DevMatrix &M, int nrow, int ncol, const int *jc, const int *ir, const double *val,
+            bool want_csr, bool *flag) {
+    if (!s || !jc || (jc[ncol] > 0 && (!ir || !val))) return fail(RSQP_ERR_ARG, "rsqp_set_*_csc");
+    if (s->firstQPsolved && !*flag) *flag = true;
+    const int nnz = jc[ncol];
+    if (M.initialised && nnz == M.nnz && !M.from_triplet) {  // same pattern: refresh values
+        HIPCHK(M.val.upload(val, nnz));
+        if (M.have_csr && rsqp_launch_gather(M.nnz, M.perm.p, M.val.p, M.rval.p, s->stream) != hipSuccess)
+            return fail(RSQP_ERR_DEVICE, "gather launch failed");
+        return RSQP_OK;
+    }
+    Compressed cs;
+    cs.nrow = nrow; cs.ncol = ncol;
+    cs.jc.assign(jc, jc + ncol + 1); cs.ir.assign(ir, ir + nnz); cs.val.assign(val, val + nnz);
+    cs.order.resize(nnz);
+    std::iota(cs.order.begin(), cs.order.end(), 0);
+    for (int c = 0; c < ncol; c++) {
+        if (jc[c] > jc[c + 1]) return fail(RSQP_ERR_ARG, "rsqp_set_*_csc: column pointers not monotone");
+        for (int k = jc[c]; k < jc[c + 1]; k++)
+            if (ir[k] < 0 || ir[k] >= nrow) return fail(RSQP_ERR_ARG, "rsqp_set_*_csc: row index out of range");
+    }
+    M.from_triplet = false;
+    int rc = upload_matrix(M, cs, want_csr);
+    s->desc_ready = false;
+    return rc;
+}
+int get_csc(const DevMatrix &M, int *jc, int *ir, double *val, int *order) {
+    if (!M.initialised) return fail(RSQP_ERR_ARG, "matrix not set");
+    if (jc) std::copy(M.h_jc.begin(), M.h_jc.end(), jc);
+    if (ir) std::copy(M.h_ir.begin(), M.h_ir.end(), ir);
+    if (order) std::copy(M.h_order.begin(), M.h_order.end(), order);
+    if (val) {
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(M.val.download(val, M.nnz));
+    }
+    return RSQP_OK;
+}
+}  // namespace
+
+extern "C" int rsqp_set_A_csc(rsqp_solver *s, const int *jc, const int *ir, const double *val) {
+    if (!s) return fail(RSQP_ERR_ARG, "null solver");
+    return set_csc(s, s->A, s->nC, s->nV, jc, ir, val, true, &s->upd_A);
+}
+extern "C" int rsqp_set_H_csc(rsqp_solver *s, const int *jc, const int *ir, const double *val) {
+    if (!s) return fail(RSQP_ERR_ARG, "null solver");
+    return set_csc(s, s->H, s->nV, s->nV, jc, ir, val, false, &s->upd_H);
+}
+extern "C" int rsqp_get_A_nnz(const rsqp_solver *s) { return s && s->A.initialised ? s->A.nnz : -1; }
+extern "C" int rsqp_get_H_nnz(const rsqp_solver *s) { return s && s->H.initialised ? s->H.nnz : -1; }
+extern "C" int rsqp_get_A_csc(const rsqp_solver *s, int *jc, int *ir, double *val, int *order) {
+    if (!s) return fail(RSQP_ERR_ARG, "null solver");
+    return get_csc(s->A, jc, ir, val, order);
+}
+extern "C" int rsqp_get_H_csc(const rsqp_solver *s, int *jc, int *ir, double *val, int *order) {
+    if (!s) return fail(RSQP_ERR_ARG, "null solver");
+    return get_csc(s->H, jc, ir, val, order);
+}
+
+extern "C" int rsqp_set_vector(rsqp_solver *s, int which, const double *v) {
+    if (!s || which < 0 || which > 4 || !v) return fail(RSQP_ERR_ARG, "rsqp_set_vector");
+    if (s->firstQPsolved) { if (which == RSQP_VEC_G) s->upd_g = true; else s->upd_bounds = true; }
+    std::copy(v, v + s->h_vec[which].size(), s->h_vec[which].begin());
+    s->vec_dirty = true;
+    return RSQP_OK;
+}
+extern "C" int rsqp_set_entry(rsqp_solver *s, int which, int location, double value) {
+    if (!s || which < 0 || which > 4 || location < 0 || location >= (int)s->h_vec[which].size())
+        return fail(RSQP_ERR_ARG, "rsqp_set_entry");
+    if (s->firstQPsolved) { if (which == RSQP_VEC_G) s->upd_g = true; else s->upd_bounds = true; }
+    s->h_vec[which][location] = value;
+    s->vec_dirty = true;
+    return RSQP_OK;
+}
+extern "C" int rsqp_get_vector(const rsqp_solver *s, int which, double *v) {
+    if (!s || which < 0 || which > 4 || !v) return fail(RSQP_ERR_ARG, "rsqp_get_vector");
+    std::copy(s->h_vec[which].begin(), s->h_vec[which].end(), v);
+    return RSQP_OK;
+}
+extern "C" int rsqp_reset_constraints(rsqp_solver *s) {
+    if (!s) return fail(RSQP_ERR_ARG, "null solver");
+    for (int k = RSQP_VEC_LB; k <= RSQP_VEC_UBA; k++) std::fill(s->h_vec[k].begin(), s->h_vec[k].end(), 0.0);
+    s->vec_dirty = true;
+    return RSQP_OK;
+}
+
+extern "C" int rsqp_solve(rsqp_solver *s, int mode, int *nWSR, const double *x0, const double *y0,
+                          const int *guess_b) {
+    if (!s || !nWSR || mode < 0 || mode > 3) return fail(RSQP_ERR_ARG, "rsqp_solve");
+    if (!s->A.initialised && s->nC > 0) return fail(RSQP_ERR_ARG, "rsqp_solve: A not set");
+    HIPCHK(hipSetDevice(s->device));
+    int rc = flush_vectors(s);
+    if (rc != RSQP_OK) return rc;
+    rc = ensure_desc(s);
+    if (rc != RSQP_OK) return rc;
+    QPPools p = pools_of(s);
+    if (mode == RSQP_MODE_WARM_REINIT) {
+        if (x0) { HIPCHK(s->d_x0.upload(x0, s->nV)); p.x0 = s->d_x0.p; }
+        if (y0) { HIPCHK(s->d_y0.upload(y0, s->nV + s->nC)); p.y0 = s->d_y0.p; }
+        if (guess_b) { HIPCHK(s->d_guess.upload(guess_b, s->nV)); p.guess_b = s->d_guess.p; }
+    }
+    hipError_t e = rsqp_launch_small_qp(p, 1, s->nV, s->nC, mode, *nWSR, s->stream);
+    if (e != hipSuccess) return fail(RSQP_ERR_DEVICE, std::string("QP kernel launch: ") + hipGetErrorString(e));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    rc = fetch_results(s);
+    if (rc != RSQP_OK) return rc;
+    HIPCHK(s->d_nwsr.download(nWSR, 1));
+    return RSQP_OK;
+}
+
+namespace {
+// qpOASESInterface::handle_error, QP branch (src/qpOASESInterface.cpp:718-757)
+int handle_error(rsqp_solver *s, int *total) {
+    int nWSR = s->qp_maxiter, rc;
+    if (infeasible(s) && s->nV >= 2 * s->nC) {
+        std::vector<double> x0(s->nV, 0.0);
+        for (int i = 0; i < s->nC; i++) {
+            x0[i + s->nV - 2 * s->nC] = std::max(0.0, s->h_vec[RSQP_VEC_LBA][i]);
+            x0[i + s->nV - s->nC] = -std::min(0.0, s->h_vec[RSQP_VEC_UBA][i]);
+        }
+        rc = rsqp_solve(s, RSQP_MODE_WARM_REINIT, &nWSR, x0.data(), nullptr, nullptr);
+    } else {
+        rc = rsqp_solve(s, RSQP_MODE_COLD, &nWSR, nullptr, nullptr, nullptr);
+    }
+    s->old_status = s->new_status = 0;
+    *total += nWSR;
+    return rc;  // the adapter throws QP_NOT_OPTIMAL when !rsqp_is_solved()
+}
+}  // namespace
+
+extern "C" int rsqp_optimize_qp(rsqp_solver *s, int *nWSR_used) {
+    if (!s) return fail(RSQP_ERR_ARG, "null solver");
+    int nWSR = s->qp_maxiter, total = 0, rc;
+    if (!s->firstQPsolved) {
+        rc = rsqp_solve(s, RSQP_MODE_COLD, &nWSR, nullptr, nullptr, nullptr);
+        if (rc != RSQP_OK) return rc;
+        if (solved(s)) s->firstQPsolved = true;
+        else {
+            // the reference leaves firstQPsolved_ false here even when the retry succeeds
+            rc = handle_error(s, &total);
+            if (rc != RSQP_OK) return rc;
+        }
+    } else {
+        // get_Matrix_change_status (:817-833)
+        const int cur = (s->upd_A || s->upd_H) ? 2 : 1;
+        if (s->old_status == 0) s->old_status = cur;
+        else {
+            if (s->new_status != 0) s->old_status = s->new_status;
+            s->new_status = cur;
+        }
+        if (s->new_status == 0)
+            rc = rsqp_solve(s, s->old_status == 1 ? RSQP_MODE_HOT_VECTORS : RSQP_MODE_HOT_MATRICES, &nWSR, nullptr,
+                            nullptr, nullptr);
+        else if (s->new_status == 1 && s->old_status == 1)
+            rc = rsqp_solve(s, RSQP_MODE_HOT_VECTORS, &nWSR, nullptr, nullptr, nullptr);
+        else if (s->new_status == 2 && s->old_status == 2)
+            rc = rsqp_solve(s, RSQP_MODE_HOT_MATRICES, &nWSR, nullptr, nullptr, nullptr);
+        else {  // status flip: init(..., x_qp, y_qp, &bounds)  (:201-208)
+            std::vector<double> x0 = s->h_x, y0 = s->h_y;
+            std::vector<int> gb = s->h_wsb;
+            rc = rsqp_solve(s, RSQP_MODE_WARM_REINIT, &nWSR, x0.data(), y0.data(), gb.data());
+            s->new_status = s->old_status = 0;
+        }
+        if (rc != RSQP_OK) return rc;
+    }
+    s->upd_A = s->upd_H = s->upd_bounds = s->upd_g = false;  // reset_flags (:488-496)
+    total += nWSR;
+    if (!solved(s)) {
+        rc = handle_error(s, &total);
+        if (rc != RSQP_OK) return rc;
+    }
+    if (nWSR_used) *nWSR_used = total;
+    return RSQP_OK;
+}
+
+extern "C" int rsqp_get_primal(const rsqp_solver *s, double *x) {
+    if (!s || !x) return fail(RSQP_ERR_ARG, "rsqp_get_primal");
+    std::copy(s->h_x.begin(), s->h_x.end(), x);
+    return RSQP_OK;
+}
+extern "C" int rsqp_get_dual(const rsqp_solver *s, double *y) {
+    if (!s || !y) return fail(RSQP_ERR_ARG, "rsqp_get_dual");
+    std::copy(s->h_y.begin(), s->h_y.end(), y);
+    return RSQP_OK;
+}
+extern "C" double rsqp_get_objective(const rsqp_solver *s) { return s ? s->obj : 0.0; }
+extern "C" int rsqp_get_status(const rsqp_solver *s) {
+    return s ? exitflag_of(s->status_word, s->last_ret) : RSQP_QPERROR_UNKNOWN;
+}
+extern "C" int rsqp_is_solved(const rsqp_solver *s) { return s && solved(s); }
+extern "C" int rsqp_get_working_set_raw(const rsqp_solver *s, int *ws_b, int *ws_c) {
+    if (!s) return fail(RSQP_ERR_ARG, "null solver");
+    if (ws_b) std::copy(s->h_wsb.begin(), s->h_wsb.end(), ws_b);
+    if (ws_c) std::copy(s->h_wsc.begin(), s->h_wsc.end(), ws_c);
+    return RSQP_OK;
+}
+
+namespace {
+int spmv_csc(rsqp_solver *s, DevMatrix &M, const double *in, double *out) {  // out[col] = sum val*in[row]
+    hipError_t e = rsqp_launch_spmv(M.blk_c.p, M.nblk_c, M.jc.p, M.ir.p, M.val.p, in, out, 1, 0, 0, 0, 0, s->stream);
+    if (e != hipSuccess) return fail(RSQP_ERR_DEVICE, "spmv launch failed");
+    return RSQP_OK;
+}
+int spmv_csr(rsqp_solver *s, DevMatrix &M, const double *in, double *out) {  // out[row] = sum val*in[col]
+    hipError_t e = rsqp_launch_spmv(M.blk_r.p, M.nblk_r, M.rp.p, M.ci.p, M.rval.p, in, out, 1, 0, 0, 0, 0, s->stream);
+    if (e != hipSuccess) return fail(RSQP_ERR_DEVICE, "spmv launch failed");
+    return RSQP_OK;
+}
+
+int run_certificate(rsqp_solver *s, rsqp_optimality_status *out, int *W_c, int *W_b, int *invalid) {
+    HIPCHK(hipSetDevice(s->device));
+    int rc = flush_vectors(s);
+    if (rc != RSQP_OK) return rc;
+    if (s->nC > 0) {
+        if ((rc = spmv_csr(s, s->A, s->d_x.p, s->d_Ax.p)) != RSQP_OK) return rc;             // A x
+        if ((rc = spmv_csc(s, s->A, s->d_y.p + s->nV, s->d_ATy.p)) != RSQP_OK) return rc;    // A'y_c
+    } else {
+        HIPCHK(hipMemsetAsync(s->d_ATy.p, 0, sizeof(double) * s->nV, s->stream));
+    }
+    if (s->H.initialised) {
+        if ((rc = spmv_csc(s, s->H, s->d_x.p, s->d_Hx.p)) != RSQP_OK) return rc;             // H x (symmetric)
+    } else {
+        HIPCHK(hipMemsetAsync(s->d_Hx.p, 0, sizeof(double) * s->nV, s->stream));
+    }
+    RsqpKktArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.nV1 = s->nV; a.nC1 = s->nC;
+    a.x = s->d_x.p; a.y = s->d_y.p; a.g = s->d_vec[RSQP_VEC_G].p; a.lb = s->d_vec[RSQP_VEC_LB].p;
+    a.ub = s->d_vec[RSQP_VEC_UB].p; a.lbA = s->d_vec[RSQP_VEC_LBA].p; a.ubA = s->d_vec[RSQP_VEC_UBA].p;
+    a.Ax = s->d_Ax.p; a.ATy = s->d_ATy.p; a.Hx = s->d_Hx.p;
+    a.ws_b = s->d_wsb.p; a.ws_c = s->d_wsc.p; a.W_b = s->d_Wb.p; a.W_c = s->d_Wc.p; a.out = s->d_kkt.p;
+    if (rsqp_launch_kkt(a, 1, s->stream) != hipSuccess) return fail(RSQP_ERR_DEVICE, "kkt launch failed");
+    HIPCHK(hipStreamSynchronize(s->stream));
+    double o[6];
+    HIPCHK(s->d_kkt.download(o, 6));
+    if (out) {
+        out->primal_violation = o[0]; out->dual_violation = o[1]; out->compl_violation = o[2];
+        out->stationarity_violation = o[3]; out->KKT_error = o[4];
+    }
+    *invalid = o[5] != 0.0;
+    if (W_b) HIPCHK(s->d_Wb.download(W_b, s->nV));
+    if (W_c) HIPCHK(s->d_Wc.download(W_c, s->nC));
+    return RSQP_OK;
+}
+}  // namespace
+
+extern "C" int rsqp_get_working_set(rsqp_solver *s, int *W_c, int *W_b) {
+    if (!s) return fail(RSQP_ERR_ARG, "null solver");
+    int invalid = 0;
+    int rc = run_certificate(s, nullptr, W_c, W_b, &invalid);
+    if (rc != RSQP_OK) return rc;
+    return invalid ? fail(RSQP_ERR_WORKING_SET, "INVALID_WORKING_SET") : RSQP_OK;
+}
+
+extern "C" int rsqp_test_optimality(rsqp_solver *s, int *W_c, int *W_b, rsqp_optimality_status *out) {
+    if (!s) return fail(RSQP_ERR_ARG, "null solver");
+    rsqp_optimality_status st;
+    int invalid = 0;
+    int rc = run_certificate(s, &st, W_c, W_b, &invalid);
+    if (rc != RSQP_OK) return rc;
+    if (out) *out = st;
+    if (invalid) return fail(RSQP_ERR_WORKING_SET, "INVALID_WORKING_SET");
+    return st.KKT_error > 1.0e-6 ? 0 : 1;  // :673
+}
+
+namespace {
+int product(rsqp_solver *s, DevMatrix &M, bool use_csr, int nin, int nout, const double *p, double *result) {
+    if (!s || !p || !result) return fail(RSQP_ERR_ARG, "product: null argument");
+    if (!M.initialised) return fail(RSQP_ERR_ARG, "product: matrix not set");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(s->d_in.upload(p, nin));
+    int rc = use_csr ? spmv_csr(s, M, s->d_in.p, s->d_out.p) : spmv_csc(s, M, s->d_in.p, s->d_out.p);
+    if (rc != RSQP_OK) return rc;
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(s->d_out.download(result, nout));
+    return RSQP_OK;
+}
+}  // namespace
+
+extern "C" int rsqp_A_times(rsqp_solver *s, const double *p, double *result) {
+    if (!s) return fail(RSQP_ERR_ARG, "null solver");
+    return product(s, s->A, true, s->nV, s->nC, p, result);
+}
+extern "C" int rsqp_A_transposed_times(rsqp_solver *s, const double *p, double *result) {
+    if (!s) return fail(RSQP_ERR_ARG, "null solver");
+    return product(s, s->A, false, s->nC, s->nV, p, result);
+}
+extern "C" int rsqp_H_times(rsqp_solver *s, const double *p, double *result) {
+    if (!s) return fail(RSQP_ERR_ARG, "null solver");
+    return product(s, s->H, false, s->nV, s->nV, p, result);
+}
+
+// =====================================================================================
+// batch of independent QPs
+// =====================================================================================
+struct rsqp_batch {
+    int nq = 0, device = 0, nVmax = 0, nCmax = 0;
+    long long sumV = 0, sumC = 0, sumAnz = 0, sumHnz = 0;
+    bool haveH = false;
+    std::vector<QPDesc> desc;
+    std::vector<int> h_csr_perm;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DevBuf<QPDesc> d_desc;
+    DevBuf<int> Ajc, Air, Arp, Aci, perm, Hjc, Hir;
+    DevBuf<double> Aval, Arv, Hval;
+    DevBuf<double> g, lb, ub, lbA, ubA, x, y, obj, state;
+    DevBuf<int> ws_b, ws_c, status, ret, nwsr, nflips;
+    DevBuf<double> Ax, ATy, Hx, kkt;
+    DevBuf<int> Wb, Wc, kV, kC;
+    DevBuf<long long> koV, koC;
+    float last_ms = 0.f;
+    ~rsqp_batch() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+QPPools pools_of(rsqp_batch *b) {
+    QPPools p;
+    std::memset(&p, 0, sizeof(p));
+    p.desc = b->d_desc.p;
+    p.Ajc = b->Ajc.p; p.Air = b->Air.p; p.Aval = b->Aval.p;
+    p.Arp = b->Arp.p; p.Aci = b->Aci.p; p.Arv = b->Arv.p;
+    p.Hjc = b->Hjc.p; p.Hir = b->Hir.p; p.Hval = b->Hval.p;
+    p.g = b->g.p; p.lb = b->lb.p; p.ub = b->ub.p; p.lbA = b->lbA.p; p.ubA = b->ubA.p;
+    p.x = b->x.p; p.y = b->y.p; p.ws_b = b->ws_b.p; p.ws_c = b->ws_c.p;
+    p.status = b->status.p; p.ret = b->ret.p; p.nwsr = b->nwsr.p; p.nflips = b->nflips.p;
+    p.obj = b->obj.p; p.state = b->state.p;
+    return p;
+}
+}  // namespace
+
+extern "C" int rsqp_batch_create(int nq, const int *nV, const int *nC, const int *Ajc, const int *Air,
+                                 const double *Aval, const int *Hjc, const int *Hir, const double *Hval,
+                                 int device, rsqp_batch **out) {
+    if (!out || nq <= 0 || !nV || !nC || !Ajc) return fail(RSQP_ERR_ARG, "rsqp_batch_create");
+    if (rsqp_device_count() <= 0) return fail(RSQP_ERR_DEVICE, "rsqp_batch_create: no HIP device visible");
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    rsqp_batch *b = new rsqp_batch();
+    struct Guard { rsqp_batch *b; ~Guard() { delete b; } } guard{b};
+    b->nq = nq;
+    HIPCHK(hipGetDevice(&b->device));
+    b->haveH = Hjc != nullptr;
+    b->desc.resize(nq);
+    std::vector<int> h_Arp, h_Aci, h_perm;
+    long long offV = 0, offC = 0, offAjc = 0, offAnz = 0, offArp = 0, offHjc = 0, offHnz = 0, offState = 0;
+    for (int q = 0; q < nq; q++) {
+        if (nV[q] <= 0 || nC[q] < 0) return fail(RSQP_ERR_ARG, "rsqp_batch_create: bad sizes");
+        QPDesc &d = b->desc[q];
+        d.nV = nV[q]; d.nC = nC[q];
+        d.offV = (int)offV; d.offC = (int)offC; d.offAjc = (int)offAjc; d.offAnz = (int)offAnz;
+        d.offArp = (int)offArp; d.offHjc = (int)offHjc; d.offHnz = (int)offHnz; d.haveH = b->haveH;
+        d.offState = offState;
+        const int *jc = Ajc + offAjc;
+        const int annz = jc[d.nV];
+        for (int k = 0; k < annz; k++)
+            if (Air[offAnz + k] < 0 || Air[offAnz + k] >= d.nC) return fail(RSQP_ERR_ARG, "rsqp_batch_create: A row index");
+        CsrCopy r;
+        csr_from_csc(d.nC, d.nV, jc, Air + offAnz, r);
+        h_Arp.insert(h_Arp.end(), r.rp.begin(), r.rp.end());
+        h_Aci.insert(h_Aci.end(), r.ci.begin(), r.ci.end());
+        for (int v : r.perm) h_perm.push_back((int)offAnz + v);
+        b->nVmax = std::max(b->nVmax, d.nV); b->nCmax = std::max(b->nCmax, d.nC);
+        offV += d.nV; offC += d.nC; offAjc += d.nV + 1; offAnz += annz; offArp += d.nC + 1;
+        if (b->haveH) {
+            const int hnnz = Hjc[offHjc + d.nV];
+            for (int k = 0; k < hnnz; k++)
+                if (Hir[offHnz + k] < 0 || Hir[offHnz + k] >= d.nV) return fail(RSQP_ERR_ARG, "rsqp_batch_create: H row index");
+            offHjc += d.nV + 1; offHnz += hnnz;
+        }
+        offState += rsqp_image_bytes(d.nV, d.nC) / 8;
+    }
+    if (!rsqp_small_qp_fits(b->nVmax, b->nCmax))
+        return fail(RSQP_ERR_TOO_LARGE, "rsqp_batch_create: a problem exceeds the LDS-resident engine");
+    b->sumV = offV; b->sumC = offC; b->sumAnz = offAnz; b->sumHnz = offHnz;
+    HIPCHK(hipStreamCreate(&b->stream));
+    HIPCHK(hipEventCreate(&b->ev0)); HIPCHK(hipEventCreate(&b->ev1));
+    HIPCHK(b->d_desc.from(b->desc));
+    HIPCHK(b->Ajc.alloc(offAjc)); HIPCHK(b->Ajc.upload(Ajc, offAjc));
+    HIPCHK(b->Air.alloc(offAnz)); HIPCHK(b->Air.upload(Air, offAnz));
+    HIPCHK(b->Aval.alloc(offAnz)); HIPCHK(b->Aval.upload(Aval, offAnz));
+    HIPCHK(b->Arp.alloc(offArp)); HIPCHK(b->Arp.upload(h_Arp.data(), h_Arp.size()));
+    HIPCHK(b->Aci.alloc(offAnz)); HIPCHK(b->Aci.upload(h_Aci.data(), h_Aci.size()));
+    HIPCHK(b->perm.alloc(offAnz)); HIPCHK(b->perm.upload(h_perm.data(), h_perm.size()));
+    HIPCHK(b->Arv.alloc(offAnz));
+    if (rsqp_launch_gather((int)offAnz, b->perm.p, b->Aval.p, b->Arv.p, b->stream) != hipSuccess)
+        return fail(RSQP_ERR_DEVICE, "gather launch failed");
+    HIPCHK(b->Hjc.alloc(b->haveH ? offHjc : 2)); HIPCHK(b->Hir.alloc(offHnz)); HIPCHK(b->Hval.alloc(offHnz));
+    if (b->haveH) {
+        HIPCHK(b->Hjc.upload(Hjc, offHjc)); HIPCHK(b->Hir.upload(Hir, offHnz)); HIPCHK(b->Hval.upload(Hval, offHnz));
+    }
+    HIPCHK(b->g.alloc(offV)); HIPCHK(b->lb.alloc(offV)); HIPCHK(b->ub.alloc(offV));
+    HIPCHK(b->lbA.alloc(offC)); HIPCHK(b->ubA.alloc(offC));
+    HIPCHK(b->x.alloc(offV)); HIPCHK(b->y.alloc(offV + offC)); HIPCHK(b->obj.alloc(nq));
+    HIPCHK(b->ws_b.alloc(offV)); HIPCHK(b->ws_c.alloc(offC));
+    HIPCHK(b->status.alloc(nq)); HIPCHK(b->ret.alloc(nq)); HIPCHK(b->nwsr.alloc(nq)); HIPCHK(b->nflips.alloc(nq));
+    HIPCHK(b->state.alloc((size_t)offState));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    guard.b = nullptr;
+    *out = b;
+    return RSQP_OK;
+}
+
+extern "C" void rsqp_batch_destroy(rsqp_batch *b) { delete b; }
+
+extern "C" int rsqp_batch_set_vectors(rsqp_batch *b, const double *g, const double *lb, const double *ub,
+                                      const double *lbA, const double *ubA) {
+    if (!b || !g || !lb || !ub || (b->sumC > 0 && (!lbA || !ubA))) return fail(RSQP_ERR_ARG, "rsqp_batch_set_vectors");
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(b->g.upload(g, b->sumV)); HIPCHK(b->lb.upload(lb, b->sumV)); HIPCHK(b->ub.upload(ub, b->sumV));
+    HIPCHK(b->lbA.upload(lbA, b->sumC)); HIPCHK(b->ubA.upload(ubA, b->sumC));
+    return RSQP_OK;
+}
+
+extern "C" int rsqp_batch_set_matrix_values(rsqp_batch *b, const double *Aval, const double *Hval) {
+    if (!b) return fail(RSQP_ERR_ARG, "null batch");
+    HIPCHK(hipSetDevice(b->device));
+    if (Aval) {
+        HIPCHK(b->Aval.upload(Aval, b->sumAnz));
+        if (rsqp_launch_gather((int)b->sumAnz, b->perm.p, b->Aval.p, b->Arv.p, b->stream) != hipSuccess)
+            return fail(RSQP_ERR_DEVICE, "gather launch failed");
+    }
+    if (Hval && b->haveH) HIPCHK(b->Hval.upload(Hval, b->sumHnz));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return RSQP_OK;
+}
+
+extern "C" int rsqp_batch_solve(rsqp_batch *b, int mode, int max_nWSR) {
+    if (!b || mode < 0 || mode > 2 || max_nWSR < 0) return fail(RSQP_ERR_ARG, "rsqp_batch_solve");
+    HIPCHK(hipSetDevice(b->device));
+    QPPools p = pools_of(b);
+    HIPCHK(hipEventRecord(b->ev0, b->stream));
+    hipError_t e = rsqp_launch_small_qp(p, b->nq, b->nVmax, b->nCmax, mode, max_nWSR, b->stream);
+    if (e != hipSuccess) return fail(RSQP_ERR_DEVICE, std::string("QP kernel launch: ") + hipGetErrorString(e));
+    HIPCHK(hipEventRecord(b->ev1, b->stream));
+    return RSQP_OK;
+}
+
+extern "C" int rsqp_batch_sync(rsqp_batch *b) {
+    if (!b) return fail(RSQP_ERR_ARG, "null batch");
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return RSQP_OK;
+}
+
+extern "C" float rsqp_batch_last_solve_ms(rsqp_batch *b) {
+    if (!b) return -1.f;
+    if (hipEventSynchronize(b->ev1) != hipSuccess) return -1.f;
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, b->ev0, b->ev1) != hipSuccess) return -1.f;
+    b->last_ms = ms;
+    return ms;
+}
+
+extern "C" int rsqp_batch_get_results(rsqp_batch *b, double *x, double *y, int *ws_b, int *ws_c, int *status,
+                                      int *nWSR, double *obj) {
+    if (!b) return fail(RSQP_ERR_ARG, "null batch");
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (x) HIPCHK(b->x.download(x, b->sumV));
+    if (y) HIPCHK(b->y.download(y, b->sumV + b->sumC));
+    if (ws_b) HIPCHK(b->ws_b.download(ws_b, b->sumV));
+    if (ws_c) HIPCHK(b->ws_c.download(ws_c, b->sumC));
+    if (status) {
+        std::vector<int> sw(b->nq), rt(b->nq);
+        HIPCHK(b->status.download(sw.data(), b->nq)); HIPCHK(b->ret.download(rt.data(), b->nq));
+        for (int q = 0; q < b->nq; q++) status[q] = exitflag_of(sw[q], rt[q]);
+    }
+    if (nWSR) HIPCHK(b->nwsr.download(nWSR, b->nq));
+    if (obj) HIPCHK(b->obj.download(obj, b->nq));
+    return RSQP_OK;
+}
+
+extern "C" int rsqp_batch_test_optimality(rsqp_batch *b, rsqp_optimality_status *out, int *ok) {
+    if (!b) return fail(RSQP_ERR_ARG, "null batch");
+    HIPCHK(hipSetDevice(b->device));
+    if (!b->Ax.p) {
+        HIPCHK(b->Ax.alloc(b->sumC)); HIPCHK(b->ATy.alloc(b->sumV)); HIPCHK(b->Hx.alloc(b->sumV));
+        HIPCHK(b->kkt.alloc(6 * (size_t)b->nq)); HIPCHK(b->Wb.alloc(b->sumV)); HIPCHK(b->Wc.alloc(b->sumC));
+        std::vector<int> kv(b->nq), kc(b->nq);
+        std::vector<long long> ov(b->nq), oc(b->nq);
+        for (int q = 0; q < b->nq; q++) {
+            kv[q] = b->desc[q].nV; kc[q] = b->desc[q].nC; ov[q] = b->desc[q].offV; oc[q] = b->desc[q].offC;
+        }
+        HIPCHK(b->kV.from(kv)); HIPCHK(b->kC.from(kc)); HIPCHK(b->koV.from(ov)); HIPCHK(b->koC.from(oc));
+    }
+    QPPools p = pools_of(b);
+    if (rsqp_launch_small_products(p, b->nq, b->Ax.p, b->ATy.p, b->Hx.p, b->stream) != hipSuccess)
+        return fail(RSQP_ERR_DEVICE, "products launch failed");
+    RsqpKktArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.nV = b->kV.p; a.nC = b->kC.p; a.offV = b->koV.p; a.offC = b->koC.p;
+    a.x = b->x.p; a.y = b->y.p; a.g = b->g.p; a.lb = b->lb.p; a.ub = b->ub.p; a.lbA = b->lbA.p; a.ubA = b->ubA.p;
+    a.Ax = b->Ax.p; a.ATy = b->ATy.p; a.Hx = b->Hx.p; a.ws_b = b->ws_b.p; a.ws_c = b->ws_c.p;
+    a.W_b = b->Wb.p; a.W_c = b->Wc.p; a.out = b->kkt.p;
+    if (rsqp_launch_kkt(a, b->nq, b->stream) != hipSuccess) return fail(RSQP_ERR_DEVICE, "kkt launch failed");
+    HIPCHK(hipStreamSynchronize(b->stream));
+    std::vector<double> o(6 * (size_t)b->nq);
+    HIPCHK(b->kkt.download(o.data(), o.size()));
+    for (int q = 0; q < b->nq; q++) {
+        if (out) {
+            out[q].primal_violation = o[6 * q]; out[q].dual_violation = o[6 * q + 1];
+            out[q].compl_violation = o[6 * q + 2]; out[q].stationarity_violation = o[6 * q + 3];
+            out[q].KKT_error = o[6 * q + 4];
+        }
+        if (ok) ok[q] = o[6 * q + 5] != 0.0 ? RSQP_ERR_WORKING_SET : (o[6 * q + 4] > 1.0e-6 ? 0 : 1);
+    }
+    return RSQP_OK;
+}
+
+// =====================================================================================
+// batched SpMV plan (device resident)
+// =====================================================================================
+struct rsqp_spmv_plan {
+    int nrow = 0, ncol = 0, nnz = 0, nbatch = 0, device = 0;
+    int nblk_c = 0, nblk_r = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // every member owns a full copy of the index arrays: distinct HBM traffic per matrix
+    DevBuf<int> jc, ir, rp, ci, perm, blk_c, blk_r;
+    DevBuf<double> val, rval, vin_r, vin_c, vout_r, vout_c;  // _r: length nrow, _c: length ncol
+    ~rsqp_spmv_plan() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+extern "C" int rsqp_spmv_plan_create(int nrow, int ncol, const int *jc, const int *ir, int nbatch, int device,
+                                     rsqp_spmv_plan **out) {
+    if (!out || nrow <= 0 || ncol <= 0 || !jc || !ir || nbatch <= 0) return fail(RSQP_ERR_ARG, "rsqp_spmv_plan_create");
+    if (rsqp_device_count() <= 0) return fail(RSQP_ERR_DEVICE, "rsqp_spmv_plan_create: no HIP device visible");
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    rsqp_spmv_plan *p = new rsqp_spmv_plan();
+    struct Guard { rsqp_spmv_plan *p; ~Guard() { delete p; } } guard{p};
+    p->nrow = nrow; p->ncol = ncol; p->nnz = jc[ncol]; p->nbatch = nbatch;
+    HIPCHK(hipGetDevice(&p->device));
+    HIPCHK(hipStreamCreate(&p->stream));
+    HIPCHK(hipEventCreate(&p->ev0)); HIPCHK(hipEventCreate(&p->ev1));
+    CsrCopy r;
+    csr_from_csc(nrow, ncol, jc, ir, r);
+    std::vector<int> bc = build_blocks(ncol, jc, rsqp_spmv_chunk()), br = build_blocks(nrow, r.rp.data(), rsqp_spmv_chunk());
+    p->nblk_c = (int)bc.size() - 1; p->nblk_r = (int)br.size() - 1;
+    HIPCHK(p->blk_c.from(bc)); HIPCHK(p->blk_r.from(br));
+    const size_t B = nbatch, nnz = p->nnz;
+    HIPCHK(p->jc.alloc(B * (ncol + 1), false)); HIPCHK(p->ir.alloc(B * nnz, false));
+    HIPCHK(p->rp.alloc(B * (nrow + 1), false)); HIPCHK(p->ci.alloc(B * nnz, false));
+    HIPCHK(p->perm.from(r.perm));
+    for (size_t m = 0; m < B; m++) {
+        HIPCHK(hipMemcpy(p->jc.p + m * (ncol + 1), jc, sizeof(int) * (ncol + 1), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(p->ir.p + m * nnz, ir, sizeof(int) * nnz, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(p->rp.p + m * (nrow + 1), r.rp.data(), sizeof(int) * (nrow + 1), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(p->ci.p + m * nnz, r.ci.data(), sizeof(int) * nnz, hipMemcpyHostToDevice));
+    }
+    HIPCHK(p->val.alloc(B * nnz)); HIPCHK(p->rval.alloc(B * nnz));
+    HIPCHK(p->vin_r.alloc(B * nrow)); HIPCHK(p->vin_c.alloc(B * ncol));
+    HIPCHK(p->vout_r.alloc(B * nrow)); HIPCHK(p->vout_c.alloc(B * ncol));
+    guard.p = nullptr;
+    *out = p;
+    return RSQP_OK;
+}
+
+extern "C" void rsqp_spmv_plan_destroy(rsqp_spmv_plan *p) { delete p; }
+
+extern "C" int rsqp_spmv_plan_upload(rsqp_spmv_plan *p, const double *vals, const double *xin, int transposed) {
+    if (!p) return fail(RSQP_ERR_ARG, "null plan");
+    HIPCHK(hipSetDevice(p->device));
+    const size_t B = p->nbatch;
+    if (vals) {
+        HIPCHK(p->val.upload(vals, B * p->nnz));
+        for (size_t m = 0; m < B; m++)
+            if (rsqp_launch_gather(p->nnz, p->perm.p, p->val.p + m * p->nnz, p->rval.p + m * p->nnz, p->stream) != hipSuccess)
+                return fail(RSQP_ERR_DEVICE, "gather launch failed");
+        HIPCHK(hipStreamSynchronize(p->stream));
+    }
+    if (xin) {
+        if (transposed) HIPCHK(p->vin_r.upload(xin, B * p->nrow));
+        else HIPCHK(p->vin_c.upload(xin, B * p->ncol));
+    }
+    return RSQP_OK;
+}
+
+extern "C" int rsqp_spmv_plan_run(rsqp_spmv_plan *p, int transposed, int repeats, float *ms_per_launch) {
+    if (!p || repeats <= 0) return fail(RSQP_ERR_ARG, "rsqp_spmv_plan_run");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipEventRecord(p->ev0, p->stream));
+    for (int r = 0; r < repeats; r++) {
+        hipError_t e;
+        if (transposed)  // A'y on the CSC arrays (SpHbMat::transposed_times)
+            e = rsqp_launch_spmv(p->blk_c.p, p->nblk_c, p->jc.p, p->ir.p, p->val.p, p->vin_r.p, p->vout_c.p, p->nbatch,
+                                 p->ncol + 1, p->nnz, p->nrow, p->ncol, p->stream);
+        else             // A x on the CSR copy (SpHbMat::times)
+            e = rsqp_launch_spmv(p->blk_r.p, p->nblk_r, p->rp.p, p->ci.p, p->rval.p, p->vin_c.p, p->vout_r.p, p->nbatch,
+                                 p->nrow + 1, p->nnz, p->ncol, p->nrow, p->stream);
+        if (e != hipSuccess) return fail(RSQP_ERR_DEVICE, "spmv launch failed");
+    }
+    HIPCHK(hipEventRecord(p->ev1, p->stream));
+    HIPCHK(hipEventSynchronize(p->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    if (ms_per_launch) *ms_per_launch = ms / repeats;
+    return RSQP_OK;
+}
+
+extern "C" int rsqp_spmv_plan_download(rsqp_spmv_plan *p, double *out, int transposed) {
+    if (!p || !out) return fail(RSQP_ERR_ARG, "rsqp_spmv_plan_download");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    if (transposed) HIPCHK(p->vout_c.download(out, (size_t)p->nbatch * p->ncol));
+    else HIPCHK(p->vout_r.download(out, (size_t)p->nbatch * p->nrow));
+    return RSQP_OK;
+}

@@ -1,0 +1,59 @@
+// rsqp_internal.h -- shared between the HIP translation units of librsqp_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RSQP_INFTY 1.0e20           // qpOASES INFTY
+#define RSQP_EPS 2.221e-16          // qpOASES EPS
+#define RSQP_EPS_DEN (1.0e3 * RSQP_EPS)
+#define RSQP_BOUND_RELAXATION 1.0e4
+#define RSQP_BOUND_TOLERANCE (1.0e6 * RSQP_EPS)
+#define RSQP_EPS_LI 1.0e-9
+#define RSQP_EPS_PD_REL 1.0e-10
+#define RSQP_EPS_PD_ABS 1.0e-25
+
+// solver status codes kept in the per-problem result record (qpOASES QProblemStatus order)
+enum { QPS_NOTINITIALISED = 0, QPS_PREPARINGAUXILIARYQP = 1, QPS_AUXILIARYQPSOLVED = 2,
+       QPS_PERFORMINGHOMOTOPY = 3, QPS_HOMOTOPYQPSOLVED = 4, QPS_SOLVED = 5 };
+enum { RET_OK = 0, RET_MAX_NWSR = 1, RET_INFEASIBLE = 2, RET_UNBOUNDED = 3, RET_SETUP_FAILED = 4 };
+
+// one problem of a batch: sizes and offsets into the pooled device arrays
+struct QPDesc {
+    int nV, nC;
+    int offV, offC;       // vector pools: g/lb/ub/x/ws_b at offV, lbA/ubA/ws_c at offC
+    int offAjc, offAnz;   // A (CSC): Ajc at offAjc (nV+1 ints), Air/Aval/Aci/Arv at offAnz
+    int offArp;           // A (CSR copy): Arp at offArp (nC+1 ints)
+    int offHjc, offHnz;   // H (CSC, full symmetric)
+    int haveH;
+    long long offState;   // persistent engine image (doubles) for hot starts
+};
+
+struct QPPools {
+    const QPDesc *desc;
+    const int *Ajc, *Air; const double *Aval;
+    const int *Arp, *Aci; const double *Arv;
+    const int *Hjc, *Hir; const double *Hval;
+    const double *g, *lb, *ub, *lbA, *ubA;
+    const double *x0, *y0; const int *guess_b;   // warm re-init inputs (may be null)
+    double *x, *y; int *ws_b, *ws_c;
+    int *status, *ret, *nwsr, *nflips; double *obj;
+    double *state;
+};
+
+// number of doubles / ints of the LDS (and persistent) image of one problem
+__host__ __device__ inline int rsqp_ld(int nV) { return nV | 1; }
+__host__ __device__ inline long long rsqp_image_doubles(int nV, int nC) {
+    long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
+    //        Q        R        T        vectors of nV   vectors of nC   y,dy        scalars
+    return ld * nV + ld * nV + sT * ld + 18LL * nV + 9LL * nC + 2LL * (nV + nC) + 8;
+}
+__host__ __device__ inline long long rsqp_image_ints(int nV, int nC) { return nV + 3LL * nC + 8; }
+__host__ __device__ inline long long rsqp_image_bytes(int nV, int nC) {
+    long long b = rsqp_image_doubles(nV, nC) * 8 + rsqp_image_ints(nV, nC) * 4;
+    return (b + 15) & ~15LL;
+}
+
+// launchers (defined in the .hip files)
+hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, int mode, int maxWSR,
+                                hipStream_t stream);
+int rsqp_small_qp_fits(int nVmax, int nCmax);

@@ -1,0 +1,37 @@
+// rsqp_sparse.h -- launchers of the sparse / certificate kernels (sparse.hip)
+#pragma once
+#include "rsqp_internal.h"
+
+#define RSQP_K_ABOVE 1
+#define RSQP_K_BELOW (-1)
+#define RSQP_K_BOTH (-99)
+#define RSQP_K_INACTIVE 0
+#define RSQP_K_INVALID 12345
+#define RSQP_K_INFTY 1.0e20
+
+// arguments of the fused certificate kernel. Either (nV, nC, offV, offC) arrays for a
+// batch, or nV1 / nC1 with null arrays for one problem.
+struct RsqpKktArgs {
+    const int *nV, *nC;
+    const long long *offV, *offC;
+    int nV1, nC1;
+    const double *x, *y, *g, *lb, *ub, *lbA, *ubA, *Ax, *ATy, *Hx;
+    const int *ws_b, *ws_c;
+    int *W_b, *W_c;
+    double *out;  // 6 doubles per problem: primal, dual, compl, stat, KKT_error, invalid
+};
+
+// row/column blocks for csx_stream_spmv: consecutive majors with at most `chunk`
+// entries per block (a longer single major gets a block of its own)
+int rsqp_spmv_chunk(void);
+
+hipError_t rsqp_launch_spmv(const int *blk, int nblk, const int *ptr, const int *idx, const double *val,
+                            const double *in, double *out, int nbatch, long long ptr_stride,
+                            long long nnz_stride, long long in_stride, long long out_stride,
+                            hipStream_t stream);
+hipError_t rsqp_launch_scatter(int n, const int *order, const int *tmap, const double *tv, double *val,
+                               hipStream_t stream);
+hipError_t rsqp_launch_gather(int n, const int *perm, const double *src, double *dst, hipStream_t stream);
+hipError_t rsqp_launch_kkt(const RsqpKktArgs &a, int nq, hipStream_t stream);
+hipError_t rsqp_launch_small_products(const QPPools &p, int nq, double *Ax, double *ATy, double *Hx,
+                                      hipStream_t stream);
