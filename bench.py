@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- QP-subproblem solves/sec of the MI355X-native engine (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: every rank solves its shard of
+independent hs071-scale QPs (the derived hs071 first QP and seeded 1 % perturbations of it,
+8 variables x 2 constraints through the QPhandler formulation) from a COLD start with ONE
+launch of the LDS-resident active-set kernel, inputs already resident in HBM. Shards are
+independent (no data-path collective) -> weak scaling; `value` = QPs of all ranks / max time.
+
+The JSON line also carries
+  roofline       -- the dominant kernel of the timed region (the batched QP kernel): algorithmic
+                    HBM bytes per launch / its HIP-event duration. The kernel is LDS/latency
+                    bound, so the fraction is small by nature; see DESIGN.md.
+  roofline_spmv  -- the n=10k x m=20k, 200k-nnz Jacobian product A'y (SpHbMat::transposed_times)
+                    batched over distinct matrices (> 2x the 256 MiB Infinity Cache), the
+                    kernel BASELINE.json's roofline target names; measured outside the timed region.
+  cpu_baseline   -- the CPU oracle (a port: qpOASES cannot be built here) on one host core,
+                    bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def qp_algorithmic_bytes(q):
+    """Bytes one cold solve has to move through HBM: CSC of A and H (8 B value + 4 B index per
+    entry, 4 B per column pointer), the five data vectors, and the result record
+    (x, y, working set, status / nWSR / objective)."""
+    nV, nC = q.nV, q.nC
+    inp = 12 * len(q.A_val) + 4 * (nV + 1) + 12 * len(q.H_val) + 4 * (nV + 1) + 8 * (3 * nV + 2 * nC)
+    out = 8 * nV + 8 * (nV + nC) + 4 * (nV + nC) + 4 + 4 + 8
+    return inp + out
+
+
+def spmv_roofline(capi, problems, nbatch, repeats):
+    n, m, nnz = 10000, 20000, 200000
+    jc, ir, rng = problems.sparse_pattern(n, m, nnz)
+    plan = capi.SpmvPlan(m, n, jc, ir, nbatch)
+    vals = rng.normal(size=(nbatch, nnz))
+    plan.upload(vals, rng.normal(size=(nbatch, n)), transposed=False)
+    plan.upload(None, rng.normal(size=(nbatch, m)), transposed=True)
+    out = {}
+    for name, tr, bytes_one in (("ATy_csc", True, 12 * nnz + 4 * (n + 1) + 8 * n + 8 * m),
+                                ("Ax_csr", False, 12 * nnz + 4 * (m + 1) + 8 * m + 8 * n)):
+        plan.run(tr, 2)
+        ms = plan.run(tr, repeats)
+        gbs = bytes_one * nbatch / (ms * 1e-3) / 1e9
+        out[name] = {"ms_per_launch": ms, "bytes_per_launch": bytes_one * nbatch, "achieved": gbs}
+    best = out["ATy_csc"]
+    res = {"kernel": "csx_stream_spmv (A'y, CSC, SpHbMat::transposed_times)", "bound": "hbm",
+           "achieved": best["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": best["achieved"] / HBM_PEAK_GBS,
+           "traffic": None, "matrices_per_launch": nbatch, "bytes_per_matrix": 12 * nnz + 4 * (n + 1) + 8 * n + 8 * m,
+           "ms_per_launch": best["ms_per_launch"], "Ax_csr_GBs": out["Ax_csr"]["achieved"]}
+    plan.close()
+    return res
+
+
+def cpu_baseline(probs, seconds):
+    """Oracle (oracle/qp_oracle.c) timed on this host, one thread. Test infrastructure used as
+    the reported baseline only -- never on the measured GPU path."""
+    import oracle as O
+    O.build()
+    handles = []
+    for q in probs:
+        qp = O.OracleQP(q.nV, q.nC)
+        qp.set_A_csc(q.A_jc, q.A_ir, q.A_val); qp.set_H_csc(q.H_jc, q.H_ir, q.H_val)
+        handles.append(qp)
+    # time the C calls only (ctypes overhead included, python list handling excluded as far as possible)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        for qp, q in zip(handles, probs):
+            qp.init(q.g, q.lb, q.ub, q.lbA, q.ubA, 1000)
+        n += len(probs)
+        t = time.perf_counter() - t0
+        if t >= seconds:
+            break
+    return {"value": n / t, "unit": "QP solves/s", "cores": 1, "kind": "port",
+            "sample": "%d cold solves of the first %d QPs of the rank-0 batch in %.1f s (in-repo C oracle, "
+                      "gcc -O2, 1 thread; qpOASES 3.2.1 is not available)" % (n, len(probs), t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=16384)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--spmv-batch", type=int, default=256)
+    ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline and roofline_spmv")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    from restartsqp_amd import build, capi, problems
+    build.build_lib()
+    if capi.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+
+    B = args.batch_per_gpu
+    probs = problems.hs071_scale_batch(B, seed=20260103 + rank)
+    batch = capi.Batch(probs, device=local_rank)
+
+    def sync():
+        batch and capi.check(capi.lib().rsqp_batch_sync(batch._h))
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        batch.solve(capi.MODE_COLD, 1000, sync=False)
+    sync()
+    t0 = time.perf_counter()
+    batch.timer_start()          # HIP events on the launch stream, around the K launches
+    for _ in range(args.steps):
+        batch.solve(capi.MODE_COLD, 1000, sync=False)
+    kernel_ms_total = batch.timer_stop_ms()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness guard: every QP solved, certificate green (outside the timed region)
+    res = batch.results()
+    ok, kkt = batch.test_optimality()
+    n_bad = sum(1 for r, o in zip(res, ok) if r["status"] != 20 or o != 1)
+
+    if rank == 0:
+        total = world * B * args.steps
+        k_ms = kernel_ms_total / args.steps   # average launch duration over the timed region
+        bytes_launch = float(sum(qp_algorithmic_bytes(q) for q in probs))
+        achieved = bytes_launch / (k_ms * 1e-3) / 1e9
+        line = {
+            "metric": "QP-subproblem solves/sec", "value": total / elapsed, "unit": "QP solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "hs071-scale QP batch (derived hs071 first QP + seeded 1 %% perturbations, "
+                                   "nV=8 x nC=2 via QPhandler [J I -I]), cold start, %d QPs/GPU per step" % B,
+                       "qps_per_gpu": B, "engine": "small_qp_kernel<64> (one wave per QP, LDS-resident)",
+                       "mean_nWSR": float(np.mean([r["nWSR"] for r in res])), "unsolved_or_kkt_fail": n_bad},
+            "roofline": {"kernel": "small_qp_kernel<64>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_launch,
+                         "note": "latency/LDS-bound kernel: HBM fraction is not its limiter"},
+        }
+        if not args.no_extras:
+            line["cpu_baseline"] = cpu_baseline(probs[:256], args.cpu_seconds)
+            line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+            line["roofline_spmv"] = spmv_roofline(capi, problems, args.spmv_batch, 5)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -164,6 +164,11 @@ int rsqp_batch_solve(rsqp_batch *b, int mode, int max_nWSR);
 int rsqp_batch_sync(rsqp_batch *b);
 /* device time of the last rsqp_batch_solve in milliseconds (HIP events on its stream) */
 float rsqp_batch_last_solve_ms(rsqp_batch *b);
+/* HIP-event stopwatch on the batch's stream: start records an event, stop records a
+ * second one, waits for it and returns the elapsed device time in ms (covers every
+ * launch enqueued in between -- what bench.py divides by the step count). */
+int rsqp_batch_timer_start(rsqp_batch *b);
+float rsqp_batch_timer_stop_ms(rsqp_batch *b);
 /* results, concatenated like the inputs; any pointer may be NULL */
 int rsqp_batch_get_results(rsqp_batch *b, double *x, double *y, int *ws_b, int *ws_c, int *status,
                            int *nWSR, double *obj);

@@ -872,12 +872,27 @@ static int homotopy(orc_qp *qp, int *nWSR) {
 }
 
 
+/* qpOASES rejects inconsistent data up front (areBoundsConsistent): lb > ub or lbA > ubA
+ * makes the QP infeasible before any working-set change */
+static int bounds_inconsistent(const orc_qp *qp) {
+    for (int v = 0; v < qp->nV; v++)
+        if (qp->lbN[v] > qp->ubN[v] + ORC_EPS) return 1;
+    for (int i = 0; i < qp->nC; i++)
+        if (qp->lbAN[i] > qp->ubAN[i] + ORC_EPS) return 1;
+    return 0;
+}
+
 /* ---------------- public solve entry points ---------------- */
 int orc_qp_init(orc_qp *qp, const double *g, const double *lb, const double *ub,
                 const double *lbA, const double *ubA, int *nWSR, const double *x0,
                 const double *y0, const int *guess_b) {
     store_targets(qp, g, lb, ub, lbA, ubA);
     qp->nflips = 0;
+    if (bounds_inconsistent(qp)) {
+        qp->infeasible = 1; qp->unbounded = 0;
+        *nWSR = 0;
+        return ORC_RET_INFEASIBLE;
+    }
     int rc = setup_aux(qp, x0, y0, guess_b, NULL);
     if (rc != ORC_RET_OK && (x0 || y0 || guess_b)) rc = setup_aux(qp, NULL, NULL, NULL, NULL);
     if (rc != ORC_RET_OK) {
@@ -892,6 +907,11 @@ int orc_qp_hotstart(orc_qp *qp, const double *g, const double *lb, const double 
     if (qp->status == ORC_QPS_NOTINITIALISED) return ORC_RET_SETUP_FAILED;
     store_targets(qp, g, lb, ub, lbA, ubA);
     qp->infeasible = qp->unbounded = 0;
+    if (bounds_inconsistent(qp)) {
+        qp->infeasible = 1;
+        *nWSR = 0;
+        return ORC_RET_INFEASIBLE;
+    }
     return homotopy(qp, nWSR);
 }
 
@@ -900,6 +920,11 @@ int orc_qp_hotstart_matrices(orc_qp *qp, const double *g, const double *lb, cons
     if (qp->status == ORC_QPS_NOTINITIALISED) return ORC_RET_SETUP_FAILED;
     int nV = qp->nV, nC = qp->nC;
     store_targets(qp, g, lb, ub, lbA, ubA);
+    if (bounds_inconsistent(qp)) {
+        qp->infeasible = 1; qp->unbounded = 0;
+        *nWSR = 0;
+        return ORC_RET_INFEASIBLE;
+    }
     double *x0 = (double *)xcalloc((size_t)nV, sizeof(double));
     double *y0 = (double *)xcalloc((size_t)nV + nC, sizeof(double));
     int *gb = (int *)xcalloc((size_t)nV, sizeof(int)), *gc = (int *)xcalloc((size_t)nC, sizeof(int));

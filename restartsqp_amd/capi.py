@@ -62,6 +62,8 @@ SYMBOLS = {
     "rsqp_batch_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rsqp_batch_sync": (C.c_int, [C.c_void_p]),
     "rsqp_batch_last_solve_ms": (C.c_float, [C.c_void_p]),
+    "rsqp_batch_timer_start": (C.c_int, [C.c_void_p]),
+    "rsqp_batch_timer_stop_ms": (C.c_float, [C.c_void_p]),
     "rsqp_batch_get_results": (C.c_int, [C.c_void_p, dp, dp, ip, ip, ip, ip, dp]),
     "rsqp_batch_test_optimality": (C.c_int, [C.c_void_p, C.c_void_p, ip]),
     "rsqp_spmv_plan_create": (C.c_int, [C.c_int, C.c_int, ip, ip, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -313,6 +315,12 @@ class Batch:
 
     def last_solve_ms(self):
         return lib().rsqp_batch_last_solve_ms(self._h)
+
+    def timer_start(self):
+        check(lib().rsqp_batch_timer_start(self._h))
+
+    def timer_stop_ms(self):
+        return lib().rsqp_batch_timer_stop_ms(self._h)
 
     def results(self):
         sV, sC = int(self.offV[-1]), int(self.offC[-1])

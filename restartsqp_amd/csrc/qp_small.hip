@@ -836,6 +836,13 @@ struct Engine {
         return rcode;
     }
 
+    __device__ bool bounds_inconsistent() {
+        double bad = 0.0;
+        PFOR(v, nV) if (lbN[v] > ubN[v] + RSQP_EPS) bad += 1.0;
+        PFOR(i, nC) if (lbAN[i] > ubAN[i] + RSQP_EPS) bad += 1.0;
+        return block_sum(bad) > 0.0;
+    }
+
     __device__ double objective() {
         H_times(x, wv2);
         double a = dot(x, wv2, nV), b = dot(gN, x, nV);
@@ -864,6 +871,11 @@ small_qp_kernel(QPPools P, int mode, int maxWSR) {
     int *siimg = reinterpret_cast<int *>(simg + nd);
 
     int rcode = RET_OK, nWSR = 0;
+    if (mode == 0) {
+        for (long long k = threadIdx.x; k < nd; k += NT) simg[k] = 0.0;
+        for (long long k = threadIdx.x; k < ni; k += NT) siimg[k] = 0;
+        SYNC();
+    }
     if (mode != 0) {  // reload the image of the previous solve
         for (long long k = threadIdx.x; k < nd; k += NT) simg[k] = img[k];
         for (long long k = threadIdx.x; k < ni; k += NT) siimg[k] = iimg[k];
@@ -873,7 +885,10 @@ small_qp_kernel(QPPools P, int mode, int maxWSR) {
         if (E.status == QPS_NOTINITIALISED) mode = 0;
     }
     E.store_targets(P.g + d.offV, P.lb + d.offV, P.ub + d.offV, P.lbA + d.offC, P.ubA + d.offC);
-    if (mode == 0) {
+    if (E.bounds_inconsistent()) {  // qpOASES areBoundsConsistent: infeasible before any change
+        E.infeasible = 1; E.unbounded = 0;
+        rcode = RET_INFEASIBLE;
+    } else if (mode == 0) {
         rcode = E.setup_aux(nullptr, nullptr, nullptr, nullptr);
     } else if (mode == 2) {  // hot start with new matrices: keep x, y and the working set
         rcode = E.setup_aux(E.x, E.y, E.Sb, E.Sc);

@@ -699,7 +699,7 @@ struct rsqp_batch {
     std::vector<QPDesc> desc;
     std::vector<int> h_csr_perm;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     DevBuf<QPDesc> d_desc;
     DevBuf<int> Ajc, Air, Arp, Aci, perm, Hjc, Hir;
     DevBuf<double> Aval, Arv, Hval;
@@ -712,6 +712,8 @@ struct rsqp_batch {
     ~rsqp_batch() {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
+        if (ev2) (void)hipEventDestroy(ev2);
+        if (ev3) (void)hipEventDestroy(ev3);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -777,6 +779,7 @@ extern "C" int rsqp_batch_create(int nq, const int *nV, const int *nC, const int
     b->sumV = offV; b->sumC = offC; b->sumAnz = offAnz; b->sumHnz = offHnz;
     HIPCHK(hipStreamCreate(&b->stream));
     HIPCHK(hipEventCreate(&b->ev0)); HIPCHK(hipEventCreate(&b->ev1));
+    HIPCHK(hipEventCreate(&b->ev2)); HIPCHK(hipEventCreate(&b->ev3));
     HIPCHK(b->d_desc.from(b->desc));
     HIPCHK(b->Ajc.alloc(offAjc)); HIPCHK(b->Ajc.upload(Ajc, offAjc));
     HIPCHK(b->Air.alloc(offAnz)); HIPCHK(b->Air.upload(Air, offAnz));
@@ -850,6 +853,21 @@ extern "C" float rsqp_batch_last_solve_ms(rsqp_batch *b) {
     float ms = -1.f;
     if (hipEventElapsedTime(&ms, b->ev0, b->ev1) != hipSuccess) return -1.f;
     b->last_ms = ms;
+    return ms;
+}
+
+extern "C" int rsqp_batch_timer_start(rsqp_batch *b) {
+    if (!b) return fail(RSQP_ERR_ARG, "null batch");
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipEventRecord(b->ev2, b->stream));
+    return RSQP_OK;
+}
+extern "C" float rsqp_batch_timer_stop_ms(rsqp_batch *b) {
+    if (!b) return -1.f;
+    float ms = -1.f;
+    if (hipEventRecord(b->ev3, b->stream) != hipSuccess) return -1.f;
+    if (hipEventSynchronize(b->ev3) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, b->ev2, b->ev3) != hipSuccess) return -1.f;
     return ms;
 }
 

@@ -1,0 +1,188 @@
+"""Synthetic inputs for the configurations named in BASELINE.json (generators only; no solver).
+
+* ``hs071_first_qp``  -- first SQP subproblem of hs071, derived analytically from the model in
+  reference ``test/CUTE_examples/hs071.nl`` (x0 = (1,5,5,1), 1 <= x <= 5, c1 = x1x2x3x4 >= 25,
+  c2 = sum x^2 = 40) with the reference defaults delta = 1, rho = 1 (``src/Options.cpp:33,44``)
+  and zero initial multipliers. "Derived", not captured from a reference run.
+* ``dense_qp``        -- SURVEY.md 8(d): n = 2048, m = 4096, seed 20260101.
+* ``sparse_qp`` / ``sparse_sequence`` -- n = 10 000, m = 20 000, 200 000 Jacobian non-zeros,
+  seed 20260102; H = diag(1 + |N(0,1)|).
+* ``hs_batch``        -- hs0xx-scale batch: hs071 fixture + definite random QPs of the shapes
+  of the 18 reference dumps, with seeded 1 % perturbations.
+"""
+import numpy as np
+
+from .qpdump import QPData, dense_to_csc
+from .types import INF, IdentityInfo, NLPInfo, SpTripletMat
+
+
+# ------------------------------------------------------------------------------------
+# hs071
+# ------------------------------------------------------------------------------------
+def hs071_nlp(x=None, lam=None):
+    """Closed-form hs071 at x (default: the .nl starting point): f, grad f, c, Jacobian (1-based
+    COO, 8 entries), Hessian of the Lagrangian f - lam'c (lower triangle, 10 entries)."""
+    x = np.array([1.0, 5.0, 5.0, 1.0]) if x is None else np.asarray(x, float)
+    lam = np.zeros(2) if lam is None else np.asarray(lam, float)
+    x1, x2, x3, x4 = x
+    f = x1 * x4 * (x1 + x2 + x3) + x3
+    grad = np.array([x4 * (2 * x1 + x2 + x3), x1 * x4, x1 * x4 + 1.0, x1 * (x1 + x2 + x3)])
+    c = np.array([x1 * x2 * x3 * x4, x1 * x1 + x2 * x2 + x3 * x3 + x4 * x4])
+    J = SpTripletMat(2, 4, [1, 1, 1, 1, 2, 2, 2, 2], [1, 2, 3, 4, 1, 2, 3, 4],
+                     [x2 * x3 * x4, x1 * x3 * x4, x1 * x2 * x4, x1 * x2 * x3, 2 * x1, 2 * x2, 2 * x3, 2 * x4], False)
+    # Hessian of f minus sum lam_i Hessian of c_i (SQPTNLP::Eval_Hessian negates lambda, src/SQPTNLP.cpp:124-126)
+    l1, l2 = lam
+    Hf = {(1, 1): 2 * x4, (2, 1): x4, (3, 1): x4, (4, 1): 2 * x1 + x2 + x3, (4, 2): x1, (4, 3): x1}
+    Hc1 = {(2, 1): x3 * x4, (3, 1): x2 * x4, (3, 2): x1 * x4, (4, 1): x2 * x3, (4, 2): x1 * x3, (4, 3): x1 * x2}
+    rows, cols, vals = [], [], []
+    for r in range(1, 5):
+        for cidx in range(1, r + 1):
+            v = Hf.get((r, cidx), 0.0) - l1 * Hc1.get((r, cidx), 0.0) - (l2 * 2.0 if r == cidx else 0.0)
+            rows.append(r); cols.append(cidx); vals.append(v)
+    H = SpTripletMat(4, 4, rows, cols, vals, True)
+    return dict(x=x, f=f, grad=grad, c=c, J=J, H=H,
+                x_l=np.ones(4), x_u=5.0 * np.ones(4), c_l=np.array([25.0, 40.0]), c_u=np.array([np.inf, 40.0]),
+                info=NLPInfo(nCon=2, nVar=4, nnz_jac_g=8, nnz_h_lag=10))
+
+
+def handler_qp(nlp, delta=1.0, rho=1.0):
+    """The QP that QPhandler builds from an NLP iterate (src/QPhandler.cpp:39-51,185-201,272-297):
+    variables (p, u, v), A = [J I -I], H = blkdiag(H_k, 0), g = (grad f, rho e)."""
+    n, m = nlp["info"].nVar, nlp["info"].nCon
+    nV = n + 2 * m
+    J, Ht = nlp["J"], nlp["H"]
+    A = np.zeros((m, nV))
+    for r, c, v in zip(J.RowIndex, J.ColIndex, J.MatVal):
+        A[r - 1, c - 1] = v
+    A[:, n:n + m] = np.eye(m)
+    A[:, n + m:] = -np.eye(m)
+    H = np.zeros((nV, nV))
+    for r, c, v in zip(Ht.RowIndex, Ht.ColIndex, Ht.MatVal):
+        H[r - 1, c - 1] = v
+        H[c - 1, r - 1] = v
+    lb = np.zeros(nV); ub = np.full(nV, INF)
+    lb[:n] = np.maximum(nlp["x_l"] - nlp["x"], -delta)
+    ub[:n] = np.minimum(nlp["x_u"] - nlp["x"], delta)
+    g = np.concatenate([nlp["grad"], rho * np.ones(2 * m)])
+    lbA = nlp["c_l"] - nlp["c"]; ubA = nlp["c_u"] - nlp["c"]
+    return QPData(nV, m, *dense_to_csc(H), *dense_to_csc(A), g, lb, ub, lbA, ubA, name="hs071_first_qp")
+
+
+def hs071_first_qp():
+    return handler_qp(hs071_nlp())
+
+
+# ------------------------------------------------------------------------------------
+# random convex QPs
+# ------------------------------------------------------------------------------------
+def random_qp(rng, nV, nC, density=0.5, name=""):
+    M = rng.normal(size=(nV, nV))
+    H = M @ M.T / nV + np.eye(nV)
+    A = rng.normal(size=(nC, nV)) * (rng.random((nC, nV)) < density)
+    g = 3.0 * rng.normal(size=nV)
+    xh = rng.normal(size=nV)
+    lb = xh - np.abs(rng.normal(size=nV)); ub = xh + np.abs(rng.normal(size=nV))
+    lbA = A @ xh - np.abs(rng.normal(size=nC)); ubA = A @ xh + np.abs(rng.normal(size=nC))
+    return QPData(nV, nC, *dense_to_csc(H), *dense_to_csc(A), g, lb, ub, lbA, ubA, name=name)
+
+
+def perturb(rng, q, rel=0.01):
+    """Seeded perturbation of g and of the bounds (keeps lb <= ub)."""
+    def pb(lo, hi):
+        fin_lo, fin_hi = np.abs(lo) < 1e17, np.abs(hi) < 1e17
+        lo2 = np.where(fin_lo, lo + rel * rng.normal(size=lo.shape), lo)
+        hi2 = np.where(fin_hi, hi + rel * rng.normal(size=hi.shape), hi)
+        return lo2, np.maximum(hi2, lo2)
+    lb, ub = pb(q.lb, q.ub)
+    lbA, ubA = pb(q.lbA, q.ubA)
+    g = q.g * (1.0 + rel * rng.normal(size=q.g.shape))
+    return QPData(q.nV, q.nC, q.H_jc, q.H_ir, q.H_val, q.A_jc, q.A_ir, q.A_val, g, lb, ub, lbA, ubA, name=q.name)
+
+
+# shapes (nV, nC) of the 18 dumps under reference test/unsolved_QP_data/
+HS_DUMP_SHAPES = [(8, 3), (10, 4), (8, 3), (5, 1), (13, 5), (7, 2), (4, 0), (15, 4), (5, 1), (16, 6), (12, 4),
+                  (12, 4), (23, 6), (5, 1), (7, 1), (20, 6), (37, 14), (69, 28)]
+
+
+def hs_batch(nq, seed=20260103, shapes=None, max_nV=None):
+    """hs0xx-scale batch: problem 0 is the hs071 first QP, the others are its seeded 1 %
+    perturbations interleaved with definite random QPs of the reference dumps' shapes."""
+    rng = np.random.default_rng(seed)
+    shapes = shapes or HS_DUMP_SHAPES
+    if max_nV:
+        shapes = [s for s in shapes if s[0] <= max_nV]
+    base = hs071_first_qp()
+    out = [base]
+    k = 0
+    while len(out) < nq:
+        if len(out) % 2 == 1:
+            out.append(perturb(rng, base))
+        else:
+            nV, nC = shapes[k % len(shapes)]
+            k += 1
+            out.append(random_qp(rng, nV, nC, density=0.4, name="hs-shape-%dx%d" % (nV, nC)))
+    return out[:nq]
+
+
+def hs071_scale_batch(nq, seed=20260103):
+    """nq QPs of exactly the hs071 shape (8 x 2): the fixture and seeded perturbations of it."""
+    rng = np.random.default_rng(seed)
+    base = hs071_first_qp()
+    return [base] + [perturb(rng, base) for _ in range(nq - 1)]
+
+
+# ------------------------------------------------------------------------------------
+# SURVEY.md 8(d) synthetic configurations
+# ------------------------------------------------------------------------------------
+def dense_qp(n=2048, m=4096, seed=20260101):
+    rng = np.random.default_rng(seed)
+    M = rng.normal(size=(n, n))
+    H = M @ M.T / n + np.eye(n)
+    A = rng.normal(size=(m, n))
+    g = rng.normal(size=n)
+    xh = rng.normal(size=n)
+    lbA = A @ xh - np.abs(rng.normal(size=m)); ubA = A @ xh + np.abs(rng.normal(size=m))
+    return QPData(n, m, *dense_to_csc(H), *dense_to_csc(A), g, -10.0 * np.ones(n), 10.0 * np.ones(n), lbA, ubA,
+                  name="dense_%dx%d" % (n, m))
+
+
+def sparse_pattern(n=10000, m=20000, nnz=200000, seed=20260102):
+    """Exactly nnz distinct positions of an m x n matrix, sampled without replacement; CSC."""
+    rng = np.random.default_rng(seed)
+    lin = rng.choice(m * n, size=nnz, replace=False)
+    rows, cols = (lin % m).astype(np.int64), (lin // m).astype(np.int64)
+    order = np.lexsort((rows, cols))
+    rows, cols = rows[order], cols[order]
+    jc = np.zeros(n + 1, np.int64)
+    np.add.at(jc, cols + 1, 1)
+    return np.cumsum(jc).astype(np.int32), rows.astype(np.int32), rng
+
+
+def sparse_qp(n=10000, m=20000, nnz=200000, seed=20260102, box=1.0):
+    jc, ir, rng = sparse_pattern(n, m, nnz, seed)
+    val = rng.normal(size=nnz)
+    h = 1.0 + np.abs(rng.normal(size=n))
+    H_jc = np.arange(n + 1, dtype=np.int32); H_ir = np.arange(n, dtype=np.int32)
+    g = rng.normal(size=n)
+    xh = rng.normal(size=n) * 0.3
+    Ax = np.zeros(m)
+    cols = np.repeat(np.arange(n), np.diff(jc))
+    np.add.at(Ax, ir, val * xh[cols])
+    lbA = Ax - np.abs(rng.normal(size=m)); ubA = Ax + np.abs(rng.normal(size=m))
+    return QPData(n, m, H_jc, H_ir, h, jc, ir, val, g, -box * np.ones(n), box * np.ones(n), lbA, ubA,
+                  name="sparse_%dx%d" % (n, m))
+
+
+def sparse_sequence(q, nsteps=50, seed=20260102):
+    """Warm-started sequence of SURVEY.md 8(d): odd k perturb g and bounds by 1 % (FIXED matrices
+    -> HOT_VECTORS), even k additionally rescale the Jacobian values by (1 + 0.01 N(0,1))
+    (VARIED -> HOT_MATRICES). Yields (QPData, matrices_changed)."""
+    rng = np.random.default_rng(seed + 1)
+    cur = q
+    for k in range(1, nsteps + 1):
+        nxt = perturb(rng, cur)
+        changed = k % 2 == 0
+        if changed:
+            nxt.A_val = cur.A_val * (1.0 + 0.01 * rng.normal(size=cur.A_val.shape))
+        cur = nxt
+        yield cur, changed

@@ -1,0 +1,335 @@
+"""Parity of the HIP path (through the C ABI of include/rsqp_hip.h) against the CPU oracle.
+
+Bar: working sets, statuses and iteration counts bit-exact; x, y within 1e-9 relative
+(fp64 everywhere; the GPU differs from the oracle only in summation order and FMA
+contraction). Products: <= 4*nnz_row*eps relative ("Summation order")."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, clamp, dump_paths, oracle_certificate, oracle_cold
+from restartsqp_amd import problems
+from restartsqp_amd.qpdump import QPData, dense_to_csc, read_qore_dump
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+def assert_same_solution(qp, r, n_oracle, check_nwsr=True):
+    assert r["status"] == qp.exitflag()
+    assert np.array_equal(qp.ws_bounds, r["ws_b"]) and np.array_equal(qp.ws_constraints, r["ws_c"])
+    if check_nwsr:
+        assert r["nWSR"] == n_oracle
+    xs, ys = max(1.0, np.abs(qp.x).max()), max(1.0, np.abs(qp.y).max())
+    assert np.abs(qp.x - r["x"]).max() <= RTOL * xs
+    assert np.abs(qp.y - r["y"]).max() <= RTOL * ys
+
+
+def test_library_on_gpu(capi):
+    assert capi.device_count() >= 1
+
+
+def test_hs071_single_qp_bit_exact_active_set(capi, oracle):
+    """BASELINE config 1: hs071 first QP, one QP on one MI355X, through optimizeQP."""
+    q = problems.hs071_first_qp()
+    s = capi.Solver(q.nV, q.nC)
+    s.set_A_csc(q.A_jc, q.A_ir, q.A_val); s.set_H_csc(q.H_jc, q.H_ir, q.H_val)
+    for w, v in zip(range(5), (q.g, q.lb, q.ub, q.lbA, q.ubA)):
+        s.set_vector(w, v)
+    n = s.optimize_qp()
+    qp, rc, n_or = oracle_cold(oracle, q)
+    wb, wc = s.working_set_raw()
+    assert s.is_solved() and s.status == 20 and n == n_or == 2
+    assert wb.tolist() == qp.ws_bounds.tolist() == [-1, 0, -1, 0, -1, -1, -1, -1]
+    assert wc.tolist() == qp.ws_constraints.tolist() == [-1, 1]
+    assert np.abs(s.x - np.array([0, -0.25, -1, 0.25, 0, 0, 0, 0])).max() < 1e-14
+    assert np.abs(s.y - qp.y).max() < 1e-12 and abs(s.objective - 0.1875) < 1e-14
+    ok, st, Wc, Wb = s.test_optimality()
+    ok_o, st_o, Wb_o, Wc_o = oracle_certificate(oracle, q, s.x, s.y, wb, wc)
+    assert ok and ok_o and Wc.tolist() == Wc_o.tolist() and Wb.tolist() == Wb_o.tolist()
+    assert abs(st.KKT_error - st_o.KKT_error) < 1e-12
+
+
+def test_batch_random_convex(capi, oracle):
+    rng = np.random.default_rng(5)
+    probs = [problems.random_qp(rng, int(rng.integers(1, 45)), int(rng.integers(0, 50))) for _ in range(96)]
+    b = capi.Batch(probs)
+    b.solve(capi.MODE_COLD, 1000)
+    ok, kkt = b.test_optimality()
+    for q, r, o, k in zip(probs, b.results(), ok, kkt):
+        qp, rc, n = oracle_cold(oracle, q)
+        assert_same_solution(qp, r, n)
+        if rc == 0:
+            assert o == 1 and k < 1e-9
+            assert abs(r["obj"] - qp.objective) <= 1e-9 * max(1.0, abs(qp.objective))
+
+
+def test_batch_edge_cases(capi, oracle):
+    """No constraints, a single variable, infinite bounds, equalities, infeasible, iteration limit."""
+    rng = np.random.default_rng(11)
+    probs = [problems.random_qp(rng, 6, 0), problems.random_qp(rng, 1, 0), problems.random_qp(rng, 1, 3)]
+    q = problems.random_qp(rng, 7, 4); q.lb[:] = -np.inf; q.ub[:] = 1e20; probs.append(q)      # free variables
+    q = problems.random_qp(rng, 7, 4); q.lbA[:] = -np.inf; probs.append(q)
+    q = problems.random_qp(rng, 9, 3); q.ubA[:] = q.lbA; probs.append(q)                       # equalities
+    q = problems.random_qp(rng, 5, 2); q.ub[:] = q.lb; probs.append(q)                          # fixed variables
+    A = np.array([[1.0, 1.0]])
+    probs.append(QPData(2, 1, *dense_to_csc(np.eye(2)), *dense_to_csc(A), np.zeros(2), -np.ones(2), np.ones(2),
+                        np.array([3.0]), np.array([np.inf])))                                   # infeasible
+    H = np.diag([1.0, -1.0])
+    probs.append(QPData(2, 0, *dense_to_csc(H), *dense_to_csc(np.zeros((0, 2))), np.array([0.0, -1.0]),
+                        np.array([-1.0, 0.0]), np.array([1.0, np.inf]), np.zeros(0), np.zeros(0)))   # unbounded
+    b = capi.Batch(probs)
+    b.solve(capi.MODE_COLD, 1000)
+    res = b.results()
+    for q, r in zip(probs, res):
+        qp, rc, n = oracle_cold(oracle, q)
+        assert_same_solution(qp, r, n)
+    assert res[-2]["status"] == 22 and res[-1]["status"] == 23
+    # iteration limit: same count, same (unfinished) status as the oracle
+    q = problems.random_qp(np.random.default_rng(3), 30, 40)
+    b = capi.Batch([q]); b.solve(capi.MODE_COLD, 3)
+    qp, rc, n = oracle_cold(oracle, q, nWSR=3)
+    r = b.results()[0]
+    assert r["nWSR"] == n == 3 and r["status"] == qp.exitflag() == 28
+
+
+def test_reference_dumps(capi, oracle):
+    """The 18 QPs of reference test/unsolved_QP_data plus hs071 against the committed oracle
+    vectors. Every dump has an indefinite or singular Hessian, so the homotopy path (and with
+    it nWSR) is not unique under rounding; the final working set, x and y are compared, nWSR
+    only where no bound flip occurred."""
+    gold = json.load(open(os.path.join(GOLDEN, "oracle_qp_solutions.json")))
+    probs = [problems.hs071_first_qp()] + [read_qore_dump(p) for p in dump_paths()]
+    b = capi.Batch(probs)
+    b.solve(capi.MODE_COLD, 1000)
+    ok, kkt = b.test_optimality()
+    for q, r, o, k in zip(probs, b.results(), ok, kkt):
+        e = gold[q.name]
+        assert r["status"] == e["exitflag"] == 20
+        assert r["ws_b"].tolist() == e["ws_b"] and r["ws_c"].tolist() == e["ws_c"]
+        if e["nflips"] == 0:
+            assert r["nWSR"] == e["nWSR"]
+        xs, ys = max(1.0, np.abs(e["x"]).max()), max(1.0, np.abs(e["y"]).max())
+        assert np.abs(np.array(e["x"]) - r["x"]).max() <= 1e-9 * xs
+        assert np.abs(np.array(e["y"]) - r["y"]).max() <= 1e-9 * ys
+        # certificate of the SAME (x, y): the residuals are cancellation noise of terms as large
+        # as the data (up to 1e11 in these dumps), so the two summation orders agree to
+        # eps * data scale, not to an absolute 1e-9
+        ok_o, st_o, _, _ = oracle_certificate(oracle, q, r["x"], r["y"], r["ws_b"], r["ws_c"])
+        scale = max(1.0, np.abs(q.g).max(), np.abs(q.H_val).max() * max(1.0, np.abs(r["x"]).max()), ys)
+        tol = 1e-13 * scale
+        assert abs(k - st_o.KKT_error) <= tol
+        if abs(st_o.KKT_error - 1e-6) > tol:
+            assert (o == 1) == ok_o
+
+
+def test_hot_start_sequence(capi, oracle):
+    """hotstart(g,lb,ub,lbA,ubA) and hotstart(H,...,A,...) keep pace with the oracle solve for solve."""
+    rng = np.random.default_rng(21)
+    probs = [problems.random_qp(rng, int(rng.integers(4, 40)), int(rng.integers(0, 35))) for _ in range(24)]
+    b = capi.Batch(probs)
+    b.solve(capi.MODE_COLD, 1000)
+    orc = []
+    for q in probs:
+        qp, rc, n = oracle_cold(oracle, q)
+        orc.append(qp)
+    for step in range(4):
+        probs = [problems.perturb(rng, q, 0.05) for q in probs]
+        changed = step % 2 == 1
+        if changed:
+            for q in probs:
+                q.A_val = q.A_val * (1.0 + 0.01 * rng.normal(size=q.A_val.shape))
+                q.H_val = q.H_val * 1.05
+            b.set_matrix_values(np.concatenate([q.A_val for q in probs]), np.concatenate([q.H_val for q in probs]))
+        b.set_vectors_from(probs)
+        b.solve(capi.MODE_HOT_MATRICES if changed else capi.MODE_HOT_VECTORS, 1000)
+        for q, qp, r in zip(probs, orc, b.results()):
+            if changed:
+                qp.set_A_csc(q.A_jc, q.A_ir, q.A_val); qp.set_H_csc(q.H_jc, q.H_ir, q.H_val)
+                rc, n = qp.hotstart_matrices(q.g, q.lb, q.ub, q.lbA, q.ubA, 1000)
+            else:
+                rc, n = qp.hotstart(q.g, q.lb, q.ub, q.lbA, q.ubA, 1000)
+            assert_same_solution(qp, r, n)
+
+
+def test_assembly_from_triplets(capi, oracle):
+    """set_A / set_H: setStructure on first call, setMatVal afterwards -- device CSC, order_
+    and refreshed values identical (exact) to the oracle's restatement of SpHbMat."""
+    rng = np.random.default_rng(31)
+    for _ in range(10):
+        n, m = int(rng.integers(2, 12)), int(rng.integers(1, 8))
+        dens = rng.random((m, n)) < 0.5
+        r, c = np.nonzero(dens)
+        perm = rng.permutation(len(r))
+        irow, jcol = r[perm] + 1, c[perm] + 1
+        val = rng.normal(size=len(r))
+        ident = [(1, n + 1, m, 1.0), (1, n + m + 1, m, -1.0)]
+        s = capi.Solver(n + 2 * m, m)
+        s.set_A_triplet(irow, jcol, val, ident)
+        jc, ir, v, order = s.get_A_csc()
+        jo, io, vo, oo = oracle.sphb_set_structure(m, n + 2 * m, irow, jcol, val, ident)
+        assert np.array_equal(jc, jo) and np.array_equal(ir, io) and np.array_equal(v, vo) and np.array_equal(order, oo)
+        val2 = rng.normal(size=len(r))
+        s.set_A_triplet(irow, jcol, val2, ident)
+        v2 = s.get_A_csc()[2]
+        assert np.array_equal(v2, oracle.sphb_set_matval(oo, val2, vo.copy(), 2 * m))
+        # products use the refreshed values, also through the CSR copy
+        x = rng.normal(size=n + 2 * m); y = rng.normal(size=m)
+        A = np.zeros((m, n + 2 * m))
+        for cc in range(n + 2 * m):
+            for k in range(jc[cc], jc[cc + 1]):
+                A[ir[k], cc] = v2[k]
+        assert np.abs(s.A_times(x) - A @ x).max() < 1e-13 and np.abs(s.A_transposed_times(y) - A.T @ y).max() < 1e-13
+        # symmetric H: lower triangle, mirrored, two writes per off-diagonal on refresh
+        L = np.tril(rng.normal(size=(n, n))) * (rng.random((n, n)) < 0.6)
+        hr, hc = np.nonzero(L)
+        if len(hr) == 0:
+            continue
+        nV = n + 2 * m
+        s.set_H_triplet(hr + 1, hc + 1, L[hr, hc], True)
+        hj, hi, hv, ho = s.get_H_csc()
+        oj, oi, ov, ooo = oracle.sphb_set_structure_sym(nV, nV, hr + 1, hc + 1, L[hr, hc], True)
+        assert np.array_equal(hj, oj) and np.array_equal(hi, oi) and np.array_equal(hv, ov) and np.array_equal(ho, ooo)
+        nv = rng.normal(size=len(hr))
+        s.set_H_triplet(hr + 1, hc + 1, nv, True)
+        assert np.array_equal(s.get_H_csc()[2], oracle.sphb_set_matval_sym(hr + 1, hc + 1, True, ooo, nv, ov.copy()))
+
+
+def test_dispatch_state_machine(capi, oracle):
+    """optimizeQP's FIXED / VARIED dispatch (qpOASESInterface.cpp:137-224, 817-833) driven by
+    the QPhandler call sequence of Algorithm::setupQP: cold init, hot start on vectors, status
+    flip -> init(..., x_qp, y_qp, &bounds), hot start with matrices; the oracle is driven by a
+    restatement of the same decisions. hs071 with c2 relaxed to an inequality (see the next
+    test for why the reference's own equality handling cannot be replayed)."""
+    from restartsqp_amd.handler import QPhandler
+    from restartsqp_amd.types import Stats
+
+    def nlp_at(x):
+        d = problems.hs071_nlp(x, lam=np.zeros(2))
+        d["c_u"] = np.array([np.inf, np.inf])
+        return d
+
+    nlp = nlp_at(None)
+    h = QPhandler(nlp["info"])
+    stats = Stats()
+    h.set_A(nlp["J"]); h.set_H(nlp["H"])
+    h.set_bounds(1.0, nlp["x_l"], nlp["x_u"], nlp["x"], nlp["c_l"], nlp["c_u"], nlp["c"])
+    h.set_g(nlp["grad"], 1.0)
+    h.solveQP(stats)
+    q = problems.handler_qp(nlp)
+    qp, rc, n = oracle_cold(oracle, q)
+    assert stats.qp_iter == n and h.get_status() == 20
+    assert np.abs(h.get_optimal_solution() - qp.x).max() < 1e-12
+    # iteration 2: rejected step, trust region shrinks (update_delta): FIXED -> hotstart(vectors)
+    h.update_delta(0.5, nlp["x_l"], nlp["x_u"], nlp["x"])
+    h.solveQP(stats)
+    q2 = problems.handler_qp(nlp, delta=0.5)
+    rc, n2 = qp.hotstart(q2.g, q2.lb, q2.ub, q2.lbA, q2.ubA, 1000)
+    assert np.abs(h.get_optimal_solution() - qp.x).max() < 1e-12 and stats.qp_iter == n + n2
+    # iteration 3: accepted step -> new J, H, bounds, gradient: FIXED -> VARIED flips the
+    # status, the adapter re-initialises from (x, y, bounds) (:201-208)
+    nlp1 = nlp_at(nlp["x"] + h.get_optimal_solution()[:4])
+    h.update_A(nlp1["J"]); h.update_H(nlp1["H"])
+    h.update_bounds(0.5, nlp1["x_l"], nlp1["x_u"], nlp1["x"], nlp1["c_l"], nlp1["c_u"], nlp1["c"])
+    h.update_grad(nlp1["grad"])
+    before = stats.qp_iter
+    h.solveQP(stats)
+    q3 = problems.handler_qp(nlp1, delta=0.5)
+    qp.set_A_csc(q3.A_jc, q3.A_ir, q3.A_val); qp.set_H_csc(q3.H_jc, q3.H_ir, q3.H_val)
+    rc, n3 = qp.init(q3.g, q3.lb, q3.ub, q3.lbA, q3.ubA, 1000, x0=qp.x, y0=qp.y, guess_b=qp.ws_bounds)
+    assert rc == 0 and stats.qp_iter - before == n3
+    assert np.abs(h.get_optimal_solution() - qp.x).max() < 1e-10
+    wb, wc = h.solverInterface_._s.working_set_raw()
+    assert np.array_equal(wb, qp.ws_bounds) and np.array_equal(wc, qp.ws_constraints)
+    # iteration 4: another accepted step: status UNDEFINED again after the re-init, so
+    # old := VARIED, new stays UNDEFINED -> hotstart(H, g, A, ...) (:177-187)
+    nlp2 = nlp_at(nlp1["x"] + h.get_optimal_solution()[:4])
+    h.update_A(nlp2["J"]); h.update_H(nlp2["H"])
+    h.update_bounds(0.5, nlp2["x_l"], nlp2["x_u"], nlp2["x"], nlp2["c_l"], nlp2["c_u"], nlp2["c"])
+    h.update_grad(nlp2["grad"])
+    before = stats.qp_iter
+    h.solveQP(stats)
+    q4 = problems.handler_qp(nlp2, delta=0.5)
+    qp.set_A_csc(q4.A_jc, q4.A_ir, q4.A_val); qp.set_H_csc(q4.H_jc, q4.H_ir, q4.H_val)
+    rc, n4 = qp.hotstart_matrices(q4.g, q4.lb, q4.ub, q4.lbA, q4.ubA, 1000)
+    assert rc == 0 and stats.qp_iter - before == n4
+    assert np.abs(h.get_optimal_solution() - qp.x).max() < 1e-10
+
+
+def test_stale_ubA_quirk_reports_infeasible(capi, oracle):
+    """QPhandler::update_bounds never refreshes ubA on the qpOASES branch
+    (src/QPhandler.cpp:358-360). With the equality c2 of hs071 an accepted step therefore leaves
+    lbA > ubA; qpOASES rejects such data as infeasible, handle_error re-inits and throws
+    QP_NOT_OPTIMAL (src/qpOASESInterface.cpp:720-756). Engine and oracle do the same."""
+    from restartsqp_amd.handler import QPhandler
+    from restartsqp_amd.types import QP_NOT_OPTIMAL, Stats
+    nlp = problems.hs071_nlp()
+    h = QPhandler(nlp["info"])
+    h.set_A(nlp["J"]); h.set_H(nlp["H"])
+    h.set_bounds(1.0, nlp["x_l"], nlp["x_u"], nlp["x"], nlp["c_l"], nlp["c_u"], nlp["c"])
+    h.set_g(nlp["grad"], 1.0)
+    h.solveQP(Stats())
+    nlp1 = problems.hs071_nlp(nlp["x"] + h.get_optimal_solution()[:4])
+    h.update_A(nlp1["J"]); h.update_H(nlp1["H"])
+    h.update_bounds(1.0, nlp1["x_l"], nlp1["x_u"], nlp1["x"], nlp1["c_l"], nlp1["c_u"], nlp1["c"])
+    h.update_grad(nlp1["grad"])
+    with pytest.raises(QP_NOT_OPTIMAL):
+        h.solveQP(Stats())
+    assert h.get_status() == 22
+    q = problems.handler_qp(nlp1)
+    q.ubA = problems.hs071_first_qp().ubA
+    assert q.lbA[1] > q.ubA[1]
+    qp, rc, n = oracle_cold(oracle, q)
+    assert rc == 2 and n == 0 and qp.exitflag() == 22
+
+
+def test_spmv_batched_parity_and_properties(capi, oracle):
+    """Stream SpMV: small case against the oracle's entry-order loops; BASELINE-size case
+    (n=10k, m=20k, 200k non-zeros) through size-independent properties: linearity,
+    <y, A x> == <A'y, x>, and agreement of the CSR-copy product with the CSC one."""
+    jc, ir, rng = problems.sparse_pattern(300, 500, 4000, seed=7)
+    nb = 3
+    vals = rng.normal(size=(nb, 4000)); x = rng.normal(size=(nb, 300)); y = rng.normal(size=(nb, 500))
+    p = capi.SpmvPlan(500, 300, jc, ir, nb)
+    p.upload(vals, x, transposed=False); p.upload(None, y, transposed=True)
+    p.run(False); p.run(True)
+    Ax, ATy = p.download(False), p.download(True)
+    for k in range(nb):
+        ax = oracle.sphb_times(500, 300, jc, ir, vals[k], x[k])
+        aty = oracle.sphb_transposed_times(500, 300, jc, ir, vals[k], y[k])
+        assert np.abs(Ax[k] - ax).max() <= 4 * 30 * 2.3e-16 * np.abs(ax).max() + 1e-300
+        assert np.array_equal(ATy[k], aty)   # same entry order as the reference loop: bit-exact
+    # full size
+    n, m, nnz = 10000, 20000, 200000
+    jc, ir, rng = problems.sparse_pattern(n, m, nnz)
+    vals = rng.normal(size=(2, nnz)); x = rng.normal(size=(2, n)); y = rng.normal(size=(2, m))
+    p = capi.SpmvPlan(m, n, jc, ir, 2)
+    p.upload(vals, x, False); p.upload(None, y, True)
+    p.run(False); p.run(True)
+    Ax, ATy = p.download(False), p.download(True)
+    for k in range(2):
+        lhs, rhs = float(y[k] @ Ax[k]), float(ATy[k] @ x[k])
+        assert abs(lhs - rhs) <= 1e-10 * max(1.0, abs(lhs))
+    p.upload(None, 2.0 * x, False); p.run(False)
+    assert np.array_equal(p.download(False), 2.0 * Ax)   # exact: scaling by 2 commutes with rounding
+
+
+def test_full_size_hs071_batch_properties(capi, oracle):
+    """BASELINE config 5 size (512 hs0xx-scale QPs) and a larger hs071-shape batch: every
+    answer carries the reference's KKT certificate; a sample is compared with the oracle;
+    solving the batch twice gives bit-identical results (deterministic reductions)."""
+    probs = problems.hs_batch(512)
+    b = capi.Batch(probs)
+    b.solve(capi.MODE_COLD, 1000)
+    res = b.results(); ok, kkt = b.test_optimality()
+    assert all(r["status"] == 20 for r in res) and all(o == 1 for o in ok)
+    for k in range(0, 512, 16):
+        qp, rc, n = oracle_cold(oracle, probs[k])
+        assert_same_solution(qp, res[k], n, check_nwsr=probs[k].name != "hs071_first_qp")
+    b.solve(capi.MODE_COLD, 1000)
+    res2 = b.results()
+    assert all(np.array_equal(a["x"], c["x"]) and np.array_equal(a["y"], c["y"]) and a["nWSR"] == c["nWSR"]
+               for a, c in zip(res, res2))

@@ -1,0 +1,168 @@
+"""The oracle's active-set solver (stand-in for qpOASES 3.2.1, parity unpinned -- see
+oracle/rsqp_oracle.h). Pinned by: (1) an independent brute-force enumeration of working sets
+on tiny strictly convex QPs, where the solution is unique; (2) the reference's own acceptance
+test, the KKT certificate of src/qpOASESInterface.cpp:498-684, on every answer including the
+reference's 18 QP dumps; (3) hot start == cold start; (4) committed regression vectors."""
+import itertools
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, clamp, dump_paths, oracle_certificate, oracle_cold
+from restartsqp_amd import problems
+from restartsqp_amd.qpdump import QPData, dense_to_csc, read_qore_dump
+
+
+def brute_force(q):
+    H, A = q.dense_H(), q.dense_A()
+    lb, ub, lbA, ubA = clamp(q.lb), clamp(q.ub), clamp(q.lbA), clamp(q.ubA)
+    nV, nC = q.nV, q.nC
+    for sb in itertools.product([-1, 0, 1], repeat=nV):
+        for sc in itertools.product([-1, 0, 1], repeat=nC):
+            rows, rhs = [], []
+            for v, s in enumerate(sb):
+                if s:
+                    e = np.zeros(nV); e[v] = 1.0
+                    rows.append(e); rhs.append(lb[v] if s == -1 else ub[v])
+            for i, s in enumerate(sc):
+                if s:
+                    rows.append(A[i]); rhs.append(lbA[i] if s == -1 else ubA[i])
+            k = len(rows)
+            if k > nV or any(abs(r) >= 1e19 for r in rhs):
+                continue
+            if k:
+                E = np.array(rows)
+                if np.linalg.matrix_rank(E) < k:
+                    continue
+                K = np.block([[H, -E.T], [E, np.zeros((k, k))]])
+                sol = np.linalg.solve(K, np.concatenate([-q.g, rhs]))
+            else:
+                sol = np.linalg.solve(H, -q.g)
+            x, lam = sol[:nV], sol[nV:]
+            Ax = A @ x
+            if np.any(x < lb - 1e-9) or np.any(x > ub + 1e-9) or np.any(Ax < lbA - 1e-9) or np.any(Ax > ubA + 1e-9):
+                continue
+            signs = [s for s in sb if s] + [s for s in sc if s]
+            if all((s == -1 and l >= -1e-9) or (s == 1 and l <= 1e-9) for s, l in zip(signs, lam)):
+                return x
+    return None
+
+
+def tiny_qp(rng):
+    nV, nC = int(rng.integers(1, 5)), int(rng.integers(0, 4))
+    q = problems.random_qp(rng, nV, nC, density=1.0)
+    for v in range(nV):
+        if rng.random() < 0.2:
+            q.lb[v] = -1e20
+        if rng.random() < 0.2:
+            q.ub[v] = np.inf
+    for i in range(nC):
+        r = rng.random()
+        if r < 0.3:
+            q.lbA[i] = -np.inf
+        elif r < 0.6:
+            q.ubA[i] = 1e20
+    return q
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_brute_force_tiny(oracle, seed):
+    q = tiny_qp(np.random.default_rng(seed))
+    qp, rc, n = oracle_cold(oracle, q, 200)
+    xb = brute_force(q)
+    assert xb is not None and rc == 0 and qp.is_solved() and qp.exitflag() == 20
+    assert np.abs(qp.x - xb).max() < 1e-8
+    ok, st, _, _ = oracle_certificate(oracle, q, qp.x, qp.y, qp.ws_bounds, qp.ws_constraints)
+    assert ok and st.KKT_error < 1e-9
+
+
+@pytest.mark.parametrize("path", dump_paths(), ids=lambda p: os.path.basename(p)[5:10])
+def test_reference_dumps_certificate(oracle, path):
+    """All 18 dumps of reference test/unsolved_QP_data (every Hessian is indefinite or
+    singular): the oracle terminates at a KKT point with a positive definite reduced
+    Hessian. The certificate is ABSOLUTE (1e-6); on the three dumps whose data reach 1e10
+    the residual is rounding-sized relative to the data but above 1e-6."""
+    q = read_qore_dump(path)
+    qp, rc, n = oracle_cold(oracle, q)
+    assert rc == 0 and qp.is_solved()
+    ok, st, _, _ = oracle_certificate(oracle, q, qp.x, qp.y, qp.ws_bounds, qp.ws_constraints)
+    scale = max(1.0, np.abs(q.g).max(), np.abs(q.H_val).max() if len(q.H_val) else 0.0)
+    assert st.KKT_error <= 1e-6 or st.KKT_error <= 1e-14 * scale
+    assert ok == (st.KKT_error <= 1e-6)
+
+
+def test_golden_regression(oracle):
+    gold = json.load(open(os.path.join(GOLDEN, "oracle_qp_solutions.json")))
+    qps = [problems.hs071_first_qp()] + [read_qore_dump(p) for p in dump_paths()]
+    assert len(gold) == len(qps) == 19
+    for q in qps:
+        qp, rc, n = oracle_cold(oracle, q)
+        e = gold[q.name]
+        assert (rc, n, qp.exitflag()) == (e["rc"], e["nWSR"], e["exitflag"])
+        assert qp.ws_bounds.tolist() == e["ws_b"] and qp.ws_constraints.tolist() == e["ws_c"]
+        assert np.allclose(qp.x, e["x"], rtol=1e-12, atol=1e-12) and np.allclose(qp.y, e["y"], rtol=1e-10, atol=1e-10)
+
+
+def test_hs071_first_qp(oracle):
+    """Hand check: p = (0, -1/4, -1, 1/4) makes the linearised c1 active at its lower side and
+    satisfies the linearised equality c2; slacks stay at zero."""
+    q = problems.hs071_first_qp()
+    qp, rc, n = oracle_cold(oracle, q)
+    assert rc == 0 and n == 2
+    assert np.allclose(qp.x, [0, -0.25, -1, 0.25, 0, 0, 0, 0], atol=1e-14)
+    assert qp.ws_constraints.tolist() == [-1, 1]
+    assert abs(qp.objective - 0.1875) < 1e-14
+    ok, st, Wb, Wc = oracle_certificate(oracle, q, qp.x, qp.y, qp.ws_bounds, qp.ws_constraints)
+    assert ok and st.KKT_error < 1e-12
+    # get_working_set quirk (qpOASESInterface.cpp:874,880): the comparison sits INSIDE fabs(),
+    # so a constraint active at its lower side is reported BOTH_SIDE whenever Ax - ubA < 1e-8,
+    # i.e. for every feasible point; the equality c2 (held at its upper side) is BOTH_SIDE too
+    assert Wc.tolist() == [-99, -99]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_hotstart_equals_cold(oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    nV, nC = int(rng.integers(5, 45)), int(rng.integers(0, 30))
+    q = problems.random_qp(rng, nV, nC)
+    qp, rc, n0 = oracle_cold(oracle, q)
+    assert rc == 0
+    for _ in range(3):
+        q = problems.perturb(rng, q, 0.05)
+        rc, n = qp.hotstart(q.g, q.lb, q.ub, q.lbA, q.ubA, 1000)
+        cold, rc2, n2 = oracle_cold(oracle, q)
+        assert rc == rc2
+        if rc == 0:
+            assert np.abs(cold.x - qp.x).max() < 1e-9 and np.array_equal(cold.ws_bounds, qp.ws_bounds)
+            assert n <= n2 + 5
+    A2 = q.A_val * (1.0 + 0.02 * rng.normal(size=q.A_val.shape))
+    q2 = QPData(q.nV, q.nC, q.H_jc, q.H_ir, q.H_val * 1.1, q.A_jc, q.A_ir, A2, q.g, q.lb, q.ub, q.lbA, q.ubA)
+    qp.set_A_csc(q2.A_jc, q2.A_ir, q2.A_val); qp.set_H_csc(q2.H_jc, q2.H_ir, q2.H_val)
+    rc, n = qp.hotstart_matrices(q2.g, q2.lb, q2.ub, q2.lbA, q2.ubA, 1000)
+    cold, rc2, n2 = oracle_cold(oracle, q2)
+    assert rc == rc2
+    if rc == 0:
+        assert np.abs(cold.x - qp.x).max() < 1e-9
+
+
+def test_infeasible_and_unbounded(oracle):
+    # x1 + x2 >= 3 with x <= 1: infeasible
+    A = np.array([[1.0, 1.0]])
+    q = QPData(2, 1, *dense_to_csc(np.eye(2)), *dense_to_csc(A), np.zeros(2), -np.ones(2), np.ones(2),
+               np.array([3.0]), np.array([np.inf]))
+    qp, rc, n = oracle_cold(oracle, q)
+    assert rc == 2 and qp.is_infeasible() and qp.exitflag() == 22
+    # indefinite direction with no bound on the far side: unbounded
+    H = np.diag([1.0, -1.0])
+    q = QPData(2, 0, *dense_to_csc(H), *dense_to_csc(np.zeros((0, 2))), np.array([0.0, -1.0]), np.array([-1.0, 0.0]),
+               np.array([1.0, np.inf]), np.zeros(0), np.zeros(0))
+    qp, rc, n = oracle_cold(oracle, q)
+    assert rc == 3 and qp.is_unbounded() and qp.exitflag() == 23
+
+
+def test_iteration_limit(oracle):
+    q = problems.random_qp(np.random.default_rng(3), 30, 40)
+    qp, rc, n = oracle_cold(oracle, q, nWSR=3)
+    assert rc == 1 and n == 3 and not qp.is_solved() and qp.exitflag() == 28
