@@ -25,6 +25,12 @@
 
 #define SYNC() __syncthreads()
 #define PFOR(i, n) for (int i = threadIdx.x; i < (n); i += NT)
+// LDS-qualified pointer types: guarantees ds_read / ds_write (a generic pointer would be
+// lowered to flat_load, which is several times slower and costs two registers)
+#define LDS __attribute__((address_space(3)))
+typedef LDS double ldouble;
+typedef LDS int lint;
+typedef LDS char lchar;
 
 namespace {
 
@@ -34,32 +40,39 @@ struct Blocking {
     int idx, side;
 };
 
-template <int NT>
+template <bool B> struct MatPtr { typedef const lint *I; typedef const ldouble *D; };
+template <> struct MatPtr<false> { typedef const int *I; typedef const double *D; };
+
+// MAT_LDS: the sparse matrices were staged into LDS behind the image (they fit for every
+// hs0xx-scale problem); otherwise they are read from global memory (L2).
+template <int NT, bool MAT_LDS>
 struct Engine {
+    typedef typename MatPtr<MAT_LDS>::I MI;
+    typedef typename MatPtr<MAT_LDS>::D MD;
     // problem
     int nV, nC, ld, sizeT, haveH;
-    const int *Ajc, *Air; const double *Aval;
-    const int *Arp, *Aci; const double *Arv;
-    const int *Hjc, *Hir; const double *Hval;
+    MI Ajc, Air; MD Aval;
+    MI Arp, Aci; MD Arv;
+    MI Hjc, Hir; MD Hval;
     // LDS image
-    double *Q, *R, *T;
-    double *x, *g, *lb, *ub, *gN, *lbN, *ubN, *dx, *wq, *wv1, *wv2, *wv3, *wv4, *rc, *rs;
-    double *Ax, *lbA, *ubA, *lbAN, *ubAN, *dAx, *wc1, *wc2;
-    double *y, *dy;
-    double *scal;  // 8 scalars for broadcasts
-    int *Sb, *Sc, *AC, *posAC;
-    int *iscal;    // 8 ints
-    double *red;   // cross-wave reduction scratch (outside the image)
+    ldouble *Q, *R, *T;
+    ldouble *x, *g, *lb, *ub, *gN, *lbN, *ubN, *dx, *wq, *wv1, *wv2, *wv3, *wv4, *rc, *rs;
+    ldouble *Ax, *lbA, *ubA, *lbAN, *ubAN, *dAx, *wc1, *wc2;
+    ldouble *y, *dy;
+    ldouble *scal;  // 8 scalars for broadcasts
+    lint *Sb, *Sc, *AC, *posAC;
+    lint *iscal;    // 8 ints
+    ldouble *red;   // cross-wave reduction scratch (outside the image)
     // uniform registers
     int nFR, nAC, status, infeasible, unbounded, nflips;
 
     // ------------------------------------------------------------------ carve
-    __device__ void carve(char *base, int nV_, int nC_) {
+    __device__ __forceinline__ void carve(lchar *base, int nV_, int nC_) {
         nV = nV_; nC = nC_; ld = rsqp_ld(nV); sizeT = nV < nC ? nV : nC;
-        double *p = reinterpret_cast<double *>(base);
-        Q = p; p += (size_t)ld * nV;
-        R = p; p += (size_t)ld * nV;
-        T = p; p += (size_t)sizeT * ld;
+        ldouble *p = (ldouble *)base;
+        Q = p; p += ld * nV;
+        R = p; p += ld * nV;
+        T = p; p += sizeT * ld;
 #define CARVE_V(name) name = p; p += nV
         CARVE_V(x); CARVE_V(g); CARVE_V(lb); CARVE_V(ub); CARVE_V(gN); CARVE_V(lbN); CARVE_V(ubN);
         CARVE_V(dx); CARVE_V(wq); CARVE_V(wv1); CARVE_V(wv2); CARVE_V(wv3); CARVE_V(wv4); CARVE_V(rc); CARVE_V(rs);
@@ -72,7 +85,7 @@ struct Engine {
         y = p; p += nV + nC;
         dy = p; p += nV + nC;
         scal = p; p += 8;
-        int *ip = reinterpret_cast<int *>(p);
+        lint *ip = (lint *)p;
         Sb = ip; ip += nV;
         Sc = ip; ip += nC;
         AC = ip; ip += nC;
@@ -81,12 +94,12 @@ struct Engine {
     }
 
     // ------------------------------------------------------------------ reductions
-    __device__ double wave_sum(double v) {
+    __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
         return v;
     }
-    __device__ double block_sum(double v) {
+    __device__ __forceinline__ double block_sum(double v) {
         v = wave_sum(v);
         if constexpr (NT > 64) {
             SYNC();
@@ -98,7 +111,7 @@ struct Engine {
         return v;
     }
     // lexicographic min of (t, id)
-    __device__ void block_argmin(double &t, int &id) {
+    __device__ __forceinline__ void block_argmin(double &t, int &id) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             double t2 = __shfl_xor(t, o);
@@ -116,14 +129,14 @@ struct Engine {
             }
         }
     }
-    __device__ double dot(const double *a, const double *b, int n) {
+    __device__ __forceinline__ double dot(const ldouble *a, const ldouble *b, int n) {
         double s = 0.0;
         PFOR(i, n) s += a[i] * b[i];
         return block_sum(s);
     }
 
     // ------------------------------------------------------------------ sparse products
-    __device__ void A_times(const double *v, double *out) {
+    __device__ __forceinline__ void A_times(const ldouble *v, ldouble *out) {
         PFOR(r, nC) {
             double s = 0.0;
             for (int k = Arp[r]; k < Arp[r + 1]; k++) s += Arv[k] * v[Aci[k]];
@@ -131,7 +144,7 @@ struct Engine {
         }
         SYNC();
     }
-    __device__ void AT_times(const double *yc, double *out) {
+    __device__ __forceinline__ void AT_times(const ldouble *yc, ldouble *out) {
         PFOR(c, nV) {
             double s = 0.0;
             for (int k = Ajc[c]; k < Ajc[c + 1]; k++) s += Aval[k] * yc[Air[k]];
@@ -139,7 +152,7 @@ struct Engine {
         }
         SYNC();
     }
-    __device__ void H_times(const double *v, double *out) {
+    __device__ __forceinline__ void H_times(const ldouble *v, ldouble *out) {
         PFOR(c, nV) {
             double s = 0.0;
             if (haveH)
@@ -149,7 +162,7 @@ struct Engine {
         SYNC();
     }
     // a[v] = A[i][v] for free v, 0 otherwise (all==true: every variable)
-    __device__ void row_of_A(int i, double *a, bool all) {
+    __device__ __forceinline__ void row_of_A(int i, ldouble *a, bool all) {
         PFOR(v, nV) a[v] = 0.0;
         SYNC();
         for (int k = Arp[i] + threadIdx.x; k < Arp[i + 1]; k += NT) {
@@ -159,9 +172,9 @@ struct Engine {
         SYNC();
     }
     // w[c] = Q[:,c] . a   for c < nFR
-    __device__ void QT_times(const double *a, double *w) {
+    __device__ __forceinline__ void QT_times(const ldouble *a, ldouble *w) {
         PFOR(c, nFR) {
-            const double *qc = Q + (size_t)c * ld;
+            const ldouble *qc = Q + c * ld;
             double s = 0.0;
             for (int v = 0; v < nV; v++) s += qc[v] * a[v];
             w[c] = s;
@@ -170,7 +183,7 @@ struct Engine {
     }
 
     // ------------------------------------------------------------------ Givens helpers
-    __device__ static void givens(double a_elim, double b_keep, double &c, double &s) {
+    __device__ __forceinline__ static void givens(double a_elim, double b_keep, double &c, double &s) {
         if (a_elim == 0.0) { c = 1.0; s = 0.0; return; }
         double r = hypot(a_elim, b_keep);
         c = b_keep / r;
@@ -178,7 +191,7 @@ struct Engine {
     }
     // rotations (j, j+1), j = j0 .. j1-1, left to right, coefficients rc/rs[j], applied
     // to the vector w (thread 0 computes them: the chain is sequential)
-    __device__ void plan_sweep(double *w, int j0, int j1, int jskip_below) {
+    __device__ __forceinline__ void plan_sweep(ldouble *w, int j0, int j1, int jskip_below) {
         if (threadIdx.x == 0) {
             for (int j = j0; j < j1; j++) {
                 double c = 1.0, s = 0.0;
@@ -192,24 +205,24 @@ struct Engine {
         SYNC();
     }
     // apply the planned sweep to the columns of Q (lane per variable, value carried)
-    __device__ void sweep_Q(int j0, int j1) {
+    __device__ __forceinline__ void sweep_Q(int j0, int j1) {
         if (j1 <= j0) return;
         PFOR(v, nV) {
-            double carry = Q[(size_t)j0 * ld + v];
+            double carry = Q[j0 * ld + v];
             for (int j = j0; j < j1; j++) {
-                double b = Q[(size_t)(j + 1) * ld + v], c = rc[j], s = rs[j];
-                Q[(size_t)j * ld + v] = c * carry - s * b;
+                double b = Q[(j + 1) * ld + v], c = rc[j], s = rs[j];
+                Q[j * ld + v] = c * carry - s * b;
                 carry = s * carry + c * b;
             }
-            Q[(size_t)j1 * ld + v] = carry;
+            Q[j1 * ld + v] = carry;
         }
         SYNC();
     }
     // same sweep on the columns of T (lane per active row)
-    __device__ void sweep_T(int j0, int j1) {
+    __device__ __forceinline__ void sweep_T(int j0, int j1) {
         if (j1 <= j0) return;
         PFOR(i, nAC) {
-            double *row = T + (size_t)i * ld;
+            ldouble *row = T + i * ld;
             double carry = row[j0];
             for (int j = j0; j < j1; j++) {
                 double b = row[j + 1], c = rc[j], s = rs[j];
@@ -222,26 +235,26 @@ struct Engine {
     }
     // column sweep (j, j+1), j = 0..nZ-2, on R followed by the row rotations that make
     // it upper triangular again
-    __device__ void sweep_R(int nZ) {
+    __device__ __forceinline__ void sweep_R(int nZ) {
         if (nZ < 2) return;
         PFOR(r, nZ) {
             int j0 = r > 0 ? r - 1 : 0;
-            double carry = R[(size_t)j0 * ld + r];
+            double carry = R[j0 * ld + r];
             for (int j = j0; j + 1 < nZ; j++) {
-                double b = R[(size_t)(j + 1) * ld + r], c = rc[j], s = rs[j];
-                R[(size_t)j * ld + r] = c * carry - s * b;
+                double b = R[(j + 1) * ld + r], c = rc[j], s = rs[j];
+                R[j * ld + r] = c * carry - s * b;
                 carry = s * carry + c * b;
             }
-            R[(size_t)(nZ - 1) * ld + r] = carry;
+            R[(nZ - 1) * ld + r] = carry;
         }
         SYNC();
         for (int j = 0; j + 1 < nZ; j++) {
-            double diag = R[(size_t)j * ld + j], sub = R[(size_t)j * ld + j + 1];
+            double diag = R[j * ld + j], sub = R[j * ld + j + 1];
             if (sub != 0.0) {  // uniform: every lane read the same LDS words
                 double r = hypot(diag, sub), cc = diag / r, ss = sub / r;
                 SYNC();
                 for (int col = j + threadIdx.x; col < nZ; col += NT) {
-                    double *pc = R + (size_t)col * ld;
+                    ldouble *pc = R + col * ld;
                     double a = pc[j], b = pc[j + 1];
                     pc[j] = cc * a + ss * b;
                     pc[j + 1] = col == j ? 0.0 : -ss * a + cc * b;
@@ -252,7 +265,7 @@ struct Engine {
     }
 
     // ------------------------------------------------------------------ independence tests
-    __device__ bool constraint_is_LI(int i) {
+    __device__ __forceinline__ bool constraint_is_LI(int i) {
         int nZ = nFR - nAC;
         if (nZ <= 0) return false;
         row_of_A(i, wv1, false);
@@ -260,7 +273,7 @@ struct Engine {
         if (na2 == 0.0) return false;
         double s = 0.0;
         PFOR(c, nZ) {
-            const double *qc = Q + (size_t)c * ld;
+            const ldouble *qc = Q + c * ld;
             double d = 0.0;
             for (int v = 0; v < nV; v++) d += qc[v] * wv1[v];
             s += d * d;
@@ -268,17 +281,17 @@ struct Engine {
         s = block_sum(s);
         return sqrt(s) > RSQP_EPS_LI * sqrt(na2);
     }
-    __device__ bool bound_is_LI(int v) {
+    __device__ __forceinline__ bool bound_is_LI(int v) {
         int nZ = nFR - nAC;
         if (nZ <= 0) return false;
         double s = 0.0;
-        PFOR(c, nZ) { double d = Q[(size_t)c * ld + v]; s += d * d; }
+        PFOR(c, nZ) { double d = Q[c * ld + v]; s += d * d; }
         s = block_sum(s);
         return sqrt(s) > RSQP_EPS_LI;
     }
 
     // ------------------------------------------------------------------ working-set updates
-    __device__ void add_constraint(int i, int st, bool upd_chol, bool skipZ) {
+    __device__ __forceinline__ void add_constraint(int i, int st, bool upd_chol, bool skipZ) {
         int nZ = nFR - nAC;
         row_of_A(i, wv1, false);
         QT_times(wv1, wq);
@@ -288,16 +301,16 @@ struct Engine {
             sweep_Q(0, j1);
             if (upd_chol) sweep_R(nZ);
         }
-        double *row = T + (size_t)nAC * ld;
+        ldouble *row = T + nAC * ld;
         PFOR(c, nV) row[c] = (c >= nZ - 1 && c < nFR) ? wq[c] : 0.0;
         if (threadIdx.x == 0) { AC[nAC] = i; posAC[i] = nAC; Sc[i] = st; }
         nAC++;
         SYNC();
     }
 
-    __device__ void add_bound(int v, int st, bool upd_chol, bool skipZ) {
+    __device__ __forceinline__ void add_bound(int v, int st, bool upd_chol, bool skipZ) {
         int nZ = nFR - nAC;
-        PFOR(c, nFR) wq[c] = Q[(size_t)c * ld + v];
+        PFOR(c, nFR) wq[c] = Q[c * ld + v];
         SYNC();
         int jz = nZ - 1 > 0 ? nZ - 1 : 0;
         plan_sweep(wq, 0, nFR - 1, skipZ ? jz : 0);
@@ -305,21 +318,21 @@ struct Engine {
         if (!skipZ && upd_chol) sweep_R(nZ);
         sweep_T(jz, nFR - 1);
         // row v is now +-e_{nFR-1}: drop that row and column
-        PFOR(c, nFR) Q[(size_t)c * ld + v] = 0.0;
-        PFOR(u, nV) Q[(size_t)(nFR - 1) * ld + u] = 0.0;
-        PFOR(i, nAC) T[(size_t)i * ld + nFR - 1] = 0.0;
+        PFOR(c, nFR) Q[c * ld + v] = 0.0;
+        PFOR(u, nV) Q[(nFR - 1) * ld + u] = 0.0;
+        PFOR(i, nAC) T[i * ld + nFR - 1] = 0.0;
         if (threadIdx.x == 0) Sb[v] = st;
         nFR--;
         SYNC();
     }
 
     // append the Cholesky column of the new null-space column zc; false = not pos. def.
-    __device__ bool chol_append(int zc) {
-        const double *z = Q + (size_t)zc * ld;
+    __device__ __forceinline__ bool chol_append(int zc) {
+        const ldouble *z = Q + zc * ld;
         H_times(z, wv2);
         double zHz = dot(z, wv2, nV);
         PFOR(j, zc) {
-            const double *qj = Q + (size_t)j * ld;
+            const ldouble *qj = Q + j * ld;
             double s = 0.0;
             for (int v = 0; v < nV; v++) s += qj[v] * wv2[v];
             wv3[j] = s;
@@ -327,33 +340,33 @@ struct Engine {
         SYNC();
         // R' r = rhs, column oriented
         for (int j = 0; j < zc; j++) {
-            double rj = wv3[j] / R[(size_t)j * ld + j];
+            double rj = wv3[j] / R[j * ld + j];
             SYNC();
             if (threadIdx.x == 0) wv3[j] = rj;
-            for (int k = j + 1 + threadIdx.x; k < zc; k += NT) wv3[k] -= R[(size_t)k * ld + j] * rj;
+            for (int k = j + 1 + threadIdx.x; k < zc; k += NT) wv3[k] -= R[k * ld + j] * rj;
             SYNC();
         }
         double rr = dot(wv3, wv3, zc);
         double rho2 = zHz - rr;
         if (!(rho2 > RSQP_EPS_PD_REL * (fabs(zHz) + rr) + RSQP_EPS_PD_ABS)) return false;
-        PFOR(j, nV) R[(size_t)zc * ld + j] = j < zc ? wv3[j] : (j == zc ? sqrt(rho2) : 0.0);
+        PFOR(j, nV) R[zc * ld + j] = j < zc ? wv3[j] : (j == zc ? sqrt(rho2) : 0.0);
         SYNC();
         return true;
     }
 
     // right-to-left sweep used by the two removals: rotation t acts on columns
     // (cfirst - t, cfirst - t + 1) and is fixed by row (row0 + t) of T
-    __device__ void removal_sweep(int row0, int nrot, int cfirst) {
+    __device__ __forceinline__ void removal_sweep(int row0, int nrot, int cfirst) {
         for (int t = 0; t < nrot; t++) {
             int i = row0 + t, c0 = cfirst - t;
-            double *ri = T + (size_t)i * ld;
+            ldouble *ri = T + i * ld;
             double c, s;
             givens(ri[c0], ri[c0 + 1], c, s);  // uniform
             SYNC();
             if (threadIdx.x == 0) { rc[t] = c; rs[t] = s; }
             if (s != 0.0) {
                 for (int ii = i + threadIdx.x; ii < nAC; ii += NT) {
-                    double *row = T + (size_t)ii * ld;
+                    ldouble *row = T + ii * ld;
                     double a = row[c0], b = row[c0 + 1];
                     row[c0] = ii == i ? 0.0 : c * a - s * b;
                     row[c0 + 1] = s * a + c * b;
@@ -363,23 +376,23 @@ struct Engine {
         }
         if (nrot <= 0) return;
         PFOR(v, nV) {
-            double keep = Q[(size_t)(cfirst + 1) * ld + v];
+            double keep = Q[(cfirst + 1) * ld + v];
             for (int t = 0; t < nrot; t++) {
                 int c0 = cfirst - t;
-                double a = Q[(size_t)c0 * ld + v], c = rc[t], s = rs[t];
-                Q[(size_t)(c0 + 1) * ld + v] = s * a + c * keep;
+                double a = Q[c0 * ld + v], c = rc[t], s = rs[t];
+                Q[(c0 + 1) * ld + v] = s * a + c * keep;
                 keep = c * a - s * keep;
             }
-            Q[(size_t)(cfirst - nrot + 1) * ld + v] = keep;
+            Q[(cfirst - nrot + 1) * ld + v] = keep;
         }
         SYNC();
     }
 
-    __device__ int remove_constraint_tq(int k) {
+    __device__ __forceinline__ int remove_constraint_tq(int k) {
         int cons = AC[k];
         SYNC();
         PFOR(c, nV)
-            for (int i = k; i + 1 < nAC; i++) T[(size_t)i * ld + c] = T[(size_t)(i + 1) * ld + c];
+            for (int i = k; i + 1 < nAC; i++) T[i * ld + c] = T[(i + 1) * ld + c];
         if (threadIdx.x == 0) {
             for (int i = k; i + 1 < nAC; i++) { AC[i] = AC[i + 1]; posAC[AC[i]] = i; }
             posAC[cons] = -1;
@@ -387,30 +400,30 @@ struct Engine {
         }
         nAC--;
         SYNC();
-        PFOR(c, nV) T[(size_t)nAC * ld + c] = 0.0;
+        PFOR(c, nV) T[nAC * ld + c] = 0.0;
         SYNC();
         removal_sweep(k, nAC - k, nFR - 2 - k);
         return nFR - nAC - 1;
     }
 
-    __device__ int remove_bound_tq(int v) {
+    __device__ __forceinline__ int remove_bound_tq(int v) {
         int cn = nFR;
         nFR++;
-        PFOR(u, nV) Q[(size_t)cn * ld + u] = u == v ? 1.0 : 0.0;
-        PFOR(c, cn) Q[(size_t)c * ld + v] = 0.0;
-        PFOR(i, nAC) T[(size_t)i * ld + cn] = 0.0;
+        PFOR(u, nV) Q[cn * ld + u] = u == v ? 1.0 : 0.0;
+        PFOR(c, cn) Q[c * ld + v] = 0.0;
+        PFOR(i, nAC) T[i * ld + cn] = 0.0;
         if (threadIdx.x == 0) Sb[v] = 0;
         SYNC();
         for (int k = Ajc[v] + threadIdx.x; k < Ajc[v + 1]; k += NT) {
             int r = Air[k];
-            if (Sc[r] != 0) T[(size_t)posAC[r] * ld + cn] = Aval[k];
+            if (Sc[r] != 0) T[posAC[r] * ld + cn] = Aval[k];
         }
         SYNC();
         removal_sweep(0, nAC, cn - 1);
         return nFR - nAC - 1;
     }
 
-    __device__ bool chol_setup() {
+    __device__ __forceinline__ bool chol_setup() {
         int nZ = nFR - nAC;
         for (int c = 0; c < nZ; c++)
             if (!chol_append(c)) return false;
@@ -418,34 +431,35 @@ struct Engine {
     }
 
     // ------------------------------------------------------------------ auxiliary QP
-    __device__ static double clampinf(double v) {
+    __device__ __forceinline__ static double clampinf(double v) {
         return v > RSQP_INFTY ? RSQP_INFTY : (v < -RSQP_INFTY ? -RSQP_INFTY : v);
     }
-    __device__ void store_targets(const double *g_, const double *lb_, const double *ub_,
+    __device__ __forceinline__ void store_targets(const double *g_, const double *lb_, const double *ub_,
                                   const double *lbA_, const double *ubA_) {
         PFOR(v, nV) { gN[v] = g_[v]; lbN[v] = clampinf(lb_[v]); ubN[v] = clampinf(ub_[v]); }
         PFOR(i, nC) { lbAN[i] = clampinf(lbA_[i]); ubAN[i] = clampinf(ubA_[i]); }
         SYNC();
     }
 
-    // x0 / y0 / guess_b / guess_c: global or LDS pointers, may be null
-    __device__ int setup_aux(const double *x0, const double *y0, const int *guess_b, const int *guess_c) {
+    // warm-start inputs are staged by the caller: x0 in wv4, y0 in dy, guessed bound status in
+    // wq and guessed constraint status in wc1 (as doubles); the flags say which are present
+    __device__ __forceinline__ int setup_aux(bool x0, bool y0, bool guess_b, bool guess_c) {
         status = QPS_PREPARINGAUXILIARYQP;
         infeasible = unbounded = 0;
         PFOR(v, nV) {
-            double xv = x0 ? x0[v] : 0.0;
+            double xv = x0 ? wv4[v] : 0.0;
             int s;
-            if (guess_b) s = guess_b[v];
+            if (guess_b) s = (int)wq[v];
             else if (x0) s = xv <= lbN[v] + RSQP_BOUND_TOLERANCE ? -1 : (xv >= ubN[v] - RSQP_BOUND_TOLERANCE ? 1 : 0);
-            else if (y0) s = y0[v] > RSQP_EPS ? -1 : (y0[v] < -RSQP_EPS ? 1 : 0);
+            else if (y0) s = dy[v] > RSQP_EPS ? -1 : (dy[v] < -RSQP_EPS ? 1 : 0);
             else s = -1;
             if (s == -1 && lbN[v] <= -RSQP_INFTY) s = (ubN[v] < RSQP_INFTY && !x0 && !guess_b) ? 1 : 0;
             if (s == 1 && ubN[v] >= RSQP_INFTY) s = 0;
-            wv4[v] = xv;          // staged: x0 may alias x (hot start with new matrices)
+            wv4[v] = xv;
             wq[v] = (double)s;
         }
-        PFOR(i, nV + nC) dy[i] = y0 ? y0[i] : 0.0;
-        PFOR(i, nC) wc1[i] = guess_c ? (double)guess_c[i] : 0.0;
+        if (!y0) { PFOR(i, nV + nC) dy[i] = 0.0; }
+        if (!guess_c) { PFOR(i, nC) wc1[i] = 0.0; }
         SYNC();
         PFOR(v, nV) { x[v] = wv4[v]; Sb[v] = (int)wq[v]; }
         PFOR(i, nV + nC) y[i] = dy[i];
@@ -456,7 +470,7 @@ struct Engine {
         if (threadIdx.x == 0) {
             int n = 0;
             for (int v = 0; v < nV; v++)
-                if (Sb[v] == 0) Q[(size_t)(n++) * ld + v] = 1.0;
+                if (Sb[v] == 0) Q[(n++) * ld + v] = 1.0;
             iscal[0] = n;
         }
         SYNC();
@@ -501,11 +515,11 @@ struct Engine {
     }
 
     // ------------------------------------------------------------------ step direction
-    __device__ static double delta_of(double target, double cur) {
+    __device__ __forceinline__ static double delta_of(double target, double cur) {
         return (fabs(target) >= RSQP_INFTY && fabs(cur) >= RSQP_INFTY) ? 0.0 : target - cur;
     }
 
-    __device__ void step_direction() {
+    __device__ __forceinline__ void step_direction() {
         int nZ = nFR - nAC;
         PFOR(v, nV) dx[v] = Sb[v] == -1 ? delta_of(lbN[v], lb[v]) : (Sb[v] == 1 ? delta_of(ubN[v], ub[v]) : 0.0);
         PFOR(i, nV + nC) dy[i] = 0.0;
@@ -522,15 +536,15 @@ struct Engine {
         // range space: T wY = bA (column oriented)
         for (int i = 0; i < nAC; i++) {
             int c = nFR - 1 - i;
-            double w = wc1[i] / T[(size_t)i * ld + c];
+            double w = wc1[i] / T[i * ld + c];
             SYNC();
             if (threadIdx.x == 0) wq[c] = w;
-            for (int ii = i + 1 + threadIdx.x; ii < nAC; ii += NT) wc1[ii] -= T[(size_t)ii * ld + c] * w;
+            for (int ii = i + 1 + threadIdx.x; ii < nAC; ii += NT) wc1[ii] -= T[ii * ld + c] * w;
             SYNC();
         }
         PFOR(v, nV) {
             double s = 0.0;
-            for (int c = nZ; c < nFR; c++) s += Q[(size_t)c * ld + v] * wq[c];
+            for (int c = nZ; c < nFR; c++) s += Q[c * ld + v] * wq[c];
             wv3[v] = s;  // xY
         }
         SYNC();
@@ -539,30 +553,30 @@ struct Engine {
         PFOR(v, nV) wv2[v] += wv1[v];
         SYNC();
         PFOR(j, nZ) {
-            const double *qj = Q + (size_t)j * ld;
+            const ldouble *qj = Q + j * ld;
             double s = 0.0;
             for (int v = 0; v < nV; v++) s += qj[v] * wv2[v];
             wq[j] = -s;
         }
         SYNC();
         for (int j = 0; j < nZ; j++) {
-            double u = wq[j] / R[(size_t)j * ld + j];
+            double u = wq[j] / R[j * ld + j];
             SYNC();
             if (threadIdx.x == 0) wq[j] = u;
-            for (int k = j + 1 + threadIdx.x; k < nZ; k += NT) wq[k] -= R[(size_t)k * ld + j] * u;
+            for (int k = j + 1 + threadIdx.x; k < nZ; k += NT) wq[k] -= R[k * ld + j] * u;
             SYNC();
         }
         for (int j = nZ - 1; j >= 0; j--) {
-            double w = wq[j] / R[(size_t)j * ld + j];
+            double w = wq[j] / R[j * ld + j];
             SYNC();
             if (threadIdx.x == 0) wq[j] = w;
-            for (int k = threadIdx.x; k < j; k += NT) wq[k] -= R[(size_t)j * ld + k] * w;
+            for (int k = threadIdx.x; k < j; k += NT) wq[k] -= R[j * ld + k] * w;
             SYNC();
         }
         PFOR(v, nV) {
             if (Sb[v] == 0) {
                 double s = wv3[v];
-                for (int j = 0; j < nZ; j++) s += Q[(size_t)j * ld + v] * wq[j];
+                for (int j = 0; j < nZ; j++) s += Q[j * ld + v] * wq[j];
                 dx[v] = s;
             }
         }
@@ -572,7 +586,7 @@ struct Engine {
         PFOR(v, nV) wv2[v] += gN[v] - g[v];
         SYNC();
         for (int c = nZ + threadIdx.x; c < nFR; c += NT) {
-            const double *qc = Q + (size_t)c * ld;
+            const ldouble *qc = Q + c * ld;
             double s = 0.0;
             for (int v = 0; v < nV; v++) s += qc[v] * wv2[v];
             wq[c] = s;
@@ -580,7 +594,7 @@ struct Engine {
         SYNC();
         for (int m = 0; m < nAC; m++) {
             int i = nAC - 1 - m, c = nZ + m;
-            const double *ri = T + (size_t)i * ld;
+            const ldouble *ri = T + i * ld;
             double d = wq[c] / ri[c];
             SYNC();
             if (threadIdx.x == 0) dy[nV + AC[i]] = d;
@@ -593,7 +607,7 @@ struct Engine {
     }
 
     // ------------------------------------------------------------------ ratio tests
-    __device__ static void cand(double num, double den, int id, double &bt, int &bid) {
+    __device__ __forceinline__ static void cand(double num, double den, int id, double &bt, int &bid) {
         if (den >= RSQP_EPS_DEN) {
             double t = (num > 0.0 ? num : 0.0) / den;
             if (t < bt || (t == bt && id < bid)) { bt = t; bid = id; }
@@ -601,7 +615,7 @@ struct Engine {
     }
     // candidate ids: [0,nC) active constr. duals, [nC,nC+nV) fixed-variable duals,
     // then inactive constr. lower / upper, then free variables lower / upper
-    __device__ Blocking ratio_tests() {
+    __device__ __forceinline__ Blocking ratio_tests() {
         double bt = 1.0;
         int bid = 0x7fffffff;
         PFOR(i, nC) {
@@ -640,7 +654,7 @@ struct Engine {
     }
 
     // ------------------------------------------------------------------ removal with guard
-    __device__ int remove_with_guard(bool is_bound, int idx) {
+    __device__ __forceinline__ int remove_with_guard(bool is_bound, int idx) {
         if (is_bound) {
             int old = Sb[idx];
             SYNC();
@@ -678,7 +692,7 @@ struct Engine {
 
     // ------------------------------------------------------------------ exchange
     // a_full in wv4. Shifts the multipliers; returns partner in (pkind, pidx)
-    __device__ int ensure_LI(int side, double &y_new, int &pkind, int &pidx) {
+    __device__ __forceinline__ int ensure_LI(int side, double &y_new, int &pkind, int &pidx) {
         int nZ = nFR - nAC;
         PFOR(v, nV) wv1[v] = Sb[v] == 0 ? wv4[v] : 0.0;
         PFOR(i, nC) wc2[i] = 0.0;
@@ -686,7 +700,7 @@ struct Engine {
         QT_times(wv1, wq);
         for (int m = 0; m < nAC; m++) {
             int i = nAC - 1 - m, c = nZ + m;
-            const double *ri = T + (size_t)i * ld;
+            const ldouble *ri = T + i * ld;
             double d = wq[c] / ri[c];
             SYNC();
             if (threadIdx.x == 0) wc2[AC[i]] = d;
@@ -730,7 +744,7 @@ struct Engine {
         return RET_OK;
     }
 
-    __device__ bool remove_partner(int pkind, int pidx) {
+    __device__ __forceinline__ bool remove_partner(int pkind, int pidx) {
         int zc;
         if (pkind == 1) {
             int k = posAC[pidx];
@@ -745,7 +759,7 @@ struct Engine {
         return chol_append(zc);
     }
 
-    __device__ int change_active_set(const Blocking &b) {
+    __device__ __forceinline__ int change_active_set(const Blocking &b) {
         if (b.kind == 1) return remove_with_guard(false, b.idx);
         if (b.kind == 2) return remove_with_guard(true, b.idx);
         if (b.kind == 3 || b.kind == 4) {
@@ -773,7 +787,7 @@ struct Engine {
     }
 
     // ------------------------------------------------------------------ homotopy
-    __device__ void drift_correction() {
+    __device__ __forceinline__ void drift_correction() {
         PFOR(v, nV) if (Sb[v] != 0) x[v] = Sb[v] == -1 ? lb[v] : ub[v];
         SYNC();
         A_times(x, Ax);
@@ -784,7 +798,7 @@ struct Engine {
         SYNC();
     }
 
-    __device__ int homotopy(int maxit, int &nWSR) {
+    __device__ __forceinline__ int homotopy(int maxit, int &nWSR) {
         int iter = 0, rcode = RET_OK;
         status = QPS_PERFORMINGHOMOTOPY;
         PFOR(v, nV) {
@@ -836,14 +850,14 @@ struct Engine {
         return rcode;
     }
 
-    __device__ bool bounds_inconsistent() {
+    __device__ __forceinline__ bool bounds_inconsistent() {
         double bad = 0.0;
         PFOR(v, nV) if (lbN[v] > ubN[v] + RSQP_EPS) bad += 1.0;
         PFOR(i, nC) if (lbAN[i] > ubAN[i] + RSQP_EPS) bad += 1.0;
         return block_sum(bad) > 0.0;
     }
 
-    __device__ double objective() {
+    __device__ __forceinline__ double objective() {
         H_times(x, wv2);
         double a = dot(x, wv2, nV), b = dot(gN, x, nV);
         return 0.5 * a + b;
@@ -851,34 +865,66 @@ struct Engine {
 };
 
 // ------------------------------------------------------------------------------------
-template <int NT>
+// bytes of LDS needed to stage the sparse matrices of one problem behind its image
+__host__ __device__ inline long long mat_lds_bytes(int nV, int nC, int annz, int hnnz) {
+    long long ints = 2LL * (nV + 1) + (nC + 1) + 2LL * annz + hnnz, dbl = 2LL * annz + hnnz;
+    return ((ints * 4 + 7) & ~7LL) + dbl * 8;
+}
+
+template <int NT, bool MAT_LDS>
 __global__ void __launch_bounds__(NT)
 small_qp_kernel(QPPools P, int mode, int maxWSR) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+    lchar *smem = (lchar *)smem_generic;
     const QPDesc d = P.desc[blockIdx.x];
-    Engine<NT> E;
+    Engine<NT, MAT_LDS> E;
     E.carve(smem, d.nV, d.nC);
-    const long long nd = rsqp_image_doubles(d.nV, d.nC), ni = rsqp_image_ints(d.nV, d.nC);
-    E.red = reinterpret_cast<double *>(smem + ((nd * 8 + ni * 4 + 15) & ~15LL));
+    const int nd = (int)rsqp_image_doubles(d.nV, d.nC), ni = (int)rsqp_image_ints(d.nV, d.nC);
+    const int img_bytes = (nd * 8 + ni * 4 + 15) & ~15;
+    E.red = (ldouble *)(smem + img_bytes);
     E.haveH = d.haveH;
-    E.Ajc = P.Ajc + d.offAjc; E.Air = P.Air + d.offAnz; E.Aval = P.Aval + d.offAnz;
-    E.Arp = P.Arp + d.offArp; E.Aci = P.Aci + d.offAnz; E.Arv = P.Arv + d.offAnz;
-    E.Hjc = P.Hjc + d.offHjc; E.Hir = P.Hir + d.offHnz; E.Hval = P.Hval + d.offHnz;
+    const int *gAjc = P.Ajc + d.offAjc, *gAir = P.Air + d.offAnz, *gArp = P.Arp + d.offArp, *gAci = P.Aci + d.offAnz;
+    const int *gHjc = P.Hjc + d.offHjc, *gHir = P.Hir + d.offHnz;
+    const double *gAval = P.Aval + d.offAnz, *gArv = P.Arv + d.offAnz, *gHval = P.Hval + d.offHnz;
+    if constexpr (MAT_LDS) {
+        // stage CSC(A), CSR(A), CSC(H) behind the image + reduction scratch
+        const int annz = gAjc[d.nV], hnnz = d.haveH ? gHjc[d.nV] : 0;
+        lint *ip = (lint *)(smem + img_bytes + 256);
+        lint *lAjc = ip; ip += d.nV + 1;
+        lint *lArp = ip; ip += d.nC + 1;
+        lint *lHjc = ip; ip += d.nV + 1;
+        lint *lAir = ip; ip += annz;
+        lint *lAci = ip; ip += annz;
+        lint *lHir = ip; ip += hnnz;
+        ldouble *dp = (ldouble *)(smem + img_bytes + 256 + (((ip - (lint *)(smem + img_bytes + 256)) * 4 + 7) & ~7));
+        ldouble *lAval = dp; dp += annz;
+        ldouble *lArv = dp; dp += annz;
+        ldouble *lHval = dp;
+        for (int k = threadIdx.x; k <= d.nV; k += NT) { lAjc[k] = gAjc[k]; lHjc[k] = d.haveH ? gHjc[k] : 0; }
+        for (int k = threadIdx.x; k <= d.nC; k += NT) lArp[k] = gArp[k];
+        for (int k = threadIdx.x; k < annz; k += NT) { lAir[k] = gAir[k]; lAci[k] = gAci[k]; lAval[k] = gAval[k]; lArv[k] = gArv[k]; }
+        for (int k = threadIdx.x; k < hnnz; k += NT) { lHir[k] = gHir[k]; lHval[k] = gHval[k]; }
+        E.Ajc = lAjc; E.Air = lAir; E.Aval = lAval; E.Arp = lArp; E.Aci = lAci; E.Arv = lArv;
+        E.Hjc = lHjc; E.Hir = lHir; E.Hval = lHval;
+    } else {
+        E.Ajc = gAjc; E.Air = gAir; E.Aval = gAval; E.Arp = gArp; E.Aci = gAci; E.Arv = gArv;
+        E.Hjc = gHjc; E.Hir = gHir; E.Hval = gHval;
+    }
     E.nflips = 0; E.infeasible = E.unbounded = 0; E.status = QPS_NOTINITIALISED; E.nFR = E.nAC = 0;
     double *img = P.state + d.offState;
     int *iimg = reinterpret_cast<int *>(img + nd);
-    double *simg = reinterpret_cast<double *>(smem);
-    int *siimg = reinterpret_cast<int *>(simg + nd);
+    ldouble *simg = (ldouble *)smem;
+    lint *siimg = (lint *)(simg + nd);
 
     int rcode = RET_OK, nWSR = 0;
     if (mode == 0) {
-        for (long long k = threadIdx.x; k < nd; k += NT) simg[k] = 0.0;
-        for (long long k = threadIdx.x; k < ni; k += NT) siimg[k] = 0;
+        for (int k = threadIdx.x; k < nd; k += NT) simg[k] = 0.0;
+        for (int k = threadIdx.x; k < ni; k += NT) siimg[k] = 0;
         SYNC();
     }
     if (mode != 0) {  // reload the image of the previous solve
-        for (long long k = threadIdx.x; k < nd; k += NT) simg[k] = img[k];
-        for (long long k = threadIdx.x; k < ni; k += NT) siimg[k] = iimg[k];
+        for (int k = threadIdx.x; k < nd; k += NT) simg[k] = img[k];
+        for (int k = threadIdx.x; k < ni; k += NT) siimg[k] = iimg[k];
         SYNC();
         E.nFR = E.iscal[1]; E.nAC = E.iscal[2]; E.status = E.iscal[3];
         SYNC();
@@ -889,14 +935,21 @@ small_qp_kernel(QPPools P, int mode, int maxWSR) {
         E.infeasible = 1; E.unbounded = 0;
         rcode = RET_INFEASIBLE;
     } else if (mode == 0) {
-        rcode = E.setup_aux(nullptr, nullptr, nullptr, nullptr);
+        rcode = E.setup_aux(false, false, false, false);
     } else if (mode == 2) {  // hot start with new matrices: keep x, y and the working set
-        rcode = E.setup_aux(E.x, E.y, E.Sb, E.Sc);
-        if (rcode != RET_OK) rcode = E.setup_aux(nullptr, nullptr, nullptr, nullptr);
+        for (int v = threadIdx.x; v < d.nV; v += NT) { E.wv4[v] = E.x[v]; E.wq[v] = (double)E.Sb[v]; }
+        for (int i = threadIdx.x; i < d.nV + d.nC; i += NT) E.dy[i] = E.y[i];
+        for (int i = threadIdx.x; i < d.nC; i += NT) E.wc1[i] = (double)E.Sc[i];
+        SYNC();
+        rcode = E.setup_aux(true, true, true, true);
+        if (rcode != RET_OK) rcode = E.setup_aux(false, false, false, false);
     } else if (mode == 3) {  // warm re-initialisation from (x0, y0, guessed bounds)
-        rcode = E.setup_aux(P.x0 ? P.x0 + d.offV : nullptr, P.y0 ? P.y0 + d.offV + d.offC : nullptr,
-                            P.guess_b ? P.guess_b + d.offV : nullptr, nullptr);
-        if (rcode != RET_OK) rcode = E.setup_aux(nullptr, nullptr, nullptr, nullptr);
+        if (P.x0) for (int v = threadIdx.x; v < d.nV; v += NT) E.wv4[v] = P.x0[d.offV + v];
+        if (P.y0) for (int i = threadIdx.x; i < d.nV + d.nC; i += NT) E.dy[i] = P.y0[d.offV + d.offC + i];
+        if (P.guess_b) for (int v = threadIdx.x; v < d.nV; v += NT) E.wq[v] = (double)P.guess_b[d.offV + v];
+        SYNC();
+        rcode = E.setup_aux(P.x0 != nullptr, P.y0 != nullptr, P.guess_b != nullptr, false);
+        if (rcode != RET_OK) rcode = E.setup_aux(false, false, false, false);
     } else {
         E.infeasible = E.unbounded = 0;
     }
@@ -917,8 +970,8 @@ small_qp_kernel(QPPools P, int mode, int maxWSR) {
         E.iscal[1] = E.nFR; E.iscal[2] = E.nAC; E.iscal[3] = E.status;
     }
     SYNC();
-    for (long long k = threadIdx.x; k < nd; k += NT) img[k] = simg[k];
-    for (long long k = threadIdx.x; k < ni; k += NT) iimg[k] = siimg[k];
+    for (int k = threadIdx.x; k < nd; k += NT) img[k] = simg[k];
+    for (int k = threadIdx.x; k < ni; k += NT) iimg[k] = siimg[k];
 }
 
 }  // namespace
@@ -929,16 +982,27 @@ int rsqp_small_qp_fits(int nVmax, int nCmax) {
     return rsqp_image_bytes(nVmax, nCmax) + 256 <= kMaxLds;
 }
 
-hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, int mode, int maxWSR,
-                                hipStream_t stream) {
+hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, long long mat_bytes_max, int mode,
+                                int maxWSR, hipStream_t stream) {
     size_t lds = (size_t)rsqp_image_bytes(nVmax, nCmax) + 256;
     if ((long long)lds > kMaxLds) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&small_qp_kernel<64>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&small_qp_kernel<64, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&small_qp_kernel<64, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(small_qp_kernel<64>, dim3(nq), dim3(64), lds, stream, p, mode, maxWSR);
+    // stage the matrices in LDS whenever image + matrices fit; mat_bytes_max is the largest
+    // per-problem staging size of the batch (host computed with rsqp_mat_lds_bytes)
+    if (mat_bytes_max >= 0 && (long long)lds + mat_bytes_max + 64 <= kMaxLds) {
+        lds += (size_t)mat_bytes_max + 64;
+        hipLaunchKernelGGL((small_qp_kernel<64, true>), dim3(nq), dim3(64), lds, stream, p, mode, maxWSR);
+    } else {
+        hipLaunchKernelGGL((small_qp_kernel<64, false>), dim3(nq), dim3(64), lds, stream, p, mode, maxWSR);
+    }
     return hipGetLastError();
 }
+
+long long rsqp_mat_lds_bytes(int nV, int nC, int annz, int hnnz) { return mat_lds_bytes(nV, nC, annz, hnnz); }

@@ -498,7 +498,9 @@ extern "C" int rsqp_solve(rsqp_solver *s, int mode, int *nWSR, const double *x0,
         if (y0) { HIPCHK(s->d_y0.upload(y0, s->nV + s->nC)); p.y0 = s->d_y0.p; }
         if (guess_b) { HIPCHK(s->d_guess.upload(guess_b, s->nV)); p.guess_b = s->d_guess.p; }
     }
-    hipError_t e = rsqp_launch_small_qp(p, 1, s->nV, s->nC, mode, *nWSR, s->stream);
+    hipError_t e = rsqp_launch_small_qp(p, 1, s->nV, s->nC,
+                                        rsqp_mat_lds_bytes(s->nV, s->nC, s->A.initialised ? s->A.nnz : 0, s->H.initialised ? s->H.nnz : 0),
+                                        mode, *nWSR, s->stream);
     if (e != hipSuccess) return fail(RSQP_ERR_DEVICE, std::string("QP kernel launch: ") + hipGetErrorString(e));
     HIPCHK(hipStreamSynchronize(s->stream));
     rc = fetch_results(s);
@@ -694,7 +696,7 @@ extern "C" int rsqp_H_times(rsqp_solver *s, const double *p, double *result) {
 // =====================================================================================
 struct rsqp_batch {
     int nq = 0, device = 0, nVmax = 0, nCmax = 0;
-    long long sumV = 0, sumC = 0, sumAnz = 0, sumHnz = 0;
+    long long sumV = 0, sumC = 0, sumAnz = 0, sumHnz = 0, mat_bytes_max = 0;
     bool haveH = false;
     std::vector<QPDesc> desc;
     std::vector<int> h_csr_perm;
@@ -766,6 +768,7 @@ extern "C" int rsqp_batch_create(int nq, const int *nV, const int *nC, const int
         for (int v : r.perm) h_perm.push_back((int)offAnz + v);
         b->nVmax = std::max(b->nVmax, d.nV); b->nCmax = std::max(b->nCmax, d.nC);
         offV += d.nV; offC += d.nC; offAjc += d.nV + 1; offAnz += annz; offArp += d.nC + 1;
+        b->mat_bytes_max = std::max(b->mat_bytes_max, rsqp_mat_lds_bytes(d.nV, d.nC, annz, b->haveH ? Hjc[offHjc + d.nV] : 0));
         if (b->haveH) {
             const int hnnz = Hjc[offHjc + d.nV];
             for (int k = 0; k < hnnz; k++)
@@ -835,7 +838,7 @@ extern "C" int rsqp_batch_solve(rsqp_batch *b, int mode, int max_nWSR) {
     HIPCHK(hipSetDevice(b->device));
     QPPools p = pools_of(b);
     HIPCHK(hipEventRecord(b->ev0, b->stream));
-    hipError_t e = rsqp_launch_small_qp(p, b->nq, b->nVmax, b->nCmax, mode, max_nWSR, b->stream);
+    hipError_t e = rsqp_launch_small_qp(p, b->nq, b->nVmax, b->nCmax, b->mat_bytes_max, mode, max_nWSR, b->stream);
     if (e != hipSuccess) return fail(RSQP_ERR_DEVICE, std::string("QP kernel launch: ") + hipGetErrorString(e));
     HIPCHK(hipEventRecord(b->ev1, b->stream));
     return RSQP_OK;

@@ -54,6 +54,7 @@ __host__ __device__ inline long long rsqp_image_bytes(int nV, int nC) {
 }
 
 // launchers (defined in the .hip files)
-hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, int mode, int maxWSR,
-                                hipStream_t stream);
+hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, long long mat_bytes_max, int mode,
+                                int maxWSR, hipStream_t stream);
+long long rsqp_mat_lds_bytes(int nV, int nC, int annz, int hnnz);
 int rsqp_small_qp_fits(int nVmax, int nCmax);

@@ -9,7 +9,7 @@ certificate. NEW_FORMULATION=false, non-QORE branch.
 import numpy as np
 
 from .interface import HipQPInterface
-from .types import INF, QP, QP_NOT_OPTIMAL, IdentityInfo, NLPInfo, Options
+from .sqptypes import INF, QP, QP_NOT_OPTIMAL, IdentityInfo, NLPInfo, Options
 
 
 class QPhandler:

@@ -10,7 +10,7 @@ would compile into the reference lives in ``restartsqp_amd/csrc/host/``.
 import numpy as np
 
 from . import capi
-from .types import (INVALID_WORKING_SET, QP, QP_NOT_OPTIMAL, IdentityInfo, NLPInfo, OptimalityStatus, Options,
+from .sqptypes import (INVALID_WORKING_SET, QP, QP_NOT_OPTIMAL, IdentityInfo, NLPInfo, OptimalityStatus, Options,
                     SpTripletMat)
 
 

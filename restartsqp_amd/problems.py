@@ -13,7 +13,7 @@
 import numpy as np
 
 from .qpdump import QPData, dense_to_csc
-from .types import INF, IdentityInfo, NLPInfo, SpTripletMat
+from .sqptypes import INF, IdentityInfo, NLPInfo, SpTripletMat
 
 
 # ------------------------------------------------------------------------------------

@@ -205,7 +205,7 @@ def test_dispatch_state_machine(capi, oracle):
     restatement of the same decisions. hs071 with c2 relaxed to an inequality (see the next
     test for why the reference's own equality handling cannot be replayed)."""
     from restartsqp_amd.handler import QPhandler
-    from restartsqp_amd.types import Stats
+    from restartsqp_amd.sqptypes import Stats
 
     def nlp_at(x):
         d = problems.hs071_nlp(x, lam=np.zeros(2))
@@ -265,7 +265,7 @@ def test_stale_ubA_quirk_reports_infeasible(capi, oracle):
     lbA > ubA; qpOASES rejects such data as infeasible, handle_error re-inits and throws
     QP_NOT_OPTIMAL (src/qpOASESInterface.cpp:720-756). Engine and oracle do the same."""
     from restartsqp_amd.handler import QPhandler
-    from restartsqp_amd.types import QP_NOT_OPTIMAL, Stats
+    from restartsqp_amd.sqptypes import QP_NOT_OPTIMAL, Stats
     nlp = problems.hs071_nlp()
     h = QPhandler(nlp["info"])
     h.set_A(nlp["J"]); h.set_H(nlp["H"])
