@@ -58,10 +58,15 @@ def spmv_roofline(capi, problems, nbatch, repeats):
         gbs = bytes_one * nbatch / (ms * 1e-3) / 1e9
         out[name] = {"ms_per_launch": ms, "bytes_per_launch": bytes_one * nbatch, "achieved": gbs}
     best = out["ATy_csc"]
-    res = {"kernel": "csx_stream_spmv (A'y, CSC, SpHbMat::transposed_times)", "bound": "hbm",
-           "achieved": best["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": best["achieved"] / HBM_PEAK_GBS,
-           "traffic": None, "matrices_per_launch": nbatch, "bytes_per_matrix": 12 * nnz + 4 * (n + 1) + 8 * n + 8 * m,
-           "ms_per_launch": best["ms_per_launch"], "Ax_csr_GBs": out["Ax_csr"]["achieved"]}
+    # bytes the kernel actually streams: the plan keeps 16-bit copies of the index arrays when
+    # both dimensions are < 65536 (10 B instead of 12 B per entry)
+    streamed = (10 * nnz + 4 * (n + 1) + 8 * n + 8 * m) * nbatch
+    res = {"kernel": "csx_ldsvec_spmv_pipe2 (A'y on CSC = SpHbMat::transposed_times; input vector resident in LDS)",
+           "bound": "hbm", "achieved": best["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": best["achieved"] / HBM_PEAK_GBS, "traffic": None, "matrices_per_launch": nbatch,
+           "bytes_per_matrix": 12 * nnz + 4 * (n + 1) + 8 * n + 8 * m, "ms_per_launch": best["ms_per_launch"],
+           "streamed_bytes_per_launch_est": streamed, "raw_stream_GBs_est": streamed / (best["ms_per_launch"] * 1e-3) / 1e9,
+           "Ax_csr_GBs": out["Ax_csr"]["achieved"], "Ax_csr_frac": out["Ax_csr"]["achieved"] / HBM_PEAK_GBS}
     plan.close()
     return res
 

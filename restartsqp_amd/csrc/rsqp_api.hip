@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -116,14 +117,13 @@ void csr_from_csc(int nrow, int ncol, const int *jc, const int *ir, CsrCopy &out
 }
 
 // blocks of consecutive majors with at most `chunk` entries; a longer major stands alone
-std::vector<int> build_blocks(int nmajor, const int *ptr, int chunk) {
-    std::vector<int> blk;
-    blk.push_back(0);
+std::vector<int4> build_blocks(int nmajor, const int *ptr, int chunk) {
+    std::vector<int4> blk;
     int start = 0;
     while (start < nmajor) {
         int end = start + 1;
         while (end < nmajor && ptr[end + 1] - ptr[start] <= chunk && end - start < 4096) end++;
-        blk.push_back(end);
+        blk.push_back(make_int4(start, end, ptr[start], ptr[end]));
         start = end;
     }
     return blk;
@@ -155,9 +155,10 @@ struct DevMatrix {
     bool initialised = false, symmetric = false, from_triplet = false;
     int n_ident_entries = 0, n_triplet = 0;
     std::vector<int> h_jc, h_ir, h_order;  // host mirror of the pattern
-    DevBuf<int> jc, ir, order, tmap, blk_c;          // CSC
+    DevBuf<int> jc, ir, order, tmap;                 // CSC
+    DevBuf<int4> blk_c, blk_r;
     DevBuf<double> val, tv;                          // tv: staging for triplet values
-    DevBuf<int> rp, ci, perm, blk_r;                 // CSR copy (A only)
+    DevBuf<int> rp, ci, perm;                        // CSR copy (A only)
     DevBuf<double> rval;
     int nblk_c = 0, nblk_r = 0;
     bool have_csr = false;
@@ -198,24 +199,24 @@ int upload_matrix(DevMatrix &M, const Compressed &c, bool want_csr) {
     M.nrow = c.nrow; M.ncol = c.ncol; M.nnz = c.nnz();
     M.h_jc = c.jc; M.h_ir = c.ir; M.h_order = c.order;
     HIPCHK(M.jc.from(c.jc));
-    HIPCHK(M.ir.alloc(std::max(M.nnz, 1), true)); HIPCHK(M.ir.upload(c.ir.data(), c.ir.size()));
-    HIPCHK(M.val.alloc(std::max(M.nnz, 1), true)); HIPCHK(M.val.upload(c.val.data(), c.val.size()));
+    HIPCHK(M.ir.alloc(M.nnz + 2, true)); HIPCHK(M.ir.upload(c.ir.data(), c.ir.size()));
+    HIPCHK(M.val.alloc(M.nnz + 2, true)); HIPCHK(M.val.upload(c.val.data(), c.val.size()));
     HIPCHK(M.order.alloc(std::max(M.nnz, 1), true)); HIPCHK(M.order.upload(c.order.data(), c.order.size()));
     if (!c.tmap.empty()) { HIPCHK(M.tmap.from(c.tmap)); }
     HIPCHK(M.tv.alloc(std::max(M.nnz, 1), true));
-    std::vector<int> blk = build_blocks(M.ncol, c.jc.data(), rsqp_spmv_chunk());
-    M.nblk_c = (int)blk.size() - 1;
+    std::vector<int4> blk = build_blocks(M.ncol, c.jc.data(), rsqp_spmv_chunk());
+    M.nblk_c = (int)blk.size();
     HIPCHK(M.blk_c.from(blk));
     M.have_csr = want_csr;
     if (want_csr) {
         CsrCopy r;
         csr_from_csc(M.nrow, M.ncol, c.jc.data(), c.ir.data(), r);
         HIPCHK(M.rp.from(r.rp));
-        HIPCHK(M.ci.alloc(std::max(M.nnz, 1), true)); HIPCHK(M.ci.upload(r.ci.data(), r.ci.size()));
+        HIPCHK(M.ci.alloc(M.nnz + 2, true)); HIPCHK(M.ci.upload(r.ci.data(), r.ci.size()));
         HIPCHK(M.perm.alloc(std::max(M.nnz, 1), true)); HIPCHK(M.perm.upload(r.perm.data(), r.perm.size()));
-        HIPCHK(M.rval.alloc(std::max(M.nnz, 1), true));
-        std::vector<int> blr = build_blocks(M.nrow, r.rp.data(), rsqp_spmv_chunk());
-        M.nblk_r = (int)blr.size() - 1;
+        HIPCHK(M.rval.alloc(M.nnz + 2, true));
+        std::vector<int4> blr = build_blocks(M.nrow, r.rp.data(), rsqp_spmv_chunk());
+        M.nblk_r = (int)blr.size();
         HIPCHK(M.blk_r.from(blr));
         if (rsqp_launch_gather(M.nnz, M.perm.p, M.val.p, M.rval.p, nullptr) != hipSuccess)
             return fail(RSQP_ERR_DEVICE, "gather launch failed");
@@ -939,7 +940,13 @@ struct rsqp_spmv_plan {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // every member owns a full copy of the index arrays: distinct HBM traffic per matrix
-    DevBuf<int> jc, ir, rp, ci, perm, blk_c, blk_r;
+    DevBuf<int> jc, ir, rp, ci, perm;
+    DevBuf<int4> blk_c, blk_r;
+    DevBuf<int> slice_c, slice_r;   // one slice = all majors (1 workgroup per member)
+    DevBuf<unsigned short> ir16, ci16;  // 16-bit index copies (vector length < 65536)
+    bool use16 = false;
+    int variant_t = 0, variant_n = 0;  // 0: stream kernel; >0: LDS-resident-vector kernel
+    int nslices = 1;
     DevBuf<double> val, rval, vin_r, vin_c, vout_r, vout_c;  // _r: length nrow, _c: length ncol
     ~rsqp_spmv_plan() {
         if (ev0) (void)hipEventDestroy(ev0);
@@ -961,12 +968,38 @@ extern "C" int rsqp_spmv_plan_create(int nrow, int ncol, const int *jc, const in
     HIPCHK(hipEventCreate(&p->ev0)); HIPCHK(hipEventCreate(&p->ev1));
     CsrCopy r;
     csr_from_csc(nrow, ncol, jc, ir, r);
-    std::vector<int> bc = build_blocks(ncol, jc, rsqp_spmv_chunk()), br = build_blocks(nrow, r.rp.data(), rsqp_spmv_chunk());
-    p->nblk_c = (int)bc.size() - 1; p->nblk_r = (int)br.size() - 1;
+    std::vector<int4> bc = build_blocks(ncol, jc, rsqp_spmv_chunk()), br = build_blocks(nrow, r.rp.data(), rsqp_spmv_chunk());
+    p->nblk_c = (int)bc.size(); p->nblk_r = (int)br.size();
     HIPCHK(p->blk_c.from(bc)); HIPCHK(p->blk_r.from(br));
+    {
+        const char *es = getenv("RSQP_SPMV_SLICES");
+        p->nslices = es ? std::max(1, atoi(es)) : 1;
+        auto cut = [&](int nmajor, const int *pt) {
+            std::vector<int> sl(p->nslices + 1, nmajor);
+            sl[0] = 0;
+            for (int q = 1; q < p->nslices; q++) {   // equal share of entries per slice
+                long long target = (long long)pt[nmajor] * q / p->nslices;
+                sl[q] = (int)(std::lower_bound(pt, pt + nmajor + 1, (int)target) - pt);
+            }
+            return sl;
+        };
+        std::vector<int> sc = cut(ncol, jc), sr = cut(nrow, r.rp.data());
+        HIPCHK(p->slice_c.from(sc)); HIPCHK(p->slice_r.from(sr));
+        // default kernel choice: vector in LDS when it fits and the batch can fill the chip
+        const char *ev = getenv("RSQP_SPMV_VARIANT");
+        int forced = ev ? atoi(ev) : -1;
+        bool fits_t = (size_t)nrow * 8 + 16 <= 160 * 1024, fits_n = (size_t)ncol * 8 + 16 <= 160 * 1024;
+        // lanes per major by average segment length (measured on MI355X, tools/spmv_sweep.py):
+        // >= 16 entries: 4 lanes x 2 entries x 3 steps; shorter: 2 lanes x 2 entries x 4 steps
+        auto pick = [](double avg) { return avg >= 16.0 ? 35 : 38; };
+        p->variant_t = forced >= 0 ? forced : (fits_t && nbatch >= 64 ? pick((double)p->nnz / ncol) : 0);
+        p->variant_n = forced >= 0 ? forced : (fits_n && nbatch >= 64 ? pick((double)p->nnz / nrow) : 0);
+        if (!fits_t) p->variant_t = 0;
+        if (!fits_n) p->variant_n = 0;
+    }
     const size_t B = nbatch, nnz = p->nnz;
-    HIPCHK(p->jc.alloc(B * (ncol + 1), false)); HIPCHK(p->ir.alloc(B * nnz, false));
-    HIPCHK(p->rp.alloc(B * (nrow + 1), false)); HIPCHK(p->ci.alloc(B * nnz, false));
+    HIPCHK(p->jc.alloc(B * (ncol + 1), false)); HIPCHK(p->ir.alloc(B * nnz + 2, false));
+    HIPCHK(p->rp.alloc(B * (nrow + 1), false)); HIPCHK(p->ci.alloc(B * nnz + 2, false));
     HIPCHK(p->perm.from(r.perm));
     for (size_t m = 0; m < B; m++) {
         HIPCHK(hipMemcpy(p->jc.p + m * (ncol + 1), jc, sizeof(int) * (ncol + 1), hipMemcpyHostToDevice));
@@ -974,7 +1007,19 @@ extern "C" int rsqp_spmv_plan_create(int nrow, int ncol, const int *jc, const in
         HIPCHK(hipMemcpy(p->rp.p + m * (nrow + 1), r.rp.data(), sizeof(int) * (nrow + 1), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(p->ci.p + m * nnz, r.ci.data(), sizeof(int) * nnz, hipMemcpyHostToDevice));
     }
-    HIPCHK(p->val.alloc(B * nnz)); HIPCHK(p->rval.alloc(B * nnz));
+    HIPCHK(p->val.alloc(B * nnz + 2)); HIPCHK(p->rval.alloc(B * nnz + 2));
+    {
+        const char *e16 = getenv("RSQP_SPMV_IDX16");
+        p->use16 = nrow < 65536 && ncol < 65536 && !(e16 && atoi(e16) == 0);
+        if (p->use16) {
+            std::vector<unsigned short> a16(ir, ir + nnz), c16(r.ci.begin(), r.ci.end());
+            HIPCHK(p->ir16.alloc(B * nnz + 4, true)); HIPCHK(p->ci16.alloc(B * nnz + 4, true));
+            for (size_t m = 0; m < B; m++) {
+                HIPCHK(hipMemcpy(p->ir16.p + m * nnz, a16.data(), 2 * nnz, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(p->ci16.p + m * nnz, c16.data(), 2 * nnz, hipMemcpyHostToDevice));
+            }
+        }
+    }
     HIPCHK(p->vin_r.alloc(B * nrow)); HIPCHK(p->vin_c.alloc(B * ncol));
     HIPCHK(p->vout_r.alloc(B * nrow)); HIPCHK(p->vout_c.alloc(B * ncol));
     guard.p = nullptr;
@@ -1008,7 +1053,13 @@ extern "C" int rsqp_spmv_plan_run(rsqp_spmv_plan *p, int transposed, int repeats
     HIPCHK(hipEventRecord(p->ev0, p->stream));
     for (int r = 0; r < repeats; r++) {
         hipError_t e;
-        if (transposed)  // A'y on the CSC arrays (SpHbMat::transposed_times)
+        if (transposed && p->variant_t > 0)
+            e = rsqp_launch_spmv_ldsvec(p->variant_t, p->nrow, p->nslices, p->slice_c.p, p->jc.p, p->ir.p, p->use16 ? p->ir16.p : nullptr, p->val.p, p->vin_r.p,
+                                        p->vout_c.p, p->nbatch, p->ncol + 1, p->nnz, p->nrow, p->ncol, p->stream);
+        else if (!transposed && p->variant_n > 0)
+            e = rsqp_launch_spmv_ldsvec(p->variant_n, p->ncol, p->nslices, p->slice_r.p, p->rp.p, p->ci.p, p->use16 ? p->ci16.p : nullptr, p->rval.p, p->vin_c.p,
+                                        p->vout_r.p, p->nbatch, p->nrow + 1, p->nnz, p->ncol, p->nrow, p->stream);
+        else if (transposed)  // A'y on the CSC arrays (SpHbMat::transposed_times)
             e = rsqp_launch_spmv(p->blk_c.p, p->nblk_c, p->jc.p, p->ir.p, p->val.p, p->vin_r.p, p->vout_c.p, p->nbatch,
                                  p->ncol + 1, p->nnz, p->nrow, p->ncol, p->stream);
         else             // A x on the CSR copy (SpHbMat::times)

@@ -25,10 +25,15 @@ struct RsqpKktArgs {
 // entries per block (a longer single major gets a block of its own)
 int rsqp_spmv_chunk(void);
 
-hipError_t rsqp_launch_spmv(const int *blk, int nblk, const int *ptr, const int *idx, const double *val,
+hipError_t rsqp_launch_spmv(const int4 *blkinfo, int nblk, const int *ptr, const int *idx, const double *val,
                             const double *in, double *out, int nbatch, long long ptr_stride,
                             long long nnz_stride, long long in_stride, long long out_stride,
                             hipStream_t stream);
+// batched product with the input vector staged in LDS (variant selects lanes per major / unroll)
+hipError_t rsqp_launch_spmv_ldsvec(int variant, int nminor, int nslices, const int *slice, const int *ptr,
+                                   const int *idx, const unsigned short *idx16, const double *val, const double *in,
+                                   double *out, int nbatch, long long ptr_stride, long long nnz_stride, long long in_stride,
+                                   long long out_stride, hipStream_t stream);
 hipError_t rsqp_launch_scatter(int n, const int *order, const int *tmap, const double *tv, double *val,
                                hipStream_t stream);
 hipError_t rsqp_launch_gather(int n, const int *perm, const double *src, double *dst, hipStream_t stream);

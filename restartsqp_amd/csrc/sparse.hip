@@ -20,38 +20,279 @@ namespace {
 
 constexpr int SPMV_NT = 256;
 constexpr int SPMV_CHUNK = 2048;  // entries staged per workgroup: 16 KiB of LDS
+constexpr int SPMV_ITERS = SPMV_CHUNK / (2 * SPMV_NT);
 
+// blkinfo[b] = {first major, end major, first entry, end entry} of block b (one 16-byte load
+// instead of the dependent chain blk -> ptr). With xcd_map the 1-D grid is decoded so that
+// all blocks of one batch member carry the same (blockIdx.x % 8): workgroups are dealt
+// round-robin over the 8 XCDs, so a member's gathered input vector is pulled into ONE L2
+// instead of eight (placement only affects speed, never results).
 __global__ void __launch_bounds__(SPMV_NT)
-csx_stream_spmv(const int *__restrict__ blk, const int *__restrict__ ptr, const int *__restrict__ idx,
-                const double *__restrict__ val, const double *__restrict__ in, double *__restrict__ out,
-                long long ptr_stride, long long nnz_stride, long long in_stride, long long out_stride) {
-    __shared__ double prod[SPMV_CHUNK];
-    const int m = blockIdx.y;
+csx_stream_spmv(const int4 *__restrict__ blkinfo, int nblk, int nbatch, int xcd_map,
+                const int *__restrict__ ptr, const int *__restrict__ idx, const double *__restrict__ val,
+                const double *__restrict__ in, double *__restrict__ out, long long ptr_stride,
+                long long nnz_stride, long long in_stride, long long out_stride) {
+    __shared__ __attribute__((aligned(16))) double prod[SPMV_CHUNK + 2];
+    int m, b;
+    if (xcd_map) {
+        const int L = blockIdx.x, j = L >> 3;
+        m = (j / nblk) * 8 + (L & 7);
+        b = j % nblk;
+        if (m >= nbatch) return;
+    } else {
+        m = blockIdx.x / nblk;
+        b = blockIdx.x % nblk;
+    }
     ptr += m * ptr_stride; idx += m * nnz_stride; val += m * nnz_stride;
     in += m * in_stride; out += m * out_stride;
-    const int r0 = blk[blockIdx.x], r1 = blk[blockIdx.x + 1];
-    const int k0 = ptr[r0], k1 = ptr[r1];
-    if (k1 - k0 <= SPMV_CHUNK) {
-        for (int k = k0 + threadIdx.x; k < k1; k += SPMV_NT) prod[k - k0] = val[k] * in[idx[k]];
+    const int4 bi = blkinfo[b];
+    const int r0 = bi.x, r1 = bi.y, k0 = bi.z, k1 = bi.w;
+    const int tid = threadIdx.x;
+    if (k1 - k0 <= SPMV_CHUNK - 2) {
+        // segment bounds of "my" major: issued now, consumed after the barrier
+        const int myr = r0 + tid;
+        int pa = 0, pb = 0;
+        if (myr < r1) { pa = ptr[myr]; pb = ptr[myr + 1]; }
+        // stream (val, idx) in 16-byte / 8-byte pieces from an even entry index; all loads are
+        // issued before the first gather so that every lane keeps 2*ITERS requests in flight
+        const int ka = k0 & ~1, klast = (k1 - 1) & ~1;
+        double2 vv[SPMV_ITERS];
+        int2 ii[SPMV_ITERS];
+#pragma unroll
+        for (int it = 0; it < SPMV_ITERS; it++) {
+            int k = ka + 2 * tid + it * 2 * SPMV_NT;
+            k = k < klast ? k : klast;  // clamp: the load is always inside this block's range
+            vv[it] = *reinterpret_cast<const double2 *>(val + k);
+            ii[it] = *reinterpret_cast<const int2 *>(idx + k);
+        }
+#pragma unroll
+        for (int it = 0; it < SPMV_ITERS; it++) {
+            const int k = ka + 2 * tid + it * 2 * SPMV_NT;
+            if (k < k1) {
+                const bool v0 = k >= k0, v1 = k + 1 < k1;
+                double2 p;
+                p.x = v0 ? vv[it].x * in[ii[it].x] : 0.0;
+                p.y = v1 ? vv[it].y * in[ii[it].y] : 0.0;
+                *reinterpret_cast<double2 *>(prod + (k - ka)) = p;
+            }
+        }
         __syncthreads();
-        for (int r = r0 + threadIdx.x; r < r1; r += SPMV_NT) {
+        if (myr < r1) {
             double s = 0.0;
-            const int a = ptr[r] - k0, b = ptr[r + 1] - k0;
-            for (int k = a; k < b; k++) s += prod[k];
+            for (int k = pa - ka; k < pb - ka; k++) s += prod[k];
+            out[myr] = s;
+        }
+        for (int r = myr + SPMV_NT; r < r1; r += SPMV_NT) {
+            double s = 0.0;
+            const int a = ptr[r] - ka, e = ptr[r + 1] - ka;
+            for (int k = a; k < e; k++) s += prod[k];
             out[r] = s;
         }
     } else {
         // a single long segment (the block builder never mixes it with others):
         // every lane accumulates a strided slice, fixed-order tree afterwards
         double s = 0.0;
-        for (int k = k0 + threadIdx.x; k < k1; k += SPMV_NT) s += val[k] * in[idx[k]];
-        prod[threadIdx.x] = s;
+        for (int k = k0 + tid; k < k1; k += SPMV_NT) s += val[k] * in[idx[k]];
+        prod[tid] = s;
         __syncthreads();
         for (int o = SPMV_NT / 2; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) prod[threadIdx.x] += prod[threadIdx.x + o];
+            if (tid < o) prod[tid] += prod[tid + o];
             __syncthreads();
         }
-        if (threadIdx.x == 0) out[r0] = prod[0];
+        if (tid == 0) out[r0] = prod[0];
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Batched product with the INPUT VECTOR RESIDENT IN LDS (MI355X: 160 KiB per CU holds the
+// whole 20 000-entry fp64 vector of the n=10k x m=20k configuration). One 1024-thread
+// workgroup per (batch member, slice of majors): it loads the member's vector once with
+// 16-byte loads, then streams its (val, idx) range from HBM while every gather is a
+// ds_read_b64 instead of a 64-byte L2 sector request. A sub-wave of G lanes owns one major
+// at a time; consecutive sub-waves own consecutive majors, so a wave-instruction touches a
+// contiguous run of entries. No barrier after the vector load, no atomics; fixed-shape
+// reduction (lane-strided partial sums + xor tree) => run-to-run deterministic.
+// ---------------------------------------------------------------------------------
+constexpr int LV_NT = 1024;
+
+template <int G, int U>
+__global__ void __launch_bounds__(LV_NT)
+csx_ldsvec_spmv(int nminor, int nslices, const int *__restrict__ slice, const int *__restrict__ ptr,
+                const int *__restrict__ idx, const double *__restrict__ val, const double *__restrict__ in,
+                double *__restrict__ out, long long ptr_stride, long long nnz_stride, long long in_stride,
+                long long out_stride) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];
+    const int m = blockIdx.x / nslices, sl = blockIdx.x % nslices;
+    ptr += m * ptr_stride; idx += m * nnz_stride; val += m * nnz_stride;
+    in += m * in_stride; out += m * out_stride;
+    const int tid = threadIdx.x;
+    for (int i = 2 * tid; i + 1 < nminor; i += 2 * LV_NT)
+        *reinterpret_cast<double2 *>(xs + i) = *reinterpret_cast<const double2 *>(in + i);
+    if (tid == 0 && (nminor & 1)) xs[nminor - 1] = in[nminor - 1];
+    __syncthreads();
+    constexpr int NG = LV_NT / G;
+    const int gid = tid / G, gl = tid % G;
+    const int c1 = slice[sl + 1];
+    for (int c = slice[sl] + gid; c < c1; c += NG) {
+        const int a = ptr[c], b = ptr[c + 1];
+        double s = 0.0;
+        // U predicated steps with clamped addresses: all 2U loads are issued back to back
+        double v[U];
+        int j[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int k = a + gl + u * G;
+            k = k < b ? k : (b > a ? b - 1 : a);
+            v[u] = val[k];
+            j[u] = idx[k];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (a + gl + u * G < b) s += v[u] * xs[j[u]];
+        for (int k = a + gl + U * G; k < b; k += G) s += val[k] * xs[idx[k]];
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (gl == 0) out[c] = s;
+    }
+}
+
+// software-pipelined form of csx_ldsvec_spmv: the segment bounds are requested two majors
+// ahead and the (val, idx) loads one major ahead of the LDS gathers that consume them, so a
+// lane always has 2U + 2 global loads in flight (loads return in order: the wait for the
+// current major's data does not drain the next major's requests).
+template <int G, int U, bool NTL>
+__global__ void __launch_bounds__(LV_NT)
+csx_ldsvec_spmv_pipe(int nminor, int nslices, const int *__restrict__ slice, const int *__restrict__ ptr,
+                     const int *__restrict__ idx, const double *__restrict__ val, const double *__restrict__ in,
+                     double *__restrict__ out, long long ptr_stride, long long nnz_stride, long long in_stride,
+                     long long out_stride) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];
+    const int m = blockIdx.x / nslices, sl = blockIdx.x % nslices;
+    ptr += m * ptr_stride; idx += m * nnz_stride; val += m * nnz_stride;
+    in += m * in_stride; out += m * out_stride;
+    const int tid = threadIdx.x;
+    constexpr int NG = LV_NT / G;
+    const int gid = tid / G, gl = tid % G;
+    const int c1 = slice[sl + 1];
+    int c = slice[sl] + gid;
+    // bounds of the first two majors of this sub-wave (clamped: always a valid address)
+    const int cl = c1 - 1;
+    int a0 = ptr[c < c1 ? c : cl], b0 = ptr[(c < c1 ? c : cl) + 1];
+    int a1 = ptr[c + NG < c1 ? c + NG : cl], b1 = ptr[(c + NG < c1 ? c + NG : cl) + 1];
+    for (int i = 2 * tid; i + 1 < nminor; i += 2 * LV_NT)
+        *reinterpret_cast<double2 *>(xs + i) = *reinterpret_cast<const double2 *>(in + i);
+    if (tid == 0 && (nminor & 1)) xs[nminor - 1] = in[nminor - 1];
+    double v[U];
+    int j[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        int k = a0 + gl + u * G;
+        k = k < b0 ? k : (b0 > a0 ? b0 - 1 : a0);
+        v[u] = NTL ? __builtin_nontemporal_load(val + k) : val[k];
+        j[u] = NTL ? __builtin_nontemporal_load(idx + k) : idx[k];
+    }
+    __syncthreads();
+    for (; c < c1; c += NG) {
+        // bounds two majors ahead
+        const int c2 = c + 2 * NG < c1 ? c + 2 * NG : cl;
+        const int a2 = ptr[c2], b2 = ptr[c2 + 1];
+        // data one major ahead
+        double vn[U];
+        int jn[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int k = a1 + gl + u * G;
+            k = k < b1 ? k : (b1 > a1 ? b1 - 1 : a1);
+            vn[u] = NTL ? __builtin_nontemporal_load(val + k) : val[k];
+            jn[u] = NTL ? __builtin_nontemporal_load(idx + k) : idx[k];
+        }
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (a0 + gl + u * G < b0) s += v[u] * xs[j[u]];
+        for (int k = a0 + gl + U * G; k < b0; k += G) s += val[k] * xs[idx[k]];
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (gl == 0) out[c] = s;
+#pragma unroll
+        for (int u = 0; u < U; u++) { v[u] = vn[u]; j[u] = jn[u]; }
+        a0 = a1; b0 = b1; a1 = a2; b1 = b2;
+    }
+}
+
+// two consecutive entries per lane (16-byte value load) and an index type template: when
+// the gathered vector has fewer than 65 536 entries the plan keeps a 16-bit copy of the index
+// array, which cuts the streamed bytes per entry from 12 to 10.
+template <class IDX> struct Idx2;
+template <> struct Idx2<int> { typedef int2 T; };
+template <> struct Idx2<unsigned short> { typedef ushort2 T; };
+
+template <int G, int U, class IDX>
+__global__ void __launch_bounds__(LV_NT)
+csx_ldsvec_spmv_pipe2(int nminor, int nslices, const int *__restrict__ slice, const int *__restrict__ ptr,
+                      const IDX *__restrict__ idx, const double *__restrict__ val, const double *__restrict__ in,
+                      double *__restrict__ out, long long ptr_stride, long long nnz_stride, long long in_stride,
+                      long long out_stride) {
+    typedef typename Idx2<IDX>::T I2;
+    extern __shared__ __attribute__((aligned(16))) double xs[];
+    const int m = blockIdx.x / nslices, sl = blockIdx.x % nslices;
+    ptr += m * ptr_stride; idx += m * nnz_stride; val += m * nnz_stride;
+    in += m * in_stride; out += m * out_stride;
+    const int tid = threadIdx.x;
+    constexpr int NG = LV_NT / G;
+    const int gid = tid / G, gl = tid % G;
+    const int c1 = slice[sl + 1];
+    int c = slice[sl] + gid;
+    const int cl = c1 - 1;
+    int a0 = ptr[c < c1 ? c : cl], b0 = ptr[(c < c1 ? c : cl) + 1];
+    int a1 = ptr[c + NG < c1 ? c + NG : cl], b1 = ptr[(c + NG < c1 ? c + NG : cl) + 1];
+    for (int i = 2 * tid; i + 1 < nminor; i += 2 * LV_NT)
+        *reinterpret_cast<double2 *>(xs + i) = *reinterpret_cast<const double2 *>(in + i);
+    if (tid == 0 && (nminor & 1)) xs[nminor - 1] = in[nminor - 1];
+    double2 v[U];
+    I2 j[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        int k = a0 + 2 * (gl + u * G);
+        const int kc = b0 - 2 > a0 ? b0 - 2 : a0;
+        k = k < kc ? k : kc;
+        __builtin_memcpy(&v[u], val + k, 16);
+        __builtin_memcpy(&j[u], idx + k, sizeof(I2));
+    }
+    __syncthreads();
+    for (; c < c1; c += NG) {
+        const int c2 = c + 2 * NG < c1 ? c + 2 * NG : cl;
+        const int a2 = ptr[c2], b2 = ptr[c2 + 1];
+        double2 vn[U];
+        I2 jn[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int k = a1 + 2 * (gl + u * G);
+            const int kc = b1 - 2 > a1 ? b1 - 2 : a1;
+            k = k < kc ? k : kc;
+            __builtin_memcpy(&vn[u], val + k, 16);
+            __builtin_memcpy(&jn[u], idx + k, sizeof(I2));
+        }
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int k = a0 + 2 * (gl + u * G);
+            const int kc = b0 - 2 > a0 ? b0 - 2 : a0;
+            // a clamped lane re-reads the last pair: use it only when k itself is in range
+            if (k <= kc && k < b0) {
+                s += v[u].x * xs[j[u].x];
+                if (k + 1 < b0) s += v[u].y * xs[j[u].y];
+            } else if (k < b0) {   // k == b0 - 1 > kc: single last entry sits in .y of the clamped pair
+                s += v[u].y * xs[j[u].y];
+            }
+        }
+        for (int k = a0 + gl + 2 * U * G; k < b0; k += G) s += val[k] * xs[idx[k]];
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (gl == 0) out[c] = s;
+#pragma unroll
+        for (int u = 0; u < U; u++) { v[u] = vn[u]; j[u] = jn[u]; }
+        a0 = a1; b0 = b1; a1 = a2; b1 = b2;
     }
 }
 
@@ -181,17 +422,113 @@ small_products_kernel(const QPDesc *desc, const int *Ajc, const int *Air, const 
 // ------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------
-hipError_t rsqp_launch_spmv(const int *blk, int nblk, const int *ptr, const int *idx, const double *val,
+hipError_t rsqp_launch_spmv(const int4 *blkinfo, int nblk, const int *ptr, const int *idx, const double *val,
                             const double *in, double *out, int nbatch, long long ptr_stride,
                             long long nnz_stride, long long in_stride, long long out_stride,
                             hipStream_t stream) {
     if (nblk <= 0 || nbatch <= 0) return hipSuccess;
-    hipLaunchKernelGGL(csx_stream_spmv, dim3(nblk, nbatch), dim3(SPMV_NT), 0, stream, blk, ptr, idx, val, in,
-                       out, ptr_stride, nnz_stride, in_stride, out_stride);
+    const int xcd_map = nbatch >= 8;
+    const long long grid = xcd_map ? (long long)((nbatch + 7) / 8) * 8 * nblk : (long long)nbatch * nblk;
+    hipLaunchKernelGGL(csx_stream_spmv, dim3((unsigned)grid), dim3(SPMV_NT), 0, stream, blkinfo, nblk, nbatch, xcd_map,
+                       ptr, idx, val, in, out, ptr_stride, nnz_stride, in_stride, out_stride);
     return hipGetLastError();
 }
 
-int rsqp_spmv_chunk(void) { return SPMV_CHUNK; }
+// capacity handed to the block builder: a block may start on an odd entry and is then read
+// from the even entry before it, so one slot of the staging array stays in reserve
+hipError_t rsqp_launch_spmv_ldsvec(int variant, int nminor, int nslices, const int *slice, const int *ptr,
+                                   const int *idx, const unsigned short *idx16, const double *val, const double *in, double *out, int nbatch,
+                                   long long ptr_stride, long long nnz_stride, long long in_stride,
+                                   long long out_stride, hipStream_t stream) {
+    const size_t lds = (size_t)nminor * 8 + 16;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+#define LV_LAUNCH(G, U)                                                                                        \
+    do {                                                                                                       \
+        static bool set_ = false;                                                                              \
+        if (!set_) {                                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_ldsvec_spmv<G, U>),                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
+            set_ = true;                                                                                       \
+        }                                                                                                      \
+        hipLaunchKernelGGL((csx_ldsvec_spmv<G, U>), dim3(nbatch * nslices), dim3(LV_NT), lds, stream, nminor,  \
+                           nslices, slice, ptr, idx, val, in, out, ptr_stride, nnz_stride, in_stride,          \
+                           out_stride);                                                                        \
+    } while (0)
+    switch (variant) {
+    case 1: LV_LAUNCH(8, 2); break;
+    case 2: LV_LAUNCH(8, 4); break;
+    case 3: LV_LAUNCH(4, 2); break;
+    case 4: LV_LAUNCH(4, 4); break;
+    case 5: LV_LAUNCH(16, 2); break;
+    case 6: LV_LAUNCH(16, 1); break;
+    case 7: LV_LAUNCH(8, 3); break;
+    case 8: LV_LAUNCH(2, 4); break;
+#define LP_LAUNCH(G, U, N)                                                                                        \
+    do {                                                                                                       \
+        static bool set_ = false;                                                                              \
+        if (!set_) {                                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_ldsvec_spmv_pipe<G, U, N>),             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
+            set_ = true;                                                                                       \
+        }                                                                                                      \
+        hipLaunchKernelGGL((csx_ldsvec_spmv_pipe<G, U, N>), dim3(nbatch * nslices), dim3(LV_NT), lds, stream,     \
+                           nminor, nslices, slice, ptr, idx, val, in, out, ptr_stride, nnz_stride, in_stride,  \
+                           out_stride);                                                                        \
+    } while (0)
+    case 11: LP_LAUNCH(8, 2, false); break;
+    case 12: LP_LAUNCH(8, 4, false); break;
+    case 13: LP_LAUNCH(4, 2, false); break;
+    case 14: LP_LAUNCH(4, 4, false); break;
+    case 15: LP_LAUNCH(8, 3, false); break;
+    case 16: LP_LAUNCH(4, 3, false); break;
+    case 17: LP_LAUNCH(8, 6, false); break;
+    case 18: LP_LAUNCH(8, 8, false); break;
+    case 19: LP_LAUNCH(4, 6, false); break;
+    case 22: LP_LAUNCH(8, 4, true); break;
+    case 24: LP_LAUNCH(4, 4, true); break;
+    case 27: LP_LAUNCH(8, 6, true); break;
+    case 29: LP_LAUNCH(4, 6, true); break;
+#undef LP_LAUNCH
+#define L2_LAUNCH(G, U)                                                                                        \
+    do {                                                                                                       \
+        if (idx16) {                                                                                           \
+            static bool set_ = false;                                                                          \
+            if (!set_) {                                                                                       \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_ldsvec_spmv_pipe2<G, U, unsigned short>), \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);             \
+                set_ = true;                                                                                   \
+            }                                                                                                  \
+            hipLaunchKernelGGL((csx_ldsvec_spmv_pipe2<G, U, unsigned short>), dim3(nbatch * nslices),          \
+                               dim3(LV_NT), lds, stream, nminor, nslices, slice, ptr, idx16, val, in, out,     \
+                               ptr_stride, nnz_stride, in_stride, out_stride);                                 \
+        } else {                                                                                               \
+            static bool set_ = false;                                                                          \
+            if (!set_) {                                                                                       \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_ldsvec_spmv_pipe2<G, U, int>),   \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);             \
+                set_ = true;                                                                                   \
+            }                                                                                                  \
+            hipLaunchKernelGGL((csx_ldsvec_spmv_pipe2<G, U, int>), dim3(nbatch * nslices), dim3(LV_NT), lds,   \
+                               stream, nminor, nslices, slice, ptr, idx, val, in, out, ptr_stride, nnz_stride, \
+                               in_stride, out_stride);                                                         \
+        }                                                                                                      \
+    } while (0)
+    case 31: L2_LAUNCH(2, 2); break;
+    case 32: L2_LAUNCH(2, 3); break;
+    case 33: L2_LAUNCH(4, 1); break;
+    case 34: L2_LAUNCH(4, 2); break;
+    case 35: L2_LAUNCH(4, 3); break;
+    case 36: L2_LAUNCH(8, 1); break;
+    case 37: L2_LAUNCH(8, 2); break;
+    case 38: L2_LAUNCH(2, 4); break;
+#undef L2_LAUNCH
+    default: return hipErrorInvalidValue;
+    }
+#undef LV_LAUNCH
+    return hipGetLastError();
+}
+
+int rsqp_spmv_chunk(void) { return SPMV_CHUNK - 2; }
 
 hipError_t rsqp_launch_scatter(int n, const int *order, const int *tmap, const double *tv, double *val,
                                hipStream_t stream) {

@@ -302,6 +302,20 @@ def test_spmv_batched_parity_and_properties(capi, oracle):
         aty = oracle.sphb_transposed_times(500, 300, jc, ir, vals[k], y[k])
         assert np.abs(Ax[k] - ax).max() <= 4 * 30 * 2.3e-16 * np.abs(ax).max() + 1e-300
         assert np.array_equal(ATy[k], aty)   # same entry order as the reference loop: bit-exact
+    # LDS-resident-vector kernel (chosen for batches >= 64): fixed-shape tree reduction, so the
+    # bound is the summation-order tolerance, not bit equality
+    jc, ir, rng = problems.sparse_pattern(700, 900, 9000, seed=9)
+    nb = 64
+    vals = rng.normal(size=(nb, 9000)); x = rng.normal(size=(nb, 700)); y = rng.normal(size=(nb, 900))
+    p = capi.SpmvPlan(900, 700, jc, ir, nb)
+    p.upload(vals, x, transposed=False); p.upload(None, y, transposed=True)
+    p.run(False); p.run(True)
+    Ax, ATy = p.download(False), p.download(True)
+    for k in range(0, nb, 7):
+        ax = oracle.sphb_times(900, 700, jc, ir, vals[k], x[k])
+        aty = oracle.sphb_transposed_times(900, 700, jc, ir, vals[k], y[k])
+        assert np.abs(Ax[k] - ax).max() <= 4 * 40 * 2.3e-16 * max(1.0, np.abs(ax).max())
+        assert np.abs(ATy[k] - aty).max() <= 4 * 40 * 2.3e-16 * max(1.0, np.abs(aty).max())
     # full size
     n, m, nnz = 10000, 20000, 200000
     jc, ir, rng = problems.sparse_pattern(n, m, nnz)
