@@ -43,6 +43,21 @@ def qp_algorithmic_bytes(q):
     return inp + out
 
 
+def pmc_traffic(substr, fetch_factor):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
+    are collected in separate runs and reported in KiB). MI355X_MICROARCH.md: on gfx950
+    FETCH_SIZE counts half the bytes of wide coalesced streaming reads -> fetch_factor 2 for
+    the streaming SpMV; WRITE_SIZE is exact. Returns None when no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    for k, v in d.items():
+        if substr in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            return fetch_factor * v["FETCH_SIZE"]["mean_per_dispatch"] * 1024 + v["WRITE_SIZE"]["mean_per_dispatch"] * 1024
+    return None
+
+
 def spmv_roofline(capi, problems, nbatch, repeats):
     n, m, nnz = 10000, 20000, 200000
     jc, ir, rng = problems.sparse_pattern(n, m, nnz)
@@ -63,7 +78,9 @@ def spmv_roofline(capi, problems, nbatch, repeats):
     streamed = (10 * nnz + 4 * (n + 1) + 8 * n + 8 * m) * nbatch
     res = {"kernel": "csx_ldsvec_spmv_pipe2 (A'y on CSC = SpHbMat::transposed_times; input vector resident in LDS)",
            "bound": "hbm", "achieved": best["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": best["achieved"] / HBM_PEAK_GBS, "traffic": None, "matrices_per_launch": nbatch,
+           "frac": best["achieved"] / HBM_PEAK_GBS,
+           "traffic": pmc_traffic("csx_ldsvec_spmv_pipe2<4, 3", 2.0) if nbatch == 256 else None,
+           "matrices_per_launch": nbatch,
            "bytes_per_matrix": 12 * nnz + 4 * (n + 1) + 8 * n + 8 * m, "ms_per_launch": best["ms_per_launch"],
            "streamed_bytes_per_launch_est": streamed, "raw_stream_GBs_est": streamed / (best["ms_per_launch"] * 1e-3) / 1e9,
            "Ax_csr_GBs": out["Ax_csr"]["achieved"], "Ax_csr_frac": out["Ax_csr"]["achieved"] / HBM_PEAK_GBS}
@@ -171,7 +188,10 @@ def main():
                        "qps_per_gpu": B, "engine": "small_qp_kernel<64> (one wave per QP, LDS-resident)",
                        "mean_nWSR": float(np.mean([r["nWSR"] for r in res])), "unsolved_or_kkt_fail": n_bad},
             "roofline": {"kernel": "small_qp_kernel<64>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic("small_qp_kernel", 1.0) if B == 16384 else None,
+                         "traffic_note": "FETCH_SIZE uncorrected (narrow loads, uncalibrated) + WRITE_SIZE; the "
+                                         "writes are the 3.2 KB/QP engine image kept for hot starts",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "latency/LDS-bound kernel: HBM fraction is not its limiter"},
         }
