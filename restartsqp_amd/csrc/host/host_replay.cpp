@@ -2,7 +2,7 @@
 // first two SQP iterations of hs071 (reference src/Algorithm.cpp:645-697 -> src/QPhandler.cpp):
 // set_A, set_H, per-element bounds, per-element g, optimizeQP, test_optimality; then a
 // trust-region update (update_delta) and a hot start. Prints one line per solve; the GPU test
-// tests/test_gpu_host_adapter.py compares the lines with the oracle.
+// tests/test_gpu_host_adapter.py compares the lines with the CPU reference restatement kept under tests.
 #include <cmath>
 #include <cstdio>
 #include <limits>
