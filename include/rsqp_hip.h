@@ -81,6 +81,11 @@ const char *rsqp_last_error(void);
  * plain-QP ctor (:54-94). device < 0 selects the current device. */
 int rsqp_create(int nV, int nC, int device, rsqp_solver **out);
 void rsqp_destroy(rsqp_solver *s);
+/* engine selection: 0 = automatic (the LDS-resident kernel when the problem image fits the
+ * 160 KiB of one CU, the HBM-resident engine otherwise), 1 = LDS-resident, 2 = HBM-resident.
+ * Both run entirely on the GPU; there is no CPU path. Call before the first solve. */
+int rsqp_set_engine(rsqp_solver *s, int engine);
+int rsqp_get_engine(const rsqp_solver *s);
 /* Options fields the adapter reads: qp_maxiter, lp_maxiter (Options.cpp:45,54) */
 int rsqp_set_options(rsqp_solver *s, int qp_maxiter, int lp_maxiter);
 

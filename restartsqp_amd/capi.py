@@ -30,6 +30,8 @@ SYMBOLS = {
     "rsqp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "rsqp_destroy": (None, [C.c_void_p]),
     "rsqp_set_options": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "rsqp_set_engine": (C.c_int, [C.c_void_p, C.c_int]),
+    "rsqp_get_engine": (C.c_int, [C.c_void_p]),
     "rsqp_set_A_triplet": (C.c_int, [C.c_void_p, C.c_int, ip, ip, dp, C.c_int, ip, ip, ip, dp]),
     "rsqp_set_H_triplet": (C.c_int, [C.c_void_p, C.c_int, ip, ip, dp, C.c_int]),
     "rsqp_set_A_csc": (C.c_int, [C.c_void_p, ip, ip, dp]),
@@ -145,6 +147,14 @@ class Solver:
             self._h = None
 
     __del__ = close
+
+    def set_engine(self, engine):
+        """0 automatic, 1 LDS-resident kernel, 2 HBM-resident engine."""
+        check(lib().rsqp_set_engine(self._h, engine))
+
+    @property
+    def engine(self):
+        return lib().rsqp_get_engine(self._h)
 
     def set_options(self, qp_maxiter=1000, lp_maxiter=100):
         check(lib().rsqp_set_options(self._h, qp_maxiter, lp_maxiter))

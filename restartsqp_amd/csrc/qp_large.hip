@@ -1,0 +1,1152 @@
+// qp_large.hip -- HBM-resident online active-set QP engine for problems that do not fit the
+// LDS-resident kernel (qp_small.hip): dense n=2048 x m=4096, sparse n=10k x m=20k.
+//
+// Same algorithm and decisions as qp_small.hip / the CPU restatement (homotopy, ratio tests
+// with lowest-candidate-id tie break, exchange on linear dependence, bound flipping), but the
+// null-space machinery is re-derived for a chip whose strength is wide bandwidth-bound
+// kernels, not long dependent chains:
+//
+//   Z  (nV x nZ)   orthonormal basis of the null space of the active rows on the free variables
+//   Y  (nV x nAC)  orthonormal basis of its complement
+//   Minv (nAC x nAC) = (A_AC,FR * Y)^-1          (row i <-> column i of Y, column j <-> AC[j])
+//   Wz   (nZ x nZ)   = (Z' H Z)^-1
+//
+// Every working-set change is a Householder reflection (rank-1 update) of Z or Y plus
+// Sherman-Morrison / bordering updates of the two explicit inverses; every solve of the step
+// direction is a GEMV. No triangular factor, no Givens chain: each operation is a handful of
+// GEMV / GER-shaped kernels that stream Z, Y, Minv, Wz once at HBM speed. Deleting a column
+// never moves a matrix: the reflection is aimed at the LAST column, which is then dropped;
+// deleting constraint k of Minv moves one column. The step directions are independent of the
+// choice of basis, so iterates and decisions equal those of the Givens formulation up to
+// rounding. Control flow runs on the host: it reads back a few scalars per working-set change
+// (ratio-test winner, independence / definiteness tests).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "rsqp_large.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ---------------------------------------------------------------------------------
+// dense building blocks (column-major, leading dimension ld)
+// ---------------------------------------------------------------------------------
+__device__ inline double block_sum(double v, double *sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// out[c] = sum_r M[c*ld + r] * x[r]      (one workgroup per column)
+__global__ void __launch_bounds__(NT) k_gemv_t(const double *__restrict__ M, long long ld, int nrows, int ncols,
+                                               const double *__restrict__ x, double *__restrict__ out) {
+    __shared__ double sh[4];
+    const int c = blockIdx.x;
+    if (c >= ncols) return;
+    const double *col = M + c * ld;
+    double s = 0.0;
+    for (int r = threadIdx.x; r < nrows; r += NT) s += col[r] * x[r];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) out[c] = s;
+}
+
+// partial[chunk*nrows + r] = sum_{c in chunk} M[c*ld + r] * w[c]
+constexpr int GEMV_CHUNK = 64;
+__global__ void __launch_bounds__(NT) k_gemv_n_part(const double *__restrict__ M, long long ld, int nrows, int ncols,
+                                                    const double *__restrict__ w, double *__restrict__ part) {
+    const int r = blockIdx.x * NT + threadIdx.x;
+    const int c0 = blockIdx.y * GEMV_CHUNK, c1 = min(c0 + GEMV_CHUNK, ncols);
+    if (r >= nrows) return;
+    double s = 0.0;
+    for (int c = c0; c < c1; c++) s += M[c * ld + r] * w[c];
+    part[(long long)blockIdx.y * nrows + r] = s;
+}
+// out[r] = beta * base[r] + alpha * sum_chunks part
+__global__ void k_gemv_n_reduce(const double *__restrict__ part, int nrows, int nchunks, double alpha, double beta,
+                                const double *__restrict__ base, double *__restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    double s = 0.0;
+    for (int k = 0; k < nchunks; k++) s += part[(long long)k * nrows + r];
+    out[r] = (base ? beta * base[r] : 0.0) + alpha * s;
+}
+
+// M[c*ld + r] += coef * t[r] * v[c]   (coef = scal[ci] * cs)
+__global__ void __launch_bounds__(NT) k_ger(double *__restrict__ M, long long ld, int nrows, int ncols,
+                                            const double *__restrict__ t, const double *__restrict__ v,
+                                            const double *__restrict__ scal, int ci, double cs) {
+    const int r = blockIdx.x * NT + threadIdx.x, c = blockIdx.y;
+    if (r >= nrows || c >= ncols) return;
+    M[c * ld + r] += cs * scal[ci] * t[r] * v[c];
+}
+
+// scal[slot] = sum_i a[i]*b[i]
+__global__ void __launch_bounds__(NT) k_dot(const double *__restrict__ a, const double *__restrict__ b, int n,
+                                            double *__restrict__ scal, int slot) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += NT) s += a[i] * b[i];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) scal[slot] = s;
+}
+
+__global__ void k_copy(const double *__restrict__ src, double *__restrict__ dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+__global__ void k_fill(double *__restrict__ dst, int n, double v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+// dst[c] = M[c*ld + row]   (row of a column-major matrix)
+__global__ void k_get_row(const double *__restrict__ M, long long ld, int row, int ncols, double *__restrict__ dst) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < ncols) dst[c] = M[c * ld + row];
+}
+__global__ void k_set_row(double *__restrict__ M, long long ld, int row, int ncols, const double *__restrict__ src,
+                          double scale) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < ncols) M[c * ld + row] = src ? scale * src[c] : 0.0;
+}
+
+// Householder vector for mapping w (length n) onto its LAST component:
+//   alpha = |w|, v = w, v[n-1] += sgn(w[n-1]) alpha, beta = 1 / (alpha (alpha + |w[n-1]|)),
+//   P = I - beta v v' maps w to  -sgn(w[n-1]) alpha e_last.
+// scal[s0] = alpha, scal[s0+1] = beta, scal[s0+2] = -sgn(w_last) (sign of the image), scal[s0+3] = |w|^2
+__global__ void __launch_bounds__(NT) k_house(const double *__restrict__ w, int n, double *__restrict__ v,
+                                              double *__restrict__ scal, int s0) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += NT) s += w[i] * w[i];
+    s = block_sum(s, sh);
+    const double alpha = sqrt(s), wl = w[n - 1], sg = wl >= 0.0 ? 1.0 : -1.0;
+    for (int i = threadIdx.x; i < n; i += NT) v[i] = w[i] + (i == n - 1 ? sg * alpha : 0.0);
+    if (threadIdx.x == 0) {
+        scal[s0] = alpha;
+        scal[s0 + 1] = alpha > 0.0 ? 1.0 / (alpha * (alpha + fabs(wl))) : 0.0;
+        scal[s0 + 2] = -sg;
+        scal[s0 + 3] = s;
+    }
+}
+
+// ---- Wz updates ------------------------------------------------------------------
+// two-sided reflection + elimination of the last row/column (null space loses its last
+// column after the reflection P = I - beta v v'):
+//   Wt = P Wz P ;  Wz' = Wt_11 - Wt_12 Wt_12' / Wt_22
+// with s = Wz v, theta = v's:  Wt[a][b] = Wz[a][b] - beta s_a v_b - beta v_a s_b + beta^2 theta v_a v_b
+// col[a] = Wt[a][last] is prepared by k_wz_lastcol; then one pass over the leading block.
+__global__ void k_wz_lastcol(const double *__restrict__ Wz, long long ld, int nZ, const double *__restrict__ s,
+                             const double *__restrict__ v, const double *__restrict__ scal, int sb, int st,
+                             double *__restrict__ col) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= nZ) return;
+    const int l = nZ - 1;
+    const double beta = scal[sb], theta = scal[st];
+    col[a] = Wz[(long long)l * ld + a] - beta * s[a] * v[l] - beta * v[a] * s[l] + beta * beta * theta * v[a] * v[l];
+}
+__global__ void __launch_bounds__(NT) k_wz_shrink(double *__restrict__ Wz, long long ld, int nZ,
+                                                  const double *__restrict__ s, const double *__restrict__ v,
+                                                  const double *__restrict__ col, const double *__restrict__ scal, int sb,
+                                                  int st) {
+    const int a = blockIdx.x * NT + threadIdx.x, b = blockIdx.y;
+    const int l = nZ - 1;
+    if (a >= l || b >= l) return;
+    const double beta = scal[sb], theta = scal[st], w22 = col[l];
+    Wz[(long long)b * ld + a] += -beta * s[a] * v[b] - beta * v[a] * s[b] + beta * beta * theta * v[a] * v[b] -
+                                 col[a] * col[b] / w22;
+}
+// bordering (null space gains column nZ): u = Wz k, rho2 = kappa - k'u
+//   Wz' = [[Wz + u u'/rho2, -u/rho2], [-u'/rho2, 1/rho2]]
+__global__ void __launch_bounds__(NT) k_wz_grow(double *__restrict__ Wz, long long ld, int nZ,
+                                                const double *__restrict__ u, const double *__restrict__ scal, int sr) {
+    const int a = blockIdx.x * NT + threadIdx.x, b = blockIdx.y;
+    if (a > nZ || b > nZ) return;
+    const double r2 = scal[sr];
+    double val;
+    if (a < nZ && b < nZ) val = Wz[(long long)b * ld + a] + u[a] * u[b] / r2;
+    else if (a == nZ && b == nZ) val = 1.0 / r2;
+    else val = -u[a < nZ ? a : b] / r2;
+    Wz[(long long)b * ld + a] = val;
+}
+
+// ---- sparse helpers ---------------------------------------------------------------
+// a[v] = A[row][v] for free v (all: every v), 0 elsewhere
+__global__ void k_row_of_A(const int *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ rv,
+                           int row, const int *__restrict__ Sb, int all, double *__restrict__ a) {
+    for (int k = rp[row] + blockIdx.x * blockDim.x + threadIdx.x; k < rp[row + 1]; k += gridDim.x * blockDim.x) {
+        const int c = ci[k];
+        if (all || Sb[c] == 0) a[c] = rv[k];
+    }
+}
+// out[j] = A[AC[j]][v]   (column v restricted to the active rows; pos = position of a row in AC or -1)
+__global__ void k_col_of_A_active(const int *__restrict__ jc, const int *__restrict__ ir, const double *__restrict__ val,
+                                  int v, const int *__restrict__ pos, double *__restrict__ out) {
+    for (int k = jc[v] + blockIdx.x * blockDim.x + threadIdx.x; k < jc[v + 1]; k += gridDim.x * blockDim.x) {
+        const int p = pos[ir[k]];
+        if (p >= 0) out[p] = val[k];
+    }
+}
+// gather / scatter between constraint-indexed vectors and working-set positions
+__global__ void k_gather_active(const double *__restrict__ full, const int *__restrict__ AC, int nAC,
+                                double *__restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nAC) out[j] = full[AC[j]];
+}
+__global__ void k_scatter_active(const double *__restrict__ act, const int *__restrict__ AC, int nAC,
+                                 double *__restrict__ full) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nAC) full[AC[j]] = act[j];
+}
+
+// ---- homotopy element-wise kernels --------------------------------------------------
+__device__ inline double delta_of(double target, double cur) {
+    return (fabs(target) >= RSQP_INFTY && fabs(cur) >= RSQP_INFTY) ? 0.0 : target - cur;
+}
+
+// dx on fixed variables, zero elsewhere
+__global__ void k_dx_fixed(int nV, const int *__restrict__ Sb, const double *__restrict__ lb,
+                           const double *__restrict__ ub, const double *__restrict__ lbN, const double *__restrict__ ubN,
+                           double *__restrict__ dx) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nV) dx[v] = Sb[v] == -1 ? delta_of(lbN[v], lb[v]) : (Sb[v] == 1 ? delta_of(ubN[v], ub[v]) : 0.0);
+}
+// bA[j] = delta b (AC[j]) - (A dx_FX)[AC[j]]
+__global__ void k_rhs_active(int nAC, const int *__restrict__ AC, const int *__restrict__ Sc,
+                             const double *__restrict__ lbA, const double *__restrict__ ubA,
+                             const double *__restrict__ lbAN, const double *__restrict__ ubAN,
+                             const double *__restrict__ Adx, double *__restrict__ bA) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nAC) return;
+    const int r = AC[j];
+    bA[j] = (Sc[r] == -1 ? delta_of(lbAN[r], lbA[r]) : delta_of(ubAN[r], ubA[r])) - Adx[r];
+}
+// out = a + (gN - g)   (a may be null)
+__global__ void k_add_dg(int nV, const double *__restrict__ a, const double *__restrict__ gN, const double *__restrict__ g,
+                         double *__restrict__ out) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nV) out[v] = (a ? a[v] : 0.0) + (gN[v] - g[v]);
+}
+__global__ void k_axpby(int n, double a, const double *__restrict__ x, double b, const double *__restrict__ y,
+                        double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a * x[i] + (y ? b * y[i] : 0.0);
+}
+// dx[v] = free ? xfree[v] : dx[v]
+__global__ void k_merge_free(int nV, const int *__restrict__ Sb, const double *__restrict__ xfree, double *__restrict__ dx) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nV && Sb[v] == 0) dx[v] = xfree[v];
+}
+// dy on fixed variables: res - A'dy_C, zero on free ones
+__global__ void k_dy_fixed(int nV, const int *__restrict__ Sb, const double *__restrict__ res,
+                           const double *__restrict__ ATdy, double *__restrict__ dy) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nV) dy[v] = Sb[v] != 0 ? res[v] - ATdy[v] : 0.0;
+}
+
+// ratio tests: candidate ids as in qp_small.hip; stage 1 per workgroup, stage 2 one workgroup
+__device__ inline void cand(double num, double den, int id, double &bt, int &bid) {
+    if (den >= RSQP_EPS_DEN) {
+        const double t = (num > 0.0 ? num : 0.0) / den;
+        if (t < bt || (t == bt && id < bid)) { bt = t; bid = id; }
+    }
+}
+__device__ inline void argmin_reduce(double &t, int &id, double *sht, int *shi) {
+    for (int o = 32; o > 0; o >>= 1) {
+        const double t2 = __shfl_xor(t, o);
+        const int id2 = __shfl_xor(id, o);
+        if (t2 < t || (t2 == t && id2 < id)) { t = t2; id = id2; }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sht[threadIdx.x >> 6] = t; shi[threadIdx.x >> 6] = id; }
+    __syncthreads();
+    t = sht[0]; id = shi[0];
+    for (int w = 1; w < NT / 64; w++)
+        if (sht[w] < t || (sht[w] == t && shi[w] < id)) { t = sht[w]; id = shi[w]; }
+}
+__global__ void __launch_bounds__(NT)
+k_ratio1(int nV, int nC, const int *__restrict__ Sb, const int *__restrict__ Sc, const double *__restrict__ x,
+         const double *__restrict__ y, const double *__restrict__ dx, const double *__restrict__ dy,
+         const double *__restrict__ Ax, const double *__restrict__ dAx, const double *__restrict__ lb,
+         const double *__restrict__ ub, const double *__restrict__ lbA, const double *__restrict__ ubA,
+         const double *__restrict__ lbN, const double *__restrict__ ubN, const double *__restrict__ lbAN,
+         const double *__restrict__ ubAN, double *__restrict__ pt, int *__restrict__ pid) {
+    __shared__ double sht[4];
+    __shared__ int shi[4];
+    double bt = 1.0;
+    int bid = 0x7fffffff;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < nC + nV; i += gridDim.x * NT) {
+        if (i < nC) {
+            const double Axi = Ax[i], dA = dAx[i];
+            if (Sc[i] != 0) {
+                const double yi = y[nV + i], d = dy[nV + i];
+                if (Sc[i] == -1) cand(yi, -d, i, bt, bid); else cand(-yi, d, i, bt, bid);
+            } else {
+                if (lbAN[i] > -RSQP_INFTY) cand(Axi - lbA[i], delta_of(lbAN[i], lbA[i]) - dA, nC + nV + i, bt, bid);
+                if (ubAN[i] < RSQP_INFTY) cand(ubA[i] - Axi, dA - delta_of(ubAN[i], ubA[i]), 2 * nC + nV + i, bt, bid);
+            }
+        } else {
+            const int v = i - nC;
+            if (Sb[v] != 0) {
+                const double yi = y[v], d = dy[v];
+                if (Sb[v] == -1) cand(yi, -d, nC + v, bt, bid); else cand(-yi, d, nC + v, bt, bid);
+            } else {
+                if (lbN[v] > -RSQP_INFTY) cand(x[v] - lb[v], delta_of(lbN[v], lb[v]) - dx[v], 3 * nC + nV + v, bt, bid);
+                if (ubN[v] < RSQP_INFTY) cand(ub[v] - x[v], dx[v] - delta_of(ubN[v], ub[v]), 3 * nC + 2 * nV + v, bt, bid);
+            }
+        }
+    }
+    if (!(bt < 1.0)) { bt = 1.0; bid = 0x7fffffff; }
+    argmin_reduce(bt, bid, sht, shi);
+    if (threadIdx.x == 0) { pt[blockIdx.x] = bt; pid[blockIdx.x] = bid; }
+}
+__global__ void __launch_bounds__(NT) k_argmin2(int n, const double *__restrict__ pt, const int *__restrict__ pid,
+                                                double *__restrict__ out_t, int *__restrict__ out_id) {
+    __shared__ double sht[4];
+    __shared__ int shi[4];
+    double bt = RSQP_INFTY * 10.0;
+    int bid = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += NT)
+        if (pt[i] < bt || (pt[i] == bt && pid[i] < bid)) { bt = pt[i]; bid = pid[i]; }
+    argmin_reduce(bt, bid, sht, shi);
+    if (threadIdx.x == 0) { *out_t = bt; *out_id = bid; }
+}
+
+// homotopy step; done: data := targets
+__global__ void k_step_v(int nV, double tau, int done, const int *__restrict__ Sb, double *__restrict__ x,
+                         double *__restrict__ g, double *__restrict__ lb, double *__restrict__ ub,
+                         const double *__restrict__ gN, const double *__restrict__ lbN, const double *__restrict__ ubN,
+                         const double *__restrict__ dx) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nV) return;
+    if (done) {
+        g[v] = gN[v]; lb[v] = lbN[v]; ub[v] = ubN[v];
+        x[v] = Sb[v] == -1 ? lb[v] : (Sb[v] == 1 ? ub[v] : x[v] + tau * dx[v]);
+    } else {
+        x[v] += tau * dx[v];
+        g[v] += tau * (gN[v] - g[v]);
+        lb[v] += tau * delta_of(lbN[v], lb[v]);
+        ub[v] += tau * delta_of(ubN[v], ub[v]);
+    }
+}
+__global__ void k_step_c(int nC, double tau, int done, double *__restrict__ lbA, double *__restrict__ ubA,
+                         const double *__restrict__ lbAN, const double *__restrict__ ubAN) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nC) return;
+    if (done) { lbA[i] = lbAN[i]; ubA[i] = ubAN[i]; }
+    else { lbA[i] += tau * delta_of(lbAN[i], lbA[i]); ubA[i] += tau * delta_of(ubAN[i], ubA[i]); }
+}
+__global__ void k_axpy(int n, double a, const double *__restrict__ x, double *__restrict__ y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += a * x[i];
+}
+// drift correction pieces
+__global__ void k_fix_x(int nV, const int *__restrict__ Sb, const double *__restrict__ lb, const double *__restrict__ ub,
+                        double *__restrict__ x) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nV && Sb[v] != 0) x[v] = Sb[v] == -1 ? lb[v] : ub[v];
+}
+__global__ void k_fix_bA(int nC, const int *__restrict__ Sc, const double *__restrict__ Ax, double *__restrict__ lbA,
+                         double *__restrict__ ubA) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nC) { if (Sc[i] == -1) lbA[i] = Ax[i]; else if (Sc[i] == 1) ubA[i] = Ax[i]; }
+}
+__global__ void k_fix_g(int nV, const double *__restrict__ ATy, const double *__restrict__ y, const double *__restrict__ Hx,
+                        double *__restrict__ g) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nV) g[v] = ATy[v] + y[v] - Hx[v];
+}
+__global__ void k_set1(double *p, int i, double v) { p[i] = v; }
+__global__ void k_seti(int *p, int i, int v) { p[i] = v; }
+__global__ void k_copy1(double *dst, int di, const double *src, int si) { dst[di] = src[si]; }
+
+// exchange partner search (ensure_LI): xiC over constraints (by index), xiB over variables
+__global__ void __launch_bounds__(NT)
+k_partner1(int nV, int nC, const int *__restrict__ Sb, const int *__restrict__ Sc, const double *__restrict__ y,
+           const double *__restrict__ xiC, const double *__restrict__ xiB, double sgn, double *__restrict__ pt,
+           int *__restrict__ pid) {
+    __shared__ double sht[4];
+    __shared__ int shi[4];
+    double bt = RSQP_INFTY;
+    int bid = 0x7fffffff;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < nC + nV; i += gridDim.x * NT) {
+        const int s = i < nC ? Sc[i] : Sb[i - nC];
+        if (s == 0) continue;
+        const double xi = sgn * (i < nC ? xiC[i] : xiB[i - nC]), yi = i < nC ? y[nV + i] : y[i - nC];
+        const double num = s == -1 ? yi : -yi, den = s == -1 ? xi : -xi;
+        if (den > RSQP_EPS_DEN) {
+            const double t = (num > 0.0 ? num : 0.0) / den;
+            if (t < bt || (t == bt && i < bid)) { bt = t; bid = i; }
+        }
+    }
+    argmin_reduce(bt, bid, sht, shi);
+    if (threadIdx.x == 0) { pt[blockIdx.x] = bt; pid[blockIdx.x] = bid; }
+}
+// y -= t * sgn * xi on the active entries
+__global__ void k_shift_duals(int nV, int nC, const int *__restrict__ Sb, const int *__restrict__ Sc, double t, double sgn,
+                              const double *__restrict__ xiC, const double *__restrict__ xiB, double *__restrict__ y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nV + nC) return;
+    if (i < nV) { if (Sb[i] != 0) y[i] -= t * sgn * xiB[i]; }
+    else if (Sc[i - nV] != 0) y[i] -= t * sgn * xiC[i - nV];
+}
+// xiB[v] = fixed ? a[v] - ATxi[v] : 0
+__global__ void k_xiB(int nV, const int *__restrict__ Sb, const double *__restrict__ a, const double *__restrict__ ATxi,
+                      double *__restrict__ xiB) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nV) xiB[v] = Sb[v] != 0 ? a[v] - ATxi[v] : 0.0;
+}
+
+// auxiliary-QP data (setup_aux tail)
+__global__ void k_aux_v(int nV, const int *__restrict__ Sb, const double *__restrict__ x, const double *__restrict__ ATy,
+                        const double *__restrict__ y, const double *__restrict__ Hx, const double *__restrict__ lbN,
+                        const double *__restrict__ ubN, double *__restrict__ g, double *__restrict__ lb,
+                        double *__restrict__ ub) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nV) return;
+    const double xv = x[v];
+    g[v] = ATy[v] + y[v] - Hx[v];
+    lb[v] = Sb[v] == -1 ? xv : fmin(lbN[v], xv - RSQP_BOUND_RELAXATION);
+    ub[v] = Sb[v] == 1 ? xv : fmax(ubN[v], xv + RSQP_BOUND_RELAXATION);
+}
+__global__ void k_aux_c(int nC, const int *__restrict__ Sc, const double *__restrict__ Ax, const double *__restrict__ lbAN,
+                        const double *__restrict__ ubAN, double *__restrict__ lbA, double *__restrict__ ubA) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nC) return;
+    const double ax = Ax[i];
+    lbA[i] = Sc[i] == -1 ? ax : fmin(lbAN[i], ax - RSQP_BOUND_RELAXATION);
+    ubA[i] = Sc[i] == 1 ? ax : fmax(ubAN[i], ax + RSQP_BOUND_RELAXATION);
+}
+__global__ void k_clamp_copy(int n, const double *__restrict__ src, double *__restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = fmin(fmax(src[i], -RSQP_INFTY), RSQP_INFTY);
+}
+__global__ void k_rerelax(int n, const int *__restrict__ S, const double *__restrict__ pos, const double *__restrict__ loN,
+                          const double *__restrict__ hiN, double *__restrict__ lo, double *__restrict__ hi) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (S[i] != -1 && lo[i] <= -RSQP_INFTY && loN[i] > -RSQP_INFTY) lo[i] = fmin(loN[i], pos[i] - RSQP_BOUND_RELAXATION);
+    if (S[i] != 1 && hi[i] >= RSQP_INFTY && hiN[i] < RSQP_INFTY) hi[i] = fmax(hiN[i], pos[i] + RSQP_BOUND_RELAXATION);
+}
+
+inline dim3 g1(int n) { return dim3((unsigned)((n + NT - 1) / NT)); }
+
+// ---- small single-thread / utility kernels -----------------------------------------------
+__global__ void k_minv_border(double *Minv, long long ldm, int nAC, const double *row,
+                                                     const double *scal, int es) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > nAC) return;
+    const double eta = scal[es];
+    if (j < nAC) {
+        Minv[(long long)j * ldm + nAC] = -row[j] / eta;   // new row nAC
+        Minv[(long long)nAC * ldm + j] = 0.0;             // new column nAC
+    } else {
+        Minv[(long long)nAC * ldm + nAC] = 1.0 / eta;
+    }
+}
+__global__ void k_eta_from_house(double *scal) { scal[5] = scal[2] * scal[0]; }
+// a1[0..nAC) = qY, a1[nAC] = q*: unit vector. vt = q~ with last += sgn(q*); beta~ = 1/(1+|q*|),
+// gamma = beta~/(1 - beta~ |qY|^2) = beta~/|q*|
+__global__ void k_house_unit(double *a1, int nAC, double *scal) {
+    const double qs = a1[nAC], sg = qs >= 0.0 ? 1.0 : -1.0, aq = fabs(qs);
+    const double beta = 1.0 / (1.0 + aq);
+    a1[nAC] = qs + sg;
+    scal[8] = beta;
+    scal[9] = beta / aq;
+    scal[10] = qs + sg;
+}
+__global__ void k_axpy_s(int n, const double *scal, int si, const double *x, double *y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += scal[si] * x[i];
+}
+// a1 = c (= Minv a_v) on entry; on exit a1 = vY = -c; nu = sqrt(1+|c|^2); vlast = 1 + nu; beta~ = 1/(nu(nu+1))
+__global__ void k_house_free(double *a1, int nAC, double *scal) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nAC; i += NT) s += a1[i] * a1[i];
+    s = block_sum(s, sh);
+    for (int i = threadIdx.x; i < nAC; i += NT) a1[i] = -a1[i];
+    if (threadIdx.x == 0) {
+        const double nu = sqrt(1.0 + s);
+        scal[8] = 1.0 / (nu * (nu + 1.0));
+        scal[10] = 1.0 + nu;
+    }
+}
+__global__ void k_add_scal_at(double *w, int v, const double *scal, int si) { w[v] += scal[si]; }
+__global__ void k_newcol_free(int nV, int v, const double *t, const double *scal, double *znew) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nV) znew[i] = (i == v ? 1.0 : 0.0) - scal[8] * t[i] * scal[10];
+}
+__global__ void k_sm_coef(double *scal) { scal[16] = scal[8] / (1.0 - scal[8] * scal[15]); }
+__global__ void k_rho2(double *scal) {
+    const double kappa = scal[11], ku = scal[12];
+    scal[13] = kappa - ku;
+    scal[14] = RSQP_EPS_PD_REL * (fabs(kappa) + fabs(ku)) + RSQP_EPS_PD_ABS;
+}
+__global__ void k_clip_y(int nV, int nC, const int *Sb, const int *Sc, double *y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nV + nC) return;
+    const int s = i < nV ? Sb[i] : Sc[i - nV];
+    const double yi = y[i];
+    if (s == 0 || (s == -1 && yi < 0.0) || (s == 1 && yi > 0.0)) y[i] = 0.0;
+}
+
+
+}  // namespace
+
+// =====================================================================================
+// host-side engine
+// =====================================================================================
+#define LCHK(call)                                             \
+    do {                                                       \
+        hipError_t e_ = (call);                                \
+        if (e_ != hipSuccess) { err_ = e_; return RET_SETUP_FAILED; } \
+    } while (0)
+
+template <class T>
+static hipError_t dalloc(T **p, size_t n) {
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(n, 1) * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemset(*p, 0, std::max<size_t>(n, 1) * sizeof(T));
+}
+
+struct RsqpLargeEngine::Impl {
+    int nV = 0, nC = 0, nAmax = 0;
+    long long ld = 0, ldm = 0;
+    hipStream_t st = nullptr;
+    hipError_t err_ = hipSuccess;
+    RsqpLargeMatrices M;
+    // dense state
+    double *Z = nullptr, *Y = nullptr, *Minv = nullptr, *Wz = nullptr;
+    // vectors (nV)
+    double *x, *g, *lb, *ub, *gN, *lbN, *ubN, *dx, *w1, *w2, *w3, *w4, *w5, *w6, *wz1, *wz2, *wz3;
+    // vectors (nC)
+    double *Ax, *lbA, *ubA, *lbAN, *ubAN, *dAx, *c1, *c2, *c3, *a1, *a2, *a3, *a4;
+    double *y, *dy, *part, *scal, *pt, *res_t;
+    int *Sb, *Sc, *AC, *posAC, *pid, *res_id;
+    // host mirrors
+    std::vector<int> hSb, hSc, hAC;
+    int nFR = 0, nAC = 0, nZ = 0;
+    int status = QPS_NOTINITIALISED, infeasible = 0, unbounded = 0, nflips = 0;
+    double *h_pinned = nullptr;  // small pinned read-back buffer
+    int *h_pinned_i = nullptr;
+    int nblk_ratio = 0;
+
+    ~Impl() {
+        double *dv[] = {Z, Y, Minv, Wz, x, g, lb, ub, gN, lbN, ubN, dx, w1, w2, w3, w4, w5, w6, wz1, wz2, wz3, Ax, lbA, ubA,
+                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t};
+        for (double *p : dv) if (p) (void)hipFree(p);
+        int *iv[] = {Sb, Sc, AC, posAC, pid, res_id};
+        for (int *p : iv) if (p) (void)hipFree(p);
+        if (h_pinned) (void)hipHostFree(h_pinned);
+        if (h_pinned_i) (void)hipHostFree(h_pinned_i);
+    }
+
+    // ---- launch helpers -----------------------------------------------------------
+    void gemv_t(const double *Mx, long long l, int nrows, int ncols, const double *xv, double *out) {
+        if (ncols > 0) hipLaunchKernelGGL(k_gemv_t, dim3(ncols), dim3(NT), 0, st, Mx, l, nrows, ncols, xv, out);
+    }
+    // out = beta*base + alpha * M w
+    void gemv_n(const double *Mx, long long l, int nrows, int ncols, const double *wv, double alpha, double beta,
+                const double *base, double *out) {
+        if (ncols <= 0) {
+            if (base && beta != 0.0) hipLaunchKernelGGL(k_axpby, g1(nrows), dim3(NT), 0, st, nrows, beta, base, 0.0, (const double *)nullptr, out);
+            else hipLaunchKernelGGL(k_fill, g1(nrows), dim3(NT), 0, st, out, nrows, 0.0);
+            return;
+        }
+        const int nch = (ncols + GEMV_CHUNK - 1) / GEMV_CHUNK;
+        hipLaunchKernelGGL(k_gemv_n_part, dim3((nrows + NT - 1) / NT, nch), dim3(NT), 0, st, Mx, l, nrows, ncols, wv, part);
+        hipLaunchKernelGGL(k_gemv_n_reduce, g1(nrows), dim3(NT), 0, st, part, nrows, nch, alpha, beta, base, out);
+    }
+    void ger(double *Mx, long long l, int nrows, int ncols, const double *t, const double *v, int ci, double cs) {
+        if (ncols > 0 && nrows > 0)
+            hipLaunchKernelGGL(k_ger, dim3((nrows + NT - 1) / NT, ncols), dim3(NT), 0, st, Mx, l, nrows, ncols, t, v, scal, ci, cs);
+    }
+    void dot(const double *a, const double *b, int n, int slot) {
+        hipLaunchKernelGGL(k_dot, dim3(1), dim3(NT), 0, st, a, b, n, scal, slot);
+    }
+    void copy(const double *s, double *d, int n) { if (n > 0) hipLaunchKernelGGL(k_copy, g1(n), dim3(NT), 0, st, s, d, n); }
+    void fill(double *d, int n, double v) { if (n > 0) hipLaunchKernelGGL(k_fill, g1(n), dim3(NT), 0, st, d, n, v); }
+    void A_times(const double *in, double *out) {   // out[nC] = A in   (CSR copy)
+        if (nC > 0) rsqp_launch_spmv(M.blk_r, M.nblk_r, M.Arp, M.Aci, M.Arv, in, out, 1, 0, 0, 0, 0, st);
+    }
+    void AT_times(const double *in, double *out) {  // out[nV] = A' in  (CSC)
+        if (nC > 0) rsqp_launch_spmv(M.blk_c, M.nblk_c, M.Ajc, M.Air, M.Aval, in, out, 1, 0, 0, 0, 0, st);
+        else fill(out, nV, 0.0);
+    }
+    void H_times(const double *in, double *out) {
+        if (M.haveH) rsqp_launch_spmv(M.blk_h, M.nblk_h, M.Hjc, M.Hir, M.Hval, in, out, 1, 0, 0, 0, 0, st);
+        else fill(out, nV, 0.0);
+    }
+    int read_scal(int s0, int n, double *out) {
+        LCHK(hipMemcpyAsync(h_pinned, scal + s0, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+        LCHK(hipStreamSynchronize(st));
+        for (int i = 0; i < n; i++) out[i] = h_pinned[i];
+        return RET_OK;
+    }
+    void row_of_A(int r, double *a, bool all) {
+        fill(a, nV, 0.0);
+        hipLaunchKernelGGL(k_row_of_A, dim3(8), dim3(NT), 0, st, M.Arp, M.Aci, M.Arv, r, Sb, all ? 1 : 0, a);
+    }
+    double *Zc(int c) { return Z + c * ld; }
+    double *Yc(int c) { return Y + c * ld; }
+
+    // ---- working-set operations -------------------------------------------------------
+    // reflection of Z that puts the direction Z w (w in wz1, length nZ) into the last column;
+    // Wz follows; the last column is then taken out of the null space. scal[0..3] = house.
+    void z_reflect_and_shrink() {
+        hipLaunchKernelGGL(k_house, dim3(1), dim3(NT), 0, st, wz1, nZ, wz2, scal, 0);   // v -> wz2
+        gemv_n(Z, ld, nV, nZ, wz2, 1.0, 0.0, nullptr, w5);                               // t = Z v
+        ger(Z, ld, nV, nZ, w5, wz2, 1, -1.0);                                            // Z -= beta t v'
+        gemv_n(Wz, ld, nZ, nZ, wz2, 1.0, 0.0, nullptr, wz3);                             // s = Wz v
+        dot(wz2, wz3, nZ, 4);                                                            // theta
+        hipLaunchKernelGGL(k_wz_lastcol, g1(nZ), dim3(NT), 0, st, Wz, ld, nZ, wz3, wz2, scal, 1, 4, w6);
+        if (nZ > 1)
+            hipLaunchKernelGGL(k_wz_shrink, dim3((nZ - 1 + NT - 1) / NT, nZ - 1), dim3(NT), 0, st, Wz, ld, nZ, wz3, wz2, w6,
+                               scal, 1, 4);
+    }
+
+    // append the Y column `ycol` (already stored at Y[:, nAC]) for constraint r whose products
+    // with the old Y are in a1 (wY) and with the new column in scal[eta_slot]
+    void minv_append(int eta_slot) {
+        // new row nAC: -(wY' Minv)/eta ; new column nAC: 0 ; corner 1/eta
+        gemv_t(Minv, ldm, nAC, nAC, a1, a2);  // a2[j] = sum_i wY[i] Minv[i][j]
+        hipLaunchKernelGGL(k_minv_border, g1(nAC + 1), dim3(NT), 0, st, Minv, ldm, nAC, a2, scal, eta_slot);
+    }
+
+    int add_constraint(int r, int side, bool skipZ) {
+        // a (free part) in w1; wZ in wz1; wY in a1 were computed by the caller (li_test_constraint)
+        if (!skipZ) {
+            z_reflect_and_shrink();
+            // new Y column = last column of the reflected Z; eta = a'y_new = image sign * alpha
+            copy(Zc(nZ - 1), Yc(nAC), nV);
+            hipLaunchKernelGGL(k_eta_from_house, dim3(1), dim3(1), 0, st, scal);  // scal[5] = scal[2]*scal[0]
+        } else {
+            // exchange / flip: the row is orthogonal to all null-space columns but the last
+            copy(Zc(nZ - 1), Yc(nAC), nV);
+            dot(w1, Zc(nZ - 1), nV, 5);
+        }
+        nZ--;
+        minv_append(5);
+        hipLaunchKernelGGL(k_seti, dim3(1), dim3(1), 0, st, AC, nAC, r);
+        hipLaunchKernelGGL(k_seti, dim3(1), dim3(1), 0, st, posAC, r, nAC);
+        hipLaunchKernelGGL(k_seti, dim3(1), dim3(1), 0, st, Sc, r, side);
+        hAC[nAC] = r; hSc[r] = side;
+        nAC++;
+        return RET_OK;
+    }
+
+    // products of constraint row r with the bases: w1 = a_FR, wz1 = Z'a, a1 = Y'a; scal[6]=|a|^2, scal[7]=|wZ|^2
+    void constraint_products(int r) {
+        row_of_A(r, w1, false);
+        gemv_t(Z, ld, nV, nZ, w1, wz1);
+        gemv_t(Y, ld, nV, nAC, w1, a1);
+        dot(w1, w1, nV, 6);
+        if (nZ > 0) dot(wz1, wz1, nZ, 7); else hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, scal, 7, 0.0);
+    }
+    void bound_products(int v) {
+        if (nZ > 0) hipLaunchKernelGGL(k_get_row, g1(nZ), dim3(NT), 0, st, Z, ld, v, nZ, wz1);
+        if (nAC > 0) hipLaunchKernelGGL(k_get_row, g1(nAC), dim3(NT), 0, st, Y, ld, v, nAC, a1);
+        hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, scal, 6, 1.0);
+        if (nZ > 0) dot(wz1, wz1, nZ, 7); else hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, scal, 7, 0.0);
+    }
+
+    // second stage shared by add_bound and (mirrored) remove_bound: reflection on [Y, extra]
+    // add_bound(v): qY (row v of Y) in a1, q* = zs[v] where zs = Z's last column after stage 1
+    int add_bound(int v, int side, bool skipZ) {
+        if (!skipZ) z_reflect_and_shrink();          // wz1 = row v of Z (from bound_products)
+        double *zs = Zc(nZ - 1);
+        nZ--;
+        // q~ = [qY ; q*]; |q~| = 1. vt = q~ with last += sgn(q*); beta~ = 1/(1+|q*|)
+        hipLaunchKernelGGL(k_copy1, dim3(1), dim3(1), 0, st, a1, nAC, zs, v);   // a1[nAC] = q*
+        hipLaunchKernelGGL(k_house_unit, dim3(1), dim3(1), 0, st, a1, nAC, scal);  // a1[nAC] += sgn; scal[8]=beta~, scal[9]=gamma, scal[10]=vlast
+        // t = Y vY + zs * vlast
+        gemv_n(Y, ld, nV, nAC, a1, 1.0, 0.0, nullptr, w5);
+        hipLaunchKernelGGL(k_axpy_s, g1(nV), dim3(NT), 0, st, nV, scal, 10, zs, w5);
+        ger(Y, ld, nV, nAC, w5, a1, 8, -1.0);        // Y -= beta~ t vY'
+        // Minv += gamma vY (vY' Minv)
+        gemv_t(Minv, ldm, nAC, nAC, a1, a2);
+        ger(Minv, ldm, nAC, nAC, a1, a2, 9, 1.0);
+        // clean row v
+        if (nAC > 0) hipLaunchKernelGGL(k_set_row, g1(nAC), dim3(NT), 0, st, Y, ld, v, nAC, (const double *)nullptr, 0.0);
+        if (nZ > 0) hipLaunchKernelGGL(k_set_row, g1(nZ), dim3(NT), 0, st, Z, ld, v, nZ, (const double *)nullptr, 0.0);
+        hipLaunchKernelGGL(k_seti, dim3(1), dim3(1), 0, st, Sb, v, side);
+        hSb[v] = side;
+        nFR--;
+        return RET_OK;
+    }
+
+    // grow Wz by the new null-space column Z[:, nZ]; returns 1 if positive definite (then nZ++)
+    int wz_grow(int *pd) {
+        double *z = Zc(nZ);
+        H_times(z, w2);
+        dot(z, w2, nV, 11);                       // kappa
+        gemv_t(Z, ld, nV, nZ, w2, wz1);           // k = Z'Hz
+        gemv_n(Wz, ld, nZ, nZ, wz1, 1.0, 0.0, nullptr, wz2);  // u = Wz k
+        if (nZ > 0) dot(wz1, wz2, nZ, 12); else hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, scal, 12, 0.0);
+        hipLaunchKernelGGL(k_rho2, dim3(1), dim3(1), 0, st, scal);   // scal[13] = rho2, scal[14] = threshold
+        double r[2];
+        if (read_scal(13, 2, r) != RET_OK) return RET_SETUP_FAILED;
+        *pd = r[0] > r[1];
+        if (*pd) {
+            hipLaunchKernelGGL(k_wz_grow, dim3((nZ + 1 + NT - 1) / NT, nZ + 1), dim3(NT), 0, st, Wz, ld, nZ, wz2, scal, 13);
+            nZ++;
+        }
+        return RET_OK;
+    }
+
+    // TQ part of removing the constraint at position k: Y loses a column, it lands in Z[:, nZ]
+    void remove_constraint_tq(int k) {
+        const int r = hAC[k];
+        copy(Minv + k * ldm, a1, nAC);                                   // u = Minv[:, k]
+        hipLaunchKernelGGL(k_house, dim3(1), dim3(NT), 0, st, a1, nAC, a2, scal, 0);  // v -> a2
+        gemv_n(Y, ld, nV, nAC, a2, 1.0, 0.0, nullptr, w5);               // t = Y v
+        ger(Y, ld, nV, nAC, w5, a2, 1, -1.0);                            // Y -= beta t v'
+        gemv_t(Minv, ldm, nAC, nAC, a2, a3);                             // s' = v' Minv
+        ger(Minv, ldm, nAC, nAC, a2, a3, 1, -1.0);                       // Minv -= beta v s'
+        copy(Yc(nAC - 1), Zc(nZ), nV);                                   // new null-space column
+        // delete row (nAC-1) [implicit] and column k: move the last column into k
+        if (k != nAC - 1) {
+            copy(Minv + (long long)(nAC - 1) * ldm, Minv + k * ldm, nAC);
+            const int rl = hAC[nAC - 1];
+            hAC[k] = rl;
+            hipLaunchKernelGGL(k_seti, dim3(1), dim3(1), 0, st, AC, k, rl);
+            hipLaunchKernelGGL(k_seti, dim3(1), dim3(1), 0, st, posAC, rl, k);
+        }
+        hipLaunchKernelGGL(k_seti, dim3(1), dim3(1), 0, st, posAC, r, -1);
+        hipLaunchKernelGGL(k_seti, dim3(1), dim3(1), 0, st, Sc, r, 0);
+        hSc[r] = 0;
+        nAC--;
+    }
+    int position_of(int r) const {
+        for (int j = 0; j < nAC; j++) if (hAC[j] == r) return j;
+        return -1;
+    }
+
+    // TQ part of freeing variable v: null space gains the column Z[:, nZ]
+    void remove_bound_tq(int v) {
+        hipLaunchKernelGGL(k_seti, dim3(1), dim3(1), 0, st, Sb, v, 0);
+        hSb[v] = 0;
+        nFR++;
+        double *znew = Zc(nZ);
+        fill(znew, nV, 0.0);
+        if (nAC == 0) {
+            hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, znew, v, 1.0);
+            return;
+        }
+        fill(a4, nAC, 0.0);
+        hipLaunchKernelGGL(k_col_of_A_active, dim3(4), dim3(NT), 0, st, M.Ajc, M.Air, M.Aval, v, posAC, a4);  // a_v
+        gemv_n(Minv, ldm, nAC, nAC, a4, 1.0, 0.0, nullptr, a1);          // c = Minv a_v
+        // c~ = [-c ; 1], nu = sqrt(1+|c|^2); vt = c~ with last += nu; beta~ = 1/(nu(nu+1))
+        hipLaunchKernelGGL(k_house_free, dim3(1), dim3(NT), 0, st, a1, nAC, scal);   // a1 := vY = -c ; scal[8]=beta~, scal[10]=vlast
+        // t = Y vY + e_v vlast
+        gemv_n(Y, ld, nV, nAC, a1, 1.0, 0.0, nullptr, w5);
+        hipLaunchKernelGGL(k_add_scal_at, dim3(1), dim3(1), 0, st, w5, v, scal, 10);
+        // p = A_AC t (before Y changes it does not matter: t is already formed)
+        A_times(w5, c3);
+        hipLaunchKernelGGL(k_gather_active, g1(nAC), dim3(NT), 0, st, c3, AC, nAC, a2);   // p
+        // new column: e_v - beta~ t vlast
+        hipLaunchKernelGGL(k_newcol_free, g1(nV), dim3(NT), 0, st, nV, v, w5, scal, znew);
+        ger(Y, ld, nV, nAC, w5, a1, 8, -1.0);                            // Y -= beta~ t vY'
+        // Sherman-Morrison: Minv += beta~/(1 - beta~ vY'q1) q1 q2',  q1 = Minv p, q2' = vY' Minv
+        gemv_n(Minv, ldm, nAC, nAC, a2, 1.0, 0.0, nullptr, a3);          // q1
+        gemv_t(Minv, ldm, nAC, nAC, a1, a4);                             // q2
+        dot(a1, a3, nAC, 15);
+        hipLaunchKernelGGL(k_sm_coef, dim3(1), dim3(1), 0, st, scal);    // scal[16] = beta~/(1 - beta~*scal[15])
+        ger(Minv, ldm, nAC, nAC, a3, a4, 16, 1.0);
+    }
+
+    // removal with definiteness guard; returns RET_OK / RET_UNBOUNDED
+    int remove_with_guard(bool is_bound, int idx, const double *lbN_h, const double *ubN_h) {
+        (void)lbN_h; (void)ubN_h;
+        int pd = 0;
+        if (is_bound) {
+            const int old = hSb[idx];
+            remove_bound_tq(idx);
+            hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, y, idx, 0.0);
+            if (wz_grow(&pd) != RET_OK) return RET_SETUP_FAILED;
+            if (pd) return RET_OK;
+            // flip: put the variable back on the opposite side (or the same if that one is infinite)
+            double b[2];
+            LCHK(hipMemcpyAsync(h_pinned, lbN + idx, 8, hipMemcpyDeviceToHost, st));
+            LCHK(hipMemcpyAsync(h_pinned + 1, ubN + idx, 8, hipMemcpyDeviceToHost, st));
+            LCHK(hipStreamSynchronize(st));
+            b[0] = h_pinned[0]; b[1] = h_pinned[1];
+            const bool cant = (old == -1 && b[1] >= RSQP_INFTY) || (old == 1 && b[0] <= -RSQP_INFTY);
+            nZ++;  // the candidate column is still Z[:, nZ]: treat it as the last null-space column
+            bound_products(idx);
+            add_bound(idx, cant ? old : -old, true);
+            if (cant) return RET_UNBOUNDED;
+            hipLaunchKernelGGL(k_copy1, dim3(1), dim3(1), 0, st, old == -1 ? ub : lb, idx, x, idx);
+            nflips++;
+            return RET_OK;
+        } else {
+            const int old = hSc[idx], k = position_of(idx);
+            remove_constraint_tq(k);
+            hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, y, nV + idx, 0.0);
+            if (wz_grow(&pd) != RET_OK) return RET_SETUP_FAILED;
+            if (pd) return RET_OK;
+            LCHK(hipMemcpyAsync(h_pinned, lbAN + idx, 8, hipMemcpyDeviceToHost, st));
+            LCHK(hipMemcpyAsync(h_pinned + 1, ubAN + idx, 8, hipMemcpyDeviceToHost, st));
+            LCHK(hipStreamSynchronize(st));
+            const bool cant = (old == -1 && h_pinned[1] >= RSQP_INFTY) || (old == 1 && h_pinned[0] <= -RSQP_INFTY);
+            nZ++;
+            constraint_products(idx);
+            add_constraint(idx, cant ? old : -old, true);
+            if (cant) return RET_UNBOUNDED;
+            hipLaunchKernelGGL(k_copy1, dim3(1), dim3(1), 0, st, old == -1 ? ubA : lbA, idx, Ax, idx);
+            nflips++;
+            return RET_OK;
+        }
+    }
+
+    // exchange: incoming row in w4 (all variables), its Y-products in a1. Finds the partner,
+    // shifts the duals. ret: RET_OK / RET_INFEASIBLE; partner in (pkind, pidx), y_new
+    int ensure_LI(int side, double *y_new, int *pkind, int *pidx) {
+        fill(c1, nC, 0.0);
+        gemv_t(Minv, ldm, nAC, nAC, a1, a2);   // hmm: xiC = Minv' wY  -> xi[j] = sum_i Minv[i][j] wY[i]
+        hipLaunchKernelGGL(k_scatter_active, g1(nAC), dim3(NT), 0, st, a2, AC, nAC, c1);
+        AT_times(c1, w2);
+        hipLaunchKernelGGL(k_xiB, g1(nV), dim3(NT), 0, st, nV, Sb, w4, w2, w3);
+        const double sgn = side == 1 ? -1.0 : 1.0;
+        hipLaunchKernelGGL(k_partner1, dim3(nblk_ratio), dim3(NT), 0, st, nV, nC, Sb, Sc, y, c1, w3, sgn, pt, pid);
+        hipLaunchKernelGGL(k_argmin2, dim3(1), dim3(NT), 0, st, nblk_ratio, pt, pid, res_t, res_id);
+        LCHK(hipMemcpyAsync(h_pinned, res_t, 8, hipMemcpyDeviceToHost, st));
+        LCHK(hipMemcpyAsync(h_pinned_i, res_id, 4, hipMemcpyDeviceToHost, st));
+        LCHK(hipStreamSynchronize(st));
+        const double t = h_pinned[0];
+        const int id = h_pinned_i[0];
+        if (id == 0x7fffffff) return RET_INFEASIBLE;
+        hipLaunchKernelGGL(k_shift_duals, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, Sc, t, sgn, c1, w3, y);
+        *y_new = sgn * t;
+        *pkind = id < nC ? 1 : 2;
+        *pidx = id < nC ? id : id - nC;
+        return RET_OK;
+    }
+
+    int li_decision(bool *li) {
+        double r[2];
+        if (read_scal(6, 2, r) != RET_OK) return RET_SETUP_FAILED;
+        *li = nZ > 0 && r[0] > 0.0 && std::sqrt(r[1]) > RSQP_EPS_LI * std::sqrt(r[0]);
+        return RET_OK;
+    }
+
+    int change_active_set(int kind, int idx, int side) {
+        if (kind == 1) return remove_with_guard(false, idx, nullptr, nullptr);
+        if (kind == 2) return remove_with_guard(true, idx, nullptr, nullptr);
+        double ynew = 0.0;
+        bool li = false, full = true;
+        if (kind == 3) constraint_products(idx); else bound_products(idx);
+        if (li_decision(&li) != RET_OK) return RET_SETUP_FAILED;
+        if (!li) {
+            int pkind = 0, pidx = -1;
+            if (kind == 3) row_of_A(idx, w4, true);
+            else { fill(w4, nV, 0.0); hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, w4, idx, 1.0); }
+            int rc = ensure_LI(side, &ynew, &pkind, &pidx);
+            if (rc != RET_OK) return rc;
+            int pd = 0;
+            if (pkind == 1) {
+                remove_constraint_tq(position_of(pidx));
+                hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, y, nV + pidx, 0.0);
+            } else {
+                remove_bound_tq(pidx);
+                hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, y, pidx, 0.0);
+            }
+            if (wz_grow(&pd) != RET_OK) return RET_SETUP_FAILED;
+            full = pd != 0;
+            if (!full) nZ++;   // keep the candidate column as the last null-space column (R-less exchange)
+            if (kind == 3) constraint_products(idx); else bound_products(idx);
+        }
+        if (kind == 3) {
+            add_constraint(idx, side, !full);
+            hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, y, nV + idx, ynew);
+        } else {
+            add_bound(idx, side, !full);
+            hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, y, idx, ynew);
+        }
+        return RET_OK;
+    }
+
+    // ---- step direction -----------------------------------------------------------------
+    void step_direction() {
+        hipLaunchKernelGGL(k_dx_fixed, g1(nV), dim3(NT), 0, st, nV, Sb, lb, ub, lbN, ubN, dx);
+        fill(dy, nV + nC, 0.0);
+        A_times(dx, c1);                                                   // A dx_FX
+        H_times(dx, w2);
+        if (nAC > 0)
+            hipLaunchKernelGGL(k_rhs_active, g1(nAC), dim3(NT), 0, st, nAC, AC, Sc, lbA, ubA, lbAN, ubAN, c1, a1);  // bA
+        hipLaunchKernelGGL(k_add_dg, g1(nV), dim3(NT), 0, st, nV, w2, gN, g, w1);   // tmpg
+        // range space: wY = Minv bA ; xY = Y wY
+        gemv_n(Minv, ldm, nAC, nAC, a1, 1.0, 0.0, nullptr, a2);
+        gemv_n(Y, ld, nV, nAC, a2, 1.0, 0.0, nullptr, w3);                 // xY
+        // null space: wZ = -Wz Z'(tmpg + H xY) ; dx_FR = xY + Z wZ
+        H_times(w3, w2);
+        hipLaunchKernelGGL(k_axpby, g1(nV), dim3(NT), 0, st, nV, 1.0, w2, 1.0, w1, w2);
+        gemv_t(Z, ld, nV, nZ, w2, wz1);
+        gemv_n(Wz, ld, nZ, nZ, wz1, -1.0, 0.0, nullptr, wz2);
+        gemv_n(Z, ld, nV, nZ, wz2, 1.0, 1.0, w3, w4);                      // xY + Z wZ
+        hipLaunchKernelGGL(k_merge_free, g1(nV), dim3(NT), 0, st, nV, Sb, w4, dx);
+        // multipliers: dyAC = Minv' Y'(H dx + dg)
+        H_times(dx, w2);
+        hipLaunchKernelGGL(k_add_dg, g1(nV), dim3(NT), 0, st, nV, w2, gN, g, w2);   // res
+        gemv_t(Y, ld, nV, nAC, w2, a1);
+        gemv_t(Minv, ldm, nAC, nAC, a1, a2);                               // a2[j] = sum_i Minv[i][j] rhsY[i]
+        if (nAC > 0) hipLaunchKernelGGL(k_scatter_active, g1(nAC), dim3(NT), 0, st, a2, AC, nAC, dy + nV);
+        AT_times(dy + nV, w3);
+        hipLaunchKernelGGL(k_dy_fixed, g1(nV), dim3(NT), 0, st, nV, Sb, w2, w3, dy);
+        A_times(dx, dAx);
+    }
+
+    void drift_correction() {
+        hipLaunchKernelGGL(k_fix_x, g1(nV), dim3(NT), 0, st, nV, Sb, lb, ub, x);
+        A_times(x, Ax);
+        if (nC > 0) hipLaunchKernelGGL(k_fix_bA, g1(nC), dim3(NT), 0, st, nC, Sc, Ax, lbA, ubA);
+        AT_times(y + nV, w1);
+        H_times(x, w2);
+        hipLaunchKernelGGL(k_fix_g, g1(nV), dim3(NT), 0, st, nV, w1, y, w2, g);
+    }
+
+    int homotopy(int maxit, int *nWSR) {
+        int iter = 0, rcode = RET_OK;
+        status = QPS_PERFORMINGHOMOTOPY;
+        hipLaunchKernelGGL(k_rerelax, g1(nV), dim3(NT), 0, st, nV, Sb, x, lbN, ubN, lb, ub);
+        if (nC > 0) hipLaunchKernelGGL(k_rerelax, g1(nC), dim3(NT), 0, st, nC, Sc, Ax, lbAN, ubAN, lbA, ubA);
+        for (;;) {
+            step_direction();
+            hipLaunchKernelGGL(k_ratio1, dim3(nblk_ratio), dim3(NT), 0, st, nV, nC, Sb, Sc, x, y, dx, dy, Ax, dAx, lb, ub,
+                               lbA, ubA, lbN, ubN, lbAN, ubAN, pt, pid);
+            hipLaunchKernelGGL(k_argmin2, dim3(1), dim3(NT), 0, st, nblk_ratio, pt, pid, res_t, res_id);
+            LCHK(hipMemcpyAsync(h_pinned, res_t, 8, hipMemcpyDeviceToHost, st));
+            LCHK(hipMemcpyAsync(h_pinned_i, res_id, 4, hipMemcpyDeviceToHost, st));
+            LCHK(hipStreamSynchronize(st));
+            double tau = h_pinned[0];
+            const int bid = h_pinned_i[0];
+            int kind = 0, idx = -1, side = 0;
+            if (bid != 0x7fffffff) {
+                if (bid < nC) { kind = 1; idx = bid; }
+                else if (bid < nC + nV) { kind = 2; idx = bid - nC; }
+                else if (bid < 2 * nC + nV) { kind = 3; idx = bid - nC - nV; side = -1; }
+                else if (bid < 3 * nC + nV) { kind = 3; idx = bid - 2 * nC - nV; side = 1; }
+                else if (bid < 3 * nC + 2 * nV) { kind = 4; idx = bid - 3 * nC - nV; side = -1; }
+                else { kind = 4; idx = bid - 3 * nC - 2 * nV; side = 1; }
+            } else tau = 1.0;
+            const int done = kind == 0;
+            hipLaunchKernelGGL(k_step_v, g1(nV), dim3(NT), 0, st, nV, tau, done, Sb, x, g, lb, ub, gN, lbN, ubN, dx);
+            hipLaunchKernelGGL(k_axpy, g1(nV + nC), dim3(NT), 0, st, nV + nC, tau, dy, y);
+            if (nC > 0) hipLaunchKernelGGL(k_step_c, g1(nC), dim3(NT), 0, st, nC, tau, done, lbA, ubA, lbAN, ubAN);
+            A_times(x, Ax);
+            if (done) { status = QPS_SOLVED; break; }
+            if (iter >= maxit) { rcode = RET_MAX_NWSR; break; }
+            if (kind == 3) hipLaunchKernelGGL(k_copy1, dim3(1), dim3(1), 0, st, side == -1 ? lbA : ubA, idx, Ax, idx);
+            else if (kind == 4) hipLaunchKernelGGL(k_copy1, dim3(1), dim3(1), 0, st, side == -1 ? lb : ub, idx, x, idx);
+            rcode = change_active_set(kind, idx, side);
+            if (rcode == RET_INFEASIBLE) { infeasible = 1; break; }
+            if (rcode == RET_UNBOUNDED) { unbounded = 1; break; }
+            if (rcode != RET_OK) break;
+            iter++;
+            drift_correction();
+        }
+        *nWSR = iter;
+        return rcode;
+    }
+
+    // ---- auxiliary QP -------------------------------------------------------------------------
+    // working-set guess on the host (hSb / hSc targets), x / y on the device already
+    int setup_aux(const std::vector<int> &gb, const std::vector<int> &gc) {
+        status = QPS_PREPARINGAUXILIARYQP;
+        infeasible = unbounded = 0;
+        nFR = nAC = nZ = 0;
+        // start with every variable fixed, then free / activate one at a time (each step is the
+        // same rank-1 machinery the homotopy uses)
+        std::vector<int> start(nV);
+        for (int v = 0; v < nV; v++) start[v] = gb[v] != 0 ? gb[v] : -1;
+        LCHK(hipMemcpyAsync(Sb, start.data(), sizeof(int) * nV, hipMemcpyHostToDevice, st));
+        hSb = start;
+        std::fill(hSc.begin(), hSc.end(), 0);
+        LCHK(hipMemsetAsync(Sc, 0, sizeof(int) * std::max(nC, 1), st));
+        LCHK(hipMemsetAsync(posAC, 0xff, sizeof(int) * std::max(nC, 1), st));
+        for (int v = 0; v < nV; v++) {
+            if (gb[v] != 0) continue;
+            remove_bound_tq(v);
+            int pd = 0;
+            if (wz_grow(&pd) != RET_OK) return RET_SETUP_FAILED;
+            if (!pd) return RET_SETUP_FAILED;
+        }
+        A_times(x, Ax);
+        for (int r = 0; r < nC; r++) {
+            if (gc[r] == 0) continue;
+            constraint_products(r);
+            bool li = false;
+            if (li_decision(&li) != RET_OK) return RET_SETUP_FAILED;
+            if (li) add_constraint(r, gc[r], false);
+        }
+        // multipliers: zero when inactive, clipped to the admissible sign
+        hipLaunchKernelGGL(k_clip_y, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, Sc, y);
+        AT_times(y + nV, w1);
+        H_times(x, w2);
+        hipLaunchKernelGGL(k_aux_v, g1(nV), dim3(NT), 0, st, nV, Sb, x, w1, y, w2, lbN, ubN, g, lb, ub);
+        if (nC > 0) hipLaunchKernelGGL(k_aux_c, g1(nC), dim3(NT), 0, st, nC, Sc, Ax, lbAN, ubAN, lbA, ubA);
+        status = QPS_AUXILIARYQPSOLVED;
+        return RET_OK;
+    }
+};
+
+// =====================================================================================
+// public wrapper
+// =====================================================================================
+RsqpLargeEngine::RsqpLargeEngine() : p_(new Impl()) {}
+RsqpLargeEngine::~RsqpLargeEngine() { delete p_; }
+
+long long RsqpLargeEngine::bytes_needed(int nV, int nC) {
+    const long long nA = std::min(nV, nC);
+    return 8LL * (2LL * nV * nV + (long long)nV * nA + nA * nA + 40LL * (nV + nC));
+}
+
+hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
+    Impl &P = *p_;
+    P.nV = nV; P.nC = nC; P.nAmax = std::min(nV, nC); P.ld = nV; P.ldm = std::max(P.nAmax, 1); P.st = stream;
+    hipError_t e;
+#define DA(ptr, n) if ((e = dalloc(&P.ptr, (size_t)(n))) != hipSuccess) return e
+    DA(Z, (size_t)nV * nV); DA(Wz, (size_t)nV * nV); DA(Y, (size_t)nV * std::max(P.nAmax, 1)); DA(Minv, (size_t)P.ldm * P.ldm);
+    DA(x, nV); DA(g, nV); DA(lb, nV); DA(ub, nV); DA(gN, nV); DA(lbN, nV); DA(ubN, nV); DA(dx, nV);
+    DA(w1, nV); DA(w2, nV); DA(w3, nV); DA(w4, nV); DA(w5, nV); DA(w6, nV); DA(wz1, nV); DA(wz2, nV); DA(wz3, nV);
+    DA(Ax, nC); DA(lbA, nC); DA(ubA, nC); DA(lbAN, nC); DA(ubAN, nC); DA(dAx, nC); DA(c1, nC); DA(c2, nC); DA(c3, nC);
+    DA(a1, P.nAmax + 2); DA(a2, P.nAmax + 2); DA(a3, P.nAmax + 2); DA(a4, P.nAmax + 2);
+    DA(y, nV + nC); DA(dy, nV + nC);
+    const int nch = (nV + GEMV_CHUNK - 1) / GEMV_CHUNK;
+    DA(part, (size_t)nch * nV);
+    DA(scal, 64);
+    P.nblk_ratio = std::min(1024, std::max(1, (nV + nC + NT - 1) / NT));
+    DA(pt, P.nblk_ratio); DA(res_t, 2);
+    DA(Sb, nV); DA(Sc, nC); DA(AC, nC); DA(posAC, nC); DA(pid, P.nblk_ratio); DA(res_id, 2);
+#undef DA
+    if ((e = hipHostMalloc(reinterpret_cast<void **>(&P.h_pinned), 64 * sizeof(double))) != hipSuccess) return e;
+    if ((e = hipHostMalloc(reinterpret_cast<void **>(&P.h_pinned_i), 64 * sizeof(int))) != hipSuccess) return e;
+    P.hSb.assign(nV, 0); P.hSc.assign(nC, 0); P.hAC.assign(std::max(nC, 1), 0);
+    return hipSuccess;
+}
+
+void RsqpLargeEngine::set_matrices(const RsqpLargeMatrices &m) { p_->M = m; }
+
+int RsqpLargeEngine::solve(int mode, const double *d_g, const double *d_lb, const double *d_ub, const double *d_lbA,
+                           const double *d_ubA, int *nWSR, const double *h_x0, const double *h_y0, const int *h_guess_b) {
+    Impl &P = *p_;
+    const int nV = P.nV, nC = P.nC;
+    hipStream_t st = P.st;
+    P.err_ = hipSuccess;
+    const int maxit = *nWSR;
+    *nWSR = 0;
+    if (mode != RSQP_LMODE_COLD && P.status == QPS_NOTINITIALISED) mode = RSQP_LMODE_COLD;
+    // targets, clamped to +-INFTY
+    hipLaunchKernelGGL(k_copy, g1(nV), dim3(NT), 0, st, d_g, P.gN, nV);
+    hipLaunchKernelGGL(k_clamp_copy, g1(nV), dim3(NT), 0, st, nV, d_lb, P.lbN);
+    hipLaunchKernelGGL(k_clamp_copy, g1(nV), dim3(NT), 0, st, nV, d_ub, P.ubN);
+    if (nC > 0) {
+        hipLaunchKernelGGL(k_clamp_copy, g1(nC), dim3(NT), 0, st, nC, d_lbA, P.lbAN);
+        hipLaunchKernelGGL(k_clamp_copy, g1(nC), dim3(NT), 0, st, nC, d_ubA, P.ubAN);
+    }
+    // consistency of the data + working-set guess need the targets on the host
+    std::vector<double> hl(nV), hu(nV), hlA(nC), huA(nC);
+    if (hipMemcpyAsync(hl.data(), P.lbN, 8 * nV, hipMemcpyDeviceToHost, st) != hipSuccess) return RET_SETUP_FAILED;
+    if (hipMemcpyAsync(hu.data(), P.ubN, 8 * nV, hipMemcpyDeviceToHost, st) != hipSuccess) return RET_SETUP_FAILED;
+    if (nC > 0) {
+        if (hipMemcpyAsync(hlA.data(), P.lbAN, 8 * nC, hipMemcpyDeviceToHost, st) != hipSuccess) return RET_SETUP_FAILED;
+        if (hipMemcpyAsync(huA.data(), P.ubAN, 8 * nC, hipMemcpyDeviceToHost, st) != hipSuccess) return RET_SETUP_FAILED;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) return RET_SETUP_FAILED;
+    bool bad = false;
+    for (int v = 0; v < nV; v++) bad |= hl[v] > hu[v] + RSQP_EPS;
+    for (int i = 0; i < nC; i++) bad |= hlA[i] > huA[i] + RSQP_EPS;
+    if (bad) {
+        P.infeasible = 1; P.unbounded = 0;
+        if (mode == RSQP_LMODE_COLD) {
+            (void)hipMemsetAsync(P.x, 0, 8 * nV, st); (void)hipMemsetAsync(P.y, 0, 8 * (nV + nC), st);
+            std::fill(P.hSb.begin(), P.hSb.end(), 0); std::fill(P.hSc.begin(), P.hSc.end(), 0);
+            (void)hipMemsetAsync(P.Sb, 0, 4 * nV, st); (void)hipMemsetAsync(P.Sc, 0, 4 * std::max(nC, 1), st);
+        }
+        return RET_INFEASIBLE;
+    }
+    int rc = RET_OK;
+    if (mode != RSQP_LMODE_HOT_VECTORS) {
+        std::vector<int> gb(nV, 0), gc(nC, 0);
+        std::vector<double> hx(nV, 0.0), hy(nV + nC, 0.0), hAx(nC, 0.0);
+        const bool have_x0 = mode == RSQP_LMODE_HOT_MATRICES || (mode == RSQP_LMODE_WARM && h_x0);
+        const bool have_y0 = mode == RSQP_LMODE_HOT_MATRICES || (mode == RSQP_LMODE_WARM && h_y0);
+        if (mode == RSQP_LMODE_HOT_MATRICES) {
+            if (hipMemcpy(hx.data(), P.x, 8 * nV, hipMemcpyDeviceToHost) != hipSuccess) return RET_SETUP_FAILED;
+            if (hipMemcpy(hy.data(), P.y, 8 * (nV + nC), hipMemcpyDeviceToHost) != hipSuccess) return RET_SETUP_FAILED;
+            gb = P.hSb; gc = P.hSc;
+        } else if (mode == RSQP_LMODE_WARM) {
+            if (h_x0) std::copy(h_x0, h_x0 + nV, hx.begin());
+            if (h_y0) std::copy(h_y0, h_y0 + nV + nC, hy.begin());
+        }
+        if (hipMemcpyAsync(P.x, hx.data(), 8 * nV, hipMemcpyHostToDevice, st) != hipSuccess) return RET_SETUP_FAILED;
+        if (hipMemcpyAsync(P.y, hy.data(), 8 * (nV + nC), hipMemcpyHostToDevice, st) != hipSuccess) return RET_SETUP_FAILED;
+        if (mode != RSQP_LMODE_HOT_MATRICES) {
+            // obtainAuxiliaryWorkingSet (see the CPU restatement): bounds
+            for (int v = 0; v < nV; v++) {
+                int s;
+                if (mode == RSQP_LMODE_WARM && h_guess_b) s = h_guess_b[v];
+                else if (have_x0) s = hx[v] <= hl[v] + RSQP_BOUND_TOLERANCE ? -1 : (hx[v] >= hu[v] - RSQP_BOUND_TOLERANCE ? 1 : 0);
+                else if (have_y0) s = hy[v] > RSQP_EPS ? -1 : (hy[v] < -RSQP_EPS ? 1 : 0);
+                else s = -1;
+                if (s == -1 && hl[v] <= -RSQP_INFTY) s = (hu[v] < RSQP_INFTY && !have_x0 && !(mode == RSQP_LMODE_WARM && h_guess_b)) ? 1 : 0;
+                if (s == 1 && hu[v] >= RSQP_INFTY) s = 0;
+                gb[v] = s;
+            }
+            if (have_x0 && nC > 0) {   // constraints from A x0
+                P.A_times(P.x, P.Ax);
+                if (hipMemcpyAsync(hAx.data(), P.Ax, 8 * nC, hipMemcpyDeviceToHost, st) != hipSuccess) return RET_SETUP_FAILED;
+                if (hipStreamSynchronize(st) != hipSuccess) return RET_SETUP_FAILED;
+            }
+            for (int i = 0; i < nC; i++) {
+                int s = 0;
+                if (have_x0) s = hAx[i] <= hlA[i] + RSQP_BOUND_TOLERANCE ? -1 : (hAx[i] >= huA[i] - RSQP_BOUND_TOLERANCE ? 1 : 0);
+                else if (have_y0) s = hy[nV + i] > RSQP_EPS ? -1 : (hy[nV + i] < -RSQP_EPS ? 1 : 0);
+                if (s == -1 && hlA[i] <= -RSQP_INFTY) s = 0;
+                if (s == 1 && huA[i] >= RSQP_INFTY) s = 0;
+                gc[i] = s;
+            }
+        }
+        P.nflips = 0;
+        rc = P.setup_aux(gb, gc);
+        if (rc != RET_OK && mode != RSQP_LMODE_COLD) {   // fall back to a cold start
+            (void)hipMemsetAsync(P.x, 0, 8 * nV, st); (void)hipMemsetAsync(P.y, 0, 8 * (nV + nC), st);
+            for (int v = 0; v < nV; v++) gb[v] = hl[v] > -RSQP_INFTY ? -1 : (hu[v] < RSQP_INFTY ? 1 : 0);
+            std::fill(gc.begin(), gc.end(), 0);
+            rc = P.setup_aux(gb, gc);
+        }
+        if (rc != RET_OK) return rc;
+    } else {
+        P.infeasible = P.unbounded = 0;
+    }
+    int n = maxit;
+    rc = P.homotopy(maxit, &n);
+    *nWSR = n;
+    (void)hipStreamSynchronize(st);
+    return rc;
+}
+
+const double *RsqpLargeEngine::d_x() const { return p_->x; }
+const double *RsqpLargeEngine::d_y() const { return p_->y; }
+const int *RsqpLargeEngine::d_Sb() const { return p_->Sb; }
+const int *RsqpLargeEngine::d_Sc() const { return p_->Sc; }
+int RsqpLargeEngine::status_word() const {
+    return p_->infeasible ? 100 + p_->status : (p_->unbounded ? 200 + p_->status : p_->status);
+}
+int RsqpLargeEngine::nflips() const { return p_->nflips; }
+hipError_t RsqpLargeEngine::last_error() const { return p_->err_; }
+double RsqpLargeEngine::objective() {
+    Impl &P = *p_;
+    P.H_times(P.x, P.w2);
+    P.dot(P.x, P.w2, P.nV, 20);
+    P.dot(P.gN, P.x, P.nV, 21);
+    double r[2] = {0, 0};
+    P.read_scal(20, 2, r);
+    return 0.5 * r[0] + r[1];
+}

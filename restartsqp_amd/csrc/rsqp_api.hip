@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/rsqp_hip.h"
+#include "rsqp_large.h"
 #include "rsqp_sparse.h"
 
 namespace {
@@ -191,6 +192,12 @@ struct rsqp_solver {
     bool upd_A = false, upd_H = false, upd_bounds = false, upd_g = false;
     int old_status = 0, new_status = 0;  // 0 UNDEFINED, 1 FIXED, 2 VARIED
     bool desc_ready = false;
+    // engine: 1 = LDS-resident kernel, 2 = HBM-resident engine
+    int engine = 1;
+    bool fits_small = true;
+    RsqpLargeEngine *large = nullptr;
+    bool large_ready = false;
+    ~rsqp_solver() { delete large; }
 };
 
 namespace {
@@ -299,10 +306,10 @@ extern "C" int rsqp_create(int nV, int nC, int device, rsqp_solver **out) {
     if (!out || nV <= 0 || nC < 0) return fail(RSQP_ERR_ARG, "rsqp_create: bad sizes");
     if (rsqp_device_count() <= 0) return fail(RSQP_ERR_DEVICE, "rsqp_create: no HIP device visible");
     if (device >= 0) HIPCHK(hipSetDevice(device));
-    if (!rsqp_small_qp_fits(nV, nC))
-        return fail(RSQP_ERR_TOO_LARGE, "rsqp_create: problem exceeds the LDS-resident engine (160 KiB image)");
     rsqp_solver *s = new rsqp_solver();
     s->nV = nV; s->nC = nC;
+    s->fits_small = rsqp_small_qp_fits(nV, nC) != 0;
+    s->engine = s->fits_small ? 1 : 2;
     HIPCHK(hipGetDevice(&s->device));
     for (int k = 0; k < 5; k++) {
         size_t n = (k <= RSQP_VEC_UB) ? nV : nC;
@@ -312,7 +319,7 @@ extern "C" int rsqp_create(int nV, int nC, int device, rsqp_solver **out) {
     HIPCHK(s->d_x.alloc(nV)); HIPCHK(s->d_y.alloc(nV + nC)); HIPCHK(s->d_obj.alloc(1));
     HIPCHK(s->d_wsb.alloc(nV)); HIPCHK(s->d_wsc.alloc(nC));
     HIPCHK(s->d_status.alloc(1)); HIPCHK(s->d_ret.alloc(1)); HIPCHK(s->d_nwsr.alloc(1)); HIPCHK(s->d_nflips.alloc(1));
-    HIPCHK(s->d_state.alloc((size_t)rsqp_image_bytes(nV, nC) / 8));
+    HIPCHK(s->d_state.alloc(s->fits_small ? (size_t)rsqp_image_bytes(nV, nC) / 8 : 1));
     HIPCHK(s->d_x0.alloc(nV)); HIPCHK(s->d_y0.alloc(nV + nC)); HIPCHK(s->d_guess.alloc(nV));
     HIPCHK(s->d_dummy_i.alloc(std::max(nV, nC) + 2)); HIPCHK(s->d_dummy_d.alloc(4));
     HIPCHK(s->d_Ax.alloc(nC)); HIPCHK(s->d_ATy.alloc(nV)); HIPCHK(s->d_Hx.alloc(nV)); HIPCHK(s->d_kkt.alloc(6));
@@ -324,6 +331,15 @@ extern "C" int rsqp_create(int nV, int nC, int device, rsqp_solver **out) {
 }
 
 extern "C" void rsqp_destroy(rsqp_solver *s) { delete s; }
+
+extern "C" int rsqp_set_engine(rsqp_solver *s, int engine) {
+    if (!s || engine < 0 || engine > 2) return fail(RSQP_ERR_ARG, "rsqp_set_engine");
+    if (engine == 1 && !s->fits_small)
+        return fail(RSQP_ERR_TOO_LARGE, "rsqp_set_engine: problem image exceeds the 160 KiB LDS-resident engine");
+    s->engine = engine == 0 ? (s->fits_small ? 1 : 2) : engine;
+    return RSQP_OK;
+}
+extern "C" int rsqp_get_engine(const rsqp_solver *s) { return s ? s->engine : -1; }
 
 extern "C" int rsqp_set_options(rsqp_solver *s, int qp_maxiter, int lp_maxiter) {
     if (!s || qp_maxiter < 0 || lp_maxiter < 0) return fail(RSQP_ERR_ARG, "rsqp_set_options");
@@ -484,6 +500,48 @@ extern "C" int rsqp_reset_constraints(rsqp_solver *s) {
     return RSQP_OK;
 }
 
+namespace {
+int solve_large(rsqp_solver *s, int mode, int *nWSR, const double *x0, const double *y0, const int *guess_b) {
+    if (!s->large) s->large = new RsqpLargeEngine();
+    if (!s->large_ready) {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        if ((long long)free_b < RsqpLargeEngine::bytes_needed(s->nV, s->nC))
+            return fail(RSQP_ERR_TOO_LARGE, "HBM-resident engine: not enough device memory");
+        HIPCHK(s->large->init(s->nV, s->nC, s->stream));
+        s->large_ready = true;
+    }
+    RsqpLargeMatrices m;
+    if (s->A.initialised) {
+        m.Ajc = s->A.jc.p; m.Air = s->A.ir.p; m.Aval = s->A.val.p; m.blk_c = s->A.blk_c.p; m.nblk_c = s->A.nblk_c;
+        m.Arp = s->A.rp.p; m.Aci = s->A.ci.p; m.Arv = s->A.rval.p; m.blk_r = s->A.blk_r.p; m.nblk_r = s->A.nblk_r;
+    }
+    if (s->H.initialised) {
+        m.Hjc = s->H.jc.p; m.Hir = s->H.ir.p; m.Hval = s->H.val.p; m.blk_h = s->H.blk_c.p; m.nblk_h = s->H.nblk_c;
+        m.haveH = 1;
+    }
+    s->large->set_matrices(m);
+    int rc = s->large->solve(mode, s->d_vec[RSQP_VEC_G].p, s->d_vec[RSQP_VEC_LB].p, s->d_vec[RSQP_VEC_UB].p,
+                             s->d_vec[RSQP_VEC_LBA].p, s->d_vec[RSQP_VEC_UBA].p, nWSR, x0, y0, guess_b);
+    if (s->large->last_error() != hipSuccess)
+        return fail(RSQP_ERR_DEVICE, std::string("HBM-resident engine: ") + hipGetErrorString(s->large->last_error()));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(s->d_x.p, s->large->d_x(), sizeof(double) * s->nV, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(s->d_y.p, s->large->d_y(), sizeof(double) * (s->nV + s->nC), hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(s->d_wsb.p, s->large->d_Sb(), sizeof(int) * s->nV, hipMemcpyDeviceToDevice));
+    if (s->nC > 0) HIPCHK(hipMemcpy(s->d_wsc.p, s->large->d_Sc(), sizeof(int) * s->nC, hipMemcpyDeviceToDevice));
+    HIPCHK(s->d_x.download(s->h_x.data(), s->nV));
+    HIPCHK(s->d_y.download(s->h_y.data(), s->nV + s->nC));
+    HIPCHK(s->d_wsb.download(s->h_wsb.data(), s->nV));
+    HIPCHK(s->d_wsc.download(s->h_wsc.data(), s->nC));
+    s->status_word = s->large->status_word();
+    s->last_ret = rc;
+    s->last_nflips = s->large->nflips();
+    s->obj = s->large->objective();
+    return RSQP_OK;
+}
+}  // namespace
+
 extern "C" int rsqp_solve(rsqp_solver *s, int mode, int *nWSR, const double *x0, const double *y0,
                           const int *guess_b) {
     if (!s || !nWSR || mode < 0 || mode > 3) return fail(RSQP_ERR_ARG, "rsqp_solve");
@@ -493,6 +551,7 @@ extern "C" int rsqp_solve(rsqp_solver *s, int mode, int *nWSR, const double *x0,
     if (rc != RSQP_OK) return rc;
     rc = ensure_desc(s);
     if (rc != RSQP_OK) return rc;
+    if (s->engine == 2) return solve_large(s, mode, nWSR, x0, y0, guess_b);
     QPPools p = pools_of(s);
     if (mode == RSQP_MODE_WARM_REINIT) {
         if (x0) { HIPCHK(s->d_x0.upload(x0, s->nV)); p.x0 = s->d_x0.p; }

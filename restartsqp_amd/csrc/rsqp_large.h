@@ -1,0 +1,38 @@
+// rsqp_large.h -- HBM-resident engine for QPs that exceed the LDS-resident kernel (qp_large.hip)
+#pragma once
+#include "rsqp_sparse.h"
+
+enum { RSQP_LMODE_COLD = 0, RSQP_LMODE_HOT_VECTORS = 1, RSQP_LMODE_HOT_MATRICES = 2, RSQP_LMODE_WARM = 3 };
+
+// device views of the solver's matrices (owned by rsqp_solver)
+struct RsqpLargeMatrices {
+    const int *Ajc = nullptr, *Air = nullptr; const double *Aval = nullptr; const int4 *blk_c = nullptr; int nblk_c = 0;
+    const int *Arp = nullptr, *Aci = nullptr; const double *Arv = nullptr; const int4 *blk_r = nullptr; int nblk_r = 0;
+    const int *Hjc = nullptr, *Hir = nullptr; const double *Hval = nullptr; const int4 *blk_h = nullptr; int nblk_h = 0;
+    int haveH = 0;
+};
+
+class RsqpLargeEngine {
+public:
+    RsqpLargeEngine();
+    ~RsqpLargeEngine();
+    RsqpLargeEngine(const RsqpLargeEngine &) = delete;
+    RsqpLargeEngine &operator=(const RsqpLargeEngine &) = delete;
+    static long long bytes_needed(int nV, int nC);
+    hipError_t init(int nV, int nC, hipStream_t stream);
+    void set_matrices(const RsqpLargeMatrices &m);
+    // vectors are device pointers; x0 / y0 / guess_b are host pointers (may be null)
+    int solve(int mode, const double *d_g, const double *d_lb, const double *d_ub, const double *d_lbA,
+              const double *d_ubA, int *nWSR, const double *h_x0, const double *h_y0, const int *h_guess_b);
+    const double *d_x() const;
+    const double *d_y() const;
+    const int *d_Sb() const;
+    const int *d_Sc() const;
+    int status_word() const;
+    int nflips() const;
+    double objective();
+    hipError_t last_error() const;
+    struct Impl;
+private:
+    Impl *p_;
+};

@@ -1,0 +1,41 @@
+"""HBM-resident engine vs oracle on small / mid-size problems (development aid)."""
+import glob, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle as O
+from restartsqp_amd import capi, problems
+from restartsqp_amd.qpdump import read_qore_dump
+
+def run(q, engine=2, nWSR=2000):
+    s = capi.Solver(q.nV, q.nC)
+    s.set_engine(engine)
+    s.set_A_csc(q.A_jc, q.A_ir, q.A_val); s.set_H_csc(q.H_jc, q.H_ir, q.H_val)
+    for w, v in zip(range(5), (q.g, q.lb, q.ub, q.lbA, q.ubA)):
+        s.set_vector(w, v)
+    s.set_options(nWSR, 100)
+    t = time.time(); n = s.solve(capi.MODE_COLD, nWSR); t = time.time() - t
+    return s, n, t
+
+def orc(q, nWSR=2000):
+    qp = O.OracleQP(q.nV, q.nC); qp.set_A_csc(q.A_jc, q.A_ir, q.A_val); qp.set_H_csc(q.H_jc, q.H_ir, q.H_val)
+    t = time.time(); rc, n = qp.init(q.g, q.lb, q.ub, q.lbA, q.ubA, nWSR); t = time.time() - t
+    return qp, rc, n, t
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+cases = [problems.hs071_first_qp()] + [problems.random_qp(rng, int(rng.integers(2, 30)), int(rng.integers(0, 30))) for _ in range(12)]
+cases += [problems.random_qp(rng, 60, 40), problems.random_qp(rng, 40, 90), problems.random_qp(rng, 150, 120, 0.2)]
+cases += [read_qore_dump(p) for p in sorted(glob.glob(os.path.join(ROOT, "tests/golden/qore_dumps/*.log")))[:6]]
+bad = 0
+for k, q in enumerate(cases):
+    s, n, t = run(q)
+    qp, rc, n2, t2 = orc(q)
+    wb, wc = s.working_set_raw()
+    same = np.array_equal(wb, qp.ws_bounds) and np.array_equal(wc, qp.ws_constraints)
+    dx = np.abs(s.x - qp.x).max() / max(1, np.abs(qp.x).max()); dy = np.abs(s.y - qp.y).max() / max(1, np.abs(qp.y).max())
+    ok, st, _, _ = s.test_optimality()
+    good = same and n == n2 and s.status == qp.exitflag() and dx < 1e-8 and dy < 1e-8
+    bad += not good
+    print("%2d %-22s %3dx%-3d nWSR %4d/%4d status %d/%d ws %s dx %.1e dy %.1e kkt %.1e  gpu %.3fs cpu %.4fs %s" % (
+        k, q.name[:22], q.nV, q.nC, n, n2, s.status, qp.exitflag(), same, dx, dy, st.KKT_error, t, t2, "" if good else "<<<"), flush=True)
+print("mismatches", bad)
