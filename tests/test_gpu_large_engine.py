@@ -1,0 +1,173 @@
+"""HBM-resident engine (qp_large.hip: Householder / explicit-inverse null-space updates) against the
+oracle -- same bar as the LDS-resident kernel: working sets, status and nWSR bit-exact, x / y to
+1e-9 relative -- and BASELINE configs 3 and 4 at full size through the reference's KKT certificate."""
+import numpy as np
+import pytest
+
+from conftest import dump_paths, oracle_cold
+from restartsqp_amd import problems
+from restartsqp_amd.qpdump import QPData, dense_to_csc, read_qore_dump
+
+pytestmark = pytest.mark.gpu
+
+
+def load(capi, q, engine=2, nWSR=100000):
+    s = capi.Solver(q.nV, q.nC)
+    s.set_engine(engine)
+    s.set_options(nWSR, 100)
+    s.set_A_csc(q.A_jc, q.A_ir, q.A_val); s.set_H_csc(q.H_jc, q.H_ir, q.H_val)
+    for w, v in zip(range(5), (q.g, q.lb, q.ub, q.lbA, q.ubA)):
+        s.set_vector(w, v)
+    return s
+
+
+def same_as_oracle(s, n, qp, n_or, check_nwsr=True):
+    wb, wc = s.working_set_raw()
+    assert s.status == qp.exitflag()
+    assert np.array_equal(wb, qp.ws_bounds) and np.array_equal(wc, qp.ws_constraints)
+    if check_nwsr:
+        assert n == n_or
+    assert np.abs(s.x - qp.x).max() <= 1e-9 * max(1.0, np.abs(qp.x).max())
+    assert np.abs(s.y - qp.y).max() <= 1e-9 * max(1.0, np.abs(qp.y).max())
+
+
+def test_random_convex_against_oracle(capi, oracle):
+    rng = np.random.default_rng(41)
+    cases = [problems.hs071_first_qp()]
+    cases += [problems.random_qp(rng, int(rng.integers(1, 40)), int(rng.integers(0, 45))) for _ in range(14)]
+    cases += [problems.random_qp(rng, 90, 60, 0.3), problems.random_qp(rng, 50, 130, 0.3)]
+    for q in cases:
+        s = load(capi, q)
+        n = s.solve(capi.MODE_COLD, 5000)
+        qp, rc, n_or = oracle_cold(oracle, q, 5000)
+        same_as_oracle(s, n, qp, n_or)
+        ok, st, _, _ = s.test_optimality()
+        assert ok and st.KKT_error < 1e-9
+
+
+def test_edge_cases(capi, oracle):
+    rng = np.random.default_rng(43)
+    cases = [problems.random_qp(rng, 6, 0), problems.random_qp(rng, 1, 3)]
+    q = problems.random_qp(rng, 7, 4); q.lb[:] = -np.inf; q.ub[:] = 1e20; cases.append(q)        # free variables
+    q = problems.random_qp(rng, 9, 3); q.ubA[:] = q.lbA; cases.append(q)                           # equalities
+    A = np.array([[1.0, 1.0]])
+    cases.append(QPData(2, 1, *dense_to_csc(np.eye(2)), *dense_to_csc(A), np.zeros(2), -np.ones(2), np.ones(2),
+                        np.array([3.0]), np.array([np.inf])))                                      # infeasible
+    H = np.diag([1.0, -1.0])
+    cases.append(QPData(2, 0, *dense_to_csc(H), *dense_to_csc(np.zeros((0, 2))), np.array([0.0, -1.0]),
+                        np.array([-1.0, 0.0]), np.array([1.0, np.inf]), np.zeros(0), np.zeros(0)))  # unbounded
+    for q in cases:
+        s = load(capi, q)
+        n = s.solve(capi.MODE_COLD, 1000)
+        qp, rc, n_or = oracle_cold(oracle, q)
+        same_as_oracle(s, n, qp, n_or)
+    q = problems.random_qp(np.random.default_rng(3), 30, 40)
+    s = load(capi, q)
+    n = s.solve(capi.MODE_COLD, 3)
+    qp, rc, n_or = oracle_cold(oracle, q, nWSR=3)
+    assert n == n_or == 3 and s.status == qp.exitflag() == 28
+
+
+def test_nonconvex_dumps(capi, oracle):
+    """Flipping bounds on the reference's (indefinite) dumps. Without a flip the run is compared
+    like a convex one. With flips the homotopy path of a non-convex QP is not unique under
+    rounding (an equality held "at its lower side" by one run is held "at its upper side" by the
+    other), so the comparison is: same primal point, same objective, same set of active
+    quantities, and the reference's certificate with the same verdict."""
+    from conftest import oracle_certificate
+    for p in dump_paths():
+        q = read_qore_dump(p)
+        s = load(capi, q)
+        n = s.solve(capi.MODE_COLD, 1000)
+        qp, rc, n_or = oracle_cold(oracle, q)
+        if qp.nflips() == 0:
+            same_as_oracle(s, n, qp, n_or)
+            continue
+        wb, wc = s.working_set_raw()
+        assert s.status == qp.exitflag() == 20
+        assert np.abs(s.x - qp.x).max() <= 1e-9 * max(1.0, np.abs(qp.x).max())
+        assert abs(s.objective - qp.objective) <= 1e-9 * max(1.0, abs(qp.objective))
+        eq_b, eq_c = q.lb == q.ub, q.lbA == q.ubA
+        assert np.array_equal(wb[~eq_b], qp.ws_bounds[~eq_b]) and np.array_equal(wc[~eq_c], qp.ws_constraints[~eq_c])
+        assert np.array_equal(wb != 0, qp.ws_bounds != 0) and np.array_equal(wc != 0, qp.ws_constraints != 0)
+        ok, st, _, _ = s.test_optimality()
+        ok_o, st_o, _, _ = oracle_certificate(oracle, q, qp.x, qp.y, qp.ws_bounds, qp.ws_constraints)
+        scale = max(1.0, np.abs(q.g).max(), np.abs(q.H_val).max() * max(1.0, np.abs(qp.x).max()), np.abs(qp.y).max())
+        assert abs(st.KKT_error - st_o.KKT_error) <= 1e-12 * scale
+
+
+def test_hot_start_modes(capi, oracle):
+    rng = np.random.default_rng(47)
+    for _ in range(4):
+        q = problems.random_qp(rng, int(rng.integers(8, 40)), int(rng.integers(3, 35)))
+        s = load(capi, q)
+        n = s.solve(capi.MODE_COLD, 5000)
+        qp, rc, n_or = oracle_cold(oracle, q, 5000)
+        same_as_oracle(s, n, qp, n_or)
+        q2 = problems.perturb(rng, q, 0.05)                      # hotstart(g, lb, ub, lbA, ubA)
+        for w, v in zip(range(5), (q2.g, q2.lb, q2.ub, q2.lbA, q2.ubA)):
+            s.set_vector(w, v)
+        n = s.solve(capi.MODE_HOT_VECTORS, 5000)
+        rc, n_or = qp.hotstart(q2.g, q2.lb, q2.ub, q2.lbA, q2.ubA, 5000)
+        same_as_oracle(s, n, qp, n_or)
+        A2 = q2.A_val * (1.0 + 0.01 * rng.normal(size=q2.A_val.shape))   # hotstart(H, g, A, ...)
+        s.set_A_csc(q2.A_jc, q2.A_ir, A2); s.set_H_csc(q2.H_jc, q2.H_ir, q2.H_val * 1.05)
+        n = s.solve(capi.MODE_HOT_MATRICES, 5000)
+        qp.set_A_csc(q2.A_jc, q2.A_ir, A2); qp.set_H_csc(q2.H_jc, q2.H_ir, q2.H_val * 1.05)
+        rc, n_or = qp.hotstart_matrices(q2.g, q2.lb, q2.ub, q2.lbA, q2.ubA, 5000)
+        same_as_oracle(s, n, qp, n_or)
+        x0, y0, gb = s.x, s.y, s.working_set_raw()[0]               # init(..., x0, y0, bounds)
+        q3 = problems.perturb(rng, q2, 0.05)
+        for w, v in zip(range(5), (q3.g, q3.lb, q3.ub, q3.lbA, q3.ubA)):
+            s.set_vector(w, v)
+        n = s.solve(capi.MODE_WARM_REINIT, 5000, x0, y0, gb)
+        rc, n_or = qp.init(q3.g, q3.lb, q3.ub, q3.lbA, q3.ubA, 5000, x0=x0, y0=y0, guess_b=gb)
+        same_as_oracle(s, n, qp, n_or)
+
+
+def test_mid_size_dense_matches_oracle(capi, oracle):
+    q = problems.dense_qp(300, 600, seed=20260101)
+    s = load(capi, q, engine=0)
+    assert s.engine == 2                      # does not fit LDS: automatic choice
+    n = s.solve(capi.MODE_COLD, 100000)
+    qp, rc, n_or = oracle_cold(oracle, q, 100000)
+    same_as_oracle(s, n, qp, n_or)
+
+
+def test_baseline_dense_2048x4096_certificate(capi):
+    """BASELINE config 3 at full size: cold start; checked through the reference's acceptance
+    test (KKT_error <= 1e-6) and size-independent properties of the answer."""
+    q = problems.dense_qp()
+    s = load(capi, q, engine=0)
+    n = s.solve(capi.MODE_COLD, 200000)
+    ok, st, Wc, Wb = s.test_optimality()
+    assert s.status == 20 and ok and st.KKT_error < 1e-8
+    x, y = s.x, s.y
+    wb, wc = s.working_set_raw()
+    assert np.all(x >= q.lb - 1e-9) and np.all(x <= q.ub + 1e-9)
+    assert np.all(y[:q.nV][wb == 0] == 0.0) and np.all(y[q.nV:][wc == 0] == 0.0)          # complementarity
+    assert np.all(y[q.nV:][wc == -1] >= 0.0) and np.all(y[q.nV:][wc == 1] <= 0.0)           # dual signs
+    assert (wc != 0).sum() + (wb != 0).sum() <= q.nV and n >= (wc != 0).sum()
+    # idempotence: a hot start on unchanged data takes no working-set change
+    assert s.solve(capi.MODE_HOT_VECTORS, 1000) == 0 and np.array_equal(s.x, x)
+
+
+def test_baseline_sparse_10k_sequence(capi):
+    """BASELINE config 4: n = 10 000, m = 20 000, 200 000 Jacobian non-zeros; cold start, then
+    warm-started QPs of the sequence (vector updates); every answer certified."""
+    q = problems.sparse_qp()
+    s = load(capi, q, engine=0)
+    n = s.solve(capi.MODE_COLD, 200000)
+    ok, st, _, _ = s.test_optimality()
+    assert s.status == 20 and ok and st.KKT_error < 1e-8 and n > 1000
+    steps = 0
+    for qk, changed in problems.sparse_sequence(q, nsteps=4):
+        if changed:
+            continue
+        for w, v in zip(range(5), (qk.g, qk.lb, qk.ub, qk.lbA, qk.ubA)):
+            s.set_vector(w, v)
+        nk = s.solve(capi.MODE_HOT_VECTORS, 200000)
+        ok, st, _, _ = s.test_optimality()
+        assert s.status == 20 and ok and nk < n // 10
+        steps += 1
+    assert steps == 2
