@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -57,11 +58,10 @@ __global__ void __launch_bounds__(NT) k_gemv_t(const double *__restrict__ M, lon
 }
 
 // partial[chunk*nrows + r] = sum_{c in chunk} M[c*ld + r] * w[c]
-constexpr int GEMV_CHUNK = 64;
 __global__ void __launch_bounds__(NT) k_gemv_n_part(const double *__restrict__ M, long long ld, int nrows, int ncols,
-                                                    const double *__restrict__ w, double *__restrict__ part) {
+                                                    int chunk, const double *__restrict__ w, double *__restrict__ part) {
     const int r = blockIdx.x * NT + threadIdx.x;
-    const int c0 = blockIdx.y * GEMV_CHUNK, c1 = min(c0 + GEMV_CHUNK, ncols);
+    const int c0 = blockIdx.y * chunk, c1 = min(c0 + chunk, ncols);
     if (r >= nrows) return;
     double s = 0.0;
     for (int c = c0; c < c1; c++) s += M[c * ld + r] * w[c];
@@ -536,10 +536,15 @@ struct RsqpLargeEngine::Impl {
     double *h_pinned = nullptr;  // small pinned read-back buffer
     int *h_pinned_i = nullptr;
     int nblk_ratio = 0;
+    long long part_cap = 0;
+    // maintained products (refreshed exactly every REFRESH working-set changes)
+    double *ATy = nullptr, *Hx = nullptr, *Hdx = nullptr, *ATdy = nullptr;
+    bool dirty_products = true;
+    int since_refresh = 0;
 
     ~Impl() {
         double *dv[] = {Z, Y, Minv, Wz, x, g, lb, ub, gN, lbN, ubN, dx, w1, w2, w3, w4, w5, w6, wz1, wz2, wz3, Ax, lbA, ubA,
-                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t};
+                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy};
         for (double *p : dv) if (p) (void)hipFree(p);
         int *iv[] = {Sb, Sc, AC, posAC, pid, res_id};
         for (int *p : iv) if (p) (void)hipFree(p);
@@ -548,20 +553,36 @@ struct RsqpLargeEngine::Impl {
     }
 
     // ---- launch helpers -----------------------------------------------------------
+    bool debug = getenv("RSQP_DEBUG") != nullptr;
+    void chk(const char *what) {
+        if (!debug) return;
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { fprintf(stderr, "[rsqp large] %s: %s (nV=%d nC=%d nZ=%d nAC=%d)\n", what, hipGetErrorString(e), nV, nC, nZ, nAC); debug = false; }
+    }
     void gemv_t(const double *Mx, long long l, int nrows, int ncols, const double *xv, double *out) {
         if (ncols > 0) hipLaunchKernelGGL(k_gemv_t, dim3(ncols), dim3(NT), 0, st, Mx, l, nrows, ncols, xv, out);
+        chk("gemv_t");
     }
     // out = beta*base + alpha * M w
     void gemv_n(const double *Mx, long long l, int nrows, int ncols, const double *wv, double alpha, double beta,
                 const double *base, double *out) {
+        if (nrows <= 0) return;
         if (ncols <= 0) {
             if (base && beta != 0.0) hipLaunchKernelGGL(k_axpby, g1(nrows), dim3(NT), 0, st, nrows, beta, base, 0.0, (const double *)nullptr, out);
             else hipLaunchKernelGGL(k_fill, g1(nrows), dim3(NT), 0, st, out, nrows, 0.0);
             return;
         }
-        const int nch = (ncols + GEMV_CHUNK - 1) / GEMV_CHUNK;
-        hipLaunchKernelGGL(k_gemv_n_part, dim3((nrows + NT - 1) / NT, nch), dim3(NT), 0, st, Mx, l, nrows, ncols, wv, part);
+        // column chunk: enough workgroups to fill 256 CUs several times over, but no more
+        // partial vectors than the scratch buffer holds (part_cap doubles)
+        const int rb = (nrows + NT - 1) / NT;
+        int chunk = 64;
+        while (chunk > 8 && (long long)rb * ((ncols + chunk - 1) / chunk) < 2048) chunk >>= 1;
+        while ((long long)((ncols + chunk - 1) / chunk) * nrows > part_cap) chunk <<= 1;
+        const int nch = (ncols + chunk - 1) / chunk;
+        hipLaunchKernelGGL(k_gemv_n_part, dim3(rb, nch), dim3(NT), 0, st, Mx, l, nrows, ncols, chunk, wv, part);
         hipLaunchKernelGGL(k_gemv_n_reduce, g1(nrows), dim3(NT), 0, st, part, nrows, nch, alpha, beta, base, out);
+        chk("gemv_n");
     }
     void ger(double *Mx, long long l, int nrows, int ncols, const double *t, const double *v, int ci, double cs) {
         if (ncols > 0 && nrows > 0)
@@ -572,16 +593,22 @@ struct RsqpLargeEngine::Impl {
     }
     void copy(const double *s, double *d, int n) { if (n > 0) hipLaunchKernelGGL(k_copy, g1(n), dim3(NT), 0, st, s, d, n); }
     void fill(double *d, int n, double v) { if (n > 0) hipLaunchKernelGGL(k_fill, g1(n), dim3(NT), 0, st, d, n, v); }
-    void A_times(const double *in, double *out) {   // out[nC] = A in   (CSR copy)
-        if (nC > 0) rsqp_launch_spmv(M.blk_r, M.nblk_r, M.Arp, M.Aci, M.Arv, in, out, 1, 0, 0, 0, 0, st);
+    // full products. A dense copy (column-major) is used when the matrix is dense enough that
+    // 8 B/entry coalesced GEMV beats 12 B/entry gather SpMV (BASELINE's dense configuration)
+    void A_times(const double *in, double *out) {   // out[nC] = A in
+        if (nC <= 0) return;
+        if (M.denseA) gemv_n(M.denseA, nC, nC, nV, in, 1.0, 0.0, nullptr, out);
+        else rsqp_launch_spmv(M.blk_r, M.nblk_r, M.Arp, M.Aci, M.Arv, in, out, 1, 0, 0, 0, 0, st);
     }
-    void AT_times(const double *in, double *out) {  // out[nV] = A' in  (CSC)
-        if (nC > 0) rsqp_launch_spmv(M.blk_c, M.nblk_c, M.Ajc, M.Air, M.Aval, in, out, 1, 0, 0, 0, 0, st);
-        else fill(out, nV, 0.0);
+    void AT_times(const double *in, double *out) {  // out[nV] = A' in
+        if (nC <= 0) fill(out, nV, 0.0);
+        else if (M.denseA) gemv_t(M.denseA, nC, nC, nV, in, out);
+        else rsqp_launch_spmv(M.blk_c, M.nblk_c, M.Ajc, M.Air, M.Aval, in, out, 1, 0, 0, 0, 0, st);
     }
     void H_times(const double *in, double *out) {
-        if (M.haveH) rsqp_launch_spmv(M.blk_h, M.nblk_h, M.Hjc, M.Hir, M.Hval, in, out, 1, 0, 0, 0, 0, st);
-        else fill(out, nV, 0.0);
+        if (!M.haveH) fill(out, nV, 0.0);
+        else if (M.denseH) gemv_t(M.denseH, nV, nV, nV, in, out);
+        else rsqp_launch_spmv(M.blk_h, M.nblk_h, M.Hjc, M.Hir, M.Hval, in, out, 1, 0, 0, 0, 0, st);
     }
     int read_scal(int s0, int n, double *out) {
         LCHK(hipMemcpyAsync(h_pinned, scal + s0, sizeof(double) * n, hipMemcpyDeviceToHost, st));
@@ -810,7 +837,7 @@ struct RsqpLargeEngine::Impl {
     int ensure_LI(int side, double *y_new, int *pkind, int *pidx) {
         fill(c1, nC, 0.0);
         gemv_t(Minv, ldm, nAC, nAC, a1, a2);   // hmm: xiC = Minv' wY  -> xi[j] = sum_i Minv[i][j] wY[i]
-        hipLaunchKernelGGL(k_scatter_active, g1(nAC), dim3(NT), 0, st, a2, AC, nAC, c1);
+        if (nAC > 0) hipLaunchKernelGGL(k_scatter_active, g1(nAC), dim3(NT), 0, st, a2, AC, nAC, c1);
         AT_times(c1, w2);
         hipLaunchKernelGGL(k_xiB, g1(nV), dim3(NT), 0, st, nV, Sb, w4, w2, w3);
         const double sgn = side == 1 ? -1.0 : 1.0;
@@ -823,6 +850,7 @@ struct RsqpLargeEngine::Impl {
         const int id = h_pinned_i[0];
         if (id == 0x7fffffff) return RET_INFEASIBLE;
         hipLaunchKernelGGL(k_shift_duals, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, Sc, t, sgn, c1, w3, y);
+        dirty_products = true;
         *y_new = sgn * t;
         *pkind = id < nC ? 1 : 2;
         *pidx = id < nC ? id : id - nC;
@@ -892,28 +920,40 @@ struct RsqpLargeEngine::Impl {
         gemv_n(Z, ld, nV, nZ, wz2, 1.0, 1.0, w3, w4);                      // xY + Z wZ
         hipLaunchKernelGGL(k_merge_free, g1(nV), dim3(NT), 0, st, nV, Sb, w4, dx);
         // multipliers: dyAC = Minv' Y'(H dx + dg)
-        H_times(dx, w2);
-        hipLaunchKernelGGL(k_add_dg, g1(nV), dim3(NT), 0, st, nV, w2, gN, g, w2);   // res
+        H_times(dx, Hdx);
+        hipLaunchKernelGGL(k_add_dg, g1(nV), dim3(NT), 0, st, nV, Hdx, gN, g, w2);   // res
         gemv_t(Y, ld, nV, nAC, w2, a1);
         gemv_t(Minv, ldm, nAC, nAC, a1, a2);                               // a2[j] = sum_i Minv[i][j] rhsY[i]
         if (nAC > 0) hipLaunchKernelGGL(k_scatter_active, g1(nAC), dim3(NT), 0, st, a2, AC, nAC, dy + nV);
-        AT_times(dy + nV, w3);
-        hipLaunchKernelGGL(k_dy_fixed, g1(nV), dim3(NT), 0, st, nV, Sb, w2, w3, dy);
+        AT_times(dy + nV, ATdy);
+        hipLaunchKernelGGL(k_dy_fixed, g1(nV), dim3(NT), 0, st, nV, Sb, w2, ATdy, dy);
         A_times(dx, dAx);
+        chk("step_direction");
     }
 
+    // A x, A'y_C and H x follow the iterate by axpy (their increments are by-products of the
+    // step direction); every REFRESH changes, and whenever an exchange shifted the duals, they
+    // are recomputed exactly so that rounding cannot accumulate
+    static constexpr int REFRESH = 8;
+    void refresh_products() {
+        A_times(x, Ax);
+        AT_times(y + nV, ATy);
+        H_times(x, Hx);
+        dirty_products = false;
+        since_refresh = 0;
+    }
     void drift_correction() {
         hipLaunchKernelGGL(k_fix_x, g1(nV), dim3(NT), 0, st, nV, Sb, lb, ub, x);
-        A_times(x, Ax);
+        if (dirty_products || ++since_refresh >= REFRESH) refresh_products();
         if (nC > 0) hipLaunchKernelGGL(k_fix_bA, g1(nC), dim3(NT), 0, st, nC, Sc, Ax, lbA, ubA);
-        AT_times(y + nV, w1);
-        H_times(x, w2);
-        hipLaunchKernelGGL(k_fix_g, g1(nV), dim3(NT), 0, st, nV, w1, y, w2, g);
+        hipLaunchKernelGGL(k_fix_g, g1(nV), dim3(NT), 0, st, nV, ATy, y, Hx, g);
+        chk("drift");
     }
 
     int homotopy(int maxit, int *nWSR) {
         int iter = 0, rcode = RET_OK;
         status = QPS_PERFORMINGHOMOTOPY;
+        refresh_products();
         hipLaunchKernelGGL(k_rerelax, g1(nV), dim3(NT), 0, st, nV, Sb, x, lbN, ubN, lb, ub);
         if (nC > 0) hipLaunchKernelGGL(k_rerelax, g1(nC), dim3(NT), 0, st, nC, Sc, Ax, lbAN, ubAN, lbA, ubA);
         for (;;) {
@@ -939,8 +979,10 @@ struct RsqpLargeEngine::Impl {
             hipLaunchKernelGGL(k_step_v, g1(nV), dim3(NT), 0, st, nV, tau, done, Sb, x, g, lb, ub, gN, lbN, ubN, dx);
             hipLaunchKernelGGL(k_axpy, g1(nV + nC), dim3(NT), 0, st, nV + nC, tau, dy, y);
             if (nC > 0) hipLaunchKernelGGL(k_step_c, g1(nC), dim3(NT), 0, st, nC, tau, done, lbA, ubA, lbAN, ubAN);
-            A_times(x, Ax);
-            if (done) { status = QPS_SOLVED; break; }
+            if (done) { A_times(x, Ax); status = QPS_SOLVED; break; }
+            if (nC > 0) hipLaunchKernelGGL(k_axpy, g1(nC), dim3(NT), 0, st, nC, tau, dAx, Ax);
+            hipLaunchKernelGGL(k_axpy, g1(nV), dim3(NT), 0, st, nV, tau, ATdy, ATy);
+            hipLaunchKernelGGL(k_axpy, g1(nV), dim3(NT), 0, st, nV, tau, Hdx, Hx);
             if (iter >= maxit) { rcode = RET_MAX_NWSR; break; }
             if (kind == 3) hipLaunchKernelGGL(k_copy1, dim3(1), dim3(1), 0, st, side == -1 ? lbA : ubA, idx, Ax, idx);
             else if (kind == 4) hipLaunchKernelGGL(k_copy1, dim3(1), dim3(1), 0, st, side == -1 ? lb : ub, idx, x, idx);
@@ -1018,8 +1060,9 @@ hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
     DA(Ax, nC); DA(lbA, nC); DA(ubA, nC); DA(lbAN, nC); DA(ubAN, nC); DA(dAx, nC); DA(c1, nC); DA(c2, nC); DA(c3, nC);
     DA(a1, P.nAmax + 2); DA(a2, P.nAmax + 2); DA(a3, P.nAmax + 2); DA(a4, P.nAmax + 2);
     DA(y, nV + nC); DA(dy, nV + nC);
-    const int nch = (nV + GEMV_CHUNK - 1) / GEMV_CHUNK;
-    DA(part, (size_t)nch * nV);
+    P.part_cap = std::max<long long>((long long)std::max(nV, nC) * 64, (long long)std::max(nV, nC) * (std::max(nV, nC) / 64 + 1));
+    DA(part, (size_t)P.part_cap);
+    DA(ATy, nV); DA(Hx, nV); DA(Hdx, nV); DA(ATdy, nV);
     DA(scal, 64);
     P.nblk_ratio = std::min(1024, std::max(1, (nV + nC + NT - 1) / NT));
     DA(pt, P.nblk_ratio); DA(res_t, 2);

@@ -197,6 +197,7 @@ struct rsqp_solver {
     bool fits_small = true;
     RsqpLargeEngine *large = nullptr;
     bool large_ready = false;
+    DevBuf<double> denseA, denseH;   // dense copies for the HBM-resident engine (dense matrices only)
     ~rsqp_solver() { delete large; }
 };
 
@@ -519,6 +520,20 @@ int solve_large(rsqp_solver *s, int mode, int *nWSR, const double *x0, const dou
     if (s->H.initialised) {
         m.Hjc = s->H.jc.p; m.Hir = s->H.ir.p; m.Hval = s->H.val.p; m.blk_h = s->H.blk_c.p; m.nblk_h = s->H.nblk_c;
         m.haveH = 1;
+    }
+    // dense copies when more than a quarter of the entries are stored (refreshed every solve
+    // that follows a matrix update: cheap next to the solve)
+    if (s->A.initialised && (double)s->A.nnz > 0.25 * (double)s->nC * s->nV) {
+        if (!s->denseA.p) HIPCHK(s->denseA.alloc((size_t)s->nC * s->nV, false));
+        if (rsqp_launch_densify(s->nC, s->nV, s->A.jc.p, s->A.ir.p, s->A.val.p, s->denseA.p, s->stream) != hipSuccess)
+            return fail(RSQP_ERR_DEVICE, "densify launch failed");
+        m.denseA = s->denseA.p;
+    }
+    if (s->H.initialised && (double)s->H.nnz > 0.25 * (double)s->nV * s->nV) {
+        if (!s->denseH.p) HIPCHK(s->denseH.alloc((size_t)s->nV * s->nV, false));
+        if (rsqp_launch_densify(s->nV, s->nV, s->H.jc.p, s->H.ir.p, s->H.val.p, s->denseH.p, s->stream) != hipSuccess)
+            return fail(RSQP_ERR_DEVICE, "densify launch failed");
+        m.denseH = s->denseH.p;
     }
     s->large->set_matrices(m);
     int rc = s->large->solve(mode, s->d_vec[RSQP_VEC_G].p, s->d_vec[RSQP_VEC_LB].p, s->d_vec[RSQP_VEC_UB].p,

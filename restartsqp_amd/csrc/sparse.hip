@@ -302,6 +302,14 @@ __global__ void scatter_values(int n, const int *__restrict__ order, const int *
     if (i < n) val[order[i]] = tv[tmap ? tmap[i] : i];
 }
 
+// dense column-major copy of a CSC matrix (the target is zero-filled beforehand)
+__global__ void densify_csc(int ncol, long long ld, const int *__restrict__ jc, const int *__restrict__ ir,
+                            const double *__restrict__ val, double *__restrict__ dense) {
+    const int c = blockIdx.x;
+    if (c >= ncol) return;
+    for (int k = jc[c] + threadIdx.x; k < jc[c + 1]; k += blockDim.x) dense[c * ld + ir[k]] = val[k];
+}
+
 __global__ void gather_values(int n, const int *__restrict__ perm, const double *__restrict__ src,
                               double *__restrict__ dst) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -540,6 +548,14 @@ hipError_t rsqp_launch_scatter(int n, const int *order, const int *tmap, const d
 hipError_t rsqp_launch_gather(int n, const int *perm, const double *src, double *dst, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(gather_values, dim3((n + 255) / 256), dim3(256), 0, stream, n, perm, src, dst);
+    return hipGetLastError();
+}
+
+hipError_t rsqp_launch_densify(int nrow, int ncol, const int *jc, const int *ir, const double *val, double *dense,
+                               hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(dense, 0, sizeof(double) * (size_t)nrow * ncol, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(densify_csc, dim3(ncol), dim3(256), 0, stream, ncol, (long long)nrow, jc, ir, val, dense);
     return hipGetLastError();
 }
 
