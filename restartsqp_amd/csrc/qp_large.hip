@@ -57,15 +57,28 @@ __global__ void __launch_bounds__(NT) k_gemv_t(const double *__restrict__ M, lon
     if (threadIdx.x == 0) out[c] = s;
 }
 
-// partial[chunk*nrows + r] = sum_{c in chunk} M[c*ld + r] * w[c]
+// out = beta*base + alpha * M w, column-major M. A workgroup owns 64 consecutive rows (one
+// 512-byte run per column) and a chunk of columns, its four waves stride the chunk; the four
+// wave sums meet in LDS in fixed order. With one chunk the result is final; otherwise the
+// partials [chunk][row] are summed in chunk order by k_gemv_n_reduce (deterministic).
 __global__ void __launch_bounds__(NT) k_gemv_n_part(const double *__restrict__ M, long long ld, int nrows, int ncols,
-                                                    int chunk, const double *__restrict__ w, double *__restrict__ part) {
-    const int r = blockIdx.x * NT + threadIdx.x;
+                                                    int chunk, const double *__restrict__ w, double *__restrict__ part,
+                                                    double alpha, double beta, const double *__restrict__ base,
+                                                    double *__restrict__ out) {
+    __shared__ double sh[4][64];
+    const int lane = threadIdx.x & 63, cl = threadIdx.x >> 6;
+    const int r = blockIdx.x * 64 + lane;
     const int c0 = blockIdx.y * chunk, c1 = min(c0 + chunk, ncols);
-    if (r >= nrows) return;
     double s = 0.0;
-    for (int c = c0; c < c1; c++) s += M[c * ld + r] * w[c];
-    part[(long long)blockIdx.y * nrows + r] = s;
+    if (r < nrows)
+        for (int c = c0 + cl; c < c1; c += 4) s += M[c * ld + r] * w[c];
+    sh[cl][lane] = s;
+    __syncthreads();
+    if (cl == 0 && r < nrows) {
+        const double t = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+        if (gridDim.y == 1) out[r] = (base ? beta * base[r] : 0.0) + alpha * t;
+        else part[(long long)blockIdx.y * nrows + r] = t;
+    }
 }
 // out[r] = beta * base[r] + alpha * sum_chunks part
 __global__ void k_gemv_n_reduce(const double *__restrict__ part, int nrows, int nchunks, double alpha, double beta,
@@ -573,15 +586,16 @@ struct RsqpLargeEngine::Impl {
             else hipLaunchKernelGGL(k_fill, g1(nrows), dim3(NT), 0, st, out, nrows, 0.0);
             return;
         }
-        // column chunk: enough workgroups to fill 256 CUs several times over, but no more
-        // partial vectors than the scratch buffer holds (part_cap doubles)
-        const int rb = (nrows + NT - 1) / NT;
-        int chunk = 64;
-        while (chunk > 8 && (long long)rb * ((ncols + chunk - 1) / chunk) < 2048) chunk >>= 1;
-        while ((long long)((ncols + chunk - 1) / chunk) * nrows > part_cap) chunk <<= 1;
-        const int nch = (ncols + chunk - 1) / chunk;
-        hipLaunchKernelGGL(k_gemv_n_part, dim3(rb, nch), dim3(NT), 0, st, Mx, l, nrows, ncols, chunk, wv, part);
-        hipLaunchKernelGGL(k_gemv_n_reduce, g1(nrows), dim3(NT), 0, st, part, nrows, nch, alpha, beta, base, out);
+        // chunks: enough workgroups to fill the 256 CUs a few times, as few partials as possible
+        const int rb = (nrows + 63) / 64;
+        int nch = std::max(1, std::min((1024 + rb - 1) / rb, (ncols + 15) / 16));
+        while ((long long)nch * nrows > part_cap) nch = (nch + 1) / 2;
+        const int chunk = (ncols + nch - 1) / nch;
+        nch = (ncols + chunk - 1) / chunk;
+        hipLaunchKernelGGL(k_gemv_n_part, dim3(rb, nch), dim3(NT), 0, st, Mx, l, nrows, ncols, chunk, wv, part, alpha, beta,
+                           base, out);
+        if (nch > 1)
+            hipLaunchKernelGGL(k_gemv_n_reduce, dim3((nrows + 63) / 64), dim3(64), 0, st, part, nrows, nch, alpha, beta, base, out);
         chk("gemv_n");
     }
     void ger(double *Mx, long long l, int nrows, int ncols, const double *t, const double *v, int ci, double cs) {
