@@ -563,10 +563,29 @@ struct RsqpLargeEngine::Impl {
         for (int *p : iv) if (p) (void)hipFree(p);
         if (h_pinned) (void)hipHostFree(h_pinned);
         if (h_pinned_i) (void)hipHostFree(h_pinned_i);
+        preport();
     }
 
     // ---- launch helpers -----------------------------------------------------------
     bool debug = getenv("RSQP_DEBUG") != nullptr;
+    // RSQP_PROFILE=1: per kernel class, HIP-event time and algorithmic bytes (serialises the stream)
+    bool profile = getenv("RSQP_PROFILE") != nullptr;
+    struct Prof { double ms = 0, bytes = 0; long long calls = 0; };
+    Prof prof[8];
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    void pbegin() { if (profile) { if (!pe0) { (void)hipEventCreate(&pe0); (void)hipEventCreate(&pe1); } (void)hipEventRecord(pe0, st); } }
+    void pend(int cls, double bytes) {
+        if (!profile) return;
+        (void)hipEventRecord(pe1, st); (void)hipEventSynchronize(pe1);
+        float ms = 0; (void)hipEventElapsedTime(&ms, pe0, pe1);
+        prof[cls].ms += ms; prof[cls].bytes += bytes; prof[cls].calls++;
+    }
+    void preport() {
+        if (!profile) return;
+        const char *nm[8] = {"gemv_n", "gemv_t", "ger", "wz_shrink", "wz_grow", "spmv", "", ""};
+        for (int k = 0; k < 6; k++)
+            if (prof[k].calls) fprintf(stderr, "[rsqp profile] %-9s calls %8lld  time %9.3f ms  bytes %10.3f GB  => %7.1f GB/s  (avg %.1f us)\n", nm[k], prof[k].calls, prof[k].ms, prof[k].bytes / 1e9, prof[k].bytes / (prof[k].ms * 1e-3) / 1e9, 1e3 * prof[k].ms / prof[k].calls);
+    }
     void chk(const char *what) {
         if (!debug) return;
         hipError_t e = hipGetLastError();
@@ -574,7 +593,9 @@ struct RsqpLargeEngine::Impl {
         if (e != hipSuccess) { fprintf(stderr, "[rsqp large] %s: %s (nV=%d nC=%d nZ=%d nAC=%d)\n", what, hipGetErrorString(e), nV, nC, nZ, nAC); debug = false; }
     }
     void gemv_t(const double *Mx, long long l, int nrows, int ncols, const double *xv, double *out) {
+        pbegin();
         if (ncols > 0) hipLaunchKernelGGL(k_gemv_t, dim3(ncols), dim3(NT), 0, st, Mx, l, nrows, ncols, xv, out);
+        pend(1, 8.0 * nrows * (double)ncols + 8.0 * nrows + 8.0 * ncols);
         chk("gemv_t");
     }
     // out = beta*base + alpha * M w
@@ -586,6 +607,7 @@ struct RsqpLargeEngine::Impl {
             else hipLaunchKernelGGL(k_fill, g1(nrows), dim3(NT), 0, st, out, nrows, 0.0);
             return;
         }
+        pbegin();
         // chunks: enough workgroups to fill the 256 CUs a few times, as few partials as possible
         const int rb = (nrows + 63) / 64;
         int nch = std::max(1, std::min((1024 + rb - 1) / rb, (ncols + 15) / 16));
@@ -596,11 +618,14 @@ struct RsqpLargeEngine::Impl {
                            base, out);
         if (nch > 1)
             hipLaunchKernelGGL(k_gemv_n_reduce, dim3((nrows + 63) / 64), dim3(64), 0, st, part, nrows, nch, alpha, beta, base, out);
+        pend(0, 8.0 * nrows * (double)ncols + 8.0 * nrows + 8.0 * ncols);
         chk("gemv_n");
     }
     void ger(double *Mx, long long l, int nrows, int ncols, const double *t, const double *v, int ci, double cs) {
+        pbegin();
         if (ncols > 0 && nrows > 0)
             hipLaunchKernelGGL(k_ger, dim3((nrows + NT - 1) / NT, ncols), dim3(NT), 0, st, Mx, l, nrows, ncols, t, v, scal, ci, cs);
+        pend(2, 16.0 * nrows * (double)ncols);
     }
     void dot(const double *a, const double *b, int n, int slot) {
         hipLaunchKernelGGL(k_dot, dim3(1), dim3(NT), 0, st, a, b, n, scal, slot);
@@ -647,9 +672,11 @@ struct RsqpLargeEngine::Impl {
         gemv_n(Wz, ld, nZ, nZ, wz2, 1.0, 0.0, nullptr, wz3);                             // s = Wz v
         dot(wz2, wz3, nZ, 4);                                                            // theta
         hipLaunchKernelGGL(k_wz_lastcol, g1(nZ), dim3(NT), 0, st, Wz, ld, nZ, wz3, wz2, scal, 1, 4, w6);
+        pbegin();
         if (nZ > 1)
             hipLaunchKernelGGL(k_wz_shrink, dim3((nZ - 1 + NT - 1) / NT, nZ - 1), dim3(NT), 0, st, Wz, ld, nZ, wz3, wz2, w6,
                                scal, 1, 4);
+        pend(3, 16.0 * (double)nZ * nZ);
     }
 
     // append the Y column `ycol` (already stored at Y[:, nAC]) for constraint r whose products
@@ -735,7 +762,9 @@ struct RsqpLargeEngine::Impl {
         if (read_scal(13, 2, r) != RET_OK) return RET_SETUP_FAILED;
         *pd = r[0] > r[1];
         if (*pd) {
+            pbegin();
             hipLaunchKernelGGL(k_wz_grow, dim3((nZ + 1 + NT - 1) / NT, nZ + 1), dim3(NT), 0, st, Wz, ld, nZ, wz2, scal, 13);
+            pend(4, 16.0 * (double)nZ * nZ);
             nZ++;
         }
         return RET_OK;
