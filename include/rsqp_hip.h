@@ -122,6 +122,11 @@ int rsqp_reset_constraints(rsqp_solver *s);
  * get_Matrix_change_status (:817-833), reset_flags (:488-496) and handle_error
  * (:686-758). *nWSR_used receives what the adapter adds to Stats::qp_iter. */
 int rsqp_optimize_qp(rsqp_solver *s, int *nWSR_used);
+/* optimizeLP (qpOASESInterface.cpp:227-284): the same engine with H = 0 and the lp_maxiter
+ * budget. As qpOASES does for an all-zero Hessian, the LP is solved as the QP with
+ * H = regVal*I, regVal = |g|_2 * 1e3*EPS, followed by one regularisation (proximal) step.
+ * Any H set on this handle is ignored. handle_error's LP branch (:688-717) included. */
+int rsqp_optimize_lp(rsqp_solver *s, int *nWSR_used);
 /* low-level: one SQProblem::init / hotstart call. nWSR: in = limit, out = used.
  * x0, y0, guess_b (qpOASES convention -1/0/+1) may be NULL. */
 int rsqp_solve(rsqp_solver *s, int mode, int *nWSR, const double *x0, const double *y0,

@@ -47,6 +47,7 @@ def lib():
         L.orc_qp_init.argtypes = [C.c_void_p] + [c_dbl_p] * 5 + [c_int_p, c_dbl_p, c_dbl_p, c_int_p]
         L.orc_qp_hotstart.argtypes = [C.c_void_p] + [c_dbl_p] * 5 + [c_int_p]
         L.orc_qp_hotstart_matrices.argtypes = [C.c_void_p] + [c_dbl_p] * 5 + [c_int_p]
+        L.orc_qp_set_regularisation.argtypes = [C.c_void_p, C.c_double]
         L.orc_qp_get_primal.argtypes = [C.c_void_p, c_dbl_p]
         L.orc_qp_get_dual.argtypes = [C.c_void_p, c_dbl_p]
         L.orc_qp_get_objective.restype = C.c_double
@@ -248,6 +249,9 @@ class OracleQP:
             return
         jc, ir, val = _i(jc), _i(ir), _d(val)
         lib().orc_qp_set_H_csc(self._h, _ip(jc), _ip(ir), _dp(val))
+
+    def set_regularisation(self, reg):
+        lib().orc_qp_set_regularisation(self._h, float(reg))
 
     def _vecs(self, g, lb, ub, lbA, ubA):
         self._keep = [_d(g), _d(lb), _d(ub), _d(lbA), _d(ubA)]

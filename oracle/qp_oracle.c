@@ -66,6 +66,7 @@ struct orc_qp {
     double *w, *wv1, *wv2, *wv3, *wc1, *wc2, *wq;
     int status, infeasible, unbounded, nflips;
     int sizeT;
+    double hreg; /* H + hreg*I: qpOASES treats an all-zero Hessian (LP) as regVal*I */
 };
 
 static double clampinf(double v) {
@@ -190,7 +191,7 @@ static void H_times(const orc_qp *qp, const double *v, double *out) {
         double s = 0.0;
         if (qp->haveH) /* symmetric: column c of H == row c */
             for (int k = qp->Hjc[c]; k < qp->Hjc[c + 1]; k++) s += qp->Hval[k] * v[qp->Hir[k]];
-        out[c] = s;
+        out[c] = s + qp->hreg * v[c];
     }
 }
 static double dotn(const double *a, const double *b, int n) {
@@ -942,6 +943,8 @@ int orc_qp_hotstart_matrices(orc_qp *qp, const double *g, const double *lb, cons
     return homotopy(qp, nWSR);
 }
 
+void orc_qp_set_regularisation(orc_qp *qp, double reg) { qp->hreg = reg; }
+
 void orc_qp_get_primal(const orc_qp *qp, double *x) { memcpy(x, qp->x, sizeof(double) * (size_t)qp->nV); }
 void orc_qp_get_dual(const orc_qp *qp, double *y) {
     memcpy(y, qp->y, sizeof(double) * ((size_t)qp->nV + qp->nC));
@@ -949,7 +952,7 @@ void orc_qp_get_dual(const orc_qp *qp, double *y) {
 double orc_qp_get_objective(const orc_qp *qp) {
     double *Hx = (double *)xcalloc((size_t)qp->nV, sizeof(double));
     H_times(qp, qp->x, Hx);
-    double o = 0.5 * dotn(qp->x, Hx, qp->nV) + dotn(qp->gN, qp->x, qp->nV);
+    double o = 0.5 * (dotn(qp->x, Hx, qp->nV) - qp->hreg * dotn(qp->x, qp->x, qp->nV)) + dotn(qp->gN, qp->x, qp->nV);
     free(Hx);
     return o;
 }

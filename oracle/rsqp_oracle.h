@@ -150,6 +150,9 @@ int orc_qp_hotstart(orc_qp *qp, const double *g, const double *lb, const double 
 int orc_qp_hotstart_matrices(orc_qp *qp, const double *g, const double *lb, const double *ub,
                              const double *lbA, const double *ubA, int *nWSR);
 
+/* H := H + reg*I for every later solve (qpOASES regularises an all-zero Hessian, i.e. the LP of
+ * optimizeLP, src/qpOASESInterface.cpp:227-284); the objective excludes the reg term */
+void orc_qp_set_regularisation(orc_qp *qp, double reg);
 void orc_qp_get_primal(const orc_qp *qp, double *x);
 void orc_qp_get_dual(const orc_qp *qp, double *y);       /* nV bound mult., then nC */
 double orc_qp_get_objective(const orc_qp *qp);

@@ -45,6 +45,7 @@ SYMBOLS = {
     "rsqp_get_vector": (C.c_int, [C.c_void_p, C.c_int, dp]),
     "rsqp_reset_constraints": (C.c_int, [C.c_void_p]),
     "rsqp_optimize_qp": (C.c_int, [C.c_void_p, ip]),
+    "rsqp_optimize_lp": (C.c_int, [C.c_void_p, ip]),
     "rsqp_solve": (C.c_int, [C.c_void_p, C.c_int, ip, dp, dp, ip]),
     "rsqp_get_primal": (C.c_int, [C.c_void_p, dp]),
     "rsqp_get_dual": (C.c_int, [C.c_void_p, dp]),
@@ -213,6 +214,11 @@ class Solver:
     def optimize_qp(self):
         n = C.c_int(0)
         check(lib().rsqp_optimize_qp(self._h, C.byref(n)))
+        return n.value
+
+    def optimize_lp(self):
+        n = C.c_int(0)
+        check(lib().rsqp_optimize_lp(self._h, C.byref(n)))
         return n.value
 
     def solve(self, mode, nWSR, x0=None, y0=None, guess_b=None):

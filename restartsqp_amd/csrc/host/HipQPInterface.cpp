@@ -44,6 +44,15 @@ void HipQPInterface::optimizeQP(std::shared_ptr<Stats> stats) {
     if (!rsqp_is_solved(solver_)) throw QP_NOT_OPTIMAL("QP solver did not reach optimality");
 }
 
+// src/qpOASESInterface.cpp:227-284
+void HipQPInterface::optimizeLP(std::shared_ptr<Stats> stats) {
+    int nWSR = 0;
+    check(rsqp_optimize_lp(solver_, &nWSR), "rsqp_optimize_lp");
+    if (stats != nullptr) stats->qp_iter_addValue(nWSR);
+    fetch_solution();
+    if (!rsqp_is_solved(solver_)) throw LP_NOT_OPTIMAL("LP solver did not reach optimality");
+}
+
 double HipQPInterface::get_obj_value() { return rsqp_get_objective(solver_); }
 Exitflag HipQPInterface::get_status() { return rsqp_get_status(solver_); }
 

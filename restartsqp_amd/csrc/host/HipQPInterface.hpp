@@ -60,6 +60,7 @@ class QPSolverInterface {
 public:
     virtual ~QPSolverInterface() = default;
     virtual void optimizeQP(std::shared_ptr<Stats> stats) = 0;
+    virtual void optimizeLP(std::shared_ptr<Stats> stats) = 0;
     virtual double *get_optimal_solution() = 0;
     virtual double get_obj_value() = 0;
     virtual double *get_multipliers_bounds() = 0;
@@ -97,6 +98,7 @@ public:
     void set_H_csc(const int *jc, const int *ir, const double *val);
 
     void optimizeQP(std::shared_ptr<Stats> stats) override;
+    void optimizeLP(std::shared_ptr<Stats> stats) override;
     double *get_optimal_solution() override { return x_qp_.values(); }
     double get_obj_value() override;
     double *get_multipliers_bounds() override { return y_qp_.values(); }

@@ -648,6 +648,7 @@ struct RsqpLargeEngine::Impl {
         if (!M.haveH) fill(out, nV, 0.0);
         else if (M.denseH) gemv_t(M.denseH, nV, nV, nV, in, out);
         else rsqp_launch_spmv(M.blk_h, M.nblk_h, M.Hjc, M.Hir, M.Hval, in, out, 1, 0, 0, 0, 0, st);
+        if (M.hreg != 0.0) hipLaunchKernelGGL(k_axpy, g1(nV), dim3(NT), 0, st, nV, M.hreg, in, out);
     }
     int read_scal(int s0, int n, double *out) {
         LCHK(hipMemcpyAsync(h_pinned, scal + s0, sizeof(double) * n, hipMemcpyDeviceToHost, st));
@@ -1232,7 +1233,8 @@ double RsqpLargeEngine::objective() {
     P.H_times(P.x, P.w2);
     P.dot(P.x, P.w2, P.nV, 20);
     P.dot(P.gN, P.x, P.nV, 21);
-    double r[2] = {0, 0};
-    P.read_scal(20, 2, r);
-    return 0.5 * r[0] + r[1];
+    P.dot(P.x, P.x, P.nV, 22);
+    double r[3] = {0, 0, 0};
+    P.read_scal(20, 3, r);
+    return 0.5 * (r[0] - P.M.hreg * r[2]) + r[1];
 }

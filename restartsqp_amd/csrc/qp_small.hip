@@ -21,6 +21,8 @@
 //     deterministic tie break.
 //   * the image is written back to HBM at the end of a solve and reloaded by the next
 //     hot start (qpOASES keeps the same data inside the SQProblem object).
+#include <cstdlib>
+
 #include "rsqp_internal.h"
 
 #define SYNC() __syncthreads()
@@ -51,6 +53,7 @@ struct Engine {
     typedef typename MatPtr<MAT_LDS>::D MD;
     // problem
     int nV, nC, ld, sizeT, haveH;
+    double hreg;
     MI Ajc, Air; MD Aval;
     MI Arp, Aci; MD Arv;
     MI Hjc, Hir; MD Hval;
@@ -157,7 +160,7 @@ struct Engine {
             double s = 0.0;
             if (haveH)
                 for (int k = Hjc[c]; k < Hjc[c + 1]; k++) s += Hval[k] * v[Hir[k]];
-            out[c] = s;
+            out[c] = s + hreg * v[c];
         }
         SYNC();
     }
@@ -859,8 +862,8 @@ struct Engine {
 
     __device__ __forceinline__ double objective() {
         H_times(x, wv2);
-        double a = dot(x, wv2, nV), b = dot(gN, x, nV);
-        return 0.5 * a + b;
+        double a = dot(x, wv2, nV), b = dot(gN, x, nV), c = dot(x, x, nV);
+        return 0.5 * (a - hreg * c) + b;
     }
 };
 
@@ -871,8 +874,10 @@ __host__ __device__ inline long long mat_lds_bytes(int nV, int nC, int annz, int
     return ((ints * 4 + 7) & ~7LL) + dbl * 8;
 }
 
-template <int NT, bool MAT_LDS>
-__global__ void __launch_bounds__(NT)
+// W = minimum waves per SIMD the register allocator has to leave room for (the kernel is
+// latency bound: throughput follows the number of resident waves until spills bite)
+template <int NT, bool MAT_LDS, int W>
+__global__ void __launch_bounds__(NT, W)
 small_qp_kernel(QPPools P, int mode, int maxWSR) {
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     lchar *smem = (lchar *)smem_generic;
@@ -883,6 +888,7 @@ small_qp_kernel(QPPools P, int mode, int maxWSR) {
     const int img_bytes = (nd * 8 + ni * 4 + 15) & ~15;
     E.red = (ldouble *)(smem + img_bytes);
     E.haveH = d.haveH;
+    E.hreg = d.hreg;
     const int *gAjc = P.Ajc + d.offAjc, *gAir = P.Air + d.offAnz, *gArp = P.Arp + d.offArp, *gAci = P.Aci + d.offAnz;
     const int *gHjc = P.Hjc + d.offHjc, *gHir = P.Hir + d.offHnz;
     const double *gAval = P.Aval + d.offAnz, *gArv = P.Arv + d.offAnz, *gHval = P.Hval + d.offHnz;
@@ -986,22 +992,40 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
                                 int maxWSR, hipStream_t stream) {
     size_t lds = (size_t)rsqp_image_bytes(nVmax, nCmax) + 256;
     if ((long long)lds > kMaxLds) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&small_qp_kernel<64, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&small_qp_kernel<64, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
-        attr_set = true;
+    // measured on MI355X (16 384 hs071-scale QPs): 3 waves/SIMD 56 M solves/s, 4: 71 M, 6: 73 M.
+    // Small images keep 6 waves busy; larger problems stay at 4 (spills grow with the bound).
+    static int forced = -2;
+    if (forced == -2) {
+        const char *e = getenv("RSQP_SMALL_WAVES");
+        forced = e ? atoi(e) : -1;
+        if (forced != -1 && (forced < 3 || forced > 6)) forced = -1;
     }
-    // stage the matrices in LDS whenever image + matrices fit; mat_bytes_max is the largest
-    // per-problem staging size of the batch (host computed with rsqp_mat_lds_bytes)
-    if (mat_bytes_max >= 0 && (long long)lds + mat_bytes_max + 64 <= kMaxLds) {
-        lds += (size_t)mat_bytes_max + 64;
-        hipLaunchKernelGGL((small_qp_kernel<64, true>), dim3(nq), dim3(64), lds, stream, p, mode, maxWSR);
+    const int waves = forced > 0 ? forced : (nVmax <= 16 ? 6 : 4);
+    const bool mat_lds = mat_bytes_max >= 0 && (long long)lds + mat_bytes_max + 64 <= kMaxLds;
+    if (mat_lds) lds += (size_t)mat_bytes_max + 64;
+#define SQ_LAUNCH(ML, W)                                                                                     \
+    do {                                                                                                     \
+        static bool set_ = false;                                                                            \
+        if (!set_) {                                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&small_qp_kernel<64, ML, W>),           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);             \
+            set_ = true;                                                                                     \
+        }                                                                                                    \
+        hipLaunchKernelGGL((small_qp_kernel<64, ML, W>), dim3(nq), dim3(64), lds, stream, p, mode, maxWSR);  \
+    } while (0)
+    // matrices are staged in LDS whenever image + matrices fit (mat_bytes_max: largest staging
+    // size of the batch, host computed with rsqp_mat_lds_bytes)
+    if (mat_lds) {
+        switch (waves) {
+        case 3: SQ_LAUNCH(true, 3); break;
+        case 5: SQ_LAUNCH(true, 5); break;
+        case 6: SQ_LAUNCH(true, 6); break;
+        default: SQ_LAUNCH(true, 4); break;
+        }
     } else {
-        hipLaunchKernelGGL((small_qp_kernel<64, false>), dim3(nq), dim3(64), lds, stream, p, mode, maxWSR);
+        SQ_LAUNCH(false, 3);
     }
+#undef SQ_LAUNCH
     return hipGetLastError();
 }
 

@@ -192,6 +192,8 @@ struct rsqp_solver {
     bool upd_A = false, upd_H = false, upd_bounds = false, upd_g = false;
     int old_status = 0, new_status = 0;  // 0 UNDEFINED, 1 FIXED, 2 VARIED
     bool desc_ready = false;
+    bool lp_mode = false;   // optimizeLP: H ignored, H := hreg*I
+    double hreg = 0.0;
     // engine: 1 = LDS-resident kernel, 2 = HBM-resident engine
     int engine = 1;
     bool fits_small = true;
@@ -244,7 +246,8 @@ int ensure_desc(rsqp_solver *s) {
     if (s->desc_ready) return RSQP_OK;
     QPDesc d;
     std::memset(&d, 0, sizeof(d));
-    d.nV = s->nV; d.nC = s->nC; d.haveH = s->H.initialised ? 1 : 0;
+    d.nV = s->nV; d.nC = s->nC; d.haveH = (s->H.initialised && !s->lp_mode) ? 1 : 0;
+    d.hreg = s->hreg;
     std::vector<QPDesc> hd(1, d);
     HIPCHK(s->d_desc.from(hd));
     s->desc_ready = true;
@@ -517,7 +520,8 @@ int solve_large(rsqp_solver *s, int mode, int *nWSR, const double *x0, const dou
         m.Ajc = s->A.jc.p; m.Air = s->A.ir.p; m.Aval = s->A.val.p; m.blk_c = s->A.blk_c.p; m.nblk_c = s->A.nblk_c;
         m.Arp = s->A.rp.p; m.Aci = s->A.ci.p; m.Arv = s->A.rval.p; m.blk_r = s->A.blk_r.p; m.nblk_r = s->A.nblk_r;
     }
-    if (s->H.initialised) {
+    m.hreg = s->hreg;
+    if (s->H.initialised && !s->lp_mode) {
         m.Hjc = s->H.jc.p; m.Hir = s->H.ir.p; m.Hval = s->H.val.p; m.blk_h = s->H.blk_c.p; m.nblk_h = s->H.nblk_c;
         m.haveH = 1;
     }
@@ -529,7 +533,7 @@ int solve_large(rsqp_solver *s, int mode, int *nWSR, const double *x0, const dou
             return fail(RSQP_ERR_DEVICE, "densify launch failed");
         m.denseA = s->denseA.p;
     }
-    if (s->H.initialised && (double)s->H.nnz > 0.25 * (double)s->nV * s->nV) {
+    if (s->H.initialised && !s->lp_mode && (double)s->H.nnz > 0.25 * (double)s->nV * s->nV) {
         if (!s->denseH.p) HIPCHK(s->denseH.alloc((size_t)s->nV * s->nV, false));
         if (rsqp_launch_densify(s->nV, s->nV, s->H.jc.p, s->H.ir.p, s->H.val.p, s->denseH.p, s->stream) != hipSuccess)
             return fail(RSQP_ERR_DEVICE, "densify launch failed");
@@ -606,6 +610,7 @@ int handle_error(rsqp_solver *s, int *total) {
 
 extern "C" int rsqp_optimize_qp(rsqp_solver *s, int *nWSR_used) {
     if (!s) return fail(RSQP_ERR_ARG, "null solver");
+    if (s->lp_mode) { s->lp_mode = false; s->hreg = 0.0; s->desc_ready = false; }
     int nWSR = s->qp_maxiter, total = 0, rc;
     if (!s->firstQPsolved) {
         rc = rsqp_solve(s, RSQP_MODE_COLD, &nWSR, nullptr, nullptr, nullptr);
@@ -644,6 +649,82 @@ extern "C" int rsqp_optimize_qp(rsqp_solver *s, int *nWSR_used) {
     if (!solved(s)) {
         rc = handle_error(s, &total);
         if (rc != RSQP_OK) return rc;
+    }
+    if (nWSR_used) *nWSR_used = total;
+    return RSQP_OK;
+}
+
+namespace {
+// qpOASESInterface::handle_error, LP branch (src/qpOASESInterface.cpp:688-717)
+int handle_error_lp(rsqp_solver *s, int *total) {
+    int nWSR = s->lp_maxiter, rc;
+    if (infeasible(s) && s->nV >= 2 * s->nC) {
+        std::vector<double> x0 = s->h_x;   // x_0 := x_qp, slack entries overwritten (:693-699)
+        for (int i = 0; i < s->nC; i++) {
+            x0[i + s->nV - 2 * s->nC] = std::max(0.0, s->h_vec[RSQP_VEC_LBA][i]);
+            x0[i + s->nV - s->nC] = -std::min(0.0, s->h_vec[RSQP_VEC_UBA][i]);
+        }
+        rc = rsqp_solve(s, RSQP_MODE_WARM_REINIT, &nWSR, x0.data(), nullptr, nullptr);
+    } else {
+        rc = rsqp_solve(s, RSQP_MODE_COLD, &nWSR, nullptr, nullptr, nullptr);
+    }
+    s->old_status = s->new_status = 0;
+    *total += nWSR;
+    return rc;   // the adapter throws LP_NOT_OPTIMAL when !rsqp_is_solved()
+}
+}  // namespace
+
+extern "C" int rsqp_optimize_lp(rsqp_solver *s, int *nWSR_used) {
+    if (!s) return fail(RSQP_ERR_ARG, "null solver");
+    double ng = 0.0;
+    for (double v : s->h_vec[RSQP_VEC_G]) ng += v * v;
+    ng = std::sqrt(ng);
+    const double reg = (ng > 0.0 ? ng : 1.0) * 1.0e3 * RSQP_EPS;   // qpOASES: getNorm(g) * epsRegularisation
+    if (!s->lp_mode || reg != s->hreg) { s->lp_mode = true; s->hreg = reg; s->desc_ready = false; }
+    int nWSR = s->lp_maxiter, total = 0, rc;
+    if (!s->firstQPsolved) {
+        rc = rsqp_solve(s, RSQP_MODE_COLD, &nWSR, nullptr, nullptr, nullptr);
+        if (rc != RSQP_OK) return rc;
+        if (solved(s)) s->firstQPsolved = true;
+        else if ((rc = handle_error_lp(s, &total)) != RSQP_OK) return rc;
+    } else {
+        const int cur = (s->upd_A || s->upd_H) ? 2 : 1;
+        if (s->old_status == 0) s->old_status = cur;
+        else {
+            if (s->new_status != 0) s->old_status = s->new_status;
+            s->new_status = cur;
+        }
+        if (s->new_status == 0)
+            rc = rsqp_solve(s, s->old_status == 1 ? RSQP_MODE_HOT_VECTORS : RSQP_MODE_HOT_MATRICES, &nWSR, nullptr,
+                            nullptr, nullptr);
+        else if (s->new_status == 1 && s->old_status == 1)
+            rc = rsqp_solve(s, RSQP_MODE_HOT_VECTORS, &nWSR, nullptr, nullptr, nullptr);
+        else if (s->new_status == 2 && s->old_status == 2)
+            rc = rsqp_solve(s, RSQP_MODE_HOT_MATRICES, &nWSR, nullptr, nullptr, nullptr);
+        else {   // :266-270: plain re-init on a status flip
+            rc = rsqp_solve(s, RSQP_MODE_COLD, &nWSR, nullptr, nullptr, nullptr);
+            s->new_status = s->old_status = 0;
+        }
+        if (rc != RSQP_OK) return rc;
+        s->upd_A = s->upd_H = s->upd_bounds = s->upd_g = false;
+        if (!solved(s) && (rc = handle_error_lp(s, &total)) != RSQP_OK) return rc;
+    }
+    total += nWSR;
+    if (solved(s)) {
+        // one regularisation step: min (reg/2)|x - x_k|^2 + g'x  <=>  gradient g - reg*x_k
+        std::vector<double> gmod = s->h_vec[RSQP_VEC_G];
+        for (int i = 0; i < s->nV; i++) gmod[i] -= reg * s->h_x[i];
+        rc = flush_vectors(s);
+        if (rc != RSQP_OK) return rc;
+        HIPCHK(s->d_vec[RSQP_VEC_G].upload(gmod.data(), s->nV));
+        int n2 = s->lp_maxiter;
+        rc = rsqp_solve(s, RSQP_MODE_HOT_VECTORS, &n2, nullptr, nullptr, nullptr);
+        s->vec_dirty = true;   // the true gradient goes back to the device with the next flush
+        if (rc != RSQP_OK) return rc;
+        total += n2;
+        double o = 0.0;
+        for (int i = 0; i < s->nV; i++) o += s->h_vec[RSQP_VEC_G][i] * s->h_x[i];
+        s->obj = o;
     }
     if (nWSR_used) *nWSR_used = total;
     return RSQP_OK;

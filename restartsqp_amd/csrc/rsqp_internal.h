@@ -25,6 +25,7 @@ struct QPDesc {
     int offArp;           // A (CSR copy): Arp at offArp (nC+1 ints)
     int offHjc, offHnz;   // H (CSC, full symmetric)
     int haveH;
+    double hreg;          // H + hreg*I (LP path: qpOASES regularises an all-zero Hessian)
     long long offState;   // persistent engine image (doubles) for hot starts
 };
 

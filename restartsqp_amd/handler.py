@@ -79,6 +79,9 @@ class QPhandler:
         if not self.test_optimality():
             raise QP_NOT_OPTIMAL("KKT certificate failed: %g" % self.solverInterface_.get_optimality_status().KKT_error)
 
+    def solveLP(self, stats=None):  # include/sqphot/QPhandler.hpp:66-68
+        self.solverInterface_.optimizeLP(stats)
+
     def test_optimality(self):  # :580-587
         self.qpOptimalStatus_ = self.solverInterface_.get_optimality_status()
         return self.solverInterface_.test_optimality(self.W_c_, self.W_b_)

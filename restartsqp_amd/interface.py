@@ -10,7 +10,7 @@ would compile into the reference lives in ``restartsqp_amd/csrc/host/``.
 import numpy as np
 
 from . import capi
-from .sqptypes import (INVALID_WORKING_SET, QP, QP_NOT_OPTIMAL, IdentityInfo, NLPInfo, OptimalityStatus, Options,
+from .sqptypes import (INVALID_WORKING_SET, LP_NOT_OPTIMAL, QP, QP_NOT_OPTIMAL, IdentityInfo, NLPInfo, OptimalityStatus, Options,
                     SpTripletMat)
 
 
@@ -70,6 +70,14 @@ class HipQPInterface:
             stats.qp_iter_addValue(nWSR)
         if not self._s.is_solved():
             raise QP_NOT_OPTIMAL("QP solver did not reach optimality (status %d)" % self._s.status)
+
+    def optimizeLP(self, stats=None):
+        """qpOASESInterface::optimizeLP (:227-284); raises LP_NOT_OPTIMAL like handle_error (:714-716)."""
+        nWSR = self._s.optimize_lp()
+        if stats is not None:
+            stats.qp_iter_addValue(nWSR)
+        if not self._s.is_solved():
+            raise LP_NOT_OPTIMAL("LP solver did not reach optimality (status %d)" % self._s.status)
 
     # ---- result getters (:290-357)
     def get_optimal_solution(self):

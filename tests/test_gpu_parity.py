@@ -347,3 +347,35 @@ def test_full_size_hs071_batch_properties(capi, oracle):
     res2 = b.results()
     assert all(np.array_equal(a["x"], c["x"]) and np.array_equal(a["y"], c["y"]) and a["nWSR"] == c["nWSR"]
                for a, c in zip(res, res2))
+
+
+def test_optimize_lp(capi, oracle):
+    """optimizeLP (qpOASESInterface.cpp:227-284): H = 0, solved like qpOASES does an all-zero
+    Hessian (regVal*I + one regularisation step). Against the oracle driven the same way, and
+    against an independent LP solver (scipy / HiGHS) for the optimal value."""
+    from scipy.optimize import linprog
+    rng = np.random.default_rng(61)
+    for engine in (1, 2):
+        for _ in range(8):
+            nV, nC = int(rng.integers(2, 14)), int(rng.integers(1, 14))
+            A = rng.normal(size=(nC, nV)); g = rng.normal(size=nV); xh = rng.normal(size=nV)
+            lb = xh - np.abs(rng.normal(size=nV)) - 0.1; ub = xh + np.abs(rng.normal(size=nV)) + 0.1
+            lbA = A @ xh - np.abs(rng.normal(size=nC)) - 0.1; ubA = A @ xh + np.abs(rng.normal(size=nC)) + 0.1
+            Ac = dense_to_csc(A)
+            s = capi.Solver(nV, nC)
+            s.set_engine(engine)
+            s.set_A_csc(*Ac)
+            for w, v in zip(range(5), (g, lb, ub, lbA, ubA)):
+                s.set_vector(w, v)
+            n = s.optimize_lp()
+            qp = oracle.OracleQP(nV, nC); qp.set_A_csc(*Ac); qp.set_H_csc(None, None, None)
+            reg = np.linalg.norm(g) * 1e3 * 2.221e-16
+            qp.set_regularisation(reg)
+            rc, n1 = qp.init(g, lb, ub, lbA, ubA, 100)
+            rc2, n2 = qp.hotstart(g - reg * qp.x, lb, ub, lbA, ubA, 100)
+            assert rc == 0 and rc2 == 0 and s.is_solved() and n == n1 + n2
+            wb, wc = s.working_set_raw()
+            assert np.array_equal(wb, qp.ws_bounds) and np.array_equal(wc, qp.ws_constraints)
+            assert np.abs(s.x - qp.x).max() <= 1e-8 * max(1.0, np.abs(qp.x).max())
+            r = linprog(g, A_ub=np.vstack([A, -A]), b_ub=np.concatenate([ubA, -lbA]), bounds=list(zip(lb, ub)))
+            assert abs(s.objective - r.fun) <= 1e-8 * max(1.0, abs(r.fun))
