@@ -44,40 +44,122 @@ __device__ inline double block_sum(double v, double *sh) {
     return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-// out[c] = sum_r M[c*ld + r] * x[r]      (one workgroup per column)
+// out[c] = sum_r M[c*ld + r] * x[r]. A workgroup owns GT_COLS consecutive columns: every lane
+// keeps GT_COLS independent 16-byte loads in flight per step and x is read once for all of them.
+// (ld and the column bases are even for every matrix of this engine, so the double2 loads are
+// 16-byte aligned; an odd tail row is handled separately.)
+constexpr int GT_COLS = 4;
 __global__ void __launch_bounds__(NT) k_gemv_t(const double *__restrict__ M, long long ld, int nrows, int ncols,
                                                const double *__restrict__ x, double *__restrict__ out) {
     __shared__ double sh[4];
-    const int c = blockIdx.x;
-    if (c >= ncols) return;
-    const double *col = M + c * ld;
-    double s = 0.0;
-    for (int r = threadIdx.x; r < nrows; r += NT) s += col[r] * x[r];
-    s = block_sum(s, sh);
-    if (threadIdx.x == 0) out[c] = s;
+    const int c0 = blockIdx.x * GT_COLS;
+    double s[GT_COLS];
+#pragma unroll
+    for (int k = 0; k < GT_COLS; k++) s[k] = 0.0;
+    const bool vec = ((ld & 1) == 0) && ((reinterpret_cast<unsigned long long>(M) & 15) == 0) &&
+                     ((reinterpret_cast<unsigned long long>(x) & 15) == 0);
+    if (vec) {
+        const int n2 = nrows >> 1;
+        for (int r = threadIdx.x; r < n2; r += NT) {
+            const double2 xv = reinterpret_cast<const double2 *>(x)[r];
+#pragma unroll
+            for (int k = 0; k < GT_COLS; k++) {
+                const int c = c0 + k < ncols ? c0 + k : ncols - 1;
+                const double2 m = reinterpret_cast<const double2 *>(M + c * ld)[r];
+                s[k] += m.x * xv.x + m.y * xv.y;
+            }
+        }
+        if ((nrows & 1) && threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < GT_COLS; k++) {
+                const int c = c0 + k < ncols ? c0 + k : ncols - 1;
+                s[k] += M[c * ld + nrows - 1] * x[nrows - 1];
+            }
+        }
+    } else {
+        for (int r = threadIdx.x; r < nrows; r += NT) {
+            const double xv = x[r];
+#pragma unroll
+            for (int k = 0; k < GT_COLS; k++) {
+                const int c = c0 + k < ncols ? c0 + k : ncols - 1;
+                s[k] += M[c * ld + r] * xv;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < GT_COLS; k++) {
+        const double t = block_sum(s[k], sh);
+        if (threadIdx.x == 0 && c0 + k < ncols) out[c0 + k] = t;
+    }
 }
 
 // out = beta*base + alpha * M w, column-major M. A workgroup owns 64 consecutive rows (one
 // 512-byte run per column) and a chunk of columns, its four waves stride the chunk; the four
 // wave sums meet in LDS in fixed order. With one chunk the result is final; otherwise the
 // partials [chunk][row] are summed in chunk order by k_gemv_n_reduce (deterministic).
+template <bool VEC>
 __global__ void __launch_bounds__(NT) k_gemv_n_part(const double *__restrict__ M, long long ld, int nrows, int ncols,
                                                     int chunk, const double *__restrict__ w, double *__restrict__ part,
                                                     double alpha, double beta, const double *__restrict__ base,
                                                     double *__restrict__ out) {
-    __shared__ double sh[4][64];
+    // VEC: a workgroup owns 128 rows, each lane two consecutive ones (16-byte loads, 1 KiB per
+    // wave-instruction); otherwise 64 rows, one per lane (odd leading dimension / unaligned)
+    constexpr int RPL = VEC ? 2 : 1;
+    __shared__ double sh[4][64 * RPL];
     const int lane = threadIdx.x & 63, cl = threadIdx.x >> 6;
-    const int r = blockIdx.x * 64 + lane;
+    const int r = (blockIdx.x * 64 + lane) * RPL;
     const int c0 = blockIdx.y * chunk, c1 = min(c0 + chunk, ncols);
-    double s = 0.0;
-    if (r < nrows)
-        for (int c = c0 + cl; c < c1; c += 4) s += M[c * ld + r] * w[c];
-    sh[cl][lane] = s;
+    double a0 = 0.0, a1 = 0.0;
+    if (VEC) {
+        if (r + 1 < nrows) {
+            double2 s0 = {0, 0}, s1 = {0, 0}, s2 = {0, 0}, s3 = {0, 0};
+            int c = c0 + cl;
+            for (; c + 12 < c1; c += 16) {
+                const double2 m0 = *reinterpret_cast<const double2 *>(M + c * ld + r);
+                const double2 m1 = *reinterpret_cast<const double2 *>(M + (c + 4) * ld + r);
+                const double2 m2 = *reinterpret_cast<const double2 *>(M + (c + 8) * ld + r);
+                const double2 m3 = *reinterpret_cast<const double2 *>(M + (c + 12) * ld + r);
+                const double w0 = w[c], w1 = w[c + 4], w2 = w[c + 8], w3 = w[c + 12];
+                s0.x += m0.x * w0; s0.y += m0.y * w0; s1.x += m1.x * w1; s1.y += m1.y * w1;
+                s2.x += m2.x * w2; s2.y += m2.y * w2; s3.x += m3.x * w3; s3.y += m3.y * w3;
+            }
+            for (; c < c1; c += 4) {
+                const double2 m0 = *reinterpret_cast<const double2 *>(M + c * ld + r);
+                s0.x += m0.x * w[c]; s0.y += m0.y * w[c];
+            }
+            a0 = (s0.x + s1.x) + (s2.x + s3.x);
+            a1 = (s0.y + s1.y) + (s2.y + s3.y);
+        } else if (r < nrows) {
+            for (int c = c0 + cl; c < c1; c += 4) a0 += M[c * ld + r] * w[c];
+        }
+        sh[cl][2 * lane] = a0;
+        sh[cl][2 * lane + (RPL - 1)] = RPL == 2 ? a1 : a0;
+    } else {
+        if (r < nrows) {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int c = c0 + cl;
+            for (; c + 12 < c1; c += 16) {
+                s0 += M[c * ld + r] * w[c];
+                s1 += M[(c + 4) * ld + r] * w[c + 4];
+                s2 += M[(c + 8) * ld + r] * w[c + 8];
+                s3 += M[(c + 12) * ld + r] * w[c + 12];
+            }
+            for (; c < c1; c += 4) s0 += M[c * ld + r] * w[c];
+            a0 = (s0 + s1) + (s2 + s3);
+        }
+        sh[cl][lane] = a0;
+    }
     __syncthreads();
-    if (cl == 0 && r < nrows) {
-        const double t = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
-        if (gridDim.y == 1) out[r] = (base ? beta * base[r] : 0.0) + alpha * t;
-        else part[(long long)blockIdx.y * nrows + r] = t;
+    if (cl == 0) {
+#pragma unroll
+        for (int k = 0; k < RPL; k++) {
+            const int rr = r + k, li = RPL * lane + k;
+            if (rr < nrows) {
+                const double t = (sh[0][li] + sh[1][li]) + (sh[2][li] + sh[3][li]);
+                if (gridDim.y == 1) out[rr] = (base ? beta * base[rr] : 0.0) + alpha * t;
+                else part[(long long)blockIdx.y * nrows + rr] = t;
+            }
+        }
     }
 }
 // out[r] = beta * base[r] + alpha * sum_chunks part
@@ -594,7 +676,8 @@ struct RsqpLargeEngine::Impl {
     }
     void gemv_t(const double *Mx, long long l, int nrows, int ncols, const double *xv, double *out) {
         pbegin();
-        if (ncols > 0) hipLaunchKernelGGL(k_gemv_t, dim3(ncols), dim3(NT), 0, st, Mx, l, nrows, ncols, xv, out);
+        if (ncols > 0)
+            hipLaunchKernelGGL(k_gemv_t, dim3((ncols + GT_COLS - 1) / GT_COLS), dim3(NT), 0, st, Mx, l, nrows, ncols, xv, out);
         pend(1, 8.0 * nrows * (double)ncols + 8.0 * nrows + 8.0 * ncols);
         chk("gemv_t");
     }
@@ -609,13 +692,18 @@ struct RsqpLargeEngine::Impl {
         }
         pbegin();
         // chunks: enough workgroups to fill the 256 CUs a few times, as few partials as possible
-        const int rb = (nrows + 63) / 64;
+        const bool vec = ((l & 1) == 0) && ((reinterpret_cast<unsigned long long>(Mx) & 15) == 0) && nrows >= 128;
+        const int rb = vec ? (nrows + 127) / 128 : (nrows + 63) / 64;
         int nch = std::max(1, std::min((1024 + rb - 1) / rb, (ncols + 15) / 16));
         while ((long long)nch * nrows > part_cap) nch = (nch + 1) / 2;
         const int chunk = (ncols + nch - 1) / nch;
         nch = (ncols + chunk - 1) / chunk;
-        hipLaunchKernelGGL(k_gemv_n_part, dim3(rb, nch), dim3(NT), 0, st, Mx, l, nrows, ncols, chunk, wv, part, alpha, beta,
-                           base, out);
+        if (vec)
+            hipLaunchKernelGGL(k_gemv_n_part<true>, dim3(rb, nch), dim3(NT), 0, st, Mx, l, nrows, ncols, chunk, wv, part,
+                               alpha, beta, base, out);
+        else
+            hipLaunchKernelGGL(k_gemv_n_part<false>, dim3(rb, nch), dim3(NT), 0, st, Mx, l, nrows, ncols, chunk, wv, part,
+                               alpha, beta, base, out);
         if (nch > 1)
             hipLaunchKernelGGL(k_gemv_n_reduce, dim3((nrows + 63) / 64), dim3(64), 0, st, part, nrows, nch, alpha, beta, base, out);
         pend(0, 8.0 * nrows * (double)ncols + 8.0 * nrows + 8.0 * ncols);
