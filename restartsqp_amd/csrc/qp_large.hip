@@ -529,6 +529,12 @@ __global__ void k_rerelax(int n, const int *__restrict__ S, const double *__rest
     if (S[i] != 1 && hi[i] >= RSQP_INFTY && hiN[i] < RSQP_INFTY) hi[i] = fmax(hiN[i], pos[i] + RSQP_BOUND_RELAXATION);
 }
 
+// Z[:, k] = e_{free[k]} (columns zero-filled beforehand)
+__global__ void k_unit_cols(double *__restrict__ Z, long long ld, const int *__restrict__ freev, int n) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) Z[k * ld + freev[k]] = 1.0;
+}
+
 inline dim3 g1(int n) { return dim3((unsigned)((n + NT - 1) / NT)); }
 
 // ---- small single-thread / utility kernels -----------------------------------------------
@@ -635,6 +641,7 @@ struct RsqpLargeEngine::Impl {
     // maintained products (refreshed exactly every REFRESH working-set changes)
     double *ATy = nullptr, *Hx = nullptr, *Hdx = nullptr, *ATdy = nullptr;
     bool dirty_products = true;
+    bool wz_enabled = true;   // false while setup_aux builds Z/Y/Minv; Wz is bordered afterwards
     int since_refresh = 0;
 
     ~Impl() {
@@ -758,6 +765,7 @@ struct RsqpLargeEngine::Impl {
         hipLaunchKernelGGL(k_house, dim3(1), dim3(NT), 0, st, wz1, nZ, wz2, scal, 0);   // v -> wz2
         gemv_n(Z, ld, nV, nZ, wz2, 1.0, 0.0, nullptr, w5);                               // t = Z v
         ger(Z, ld, nV, nZ, w5, wz2, 1, -1.0);                                            // Z -= beta t v'
+        if (!wz_enabled) return;
         gemv_n(Wz, ld, nZ, nZ, wz2, 1.0, 0.0, nullptr, wz3);                             // s = Wz v
         dot(wz2, wz3, nZ, 4);                                                            // theta
         hipLaunchKernelGGL(k_wz_lastcol, g1(nZ), dim3(NT), 0, st, Wz, ld, nZ, wz3, wz2, scal, 1, 4, w6);
@@ -1135,29 +1143,39 @@ struct RsqpLargeEngine::Impl {
         status = QPS_PREPARINGAUXILIARYQP;
         infeasible = unbounded = 0;
         nFR = nAC = nZ = 0;
-        // start with every variable fixed, then free / activate one at a time (each step is the
-        // same rank-1 machinery the homotopy uses)
-        std::vector<int> start(nV);
-        for (int v = 0; v < nV; v++) start[v] = gb[v] != 0 ? gb[v] : -1;
-        LCHK(hipMemcpyAsync(Sb, start.data(), sizeof(int) * nV, hipMemcpyHostToDevice, st));
-        hSb = start;
+        // 1. bounds: Z = unit columns of the free variables (no constraint active yet)
+        LCHK(hipMemcpyAsync(Sb, gb.data(), sizeof(int) * nV, hipMemcpyHostToDevice, st));
+        hSb = gb;
         std::fill(hSc.begin(), hSc.end(), 0);
         LCHK(hipMemsetAsync(Sc, 0, sizeof(int) * std::max(nC, 1), st));
         LCHK(hipMemsetAsync(posAC, 0xff, sizeof(int) * std::max(nC, 1), st));
-        for (int v = 0; v < nV; v++) {
-            if (gb[v] != 0) continue;
-            remove_bound_tq(v);
-            int pd = 0;
-            if (wz_grow(&pd) != RET_OK) return RET_SETUP_FAILED;
-            if (!pd) return RET_SETUP_FAILED;
+        std::vector<int> freev;
+        for (int v = 0; v < nV; v++) if (gb[v] == 0) freev.push_back(v);
+        nFR = nZ = (int)freev.size();
+        if (nZ > 0) {
+            LCHK(hipMemsetAsync(Z, 0, sizeof(double) * (size_t)ld * nZ, st));
+            // free-variable index list staged in dy (read as ints; dy is rewritten before its next use)
+            LCHK(hipMemcpyAsync(reinterpret_cast<int *>(dy), freev.data(), sizeof(int) * freev.size(), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_unit_cols, g1(nZ), dim3(NT), 0, st, Z, ld, reinterpret_cast<const int *>(dy), nZ);
         }
+        // 2. constraints: reflections of Z only; the inverse reduced Hessian is built afterwards
+        wz_enabled = false;
         A_times(x, Ax);
         for (int r = 0; r < nC; r++) {
             if (gc[r] == 0) continue;
             constraint_products(r);
             bool li = false;
-            if (li_decision(&li) != RET_OK) return RET_SETUP_FAILED;
+            if (li_decision(&li) != RET_OK) { wz_enabled = true; return RET_SETUP_FAILED; }
             if (li) add_constraint(r, gc[r], false);
+        }
+        wz_enabled = true;
+        // 3. Wz = (Z'HZ)^-1 by bordering over the final null-space columns
+        const int nZf = nZ;
+        nZ = 0;
+        for (int k = 0; k < nZf; k++) {
+            int pd = 0;
+            if (wz_grow(&pd) != RET_OK) return RET_SETUP_FAILED;
+            if (!pd) return RET_SETUP_FAILED;
         }
         // multipliers: zero when inactive, clipped to the admissible sign
         hipLaunchKernelGGL(k_clip_y, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, Sc, y);

@@ -32,3 +32,13 @@ if which != "dense":
         t = time.time(); n = s.solve(capi.MODE_HOT_VECTORS, 200000); t = time.time() - t
         ok, st, _, _ = s.test_optimality()
         print("  hot step %d: nWSR %d in %.3f s status %d KKT %.2e" % (k, n, t, s.status, st.KKT_error), flush=True)
+if which != "dense" and len(sys.argv) > 3:
+    qk, changed = None, False
+    for qk, changed in problems.sparse_sequence(q, nsteps=2):
+        pass
+    s.set_A_csc(qk.A_jc, qk.A_ir, qk.A_val)
+    for w, v in zip(range(5), (qk.g, qk.lb, qk.ub, qk.lbA, qk.ubA)):
+        s.set_vector(w, v)
+    t = time.time(); n = s.solve(capi.MODE_HOT_MATRICES, 200000); t = time.time() - t
+    ok, st, _, _ = s.test_optimality()
+    print("  hot MATRICES step: nWSR %d in %.3f s status %d KKT %.2e" % (n, t, s.status, st.KKT_error), flush=True)
