@@ -162,14 +162,21 @@ __global__ void __launch_bounds__(NT) k_gemv_n_part(const double *__restrict__ M
         }
     }
 }
-// out[r] = beta * base[r] + alpha * sum_chunks part
-__global__ void k_gemv_n_reduce(const double *__restrict__ part, int nrows, int nchunks, double alpha, double beta,
-                                const double *__restrict__ base, double *__restrict__ out) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrows) return;
+// out[r] = beta * base[r] + alpha * sum_chunks part. 64 rows per workgroup, the four waves take
+// every fourth partial; combined in LDS in fixed order.
+__global__ void __launch_bounds__(NT) k_gemv_n_reduce(const double *__restrict__ part, int nrows, int nchunks,
+                                                      double alpha, double beta, const double *__restrict__ base,
+                                                      double *__restrict__ out) {
+    __shared__ double sh[4][64];
+    const int lane = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const int r = blockIdx.x * 64 + lane;
     double s = 0.0;
-    for (int k = 0; k < nchunks; k++) s += part[(long long)k * nrows + r];
-    out[r] = (base ? beta * base[r] : 0.0) + alpha * s;
+    if (r < nrows)
+        for (int k = pg; k < nchunks; k += 4) s += part[(long long)k * nrows + r];
+    sh[pg][lane] = s;
+    __syncthreads();
+    if (pg == 0 && r < nrows)
+        out[r] = (base ? beta * base[r] : 0.0) + alpha * ((sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]));
 }
 
 // M[c*ld + r] += coef * t[r] * v[c]   (coef = scal[ci] * cs)
@@ -401,7 +408,7 @@ k_ratio1(int nV, int nC, const int *__restrict__ Sb, const int *__restrict__ Sc,
     if (threadIdx.x == 0) { pt[blockIdx.x] = bt; pid[blockIdx.x] = bid; }
 }
 __global__ void __launch_bounds__(NT) k_argmin2(int n, const double *__restrict__ pt, const int *__restrict__ pid,
-                                                double *__restrict__ out_t, int *__restrict__ out_id) {
+                                                double *__restrict__ ctl) {
     __shared__ double sht[4];
     __shared__ int shi[4];
     double bt = RSQP_INFTY * 10.0;
@@ -409,7 +416,7 @@ __global__ void __launch_bounds__(NT) k_argmin2(int n, const double *__restrict_
     for (int i = threadIdx.x; i < n; i += NT)
         if (pt[i] < bt || (pt[i] == bt && pid[i] < bid)) { bt = pt[i]; bid = pid[i]; }
     argmin_reduce(bt, bid, sht, shi);
-    if (threadIdx.x == 0) { *out_t = bt; *out_id = bid; }
+    if (threadIdx.x == 0) { ctl[0] = bt; ctl[1] = (double)bid; }   // ctl: host-mapped decision block
 }
 
 // homotopy step; done: data := targets
@@ -529,6 +536,87 @@ __global__ void k_rerelax(int n, const int *__restrict__ S, const double *__rest
     if (S[i] != 1 && hi[i] >= RSQP_INFTY && hiN[i] < RSQP_INFTY) hi[i] = fmax(hiN[i], pos[i] + RSQP_BOUND_RELAXATION);
 }
 
+// ---- fused helpers (fewer launches per working-set change) -------------------------------
+// dx on the fixed variables (zero elsewhere) and dy := 0, one launch over nV + nC
+__global__ void k_dx_fixed_zero_dy(int nV, int nC, const int *__restrict__ Sb, const double *__restrict__ lb,
+                                   const double *__restrict__ ub, const double *__restrict__ lbN,
+                                   const double *__restrict__ ubN, double *__restrict__ dx, double *__restrict__ dy) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nV) dx[i] = Sb[i] == -1 ? delta_of(lbN[i], lb[i]) : (Sb[i] == 1 ? delta_of(ubN[i], ub[i]) : 0.0);
+    if (i < nV + nC) dy[i] = 0.0;
+}
+// homotopy step of everything indexed by variables / by constraints
+__global__ void k_step_all_v(int nV, double tau, int done, const int *__restrict__ Sb, double *__restrict__ x,
+                             double *__restrict__ g, double *__restrict__ lb, double *__restrict__ ub,
+                             const double *__restrict__ gN, const double *__restrict__ lbN, const double *__restrict__ ubN,
+                             const double *__restrict__ dx, const double *__restrict__ ATdy, double *__restrict__ ATy,
+                             const double *__restrict__ Hdx, double *__restrict__ Hx) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nV) return;
+    if (done) {
+        g[v] = gN[v]; lb[v] = lbN[v]; ub[v] = ubN[v];
+        x[v] = Sb[v] == -1 ? lb[v] : (Sb[v] == 1 ? ub[v] : x[v] + tau * dx[v]);
+    } else {
+        x[v] += tau * dx[v];
+        g[v] += tau * (gN[v] - g[v]);
+        lb[v] += tau * delta_of(lbN[v], lb[v]);
+        ub[v] += tau * delta_of(ubN[v], ub[v]);
+        ATy[v] += tau * ATdy[v];
+        Hx[v] += tau * Hdx[v];
+    }
+}
+__global__ void k_step_all_c(int nC, double tau, int done, double *__restrict__ lbA, double *__restrict__ ubA,
+                             const double *__restrict__ lbAN, const double *__restrict__ ubAN,
+                             const double *__restrict__ dAx, double *__restrict__ Ax) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nC) return;
+    if (done) { lbA[i] = lbAN[i]; ubA[i] = ubAN[i]; }
+    else {
+        lbA[i] += tau * delta_of(lbAN[i], lbA[i]);
+        ubA[i] += tau * delta_of(ubAN[i], ubA[i]);
+        Ax[i] += tau * dAx[i];
+    }
+}
+// drift correction without a refresh of the products: x on its bounds, active constraint sides on
+// A x, gradient from stationarity -- one launch over max(nV, nC)
+__global__ void k_drift_all(int nV, int nC, const int *__restrict__ Sb, const int *__restrict__ Sc,
+                            const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ x,
+                            const double *__restrict__ Ax, double *__restrict__ lbA, double *__restrict__ ubA,
+                            const double *__restrict__ ATy, const double *__restrict__ y, const double *__restrict__ Hx,
+                            double *__restrict__ g) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nV) {
+        if (Sb[i] != 0) x[i] = Sb[i] == -1 ? lb[i] : ub[i];
+        g[i] = ATy[i] + y[i] - Hx[i];
+    }
+    if (i < nC) { if (Sc[i] == -1) lbA[i] = Ax[i]; else if (Sc[i] == 1) ubA[i] = Ax[i]; }
+}
+// working-set bookkeeping of an added constraint
+__global__ void k_set_ws(int *AC, int *posAC, int *Sc, int nAC, int r, int side) { AC[nAC] = r; posAC[r] = nAC; Sc[r] = side; }
+// zero a (length nV) and scatter row `row` of A into it: one workgroup
+__global__ void __launch_bounds__(NT) k_row_of_A_fused(const int *__restrict__ rp, const int *__restrict__ ci,
+                                                       const double *__restrict__ rv, int row, const int *__restrict__ Sb,
+                                                       int all, int nV, double *__restrict__ a) {
+    for (int v = threadIdx.x; v < nV; v += NT) a[v] = 0.0;
+    __syncthreads();
+    for (int k = rp[row] + threadIdx.x; k < rp[row + 1]; k += NT) {
+        const int c = ci[k];
+        if (all || Sb[c] == 0) a[c] = rv[k];
+    }
+}
+// scal[s1] = |a|^2 (n1 entries; 1.0 if a is null), scal[s2] = |b|^2 (n2 entries); both published to ctl
+__global__ void __launch_bounds__(NT) k_norms_publish(const double *__restrict__ a, int n1, const double *__restrict__ b,
+                                                      int n2, double *__restrict__ scal, int s1, int s2,
+                                                      double *__restrict__ ctl) {
+    __shared__ double sh[4];
+    double p = 0.0, q = 0.0;
+    if (a) for (int i = threadIdx.x; i < n1; i += NT) p += a[i] * a[i];
+    for (int i = threadIdx.x; i < n2; i += NT) q += b[i] * b[i];
+    p = a ? block_sum(p, sh) : 1.0;
+    q = block_sum(q, sh);
+    if (threadIdx.x == 0) { scal[s1] = p; scal[s2] = q; ctl[2] = p; ctl[3] = q; }
+}
+
 // Z[:, k] = e_{free[k]} (columns zero-filled beforehand)
 __global__ void k_unit_cols(double *__restrict__ Z, long long ld, const int *__restrict__ freev, int n) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -584,10 +672,11 @@ __global__ void k_newcol_free(int nV, int v, const double *t, const double *scal
     if (i < nV) znew[i] = (i == v ? 1.0 : 0.0) - scal[8] * t[i] * scal[10];
 }
 __global__ void k_sm_coef(double *scal) { scal[16] = scal[8] / (1.0 - scal[8] * scal[15]); }
-__global__ void k_rho2(double *scal) {
+__global__ void k_rho2(double *scal, double *ctl) {
     const double kappa = scal[11], ku = scal[12];
     scal[13] = kappa - ku;
     scal[14] = RSQP_EPS_PD_REL * (fabs(kappa) + fabs(ku)) + RSQP_EPS_PD_ABS;
+    ctl[4] = scal[13]; ctl[5] = scal[14];
 }
 __global__ void k_clip_y(int nV, int nC, const int *Sb, const int *Sc, double *y) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -634,6 +723,7 @@ struct RsqpLargeEngine::Impl {
     std::vector<int> hSb, hSc, hAC;
     int nFR = 0, nAC = 0, nZ = 0;
     int status = QPS_NOTINITIALISED, infeasible = 0, unbounded = 0, nflips = 0;
+    double *h_ctl = nullptr, *d_ctl = nullptr;   // host-mapped decision block written by kernels
     double *h_pinned = nullptr;  // small pinned read-back buffer
     int *h_pinned_i = nullptr;
     int nblk_ratio = 0;
@@ -650,6 +740,7 @@ struct RsqpLargeEngine::Impl {
         for (double *p : dv) if (p) (void)hipFree(p);
         int *iv[] = {Sb, Sc, AC, posAC, pid, res_id};
         for (int *p : iv) if (p) (void)hipFree(p);
+        if (h_ctl) (void)hipHostFree(h_ctl);
         if (h_pinned) (void)hipHostFree(h_pinned);
         if (h_pinned_i) (void)hipHostFree(h_pinned_i);
         preport();
@@ -701,7 +792,7 @@ struct RsqpLargeEngine::Impl {
         // chunks: enough workgroups to fill the 256 CUs a few times, as few partials as possible
         const bool vec = ((l & 1) == 0) && ((reinterpret_cast<unsigned long long>(Mx) & 15) == 0) && nrows >= 128;
         const int rb = vec ? (nrows + 127) / 128 : (nrows + 63) / 64;
-        int nch = std::max(1, std::min((1024 + rb - 1) / rb, (ncols + 15) / 16));
+        int nch = std::max(1, std::min(std::min((768 + rb - 1) / rb, 32), (ncols + 15) / 16));
         while ((long long)nch * nrows > part_cap) nch = (nch + 1) / 2;
         const int chunk = (ncols + nch - 1) / nch;
         nch = (ncols + chunk - 1) / chunk;
@@ -712,7 +803,7 @@ struct RsqpLargeEngine::Impl {
             hipLaunchKernelGGL(k_gemv_n_part<false>, dim3(rb, nch), dim3(NT), 0, st, Mx, l, nrows, ncols, chunk, wv, part,
                                alpha, beta, base, out);
         if (nch > 1)
-            hipLaunchKernelGGL(k_gemv_n_reduce, dim3((nrows + 63) / 64), dim3(64), 0, st, part, nrows, nch, alpha, beta, base, out);
+            hipLaunchKernelGGL(k_gemv_n_reduce, dim3((nrows + 63) / 64), dim3(NT), 0, st, part, nrows, nch, alpha, beta, base, out);
         pend(0, 8.0 * nrows * (double)ncols + 8.0 * nrows + 8.0 * ncols);
         chk("gemv_n");
     }
@@ -752,8 +843,7 @@ struct RsqpLargeEngine::Impl {
         return RET_OK;
     }
     void row_of_A(int r, double *a, bool all) {
-        fill(a, nV, 0.0);
-        hipLaunchKernelGGL(k_row_of_A, dim3(8), dim3(NT), 0, st, M.Arp, M.Aci, M.Arv, r, Sb, all ? 1 : 0, a);
+        hipLaunchKernelGGL(k_row_of_A_fused, dim3(1), dim3(NT), 0, st, M.Arp, M.Aci, M.Arv, r, Sb, all ? 1 : 0, nV, a);
     }
     double *Zc(int c) { return Z + c * ld; }
     double *Yc(int c) { return Y + c * ld; }
@@ -798,9 +888,7 @@ struct RsqpLargeEngine::Impl {
         }
         nZ--;
         minv_append(5);
-        hipLaunchKernelGGL(k_seti, dim3(1), dim3(1), 0, st, AC, nAC, r);
-        hipLaunchKernelGGL(k_seti, dim3(1), dim3(1), 0, st, posAC, r, nAC);
-        hipLaunchKernelGGL(k_seti, dim3(1), dim3(1), 0, st, Sc, r, side);
+        hipLaunchKernelGGL(k_set_ws, dim3(1), dim3(1), 0, st, AC, posAC, Sc, nAC, r, side);
         hAC[nAC] = r; hSc[r] = side;
         nAC++;
         return RET_OK;
@@ -811,14 +899,12 @@ struct RsqpLargeEngine::Impl {
         row_of_A(r, w1, false);
         gemv_t(Z, ld, nV, nZ, w1, wz1);
         gemv_t(Y, ld, nV, nAC, w1, a1);
-        dot(w1, w1, nV, 6);
-        if (nZ > 0) dot(wz1, wz1, nZ, 7); else hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, scal, 7, 0.0);
+        hipLaunchKernelGGL(k_norms_publish, dim3(1), dim3(NT), 0, st, w1, nV, wz1, nZ, scal, 6, 7, d_ctl);
     }
     void bound_products(int v) {
         if (nZ > 0) hipLaunchKernelGGL(k_get_row, g1(nZ), dim3(NT), 0, st, Z, ld, v, nZ, wz1);
         if (nAC > 0) hipLaunchKernelGGL(k_get_row, g1(nAC), dim3(NT), 0, st, Y, ld, v, nAC, a1);
-        hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, scal, 6, 1.0);
-        if (nZ > 0) dot(wz1, wz1, nZ, 7); else hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, scal, 7, 0.0);
+        hipLaunchKernelGGL(k_norms_publish, dim3(1), dim3(NT), 0, st, (const double *)nullptr, 0, wz1, nZ, scal, 6, 7, d_ctl);
     }
 
     // second stage shared by add_bound and (mirrored) remove_bound: reflection on [Y, extra]
@@ -854,10 +940,9 @@ struct RsqpLargeEngine::Impl {
         gemv_t(Z, ld, nV, nZ, w2, wz1);           // k = Z'Hz
         gemv_n(Wz, ld, nZ, nZ, wz1, 1.0, 0.0, nullptr, wz2);  // u = Wz k
         if (nZ > 0) dot(wz1, wz2, nZ, 12); else hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, scal, 12, 0.0);
-        hipLaunchKernelGGL(k_rho2, dim3(1), dim3(1), 0, st, scal);   // scal[13] = rho2, scal[14] = threshold
-        double r[2];
-        if (read_scal(13, 2, r) != RET_OK) return RET_SETUP_FAILED;
-        *pd = r[0] > r[1];
+        hipLaunchKernelGGL(k_rho2, dim3(1), dim3(1), 0, st, scal, d_ctl);   // scal[13] = rho2, scal[14] = threshold
+        LCHK(hipStreamSynchronize(st));
+        *pd = h_ctl[4] > h_ctl[5];
         if (*pd) {
             pbegin();
             hipLaunchKernelGGL(k_wz_grow, dim3((nZ + 1 + NT - 1) / NT, nZ + 1), dim3(NT), 0, st, Wz, ld, nZ, wz2, scal, 13);
@@ -982,12 +1067,10 @@ struct RsqpLargeEngine::Impl {
         hipLaunchKernelGGL(k_xiB, g1(nV), dim3(NT), 0, st, nV, Sb, w4, w2, w3);
         const double sgn = side == 1 ? -1.0 : 1.0;
         hipLaunchKernelGGL(k_partner1, dim3(nblk_ratio), dim3(NT), 0, st, nV, nC, Sb, Sc, y, c1, w3, sgn, pt, pid);
-        hipLaunchKernelGGL(k_argmin2, dim3(1), dim3(NT), 0, st, nblk_ratio, pt, pid, res_t, res_id);
-        LCHK(hipMemcpyAsync(h_pinned, res_t, 8, hipMemcpyDeviceToHost, st));
-        LCHK(hipMemcpyAsync(h_pinned_i, res_id, 4, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(k_argmin2, dim3(1), dim3(NT), 0, st, nblk_ratio, pt, pid, d_ctl);
         LCHK(hipStreamSynchronize(st));
-        const double t = h_pinned[0];
-        const int id = h_pinned_i[0];
+        const double t = h_ctl[0];
+        const int id = (int)h_ctl[1];
         if (id == 0x7fffffff) return RET_INFEASIBLE;
         hipLaunchKernelGGL(k_shift_duals, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, Sc, t, sgn, c1, w3, y);
         dirty_products = true;
@@ -998,9 +1081,9 @@ struct RsqpLargeEngine::Impl {
     }
 
     int li_decision(bool *li) {
-        double r[2];
-        if (read_scal(6, 2, r) != RET_OK) return RET_SETUP_FAILED;
-        *li = nZ > 0 && r[0] > 0.0 && std::sqrt(r[1]) > RSQP_EPS_LI * std::sqrt(r[0]);
+        LCHK(hipStreamSynchronize(st));
+        const double a2 = h_ctl[2], w2n = h_ctl[3];
+        *li = nZ > 0 && a2 > 0.0 && std::sqrt(w2n) > RSQP_EPS_LI * std::sqrt(a2);
         return RET_OK;
     }
 
@@ -1042,8 +1125,7 @@ struct RsqpLargeEngine::Impl {
 
     // ---- step direction -----------------------------------------------------------------
     void step_direction() {
-        hipLaunchKernelGGL(k_dx_fixed, g1(nV), dim3(NT), 0, st, nV, Sb, lb, ub, lbN, ubN, dx);
-        fill(dy, nV + nC, 0.0);
+        hipLaunchKernelGGL(k_dx_fixed_zero_dy, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, lb, ub, lbN, ubN, dx, dy);
         A_times(dx, c1);                                                   // A dx_FX
         H_times(dx, w2);
         if (nAC > 0)
@@ -1083,10 +1165,12 @@ struct RsqpLargeEngine::Impl {
         since_refresh = 0;
     }
     void drift_correction() {
-        hipLaunchKernelGGL(k_fix_x, g1(nV), dim3(NT), 0, st, nV, Sb, lb, ub, x);
-        if (dirty_products || ++since_refresh >= REFRESH) refresh_products();
-        if (nC > 0) hipLaunchKernelGGL(k_fix_bA, g1(nC), dim3(NT), 0, st, nC, Sc, Ax, lbA, ubA);
-        hipLaunchKernelGGL(k_fix_g, g1(nV), dim3(NT), 0, st, nV, ATy, y, Hx, g);
+        if (dirty_products || ++since_refresh >= REFRESH) {
+            hipLaunchKernelGGL(k_fix_x, g1(nV), dim3(NT), 0, st, nV, Sb, lb, ub, x);
+            refresh_products();
+        }
+        hipLaunchKernelGGL(k_drift_all, g1(std::max(nV, nC)), dim3(NT), 0, st, nV, nC, Sb, Sc, lb, ub, x, Ax, lbA, ubA, ATy,
+                           y, Hx, g);
         chk("drift");
     }
 
@@ -1100,12 +1184,10 @@ struct RsqpLargeEngine::Impl {
             step_direction();
             hipLaunchKernelGGL(k_ratio1, dim3(nblk_ratio), dim3(NT), 0, st, nV, nC, Sb, Sc, x, y, dx, dy, Ax, dAx, lb, ub,
                                lbA, ubA, lbN, ubN, lbAN, ubAN, pt, pid);
-            hipLaunchKernelGGL(k_argmin2, dim3(1), dim3(NT), 0, st, nblk_ratio, pt, pid, res_t, res_id);
-            LCHK(hipMemcpyAsync(h_pinned, res_t, 8, hipMemcpyDeviceToHost, st));
-            LCHK(hipMemcpyAsync(h_pinned_i, res_id, 4, hipMemcpyDeviceToHost, st));
+            hipLaunchKernelGGL(k_argmin2, dim3(1), dim3(NT), 0, st, nblk_ratio, pt, pid, d_ctl);
             LCHK(hipStreamSynchronize(st));
-            double tau = h_pinned[0];
-            const int bid = h_pinned_i[0];
+            double tau = h_ctl[0];
+            const int bid = (int)h_ctl[1];
             int kind = 0, idx = -1, side = 0;
             if (bid != 0x7fffffff) {
                 if (bid < nC) { kind = 1; idx = bid; }
@@ -1116,13 +1198,12 @@ struct RsqpLargeEngine::Impl {
                 else { kind = 4; idx = bid - 3 * nC - 2 * nV; side = 1; }
             } else tau = 1.0;
             const int done = kind == 0;
-            hipLaunchKernelGGL(k_step_v, g1(nV), dim3(NT), 0, st, nV, tau, done, Sb, x, g, lb, ub, gN, lbN, ubN, dx);
+            hipLaunchKernelGGL(k_step_all_v, g1(nV), dim3(NT), 0, st, nV, tau, done, Sb, x, g, lb, ub, gN, lbN, ubN, dx, ATdy,
+                               ATy, Hdx, Hx);
             hipLaunchKernelGGL(k_axpy, g1(nV + nC), dim3(NT), 0, st, nV + nC, tau, dy, y);
-            if (nC > 0) hipLaunchKernelGGL(k_step_c, g1(nC), dim3(NT), 0, st, nC, tau, done, lbA, ubA, lbAN, ubAN);
+            if (nC > 0)
+                hipLaunchKernelGGL(k_step_all_c, g1(nC), dim3(NT), 0, st, nC, tau, done, lbA, ubA, lbAN, ubAN, dAx, Ax);
             if (done) { A_times(x, Ax); status = QPS_SOLVED; break; }
-            if (nC > 0) hipLaunchKernelGGL(k_axpy, g1(nC), dim3(NT), 0, st, nC, tau, dAx, Ax);
-            hipLaunchKernelGGL(k_axpy, g1(nV), dim3(NT), 0, st, nV, tau, ATdy, ATy);
-            hipLaunchKernelGGL(k_axpy, g1(nV), dim3(NT), 0, st, nV, tau, Hdx, Hx);
             if (iter >= maxit) { rcode = RET_MAX_NWSR; break; }
             if (kind == 3) hipLaunchKernelGGL(k_copy1, dim3(1), dim3(1), 0, st, side == -1 ? lbA : ubA, idx, Ax, idx);
             else if (kind == 4) hipLaunchKernelGGL(k_copy1, dim3(1), dim3(1), 0, st, side == -1 ? lb : ub, idx, x, idx);
@@ -1218,6 +1299,8 @@ hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
     DA(pt, P.nblk_ratio); DA(res_t, 2);
     DA(Sb, nV); DA(Sc, nC); DA(AC, nC); DA(posAC, nC); DA(pid, P.nblk_ratio); DA(res_id, 2);
 #undef DA
+    if ((e = hipHostMalloc(reinterpret_cast<void **>(&P.h_ctl), 64 * sizeof(double), hipHostMallocMapped)) != hipSuccess) return e;
+    if ((e = hipHostGetDevicePointer(reinterpret_cast<void **>(&P.d_ctl), P.h_ctl, 0)) != hipSuccess) return e;
     if ((e = hipHostMalloc(reinterpret_cast<void **>(&P.h_pinned), 64 * sizeof(double))) != hipSuccess) return e;
     if ((e = hipHostMalloc(reinterpret_cast<void **>(&P.h_pinned_i), 64 * sizeof(int))) != hipSuccess) return e;
     P.hSb.assign(nV, 0); P.hSc.assign(nC, 0); P.hAC.assign(std::max(nC, 1), 0);
