@@ -146,6 +146,40 @@ def large_configs(capi, problems, hot_steps=6):
     return out
 
 
+def hs071_single_qp_latency(problems, iters=3000):
+    """Wall-clock per SQP iteration of hs071 at the boundary, ONE QP at a time: the C++ host
+    adapter (restartsqp_amd/csrc/host) replays QPhandler::update_delta + solveQP (hot start +
+    mandatory KKT certificate). A single 8-variable QP is launch/sync-latency bound on any GPU;
+    the CPU oracle does the same work in a few microseconds -- reported for honesty."""
+    import subprocess
+    import oracle as O
+    host = os.path.join(ROOT, "restartsqp_amd", "csrc", "host")
+    subprocess.check_call(["make", "-s", "-C", host, "host_replay"])
+    out = subprocess.run([os.path.join(host, "host_replay"), "--bench", str(iters)], capture_output=True, text=True,
+                         timeout=300).stdout
+    res = {}
+    for line in out.splitlines():
+        if line.startswith("bench "):
+            tok = line.split()
+            res["gpu_us_" + ("solveQP" if "certificate" in tok[1] else "optimizeQP_only")] = float(tok[3])
+    q1, q2 = problems.handler_qp(problems.hs071_nlp(), delta=1.0), problems.handler_qp(problems.hs071_nlp(), delta=0.5)
+    qp = O.OracleQP(q1.nV, q1.nC)
+    qp.set_A_csc(q1.A_jc, q1.A_ir, q1.A_val); qp.set_H_csc(q1.H_jc, q1.H_ir, q1.H_val)
+    qp.init(q1.g, q1.lb, q1.ub, q1.lbA, q1.ubA, 1000)
+    A, H = (q1.A_jc, q1.A_ir, q1.A_val), (q1.H_jc, q1.H_ir, q1.H_val)
+    cl = lambda v: np.clip(v, -1e20, 1e20)
+    t0 = time.perf_counter()
+    for it in range(iters):
+        q = q2 if it & 1 else q1
+        qp.hotstart(q.g, q.lb, q.ub, q.lbA, q.ubA, 1000)
+        x, y = qp.x, qp.y
+        Wb, Wc = O.kkt_get_working_set(q.nV, q.nC, A, x, cl(q.lb), cl(q.ub), cl(q.lbA), cl(q.ubA), qp.ws_bounds,
+                                       qp.ws_constraints)
+        O.kkt_test_optimality(q.nV, q.nC, A, H, q.g, cl(q.lb), cl(q.ub), cl(q.lbA), cl(q.ubA), x, y, Wb, Wc)
+    res["cpu_oracle_us_solveQP_incl_python_ctypes"] = 1e6 * (time.perf_counter() - t0) / iters
+    return res
+
+
 def cpu_baseline(probs, seconds):
     """Oracle (oracle/qp_oracle.c) timed on this host, one thread. Test infrastructure used as
     the reported baseline only -- never on the measured GPU path."""
@@ -258,6 +292,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(probs[:256], args.cpu_seconds)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
             line["roofline_spmv"] = spmv_roofline(capi, problems, args.spmv_batch, 5)
+            line["hs071_single_qp"] = hs071_single_qp_latency(problems)
             if not args.no_large:
                 line["large_engine"] = large_configs(capi, problems)
         print(json.dumps(line))

@@ -3,15 +3,19 @@
 // set_A, set_H, per-element bounds, per-element g, optimizeQP, test_optimality; then a
 // trust-region update (update_delta) and a hot start. Prints one line per solve; the GPU test
 // tests/test_gpu_host_adapter.py compares the lines with the CPU reference restatement kept under tests.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <limits>
 
 #include "HipQPInterface.hpp"
 
 using namespace rsqp;
 
-int main() {
+int main(int argc, char **argv) {
+    const int bench_iters = (argc > 2 && std::strcmp(argv[1], "--bench") == 0) ? std::atoi(argv[2]) : 0;
     const double INF = 1.0e18;  // include/sqphot/Utils.hpp:35
     NLPInfo info{2, 4, 8, 10};
     auto options = std::make_shared<Options>();
@@ -59,6 +63,29 @@ int main() {
                         stats->qp_iter, ok ? 1 : 0, qp.get_optimality_status().KKT_error, qp.get_obj_value());
             for (int i = 0; i < 8; i++) std::printf(" %.15g", x[i]);
             std::printf(" Wc %d %d\n", (int)Wc[0], (int)Wc[1]);
+        }
+        if (bench_iters > 0) {
+            // "wall-clock per SQP iteration" at the boundary: QPhandler::update_delta (8 scalar
+            // setters) + solveQP (optimizeQP + mandatory KKT certificate), alternating radii
+            for (int pass = 0; pass < 2; pass++) {
+                const bool with_cert = pass == 0;
+                auto t0 = std::chrono::steady_clock::now();
+                for (int it = 0; it < bench_iters; it++) {
+                    delta = (it & 1) ? 0.5 : 1.0;
+                    for (int i = 0; i < 4; i++) {
+                        qp.set_lb(i, std::fmax(x_l[i] - x_k[i], -delta));
+                        qp.set_ub(i, std::fmin(x_u[i] - x_k[i], delta));
+                    }
+                    qp.optimizeQP(stats);
+                    if (with_cert) {
+                        ActiveType Wc[2], Wb[8];
+                        if (!qp.test_optimality(Wc, Wb)) { std::printf("bench: certificate failed\n"); return 3; }
+                    }
+                }
+                const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                std::printf("bench %s us_per_sqp_iteration %.2f iters %d\n", with_cert ? "solveQP(optimizeQP+certificate)" : "optimizeQP_only",
+                            us / bench_iters, bench_iters);
+            }
         }
     } catch (const std::exception &e) {
         std::printf("EXCEPTION %s\n", e.what());

@@ -36,15 +36,18 @@ template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    T *host = nullptr;   // non-null: p is the device view of host-mapped pinned memory owned elsewhere
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !host) (void)hipFree(p);
         p = nullptr;
+        host = nullptr;
         n = 0;
     }
+    void map(T *dev, T *hst, size_t count) { release(); p = dev; host = hst; n = count; }
     hipError_t alloc(size_t count, bool zero = true) {
         release();
         n = count;
@@ -55,6 +58,7 @@ struct DevBuf {
     }
     hipError_t upload(const T *h, size_t count) {
         if (count == 0) return hipSuccess;
+        if (host) { std::memcpy(host, h, count * sizeof(T)); return hipSuccess; }
         return hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice);
     }
     hipError_t from(const std::vector<T> &h) {
@@ -64,6 +68,7 @@ struct DevBuf {
     }
     hipError_t download(T *h, size_t count) const {
         if (count == 0) return hipSuccess;
+        if (host) { std::memcpy(h, host, count * sizeof(T)); return hipSuccess; }   // caller has synchronised
         return hipMemcpy(h, p, count * sizeof(T), hipMemcpyDeviceToHost);
     }
 };
@@ -192,6 +197,9 @@ struct rsqp_solver {
     bool upd_A = false, upd_H = false, upd_bounds = false, upd_g = false;
     int old_status = 0, new_status = 0;  // 0 UNDEFINED, 1 FIXED, 2 VARIED
     bool desc_ready = false;
+    // small problems: vectors in and results out live in ONE host-mapped pinned block that the
+    // kernels read / write directly (zero-copy): a solve costs one launch and one sync
+    void *io_host = nullptr;
     bool lp_mode = false;   // optimizeLP: H ignored, H := hreg*I
     double hreg = 0.0;
     // engine: 1 = LDS-resident kernel, 2 = HBM-resident engine
@@ -200,7 +208,16 @@ struct rsqp_solver {
     RsqpLargeEngine *large = nullptr;
     bool large_ready = false;
     DevBuf<double> denseA, denseH;   // dense copies for the HBM-resident engine (dense matrices only)
-    ~rsqp_solver() { delete large; }
+    ~rsqp_solver() {
+        delete large;
+        if (io_host) {   // mapped views first, then the block
+            for (int k = 0; k < 5; k++) d_vec[k].release();
+            d_x.release(); d_y.release(); d_obj.release(); d_wsb.release(); d_wsc.release();
+            d_kkt.release(); d_Wb.release(); d_Wc.release();
+            d_status.release(); d_ret.release(); d_nwsr.release(); d_nflips.release();
+            (void)hipHostFree(io_host);
+        }
+    }
 };
 
 namespace {
@@ -315,20 +332,48 @@ extern "C" int rsqp_create(int nV, int nC, int device, rsqp_solver **out) {
     s->fits_small = rsqp_small_qp_fits(nV, nC) != 0;
     s->engine = s->fits_small ? 1 : 2;
     HIPCHK(hipGetDevice(&s->device));
-    for (int k = 0; k < 5; k++) {
-        size_t n = (k <= RSQP_VEC_UB) ? nV : nC;
-        s->h_vec[k].assign(n, 0.0);
-        HIPCHK(s->d_vec[k].alloc(n));
+    for (int k = 0; k < 5; k++) s->h_vec[k].assign((k <= RSQP_VEC_UB) ? nV : nC, 0.0);
+    if (s->fits_small) {
+        const size_t nd = 3 * (size_t)nV + 2 * (size_t)nC + nV + (nV + nC) + 1 + 6;      // doubles
+        const size_t ni = 2 * ((size_t)nV + nC) + 4;                                       // ints
+        const size_t bytes = nd * 8 + ni * 4 + 64;
+        HIPCHK(hipHostMalloc(&s->io_host, bytes, hipHostMallocMapped));
+        std::memset(s->io_host, 0, bytes);
+        void *dev = nullptr;
+        HIPCHK(hipHostGetDevicePointer(&dev, s->io_host, 0));
+        double *hd = static_cast<double *>(s->io_host), *dd = static_cast<double *>(dev);
+        size_t o = 0;
+        for (int k = 0; k < 5; k++) {
+            const size_t n = (k <= RSQP_VEC_UB) ? nV : nC;
+            s->d_vec[k].map(dd + o, hd + o, n);
+            o += n;
+        }
+        s->d_x.map(dd + o, hd + o, nV); o += nV;
+        s->d_y.map(dd + o, hd + o, nV + nC); o += nV + nC;
+        s->d_obj.map(dd + o, hd + o, 1); o += 1;
+        s->d_kkt.map(dd + o, hd + o, 6); o += 6;
+        int *hi = reinterpret_cast<int *>(hd + o), *di = reinterpret_cast<int *>(dd + o);
+        size_t q = 0;
+        s->d_wsb.map(di + q, hi + q, nV); q += nV;
+        s->d_wsc.map(di + q, hi + q, nC); q += nC;
+        s->d_status.map(di + q, hi + q, 1); q++;
+        s->d_ret.map(di + q, hi + q, 1); q++;
+        s->d_nwsr.map(di + q, hi + q, 1); q++;
+        s->d_nflips.map(di + q, hi + q, 1); q++;
+        s->d_Wb.map(di + q, hi + q, nV); q += nV;
+        s->d_Wc.map(di + q, hi + q, nC); q += nC;
+    } else {
+        for (int k = 0; k < 5; k++) HIPCHK(s->d_vec[k].alloc((k <= RSQP_VEC_UB) ? nV : nC));
+        HIPCHK(s->d_x.alloc(nV)); HIPCHK(s->d_y.alloc(nV + nC)); HIPCHK(s->d_obj.alloc(1));
+        HIPCHK(s->d_wsb.alloc(nV)); HIPCHK(s->d_wsc.alloc(nC));
+        HIPCHK(s->d_status.alloc(1)); HIPCHK(s->d_ret.alloc(1)); HIPCHK(s->d_nwsr.alloc(1)); HIPCHK(s->d_nflips.alloc(1));
+        HIPCHK(s->d_kkt.alloc(6)); HIPCHK(s->d_Wb.alloc(nV)); HIPCHK(s->d_Wc.alloc(nC));
     }
-    HIPCHK(s->d_x.alloc(nV)); HIPCHK(s->d_y.alloc(nV + nC)); HIPCHK(s->d_obj.alloc(1));
-    HIPCHK(s->d_wsb.alloc(nV)); HIPCHK(s->d_wsc.alloc(nC));
-    HIPCHK(s->d_status.alloc(1)); HIPCHK(s->d_ret.alloc(1)); HIPCHK(s->d_nwsr.alloc(1)); HIPCHK(s->d_nflips.alloc(1));
     HIPCHK(s->d_state.alloc(s->fits_small ? (size_t)rsqp_image_bytes(nV, nC) / 8 : 1));
     HIPCHK(s->d_x0.alloc(nV)); HIPCHK(s->d_y0.alloc(nV + nC)); HIPCHK(s->d_guess.alloc(nV));
     HIPCHK(s->d_dummy_i.alloc(std::max(nV, nC) + 2)); HIPCHK(s->d_dummy_d.alloc(4));
-    HIPCHK(s->d_Ax.alloc(nC)); HIPCHK(s->d_ATy.alloc(nV)); HIPCHK(s->d_Hx.alloc(nV)); HIPCHK(s->d_kkt.alloc(6));
+    HIPCHK(s->d_Ax.alloc(nC)); HIPCHK(s->d_ATy.alloc(nV)); HIPCHK(s->d_Hx.alloc(nV));
     HIPCHK(s->d_in.alloc(std::max(nV, nC))); HIPCHK(s->d_out.alloc(std::max(nV, nC)));
-    HIPCHK(s->d_Wb.alloc(nV)); HIPCHK(s->d_Wc.alloc(nC));
     s->h_x.assign(nV, 0.0); s->h_y.assign(nV + nC, 0.0); s->h_wsb.assign(nV, 0); s->h_wsc.assign(nC, 0);
     *out = s;
     return RSQP_OK;
@@ -545,10 +590,10 @@ int solve_large(rsqp_solver *s, int mode, int *nWSR, const double *x0, const dou
     if (s->large->last_error() != hipSuccess)
         return fail(RSQP_ERR_DEVICE, std::string("HBM-resident engine: ") + hipGetErrorString(s->large->last_error()));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(s->d_x.p, s->large->d_x(), sizeof(double) * s->nV, hipMemcpyDeviceToDevice));
-    HIPCHK(hipMemcpy(s->d_y.p, s->large->d_y(), sizeof(double) * (s->nV + s->nC), hipMemcpyDeviceToDevice));
-    HIPCHK(hipMemcpy(s->d_wsb.p, s->large->d_Sb(), sizeof(int) * s->nV, hipMemcpyDeviceToDevice));
-    if (s->nC > 0) HIPCHK(hipMemcpy(s->d_wsc.p, s->large->d_Sc(), sizeof(int) * s->nC, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(s->d_x.p, s->large->d_x(), sizeof(double) * s->nV, hipMemcpyDefault));
+    HIPCHK(hipMemcpy(s->d_y.p, s->large->d_y(), sizeof(double) * (s->nV + s->nC), hipMemcpyDefault));
+    HIPCHK(hipMemcpy(s->d_wsb.p, s->large->d_Sb(), sizeof(int) * s->nV, hipMemcpyDefault));
+    if (s->nC > 0) HIPCHK(hipMemcpy(s->d_wsc.p, s->large->d_Sc(), sizeof(int) * s->nC, hipMemcpyDefault));
     HIPCHK(s->d_x.download(s->h_x.data(), s->nV));
     HIPCHK(s->d_y.download(s->h_y.data(), s->nV + s->nC));
     HIPCHK(s->d_wsb.download(s->h_wsb.data(), s->nV));
@@ -768,13 +813,20 @@ int run_certificate(rsqp_solver *s, rsqp_optimality_status *out, int *W_c, int *
     HIPCHK(hipSetDevice(s->device));
     int rc = flush_vectors(s);
     if (rc != RSQP_OK) return rc;
-    if (s->nC > 0) {
+    if (s->fits_small && s->A.initialised == (s->nC > 0)) {
+        // hs0xx-scale: all three products in one launch (one workgroup), results by zero-copy
+        if ((rc = ensure_desc(s)) != RSQP_OK) return rc;
+        QPPools p = pools_of(s);
+        if (rsqp_launch_small_products(p, 1, s->d_Ax.p, s->d_ATy.p, s->d_Hx.p, s->stream) != hipSuccess)
+            return fail(RSQP_ERR_DEVICE, "products launch failed");
+    } else if (s->nC > 0) {
         if ((rc = spmv_csr(s, s->A, s->d_x.p, s->d_Ax.p)) != RSQP_OK) return rc;             // A x
         if ((rc = spmv_csc(s, s->A, s->d_y.p + s->nV, s->d_ATy.p)) != RSQP_OK) return rc;    // A'y_c
     } else {
         HIPCHK(hipMemsetAsync(s->d_ATy.p, 0, sizeof(double) * s->nV, s->stream));
     }
-    if (s->H.initialised) {
+    if (s->fits_small && s->A.initialised == (s->nC > 0)) {
+    } else if (s->H.initialised) {
         if ((rc = spmv_csc(s, s->H, s->d_x.p, s->d_Hx.p)) != RSQP_OK) return rc;             // H x (symmetric)
     } else {
         HIPCHK(hipMemsetAsync(s->d_Hx.p, 0, sizeof(double) * s->nV, s->stream));
