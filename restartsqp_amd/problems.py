@@ -99,6 +99,26 @@ def perturb(rng, q, rel=0.01):
     return QPData(q.nV, q.nC, q.H_jc, q.H_ir, q.H_val, q.A_jc, q.A_ir, q.A_val, g, lb, ub, lbA, ubA, name=q.name)
 
 
+def degenerate_qp(rng, kind):
+    """Small QPs with the degeneracies an active-set method has to survive: 0 duplicate
+    constraint, 1 zero row, 2 constraint parallel to a bound, 3 integer data (ties), 4 singular H."""
+    nV, nC = int(rng.integers(2, 10)), int(rng.integers(2, 12))
+    q = random_qp(rng, nV, nC, density=0.7)
+    A, H = q.dense_A(), q.dense_H()
+    if kind == 0:
+        A[1] = A[0]; q.lbA[1] = q.lbA[0]; q.ubA[1] = q.ubA[0]
+    elif kind == 1:
+        A[0] = 0.0; q.lbA[0] = -1.0; q.ubA[0] = 1.0
+    elif kind == 2:
+        A[0] = 0.0; A[0, 0] = 1.0; q.lbA[0] = q.lb[0]; q.ubA[0] = q.ub[0]
+    elif kind == 3:
+        A = np.round(2.0 * A); q.g = np.round(q.g); q.lb = np.floor(q.lb); q.ub = np.ceil(q.ub) + 1.0
+        q.lbA = -2.0 * np.ones(nC); q.ubA = 2.0 * np.ones(nC)
+    elif kind == 4:
+        H[:, -1] = 0.0; H[-1, :] = 0.0
+    return QPData(nV, nC, *dense_to_csc(H), *dense_to_csc(A), q.g, q.lb, q.ub, q.lbA, q.ubA, name="degenerate-%d" % kind)
+
+
 # shapes (nV, nC) of the 18 dumps under reference test/unsolved_QP_data/
 HS_DUMP_SHAPES = [(8, 3), (10, 4), (8, 3), (5, 1), (13, 5), (7, 2), (4, 0), (15, 4), (5, 1), (16, 6), (12, 4),
                   (12, 4), (23, 6), (5, 1), (7, 1), (20, 6), (37, 14), (69, 28)]

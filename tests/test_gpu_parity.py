@@ -379,3 +379,28 @@ def test_optimize_lp(capi, oracle):
             assert np.abs(s.x - qp.x).max() <= 1e-8 * max(1.0, np.abs(qp.x).max())
             r = linprog(g, A_ub=np.vstack([A, -A]), b_ub=np.concatenate([ubA, -lbA]), bounds=list(zip(lb, ub)))
             assert abs(s.objective - r.fun) <= 1e-8 * max(1.0, abs(r.fun))
+
+
+def test_degenerate_inputs_both_engines(capi, oracle):
+    """Same degenerate inputs as tests/test_oracle_qp.py::test_degenerate_inputs: the kernels make
+    the same tie-breaking decisions as the oracle (lowest candidate id)."""
+    rng = np.random.default_rng(0)
+    probs = [problems.degenerate_qp(rng, t % 5) for t in range(100)]
+    b = capi.Batch(probs)
+    b.solve(capi.MODE_COLD, 500)
+    res = b.results()
+    for q, r in zip(probs, res):
+        qp, rc, n = oracle_cold(oracle, q, 500)
+        assert_same_solution(qp, r, n)
+    for q in probs[:25]:
+        s = capi.Solver(q.nV, q.nC)
+        s.set_engine(2)
+        s.set_A_csc(q.A_jc, q.A_ir, q.A_val); s.set_H_csc(q.H_jc, q.H_ir, q.H_val)
+        for w, v in zip(range(5), (q.g, q.lb, q.ub, q.lbA, q.ubA)):
+            s.set_vector(w, v)
+        n = s.solve(capi.MODE_COLD, 500)
+        qp, rc, n_or = oracle_cold(oracle, q, 500)
+        wb, wc = s.working_set_raw()
+        assert s.status == qp.exitflag() and n == n_or
+        assert np.array_equal(wb, qp.ws_bounds) and np.array_equal(wc, qp.ws_constraints)
+        assert np.abs(s.x - qp.x).max() <= 1e-9 * max(1.0, np.abs(qp.x).max())

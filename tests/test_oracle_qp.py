@@ -166,3 +166,21 @@ def test_iteration_limit(oracle):
     q = problems.random_qp(np.random.default_rng(3), 30, 40)
     qp, rc, n = oracle_cold(oracle, q, nWSR=3)
     assert rc == 1 and n == 3 and not qp.is_solved() and qp.exitflag() == 28
+
+
+def test_degenerate_inputs(oracle):
+    """Duplicate / zero / bound-parallel constraints, integer data (ties), singular Hessians:
+    every run ends in a certified KKT point or in a verdict of infeasibility that an LP solver
+    confirms; none runs into the iteration limit."""
+    from scipy.optimize import linprog
+    rng = np.random.default_rng(0)
+    for t in range(150):
+        q = problems.degenerate_qp(rng, t % 5)
+        qp, rc, n = oracle_cold(oracle, q, 500)
+        A = q.dense_A()
+        r = linprog(np.zeros(q.nV), A_ub=np.vstack([A, -A]), b_ub=np.concatenate([q.ubA, -q.lbA]),
+                    bounds=list(zip(q.lb, q.ub)))
+        assert rc in (0, 2) and (rc == 2) == (r.status != 0)
+        if rc == 0:
+            ok, st, _, _ = oracle_certificate(oracle, q, qp.x, qp.y, qp.ws_bounds, qp.ws_constraints)
+            assert ok
