@@ -1,5 +1,6 @@
-// qp_small.hip -- batched online active-set QP engine for gfx950: ONE QP PER WORKGROUP,
-// the whole solver state (Q, T, R, iterate, working set) resident in LDS.
+// qp_small.hip -- batched online active-set QP engine for gfx950: the whole solver state of a
+// problem (Q, T, R, iterate, working set) resident in LDS, L = 16 / 32 / 64 lanes of a wave per
+// problem (64 / L problems share a one-wave workgroup).
 //
 // Replaces, for hs0xx-scale problems, the qpOASES 3.2.1 SQProblem::init / hotstart calls
 // made at reference src/qpOASESInterface.cpp:155,180,184,191,197,204. Algorithm = dense
@@ -9,30 +10,66 @@
 //   dependence, bound flipping when Z'HZ would lose definiteness.
 //
 // MI355X mapping:
-//   * grid = number of QPs; workgroup = NT threads (one wave for NT = 64) -- a batch
-//     fills the 256 CUs with independent problems; no inter-workgroup communication.
+//   * workgroup = one wave = 64 / L problems, grid = ceil(nq * L / 64) -- a batch fills the 256
+//     CUs with independent problems; no inter-workgroup communication and no s_barrier: the
+//     problems of a wave follow their own control flow under exec masking, and a wave's LDS
+//     instructions execute in program order, so a compiler fence is all the sync it needs.
+//     hs0xx-scale problems (nV <= 16) use L = 16: their vectors never filled 64 lanes.
 //   * LDS image per problem (rsqp_image_bytes): Q and R column-major with an ODD leading
 //     dimension so that the lane<->row and lane<->column access patterns below are both
 //     bank-conflict free for ds_read_b64; T row-major with the same stride.
 //   * sparse H / A stay in global memory in CSC (+ a CSR copy of A): they are read-only
 //     and L2-resident; lane-per-row / lane-per-column products, no atomics.
-//   * reductions are wave butterflies (__shfl_xor, identical result in every lane) so
-//     all control flow stays wave-uniform; argmin carries the candidate id for the
-//     deterministic tie break.
+//   * reductions are butterflies over the L lanes of a problem (__shfl_xor, identical result
+//     in each of them) so control flow stays uniform per problem; argmin carries the candidate
+//     id for the deterministic tie break. With nV <= L every lane owns at most one entry of a
+//     vector, so the sums are bit-identical for every L (tools/small_pack_check.py).
 //   * the image is written back to HBM at the end of a solve and reloaded by the next
 //     hot start (qpOASES keeps the same data inside the SQProblem object).
 #include <cstdlib>
 
 #include "rsqp_internal.h"
 
+// A workgroup is ONE wave: LDS instructions of a wave execute in program order, so making a
+// write visible to the other lanes only needs the compiler to keep the order (no s_barrier,
+// which would also be illegal inside the per-problem divergent control flow of packed waves).
+#ifdef RSQP_SYNC_BARRIER  // diagnostic: only legal while all problems of a wave run in lockstep
 #define SYNC() __syncthreads()
-#define PFOR(i, n) for (int i = threadIdx.x; i < (n); i += NT)
+#else
+#define SYNC()                                               \
+    do {                                                     \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                     \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+#endif
+#define PFOR(i, n) for (int i = lane; i < (n); i += L)
 // LDS-qualified pointer types: guarantees ds_read / ds_write (a generic pointer would be
 // lowered to flat_load, which is several times slower and costs two registers)
 #define LDS __attribute__((address_space(3)))
 typedef LDS double ldouble;
 typedef LDS int lint;
 typedef LDS char lchar;
+
+// diagnostic build only (-DRSQP_STAMPS, tools/stamp_small_kernel.py): cycles per phase of block 0
+#ifdef RSQP_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP(k)                                                                                    \
+    do {                                                                                            \
+        long long t_ = clock64();                                                                   \
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_stamps[k], (unsigned long long)(t_ - tlast)); \
+        tlast = t_;                                                                                 \
+    } while (0)
+extern "C" void rsqp_debug_stamps(unsigned long long *out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
+    }
+}
+#else
+#define STAMP(k) do { } while (0)
+#endif
 
 namespace {
 
@@ -47,7 +84,7 @@ template <> struct MatPtr<false> { typedef const int *I; typedef const double *D
 
 // MAT_LDS: the sparse matrices were staged into LDS behind the image (they fit for every
 // hs0xx-scale problem); otherwise they are read from global memory (L2).
-template <int NT, bool MAT_LDS>
+template <int L, bool MAT_LDS>
 struct Engine {
     typedef typename MatPtr<MAT_LDS>::I MI;
     typedef typename MatPtr<MAT_LDS>::D MD;
@@ -65,9 +102,10 @@ struct Engine {
     ldouble *scal;  // 8 scalars for broadcasts
     lint *Sb, *Sc, *AC, *posAC;
     lint *iscal;    // 8 ints
-    ldouble *red;   // cross-wave reduction scratch (outside the image)
-    // uniform registers
+    // uniform over the L lanes of the problem
+    int lane;
     int nFR, nAC, status, infeasible, unbounded, nflips;
+    long long tlast;
 
     // ------------------------------------------------------------------ carve
     __device__ __forceinline__ void carve(lchar *base, int nV_, int nC_) {
@@ -97,39 +135,20 @@ struct Engine {
     }
 
     // ------------------------------------------------------------------ reductions
-    __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        return v;
-    }
+    // butterflies over the L lanes of this problem (xor offsets < L never leave the group);
+    // every lane of the group ends with the same value, so control flow stays group-uniform
     __device__ __forceinline__ double block_sum(double v) {
-        v = wave_sum(v);
-        if constexpr (NT > 64) {
-            SYNC();
-            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-            SYNC();
-            v = 0.0;
-            for (int w = 0; w < NT / 64; w++) v += red[w];
-        }
+#pragma unroll
+        for (int o = L / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
         return v;
     }
     // lexicographic min of (t, id)
     __device__ __forceinline__ void block_argmin(double &t, int &id) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
+        for (int o = L / 2; o > 0; o >>= 1) {
             double t2 = __shfl_xor(t, o);
             int id2 = __shfl_xor(id, o);
             if (t2 < t || (t2 == t && id2 < id)) { t = t2; id = id2; }
-        }
-        if constexpr (NT > 64) {
-            SYNC();
-            if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = t; red[8 + (threadIdx.x >> 6)] = (double)id; }
-            SYNC();
-            t = red[0]; id = (int)red[8];
-            for (int w = 1; w < NT / 64; w++) {
-                double t2 = red[w]; int id2 = (int)red[8 + w];
-                if (t2 < t || (t2 == t && id2 < id)) { t = t2; id = id2; }
-            }
         }
     }
     __device__ __forceinline__ double dot(const ldouble *a, const ldouble *b, int n) {
@@ -168,7 +187,7 @@ struct Engine {
     __device__ __forceinline__ void row_of_A(int i, ldouble *a, bool all) {
         PFOR(v, nV) a[v] = 0.0;
         SYNC();
-        for (int k = Arp[i] + threadIdx.x; k < Arp[i + 1]; k += NT) {
+        for (int k = Arp[i] + lane; k < Arp[i + 1]; k += L) {
             int c = Aci[k];
             if (all || Sb[c] == 0) a[c] = Arv[k];
         }
@@ -195,7 +214,7 @@ struct Engine {
     // rotations (j, j+1), j = j0 .. j1-1, left to right, coefficients rc/rs[j], applied
     // to the vector w (thread 0 computes them: the chain is sequential)
     __device__ __forceinline__ void plan_sweep(ldouble *w, int j0, int j1, int jskip_below) {
-        if (threadIdx.x == 0) {
+        if (lane == 0) {
             for (int j = j0; j < j1; j++) {
                 double c = 1.0, s = 0.0;
                 if (j >= jskip_below) givens(w[j], w[j + 1], c, s);
@@ -256,7 +275,7 @@ struct Engine {
             if (sub != 0.0) {  // uniform: every lane read the same LDS words
                 double r = hypot(diag, sub), cc = diag / r, ss = sub / r;
                 SYNC();
-                for (int col = j + threadIdx.x; col < nZ; col += NT) {
+                for (int col = j + lane; col < nZ; col += L) {
                     ldouble *pc = R + col * ld;
                     double a = pc[j], b = pc[j + 1];
                     pc[j] = cc * a + ss * b;
@@ -306,7 +325,7 @@ struct Engine {
         }
         ldouble *row = T + nAC * ld;
         PFOR(c, nV) row[c] = (c >= nZ - 1 && c < nFR) ? wq[c] : 0.0;
-        if (threadIdx.x == 0) { AC[nAC] = i; posAC[i] = nAC; Sc[i] = st; }
+        if (lane == 0) { AC[nAC] = i; posAC[i] = nAC; Sc[i] = st; }
         nAC++;
         SYNC();
     }
@@ -324,7 +343,7 @@ struct Engine {
         PFOR(c, nFR) Q[c * ld + v] = 0.0;
         PFOR(u, nV) Q[(nFR - 1) * ld + u] = 0.0;
         PFOR(i, nAC) T[i * ld + nFR - 1] = 0.0;
-        if (threadIdx.x == 0) Sb[v] = st;
+        if (lane == 0) Sb[v] = st;
         nFR--;
         SYNC();
     }
@@ -345,8 +364,8 @@ struct Engine {
         for (int j = 0; j < zc; j++) {
             double rj = wv3[j] / R[j * ld + j];
             SYNC();
-            if (threadIdx.x == 0) wv3[j] = rj;
-            for (int k = j + 1 + threadIdx.x; k < zc; k += NT) wv3[k] -= R[k * ld + j] * rj;
+            if (lane == 0) wv3[j] = rj;
+            for (int k = j + 1 + lane; k < zc; k += L) wv3[k] -= R[k * ld + j] * rj;
             SYNC();
         }
         double rr = dot(wv3, wv3, zc);
@@ -366,9 +385,9 @@ struct Engine {
             double c, s;
             givens(ri[c0], ri[c0 + 1], c, s);  // uniform
             SYNC();
-            if (threadIdx.x == 0) { rc[t] = c; rs[t] = s; }
+            if (lane == 0) { rc[t] = c; rs[t] = s; }
             if (s != 0.0) {
-                for (int ii = i + threadIdx.x; ii < nAC; ii += NT) {
+                for (int ii = i + lane; ii < nAC; ii += L) {
                     ldouble *row = T + ii * ld;
                     double a = row[c0], b = row[c0 + 1];
                     row[c0] = ii == i ? 0.0 : c * a - s * b;
@@ -396,7 +415,7 @@ struct Engine {
         SYNC();
         PFOR(c, nV)
             for (int i = k; i + 1 < nAC; i++) T[i * ld + c] = T[(i + 1) * ld + c];
-        if (threadIdx.x == 0) {
+        if (lane == 0) {
             for (int i = k; i + 1 < nAC; i++) { AC[i] = AC[i + 1]; posAC[AC[i]] = i; }
             posAC[cons] = -1;
             Sc[cons] = 0;
@@ -415,9 +434,9 @@ struct Engine {
         PFOR(u, nV) Q[cn * ld + u] = u == v ? 1.0 : 0.0;
         PFOR(c, cn) Q[c * ld + v] = 0.0;
         PFOR(i, nAC) T[i * ld + cn] = 0.0;
-        if (threadIdx.x == 0) Sb[v] = 0;
+        if (lane == 0) Sb[v] = 0;
         SYNC();
-        for (int k = Ajc[v] + threadIdx.x; k < Ajc[v + 1]; k += NT) {
+        for (int k = Ajc[v] + lane; k < Ajc[v + 1]; k += L) {
             int r = Air[k];
             if (Sc[r] != 0) T[posAC[r] * ld + cn] = Aval[k];
         }
@@ -466,11 +485,11 @@ struct Engine {
         SYNC();
         PFOR(v, nV) { x[v] = wv4[v]; Sb[v] = (int)wq[v]; }
         PFOR(i, nV + nC) y[i] = dy[i];
-        for (int k = threadIdx.x; k < ld * nV; k += NT) { Q[k] = 0.0; R[k] = 0.0; }
-        for (int k = threadIdx.x; k < sizeT * ld; k += NT) T[k] = 0.0;
+        for (int k = lane; k < ld * nV; k += L) { Q[k] = 0.0; R[k] = 0.0; }
+        for (int k = lane; k < sizeT * ld; k += L) T[k] = 0.0;
         PFOR(i, nC) { Sc[i] = 0; posAC[i] = -1; }
         SYNC();
-        if (threadIdx.x == 0) {
+        if (lane == 0) {
             int n = 0;
             for (int v = 0; v < nV; v++)
                 if (Sb[v] == 0) Q[(n++) * ld + v] = 1.0;
@@ -541,8 +560,8 @@ struct Engine {
             int c = nFR - 1 - i;
             double w = wc1[i] / T[i * ld + c];
             SYNC();
-            if (threadIdx.x == 0) wq[c] = w;
-            for (int ii = i + 1 + threadIdx.x; ii < nAC; ii += NT) wc1[ii] -= T[ii * ld + c] * w;
+            if (lane == 0) wq[c] = w;
+            for (int ii = i + 1 + lane; ii < nAC; ii += L) wc1[ii] -= T[ii * ld + c] * w;
             SYNC();
         }
         PFOR(v, nV) {
@@ -565,15 +584,15 @@ struct Engine {
         for (int j = 0; j < nZ; j++) {
             double u = wq[j] / R[j * ld + j];
             SYNC();
-            if (threadIdx.x == 0) wq[j] = u;
-            for (int k = j + 1 + threadIdx.x; k < nZ; k += NT) wq[k] -= R[k * ld + j] * u;
+            if (lane == 0) wq[j] = u;
+            for (int k = j + 1 + lane; k < nZ; k += L) wq[k] -= R[k * ld + j] * u;
             SYNC();
         }
         for (int j = nZ - 1; j >= 0; j--) {
             double w = wq[j] / R[j * ld + j];
             SYNC();
-            if (threadIdx.x == 0) wq[j] = w;
-            for (int k = threadIdx.x; k < j; k += NT) wq[k] -= R[j * ld + k] * w;
+            if (lane == 0) wq[j] = w;
+            for (int k = lane; k < j; k += L) wq[k] -= R[j * ld + k] * w;
             SYNC();
         }
         PFOR(v, nV) {
@@ -588,7 +607,7 @@ struct Engine {
         H_times(dx, wv2);
         PFOR(v, nV) wv2[v] += gN[v] - g[v];
         SYNC();
-        for (int c = nZ + threadIdx.x; c < nFR; c += NT) {
+        for (int c = nZ + lane; c < nFR; c += L) {
             const ldouble *qc = Q + c * ld;
             double s = 0.0;
             for (int v = 0; v < nV; v++) s += qc[v] * wv2[v];
@@ -600,8 +619,8 @@ struct Engine {
             const ldouble *ri = T + i * ld;
             double d = wq[c] / ri[c];
             SYNC();
-            if (threadIdx.x == 0) dy[nV + AC[i]] = d;
-            for (int cc = c + 1 + threadIdx.x; cc < nFR; cc += NT) wq[cc] -= ri[cc] * d;
+            if (lane == 0) dy[nV + AC[i]] = d;
+            for (int cc = c + 1 + lane; cc < nFR; cc += L) wq[cc] -= ri[cc] * d;
             SYNC();
         }
         AT_times(dy + nV, wv3);
@@ -662,7 +681,7 @@ struct Engine {
             int old = Sb[idx];
             SYNC();
             int zc = remove_bound_tq(idx);
-            if (threadIdx.x == 0) y[idx] = 0.0;
+            if (lane == 0) y[idx] = 0.0;
             SYNC();
             if (chol_append(zc)) return RET_OK;
             if ((old == -1 && ubN[idx] >= RSQP_INFTY) || (old == 1 && lbN[idx] <= -RSQP_INFTY)) {
@@ -670,7 +689,7 @@ struct Engine {
                 return RET_UNBOUNDED;
             }
             add_bound(idx, -old, false, true);
-            if (threadIdx.x == 0) { if (old == -1) ub[idx] = x[idx]; else lb[idx] = x[idx]; }
+            if (lane == 0) { if (old == -1) ub[idx] = x[idx]; else lb[idx] = x[idx]; }
             nflips++;
             SYNC();
             return RET_OK;
@@ -678,7 +697,7 @@ struct Engine {
             int old = Sc[idx], k = posAC[idx];
             SYNC();
             int zc = remove_constraint_tq(k);
-            if (threadIdx.x == 0) y[nV + idx] = 0.0;
+            if (lane == 0) y[nV + idx] = 0.0;
             SYNC();
             if (chol_append(zc)) return RET_OK;
             if ((old == -1 && ubAN[idx] >= RSQP_INFTY) || (old == 1 && lbAN[idx] <= -RSQP_INFTY)) {
@@ -686,7 +705,7 @@ struct Engine {
                 return RET_UNBOUNDED;
             }
             add_constraint(idx, -old, false, true);
-            if (threadIdx.x == 0) { if (old == -1) ubA[idx] = Ax[idx]; else lbA[idx] = Ax[idx]; }
+            if (lane == 0) { if (old == -1) ubA[idx] = Ax[idx]; else lbA[idx] = Ax[idx]; }
             nflips++;
             SYNC();
             return RET_OK;
@@ -706,8 +725,8 @@ struct Engine {
             const ldouble *ri = T + i * ld;
             double d = wq[c] / ri[c];
             SYNC();
-            if (threadIdx.x == 0) wc2[AC[i]] = d;
-            for (int cc = c + 1 + threadIdx.x; cc < nFR; cc += NT) wq[cc] -= ri[cc] * d;
+            if (lane == 0) wc2[AC[i]] = d;
+            for (int cc = c + 1 + lane; cc < nFR; cc += L) wq[cc] -= ri[cc] * d;
             SYNC();
         }
         AT_times(wc2, wv2);
@@ -753,10 +772,10 @@ struct Engine {
             int k = posAC[pidx];
             SYNC();
             zc = remove_constraint_tq(k);
-            if (threadIdx.x == 0) y[nV + pidx] = 0.0;
+            if (lane == 0) y[nV + pidx] = 0.0;
         } else {
             zc = remove_bound_tq(pidx);
-            if (threadIdx.x == 0) y[pidx] = 0.0;
+            if (lane == 0) y[pidx] = 0.0;
         }
         SYNC();
         return chol_append(zc);
@@ -779,10 +798,10 @@ struct Engine {
             }
             if (b.kind == 3) {
                 add_constraint(b.idx, b.side, full, !full);
-                if (threadIdx.x == 0) y[nV + b.idx] = ynew;
+                if (lane == 0) y[nV + b.idx] = ynew;
             } else {
                 add_bound(b.idx, b.side, full, !full);
-                if (threadIdx.x == 0) y[b.idx] = ynew;
+                if (lane == 0) y[b.idx] = ynew;
             }
             SYNC();
         }
@@ -814,8 +833,11 @@ struct Engine {
         }
         SYNC();
         for (;;) {
+            STAMP(7);
             step_direction();
+            STAMP(3);
             Blocking b = ratio_tests();
+            STAMP(4);
             double tau = b.tau;
             bool done = b.kind == 0;
             PFOR(v, nV) {
@@ -836,14 +858,16 @@ struct Engine {
             }
             SYNC();
             A_times(x, Ax);
+            STAMP(5);
             if (done) { status = QPS_SOLVED; break; }
             if (iter >= maxit) { rcode = RET_MAX_NWSR; break; }
-            if (threadIdx.x == 0) {
+            if (lane == 0) {
                 if (b.kind == 3) { if (b.side == -1) lbA[b.idx] = Ax[b.idx]; else ubA[b.idx] = Ax[b.idx]; }
                 else if (b.kind == 4) { if (b.side == -1) lb[b.idx] = x[b.idx]; else ub[b.idx] = x[b.idx]; }
             }
             SYNC();
             rcode = change_active_set(b);
+            STAMP(6);
             if (rcode == RET_INFEASIBLE) { infeasible = 1; break; }
             if (rcode == RET_UNBOUNDED) { unbounded = 1; break; }
             iter++;
@@ -874,42 +898,50 @@ __host__ __device__ inline long long mat_lds_bytes(int nV, int nC, int annz, int
     return ((ints * 4 + 7) & ~7LL) + dbl * 8;
 }
 
-// W = minimum waves per SIMD the register allocator has to leave room for (the kernel is
-// latency bound: throughput follows the number of resident waves until spills bite)
-template <int NT, bool MAT_LDS, int W>
-__global__ void __launch_bounds__(NT, W)
-small_qp_kernel(QPPools P, int mode, int maxWSR) {
+// L = lanes per problem (64 / L problems share one wave; each owns `stride` bytes of LDS),
+// W = minimum waves per SIMD the register allocator has to leave room for
+template <int L, bool MAT_LDS, int W>
+__global__ void __launch_bounds__(64, W)
+small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
-    lchar *smem = (lchar *)smem_generic;
-    const QPDesc d = P.desc[blockIdx.x];
-    Engine<NT, MAT_LDS> E;
+    const int lane = L == 64 ? (int)threadIdx.x : (int)threadIdx.x & (L - 1);
+    const int grp = L == 64 ? 0 : (int)threadIdx.x / L;  // L == 64: everything below stays wave-uniform
+    const int q = blockIdx.x * (64 / L) + grp;
+    if (q >= nq) return;  // no workgroup barrier anywhere below: idle groups may leave
+    lchar *smem = (lchar *)smem_generic + grp * stride;
+    const QPDesc d = P.desc[q];
+    Engine<L, MAT_LDS> E;
+    E.lane = lane;
+#ifdef RSQP_STAMPS
+    E.tlast = clock64();
+    long long &tlast = E.tlast;
+#endif
     E.carve(smem, d.nV, d.nC);
     const int nd = (int)rsqp_image_doubles(d.nV, d.nC), ni = (int)rsqp_image_ints(d.nV, d.nC);
     const int img_bytes = (nd * 8 + ni * 4 + 15) & ~15;
-    E.red = (ldouble *)(smem + img_bytes);
     E.haveH = d.haveH;
     E.hreg = d.hreg;
     const int *gAjc = P.Ajc + d.offAjc, *gAir = P.Air + d.offAnz, *gArp = P.Arp + d.offArp, *gAci = P.Aci + d.offAnz;
     const int *gHjc = P.Hjc + d.offHjc, *gHir = P.Hir + d.offHnz;
     const double *gAval = P.Aval + d.offAnz, *gArv = P.Arv + d.offAnz, *gHval = P.Hval + d.offHnz;
     if constexpr (MAT_LDS) {
-        // stage CSC(A), CSR(A), CSC(H) behind the image + reduction scratch
+        // stage CSC(A), CSR(A), CSC(H) behind the image
         const int annz = gAjc[d.nV], hnnz = d.haveH ? gHjc[d.nV] : 0;
-        lint *ip = (lint *)(smem + img_bytes + 256);
+        lint *ip0 = (lint *)(smem + img_bytes), *ip = ip0;
         lint *lAjc = ip; ip += d.nV + 1;
         lint *lArp = ip; ip += d.nC + 1;
         lint *lHjc = ip; ip += d.nV + 1;
         lint *lAir = ip; ip += annz;
         lint *lAci = ip; ip += annz;
         lint *lHir = ip; ip += hnnz;
-        ldouble *dp = (ldouble *)(smem + img_bytes + 256 + (((ip - (lint *)(smem + img_bytes + 256)) * 4 + 7) & ~7));
+        ldouble *dp = (ldouble *)(smem + img_bytes + (((ip - ip0) * 4 + 7) & ~7));
         ldouble *lAval = dp; dp += annz;
         ldouble *lArv = dp; dp += annz;
         ldouble *lHval = dp;
-        for (int k = threadIdx.x; k <= d.nV; k += NT) { lAjc[k] = gAjc[k]; lHjc[k] = d.haveH ? gHjc[k] : 0; }
-        for (int k = threadIdx.x; k <= d.nC; k += NT) lArp[k] = gArp[k];
-        for (int k = threadIdx.x; k < annz; k += NT) { lAir[k] = gAir[k]; lAci[k] = gAci[k]; lAval[k] = gAval[k]; lArv[k] = gArv[k]; }
-        for (int k = threadIdx.x; k < hnnz; k += NT) { lHir[k] = gHir[k]; lHval[k] = gHval[k]; }
+        for (int k = lane; k <= d.nV; k += L) { lAjc[k] = gAjc[k]; lHjc[k] = d.haveH ? gHjc[k] : 0; }
+        for (int k = lane; k <= d.nC; k += L) lArp[k] = gArp[k];
+        for (int k = lane; k < annz; k += L) { lAir[k] = gAir[k]; lAci[k] = gAci[k]; lAval[k] = gAval[k]; lArv[k] = gArv[k]; }
+        for (int k = lane; k < hnnz; k += L) { lHir[k] = gHir[k]; lHval[k] = gHval[k]; }
         E.Ajc = lAjc; E.Air = lAir; E.Aval = lAval; E.Arp = lArp; E.Aci = lAci; E.Arv = lArv;
         E.Hjc = lHjc; E.Hir = lHir; E.Hval = lHval;
     } else {
@@ -924,18 +956,19 @@ small_qp_kernel(QPPools P, int mode, int maxWSR) {
 
     int rcode = RET_OK, nWSR = 0;
     if (mode == 0) {
-        for (int k = threadIdx.x; k < nd; k += NT) simg[k] = 0.0;
-        for (int k = threadIdx.x; k < ni; k += NT) siimg[k] = 0;
+        for (int k = lane; k < nd; k += L) simg[k] = 0.0;
+        for (int k = lane; k < ni; k += L) siimg[k] = 0;
         SYNC();
     }
     if (mode != 0) {  // reload the image of the previous solve
-        for (int k = threadIdx.x; k < nd; k += NT) simg[k] = img[k];
-        for (int k = threadIdx.x; k < ni; k += NT) siimg[k] = iimg[k];
+        for (int k = lane; k < nd; k += L) simg[k] = img[k];
+        for (int k = lane; k < ni; k += L) siimg[k] = iimg[k];
         SYNC();
         E.nFR = E.iscal[1]; E.nAC = E.iscal[2]; E.status = E.iscal[3];
         SYNC();
         if (E.status == QPS_NOTINITIALISED) mode = 0;
     }
+    STAMP(0);
     E.store_targets(P.g + d.offV, P.lb + d.offV, P.ub + d.offV, P.lbA + d.offC, P.ubA + d.offC);
     if (E.bounds_inconsistent()) {  // qpOASES areBoundsConsistent: infeasible before any change
         E.infeasible = 1; E.unbounded = 0;
@@ -943,88 +976,120 @@ small_qp_kernel(QPPools P, int mode, int maxWSR) {
     } else if (mode == 0) {
         rcode = E.setup_aux(false, false, false, false);
     } else if (mode == 2) {  // hot start with new matrices: keep x, y and the working set
-        for (int v = threadIdx.x; v < d.nV; v += NT) { E.wv4[v] = E.x[v]; E.wq[v] = (double)E.Sb[v]; }
-        for (int i = threadIdx.x; i < d.nV + d.nC; i += NT) E.dy[i] = E.y[i];
-        for (int i = threadIdx.x; i < d.nC; i += NT) E.wc1[i] = (double)E.Sc[i];
+        for (int v = lane; v < d.nV; v += L) { E.wv4[v] = E.x[v]; E.wq[v] = (double)E.Sb[v]; }
+        for (int i = lane; i < d.nV + d.nC; i += L) E.dy[i] = E.y[i];
+        for (int i = lane; i < d.nC; i += L) E.wc1[i] = (double)E.Sc[i];
         SYNC();
         rcode = E.setup_aux(true, true, true, true);
         if (rcode != RET_OK) rcode = E.setup_aux(false, false, false, false);
     } else if (mode == 3) {  // warm re-initialisation from (x0, y0, guessed bounds)
-        if (P.x0) for (int v = threadIdx.x; v < d.nV; v += NT) E.wv4[v] = P.x0[d.offV + v];
-        if (P.y0) for (int i = threadIdx.x; i < d.nV + d.nC; i += NT) E.dy[i] = P.y0[d.offV + d.offC + i];
-        if (P.guess_b) for (int v = threadIdx.x; v < d.nV; v += NT) E.wq[v] = (double)P.guess_b[d.offV + v];
+        if (P.x0) for (int v = lane; v < d.nV; v += L) E.wv4[v] = P.x0[d.offV + v];
+        if (P.y0) for (int i = lane; i < d.nV + d.nC; i += L) E.dy[i] = P.y0[d.offV + d.offC + i];
+        if (P.guess_b) for (int v = lane; v < d.nV; v += L) E.wq[v] = (double)P.guess_b[d.offV + v];
         SYNC();
         rcode = E.setup_aux(P.x0 != nullptr, P.y0 != nullptr, P.guess_b != nullptr, false);
         if (rcode != RET_OK) rcode = E.setup_aux(false, false, false, false);
     } else {
         E.infeasible = E.unbounded = 0;
     }
+    STAMP(2);
     if (rcode == RET_OK) rcode = E.homotopy(maxWSR, nWSR);
     double obj = E.objective();
+    STAMP(8);
 
     // results
-    for (int v = threadIdx.x; v < d.nV; v += NT) { P.x[d.offV + v] = E.x[v]; P.ws_b[d.offV + v] = E.Sb[v]; }
-    for (int i = threadIdx.x; i < d.nV + d.nC; i += NT) P.y[d.offV + d.offC + i] = E.y[i];
-    for (int i = threadIdx.x; i < d.nC; i += NT) P.ws_c[d.offC + i] = E.Sc[i];
-    if (threadIdx.x == 0) {
+    for (int v = lane; v < d.nV; v += L) { P.x[d.offV + v] = E.x[v]; P.ws_b[d.offV + v] = E.Sb[v]; }
+    for (int i = lane; i < d.nV + d.nC; i += L) P.y[d.offV + d.offC + i] = E.y[i];
+    for (int i = lane; i < d.nC; i += L) P.ws_c[d.offC + i] = E.Sc[i];
+    if (lane == 0) {
         int st = E.status;
-        P.status[blockIdx.x] = E.infeasible ? 100 + st : (E.unbounded ? 200 + st : st);
-        P.ret[blockIdx.x] = rcode;
-        P.nwsr[blockIdx.x] = nWSR;
-        P.nflips[blockIdx.x] = E.nflips;
-        P.obj[blockIdx.x] = obj;
+        P.status[q] = E.infeasible ? 100 + st : (E.unbounded ? 200 + st : st);
+        P.ret[q] = rcode;
+        P.nwsr[q] = nWSR;
+        P.nflips[q] = E.nflips;
+        P.obj[q] = obj;
         E.iscal[1] = E.nFR; E.iscal[2] = E.nAC; E.iscal[3] = E.status;
     }
     SYNC();
-    for (int k = threadIdx.x; k < nd; k += NT) img[k] = simg[k];
-    for (int k = threadIdx.x; k < ni; k += NT) iimg[k] = siimg[k];
+    for (int k = lane; k < nd; k += L) img[k] = simg[k];
+    for (int k = lane; k < ni; k += L) iimg[k] = siimg[k];
+    STAMP(9);
 }
 
 }  // namespace
 
 static const long long kMaxLds = 160 * 1024;
 
+static long long align16(long long v) { return (v + 15) & ~15LL; }
+
 int rsqp_small_qp_fits(int nVmax, int nCmax) {
-    return rsqp_image_bytes(nVmax, nCmax) + 256 <= kMaxLds;
+    return align16(rsqp_image_bytes(nVmax, nCmax)) <= kMaxLds;
+}
+
+static int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
 
 hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, long long mat_bytes_max, int mode,
                                 int maxWSR, hipStream_t stream) {
-    size_t lds = (size_t)rsqp_image_bytes(nVmax, nCmax) + 256;
-    if ((long long)lds > kMaxLds) return hipErrorInvalidValue;
-    // measured on MI355X (16 384 hs071-scale QPs): 3 waves/SIMD 56 M solves/s, 4: 71 M, 6: 73 M.
-    // Small images keep 6 waves busy; larger problems stay at 4 (spills grow with the bound).
-    static int forced = -2;
-    if (forced == -2) {
-        const char *e = getenv("RSQP_SMALL_WAVES");
-        forced = e ? atoi(e) : -1;
-        if (forced != -1 && (forced < 3 || forced > 6)) forced = -1;
-    }
-    const int waves = forced > 0 ? forced : (nVmax <= 16 ? 6 : 4);
-    const bool mat_lds = mat_bytes_max >= 0 && (long long)lds + mat_bytes_max + 64 <= kMaxLds;
-    if (mat_lds) lds += (size_t)mat_bytes_max + 64;
-#define SQ_LAUNCH(ML, W)                                                                                     \
-    do {                                                                                                     \
-        static bool set_ = false;                                                                            \
-        if (!set_) {                                                                                         \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&small_qp_kernel<64, ML, W>),           \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);             \
-            set_ = true;                                                                                     \
-        }                                                                                                    \
-        hipLaunchKernelGGL((small_qp_kernel<64, ML, W>), dim3(nq), dim3(64), lds, stream, p, mode, maxWSR);  \
+    if (nq <= 0) return hipSuccess;
+    const long long img = align16(rsqp_image_bytes(nVmax, nCmax));
+    if (img > kMaxLds) return hipErrorInvalidValue;
+    const bool mat_lds = mat_bytes_max >= 0 && img + align16(mat_bytes_max) <= kMaxLds;
+    // LDS of one problem; an odd number of 16-byte units spreads the problems that share a wave
+    // over the banks
+    long long stride = img + (mat_lds ? align16(mat_bytes_max) : 0);
+    if (((stride >> 4) & 1) == 0) stride += 16;
+    // lanes per problem: the vectors of the engine have nV (+ nC) entries, a wave of 64 lanes is
+    // mostly idle on hs0xx-scale problems, so 64 / L of them share a wave. Problems in one wave
+    // follow their own control flow (exec masking); the LDS capacity bounds the problems in flight.
+    static const int forcedL = env_int("RSQP_SMALL_LANES", -1), forcedW = env_int("RSQP_SMALL_WAVES", -1);
+    int L = nVmax <= 16 ? 16 : (nVmax <= 32 ? 32 : 64);
+    if (forcedL == 16 || forcedL == 32 || forcedL == 64) L = forcedL;
+    if (!mat_lds) L = 64;
+    while (L < 64 && (64 / L) * stride > kMaxLds) L *= 2;
+    if (L == 64 && stride > kMaxLds) stride = mat_lds ? img + align16(mat_bytes_max) : img;
+    const int G = 64 / L, nblk = (nq + G - 1) / G;
+    const size_t lds = (size_t)(G * stride);
+    // minimum resident waves per SIMD = register budget. One problem per wave keeps the uniform
+    // state in SGPRs and runs best with 6 (small images) or 4 waves; packed waves hold that state
+    // in VGPRs and need ~230 of them, so they run 2 waves/SIMD without spills (measured on
+    // 16 384 hs071-scale QPs: L=16 W=2 159 M solves/s, W=3 142 M, W=4 116 M; L=64 W=6 74 M).
+    // Packed builds with W=6 (80 VGPRs, ~180 spilled) returned wrong results and are not built.
+    int waves = L == 64 ? (nVmax <= 16 ? 6 : 4) : 2;
+    if (forcedW >= 2 && forcedW <= (L == 64 ? 6 : 4)) waves = forcedW;
+#define SQ_LAUNCH(LL, ML, W)                                                                                  \
+    do {                                                                                                      \
+        static bool set_ = false;                                                                             \
+        if (!set_) {                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&small_qp_kernel<LL, ML, W>),            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);              \
+            set_ = true;                                                                                      \
+        }                                                                                                     \
+        hipLaunchKernelGGL((small_qp_kernel<LL, ML, W>), dim3(nblk), dim3(64), lds, stream, p, nq,            \
+                           (int)stride, mode, maxWSR);                                                        \
     } while (0)
-    // matrices are staged in LDS whenever image + matrices fit (mat_bytes_max: largest staging
-    // size of the batch, host computed with rsqp_mat_lds_bytes)
-    if (mat_lds) {
-        switch (waves) {
-        case 3: SQ_LAUNCH(true, 3); break;
-        case 5: SQ_LAUNCH(true, 5); break;
-        case 6: SQ_LAUNCH(true, 6); break;
-        default: SQ_LAUNCH(true, 4); break;
-        }
-    } else {
-        SQ_LAUNCH(false, 3);
+#define SQ_WAVES(LL)                                                                                          \
+    switch (waves) {                                                                                          \
+    case 3: SQ_LAUNCH(LL, true, 3); break;                                                                    \
+    case 4: SQ_LAUNCH(LL, true, 4); break;                                                                    \
+    default: SQ_LAUNCH(LL, true, 2); break;                                                                   \
     }
+    if (!mat_lds) {
+        SQ_LAUNCH(64, false, 3);
+    } else if (L == 16) {
+        SQ_WAVES(16)
+    } else if (L == 32) {
+        SQ_WAVES(32)
+    } else {
+        switch (waves) {
+        case 3: SQ_LAUNCH(64, true, 3); break;
+        case 6: SQ_LAUNCH(64, true, 6); break;
+        default: SQ_LAUNCH(64, true, 4); break;
+        }
+    }
+#undef SQ_WAVES
 #undef SQ_LAUNCH
     return hipGetLastError();
 }

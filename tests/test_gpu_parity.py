@@ -404,3 +404,16 @@ def test_degenerate_inputs_both_engines(capi, oracle):
         assert s.status == qp.exitflag() and n == n_or
         assert np.array_equal(wb, qp.ws_bounds) and np.array_equal(wc, qp.ws_constraints)
         assert np.abs(s.x - qp.x).max() <= 1e-9 * max(1.0, np.abs(qp.x).max())
+
+
+@pytest.mark.gpu
+def test_packed_waves_match_one_problem_per_wave():
+    """64/L problems share a wave in the LDS engine (L = 16 / 32 lanes per problem). Every packing
+    must return bit-identical x, y, working sets, nWSR and objective, cold and hot start, on
+    heterogeneous batches (problems of one wave diverge). Each setting runs in its own process
+    because the launcher reads RSQP_SMALL_LANES once."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "small_pack_check.py"), "--quick"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ALL IDENTICAL" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
