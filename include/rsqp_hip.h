@@ -199,6 +199,25 @@ int rsqp_spmv_plan_upload(rsqp_spmv_plan *p, const double *vals, const double *x
 int rsqp_spmv_plan_run(rsqp_spmv_plan *p, int transposed, int repeats, float *ms_per_launch);
 int rsqp_spmv_plan_download(rsqp_spmv_plan *p, double *out, int transposed);
 
+/* ------------------------------------------------------------------------------------ */
+/* dense f64 building blocks of the HBM-resident engine (MFMA GEMM, blocked QR, Cholesky) */
+/* ------------------------------------------------------------------------------------ */
+/* They rebuild the TQ factorisation and the projected Hessian when a solve starts from a
+ * non-empty working set -- qpOASES setupTQfactorisation / computeProjectedCholesky inside
+ * SQProblem::hotstart(H, g, A, ...) and init(..., xOpt, yOpt, guessedBounds), reference call
+ * sites src/qpOASESInterface.cpp:184,197,204-206. Host-pointer entries (column-major), for
+ * verification and benchmarking; the engine calls the device versions directly.
+ * C = alpha op(A) op(B) + beta C; *ms (may be NULL) = device time of `repeats` launches / repeats */
+int rsqp_dense_gemm(int transA, int transB, int m, int n, int k, double alpha, const double *A, int lda,
+                    const double *B, int ldb, double beta, double *C, int ldc, int repeats, float *ms);
+/* Householder QR of B (m x n, m >= n): Q (m x m) and Rinv = R^-1 (n x n) are returned, B is
+ * overwritten by R / the reflectors; *ndep = columns found linearly dependent (remaining norm
+ * <= eps_li * original norm), the outputs are only valid when it is 0 */
+int rsqp_dense_qr(int m, int n, double *B, double *Q, double *Rinv, double eps_li, int *ndep, float *ms);
+/* Cholesky G = U'U (upper) of a symmetric n x n matrix, then Ginv = G^-1; *not_pd != 0 when a
+ * pivot fails d > pd_rel (|g_jj| + sum) + pd_abs */
+int rsqp_dense_chol_inverse(int n, double *G, double *Ginv, double pd_rel, double pd_abs, int *not_pd, float *ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,8 +6,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB = os.path.join(LIB_DIR, "librsqp_hip.so")
-SOURCES = ["rsqp_api.hip", "qp_small.hip", "qp_large.hip", "sparse.hip"]
-HEADERS = ["rsqp_internal.h", "rsqp_sparse.h", "rsqp_large.h", os.path.join("..", "..", "include", "rsqp_hip.h")]
+SOURCES = ["rsqp_api.hip", "qp_small.hip", "qp_large.hip", "sparse.hip", "dense_la.hip"]
+HEADERS = ["rsqp_internal.h", "rsqp_sparse.h", "rsqp_large.h", "rsqp_dense.h", os.path.join("..", "..", "include", "rsqp_hip.h")]
 
 
 def needs_build():

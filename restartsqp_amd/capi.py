@@ -23,7 +23,14 @@ ip = C.POINTER(C.c_int)
 dp = C.POINTER(C.c_double)
 
 # every exported symbol of include/rsqp_hip.h: name -> (restype, argtypes)
+fp = C.POINTER(C.c_float)
 SYMBOLS = {
+    "rsqp_dense_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double), C.c_int,
+                                  C.POINTER(C.c_double), C.c_int, C.c_double, C.POINTER(C.c_double), C.c_int, C.c_int, fp]),
+    "rsqp_dense_qr": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                C.c_double, C.POINTER(C.c_int), fp]),
+    "rsqp_dense_chol_inverse": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double,
+                                          C.POINTER(C.c_int), fp]),
     "rsqp_version": (C.c_char_p, []),
     "rsqp_device_count": (C.c_int, []),
     "rsqp_last_error": (C.c_char_p, []),

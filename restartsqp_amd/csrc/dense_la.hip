@@ -1,0 +1,608 @@
+// dense_la.hip -- dense f64 building blocks for gfx950 (see rsqp_dense.h).
+//
+//   * k_dgemm: LDS-tiled GEMM on v_mfma_f64_16x16x4_f64. Workgroup = 4 waves (2 x 2), tile TM x TN
+//     (64 / 128), K step 16. Both operand tiles are staged in LDS as [k][index] so that the
+//     fragment of an MFMA (lane l: index l & 15, k = l >> 4) is one ds_read_b64 with 16 consecutive
+//     lanes on consecutive words; the next K tile is fetched into registers while the current one
+//     is multiplied. The roles of the two MFMA operands are swapped (D = B_frag x A_frag) so that
+//     the 16 lanes that share a result register hold 16 consecutive ROWS of C: column-major C
+//     is then written in 128-byte segments.
+//   * blocked Householder QR / explicit Q / triangular inverse / Cholesky: panels of NB = 64
+//     columns are factored by small kernels, everything else is rsqp_dgemm.
+#include <algorithm>
+#include <cstdio>
+
+#include "rsqp_dense.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int GK = 16;    // K step of the GEMM
+constexpr int GPAD = 4;   // LDS row padding (doubles): row stride = 8 words mod 64 banks
+
+// one operand tile (GK x T) -> registers. kcontig: element (kk, t) at X[kk + t * ld], else X[t + kk * ld]
+template <int T>
+__device__ __forceinline__ void load_tile(double (&r)[GK * T / 256], const double *X, long long ld, bool kcontig, int k0,
+                                          int t0, int kmax, int tmax) {
+    constexpr int E = GK * T / 256;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        int kk, t;
+        if (kcontig) { kk = tid & 15; t = (tid >> 4) + 16 * e; }
+        else { t = tid % T; kk = tid / T + (256 / T) * e; }
+        const int gk = k0 + kk, gt = t0 + t;
+        double v = 0.0;
+        if (gk < kmax && gt < tmax) v = kcontig ? X[gk + (long long)gt * ld] : X[gt + (long long)gk * ld];
+        r[e] = v;
+    }
+}
+template <int T>
+__device__ __forceinline__ void store_tile(const double (&r)[GK * T / 256], double (*S)[T + GPAD], bool kcontig) {
+    constexpr int E = GK * T / 256;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        int kk, t;
+        if (kcontig) { kk = tid & 15; t = (tid >> 4) + 16 * e; }
+        else { t = tid % T; kk = tid / T + (256 / T) * e; }
+        S[kk][t] = r[e];
+    }
+}
+
+template <int TM, int TN>
+__global__ void __launch_bounds__(256)
+k_dgemm(int ta, int tb, int m, int n, int kfull, int kc, double alpha, const double *__restrict__ A, long long lda,
+        const double *__restrict__ B, long long ldb, double beta, double *__restrict__ C, long long ldc) {
+    __shared__ double As[GK][TM + GPAD];
+    __shared__ double Bs[GK][TN + GPAD];
+    constexpr int MI = TM / 32, NJ = TN / 32;   // 16x16 blocks per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int i0 = blockIdx.x * TM, j0 = blockIdx.y * TN;
+    const bool akc = ta != 0, bkc = tb == 0;   // k-contiguous operands
+    // split K: slice blockIdx.z of the inner dimension, partial result into its own m x n slab
+    const int kbeg = blockIdx.z * kc, k = min(kfull, kbeg + kc);
+    C += (long long)blockIdx.z * m * n;
+    d4 acc[NJ][MI];
+#pragma unroll
+    for (int a = 0; a < NJ; a++)
+#pragma unroll
+        for (int b = 0; b < MI; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+    double ra[GK * TM / 256], rb[GK * TN / 256];
+    load_tile<TM>(ra, A, lda, akc, kbeg, i0, k, m);
+    load_tile<TN>(rb, B, ldb, bkc, kbeg, j0, k, n);
+    for (int k0 = kbeg; k0 < k; k0 += GK) {
+        store_tile<TM>(ra, As, akc);
+        store_tile<TN>(rb, Bs, bkc);
+        __syncthreads();
+        if (k0 + GK < k) {
+            load_tile<TM>(ra, A, lda, akc, k0 + GK, i0, k, m);
+            load_tile<TN>(rb, B, ldb, bkc, k0 + GK, j0, k, n);
+        }
+#pragma unroll
+        for (int k4 = 0; k4 < GK; k4 += 4) {
+            double af[MI], bf[NJ];
+#pragma unroll
+            for (int b = 0; b < MI; b++) af[b] = As[k4 + (lane >> 4)][wm * (TM / 2) + b * 16 + (lane & 15)];
+#pragma unroll
+            for (int a = 0; a < NJ; a++) bf[a] = Bs[k4 + (lane >> 4)][wn * (TN / 2) + a * 16 + (lane & 15)];
+#pragma unroll
+            for (int a = 0; a < NJ; a++)
+#pragma unroll
+                for (int b = 0; b < MI; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[a], af[b], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // result register r of block (a, b): C row i = .. + (lane & 15), column j = .. + (lane >> 4) + 4 r
+#pragma unroll
+    for (int a = 0; a < NJ; a++)
+#pragma unroll
+        for (int b = 0; b < MI; b++) {
+            const int i = i0 + wm * (TM / 2) + b * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int j = j0 + wn * (TN / 2) + a * 16 + (lane >> 4) + 4 * r;
+                if (i < m && j < n) {
+                    double *c = C + i + (long long)j * ldc;
+                    const double v = alpha * acc[a][b][r];
+                    *c = beta == 0.0 ? v : v + beta * *c;
+                }
+            }
+        }
+}
+
+// deterministic split-K: partial products into `ws` ([split][n][m]), then summed in order
+__global__ void k_splitk_reduce(int m, int n, int splits, const double *__restrict__ ws, double alpha, double beta,
+                                double *__restrict__ C, long long ldc) {
+    const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (e >= (long long)m * n) return;
+    const int i = (int)(e % m), j = (int)(e / m);
+    double s = 0.0;
+    for (int z = 0; z < splits; z++) s += ws[(long long)z * m * n + e];
+    double *c = C + i + (long long)j * ldc;
+    *c = beta == 0.0 ? alpha * s : alpha * s + beta * *c;
+}
+
+}  // namespace
+
+static hipError_t dgemm_ws(bool transA, bool transB, int m, int n, int k, double alpha, const double *A, long long lda,
+                           const double *B, long long ldb, double beta, double *C, long long ldc, double *ws,
+                           long long ws_cap, hipStream_t st) {
+    if (m <= 0 || n <= 0) return hipSuccess;
+    const int ta = transA ? 1 : 0, tb = transB ? 1 : 0;
+    // large tiles when they still give every CU work, small ones otherwise
+    const long long big = (long long)((m + 127) / 128) * ((n + 127) / 128);
+    int TM = 128, TN = 128;
+    if (big < 512) {
+        TM = m <= 64 || (long long)((m + 63) / 64) * ((n + 127) / 128) < 512 ? 64 : 128;
+        TN = n <= 64 || (long long)((m + TM - 1) / TM) * ((n + 127) / 128) < 512 ? 64 : 128;
+    }
+    const int bx = (m + TM - 1) / TM, by = (n + TN - 1) / TN;
+    // a long inner dimension over few output tiles: split K so that the chip has work
+    int splits = 1;
+    if (ws && (long long)bx * by < 64 && k >= 1024) {
+        splits = (int)std::min<long long>(std::min<long long>(256 / ((long long)bx * by), k / 256), ws_cap / ((long long)m * n));
+        if (splits < 2) splits = 1;
+    }
+    int kc = k;
+    if (splits > 1) { kc = ((k + splits - 1) / splits + GK - 1) / GK * GK; splits = (k + kc - 1) / kc; }
+    dim3 grid(bx, by, splits);
+    double *Cout = splits > 1 ? ws : C;
+    const long long ldo = splits > 1 ? m : ldc;
+    const double al = splits > 1 ? 1.0 : alpha, be = splits > 1 ? 0.0 : beta;
+#define GEMM_LAUNCH(a, b) hipLaunchKernelGGL((k_dgemm<a, b>), grid, dim3(256), 0, st, ta, tb, m, n, k, kc, al, A, lda, B, ldb, be, Cout, ldo)
+    if (TM == 128 && TN == 128) GEMM_LAUNCH(128, 128);
+    else if (TM == 64 && TN == 128) GEMM_LAUNCH(64, 128);
+    else if (TM == 128 && TN == 64) GEMM_LAUNCH(128, 64);
+    else GEMM_LAUNCH(64, 64);
+#undef GEMM_LAUNCH
+    if (splits > 1) {
+        const long long tot = (long long)m * n;
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m, n, splits, ws, alpha, beta, C, ldc);
+    }
+    return hipGetLastError();
+}
+
+hipError_t rsqp_dgemm(bool transA, bool transB, int m, int n, int k, double alpha, const double *A, long long lda,
+                      const double *B, long long ldb, double beta, double *C, long long ldc, hipStream_t st) {
+    return dgemm_ws(transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, 0, st);
+}
+
+// =====================================================================================
+// blocked factorisations
+// =====================================================================================
+namespace {
+
+constexpr int NB = 64;
+
+__device__ __forceinline__ double block_sum256(double v, double *red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(256) k_colnorm2(int m, const double *__restrict__ B, long long ldb, double *__restrict__ out) {
+    __shared__ double red[4];
+    const double *c = B + (long long)blockIdx.x * ldb;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < m; i += 256) s += c[i] * c[i];
+    s = block_sum256(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
+// Column j of the panel that starts at k0. Every workgroup derives the Householder reflector of
+// column j (rows j..m-1) on its own -- the column is read-only during this launch -- and then
+// workgroup 0 stores it (explicit, unit diagonal) in V / tau / rdiag, workgroup b > 0 applies it
+// to panel column j + b.
+__global__ void __launch_bounds__(256)
+k_qr_col(double *__restrict__ B, long long ldb, int m, int j, int k0, double *__restrict__ V, long long ldv,
+         double *__restrict__ tau, double *__restrict__ rdiag, const double *__restrict__ norm2, double eps_li,
+         int *__restrict__ flag) {
+    __shared__ double red[4];
+    const double *cj = B + (long long)j * ldb;
+    double s = 0.0;
+    for (int i = j + 1 + threadIdx.x; i < m; i += 256) s += cj[i] * cj[i];
+    const double sigma = block_sum256(s, red);
+    const double alpha = cj[j];
+    double tj = 0.0, beta = alpha, scale = 0.0;
+    if (sigma != 0.0) {
+        const double nrm = sqrt(alpha * alpha + sigma);
+        beta = alpha >= 0.0 ? -nrm : nrm;
+        tj = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            tau[j] = tj; rdiag[j] = beta;
+            if (!(sqrt(alpha * alpha + sigma) > eps_li * sqrt(norm2[j]))) atomicAdd(flag, 1);
+        }
+        double *v = V + (long long)(j - k0) * ldv;
+        for (int i = k0 + threadIdx.x; i < m; i += 256) v[i - k0] = i < j ? 0.0 : (i == j ? 1.0 : cj[i] * scale);
+        return;
+    }
+    double *cc = B + (long long)(j + blockIdx.x) * ldb;
+    double d = 0.0;
+    for (int i = j + 1 + threadIdx.x; i < m; i += 256) d += cj[i] * cc[i];
+    d = block_sum256(d, red);
+    const double w = tj * (cc[j] + scale * d);
+    __syncthreads();
+    if (threadIdx.x == 0) cc[j] -= w;
+    const double sw = scale * w;
+    for (int i = j + 1 + threadIdx.x; i < m; i += 256) cc[i] -= cj[i] * sw;
+}
+
+// T factor of a panel (forward, columnwise: H_1 ... H_jb = I - V T V') from S = V'V and tau;
+// also stores the panel's R diagonal and the scaled reflectors back into B
+__global__ void __launch_bounds__(256)
+k_qr_T(int jb, const double *__restrict__ S, const double *__restrict__ tau, double *__restrict__ T) {
+    __shared__ double Ts[NB][NB + 1], Ss[NB][NB + 1];
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        const int r = e % NB, c = e / NB;
+        Ts[r][c] = 0.0;
+        Ss[r][c] = (r < jb && c < jb) ? S[r + c * jb] : 0.0;
+    }
+    __syncthreads();
+    for (int i = 0; i < jb; i++) {
+        const double ti = tau[i];
+        double acc = 0.0;
+        const int r = threadIdx.x;
+        if (r < i) for (int c = r; c < i; c++) acc += Ts[r][c] * Ss[c][i];
+        __syncthreads();
+        if (r < i) Ts[r][i] = -ti * acc;
+        if (r == i) Ts[i][i] = ti;
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < NB * NB; e += 256) T[e] = Ts[e % NB][e / NB];
+}
+
+__global__ void k_panel_writeback(double *__restrict__ B, long long ldb, int m, int k0, int jb, const double *__restrict__ V,
+                                  long long ldv, const double *__restrict__ rdiag) {
+    const int c = blockIdx.y;
+    const int i = k0 + c + blockIdx.x * blockDim.x + threadIdx.x;   // rows from the diagonal down
+    if (i >= m) return;
+    B[i + (long long)(k0 + c) * ldb] = i == k0 + c ? rdiag[k0 + c] : V[(i - k0) + (long long)c * ldv];
+}
+
+// explicit reflectors of a stored panel (for rsqp_dorgqr)
+__global__ void k_build_V(const double *__restrict__ B, long long ldb, int m, int k0, int jb, double *__restrict__ V, long long ldv) {
+    const int c = blockIdx.y;
+    const int i = k0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    V[(i - k0) + (long long)c * ldv] = i < k0 + c ? 0.0 : (i == k0 + c ? 1.0 : B[i + (long long)(k0 + c) * ldb]);
+}
+
+// W (jb x nt, ld NB) <- T' W (trans != 0) or T W; one thread per column, T in LDS
+__global__ void __launch_bounds__(64) k_apply_T(int jb, int nt, const double *__restrict__ T, int trans, double *__restrict__ W) {
+    __shared__ double Ts[NB][NB + 1];
+    for (int e = threadIdx.x; e < NB * NB; e += 64) Ts[e % NB][e / NB] = T[e];
+    __syncthreads();
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= nt) return;
+    double w[NB];
+    double *col = W + (long long)c * NB;
+#pragma unroll
+    for (int r = 0; r < NB; r++) w[r] = r < jb ? col[r] : 0.0;
+    if (trans) {
+#pragma unroll
+        for (int r = NB - 1; r >= 0; r--) {   // out[r] = sum_{c2 <= r} T[c2][r] w[c2]
+            double s = 0.0;
+#pragma unroll
+            for (int c2 = 0; c2 <= r; c2++) s += Ts[c2][r] * w[c2];
+            if (r < jb) col[r] = s;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < NB; r++) {        // out[r] = sum_{c2 >= r} T[r][c2] w[c2]
+            double s = 0.0;
+#pragma unroll
+            for (int c2 = r; c2 < NB; c2++) s += Ts[r][c2] * w[c2];
+            if (r < jb) col[r] = s;
+        }
+    }
+}
+
+__global__ void k_set_identity(int m, double *__restrict__ Q, long long ldq) {
+    const int j = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) Q[i + (long long)j * ldq] = i == j ? 1.0 : 0.0;
+}
+
+// inverse of every NB x NB diagonal block of the upper triangular R into X (zero elsewhere in the block)
+__global__ void __launch_bounds__(64) k_trinv_diag(int n, const double *__restrict__ R, long long ldr, double *__restrict__ X, long long ldx) {
+    __shared__ double Rs[NB][NB + 1], Xs[NB][NB + 1];
+    const int b0 = blockIdx.x * NB, nb = min(NB, n - b0);
+    const int t = threadIdx.x;
+    for (int e = t; e < NB * NB; e += 64) {
+        const int r = e % NB, c = e / NB;
+        Rs[r][c] = (r < nb && c < nb && r <= c) ? R[(b0 + r) + (long long)(b0 + c) * ldr] : (r == c ? 1.0 : 0.0);
+        Xs[r][c] = 0.0;
+    }
+    __syncthreads();
+    // thread t solves R x = e_t by back substitution (column t of the inverse)
+    if (t < nb) {
+        for (int r = t; r >= 0; r--) {
+            double s = r == t ? 1.0 : 0.0;
+            for (int c = r + 1; c <= t; c++) s -= Rs[r][c] * Xs[c][t];
+            Xs[r][t] = s / Rs[r][r];
+        }
+    }
+    __syncthreads();
+    for (int e = t; e < NB * NB; e += 64) {
+        const int r = e % NB, c = e / NB;
+        if (r < nb && c < nb) X[(b0 + r) + (long long)(b0 + c) * ldx] = Xs[r][c];
+    }
+}
+
+__global__ void k_zero_lower(int n, double *__restrict__ X, long long ldx) {
+    const int j = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && i > j) X[i + (long long)j * ldx] = 0.0;
+}
+__global__ void k_zero_block(int m, int n, double *__restrict__ X, long long ldx) {
+    const int j = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m && j < n) X[i + (long long)j * ldx] = 0.0;
+}
+
+// unblocked Cholesky (upper, G = U'U) of one NB x NB diagonal block in LDS with the definiteness
+// test of the engine; also returns the inverse of the block's factor in Uinv (upper)
+__global__ void __launch_bounds__(64)
+k_potf2(int nb, double *__restrict__ G, long long ldg, const double *__restrict__ diag0, double pd_rel, double pd_abs,
+        double *__restrict__ Uinv, int *__restrict__ flag) {
+    __shared__ double Gs[NB][NB + 1], Xs[NB][NB + 1];
+    __shared__ int bad;
+    const int t = threadIdx.x;
+    if (t == 0) bad = 0;
+    for (int e = t; e < NB * NB; e += 64) {
+        const int r = e % NB, c = e / NB;
+        Gs[r][c] = (r < nb && c < nb && r <= c) ? G[r + (long long)c * ldg] : (r == c ? 1.0 : 0.0);
+        Xs[r][c] = 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < nb; j++) {
+        // pivot: d2 = g_jj - sum_k u_kj^2 (the part of the sum from earlier panels is already in g_jj)
+        double d2 = Gs[j][j];
+        for (int k = 0; k < j; k++) d2 -= Gs[k][j] * Gs[k][j];
+        const double g0 = diag0[j], sum = g0 - d2;
+        const bool ok = d2 > pd_rel * (fabs(g0) + (sum > 0.0 ? sum : 0.0)) + pd_abs;
+        if (!ok && t == 0) bad = 1;
+        const double d = ok ? sqrt(d2) : 1.0;
+        __syncthreads();
+        // row j of U: u_jc = (g_jc - sum_k u_kj u_kc) / d, c > j
+        if (t > j && t < nb) {
+            double s = Gs[j][t];
+            for (int k = 0; k < j; k++) s -= Gs[k][j] * Gs[k][t];
+            Gs[j][t] = s / d;
+        }
+        if (t == j) Gs[j][j] = d;
+        __syncthreads();
+    }
+    if (t < nb) {
+        for (int r = t; r >= 0; r--) {
+            double s = r == t ? 1.0 : 0.0;
+            for (int c = r + 1; c <= t; c++) s -= Gs[r][c] * Xs[c][t];
+            Xs[r][t] = s / Gs[r][r];
+        }
+    }
+    __syncthreads();
+    for (int e = t; e < NB * NB; e += 64) {
+        const int r = e % NB, c = e / NB;
+        if (r < nb && c < nb) G[r + (long long)c * ldg] = r <= c ? Gs[r][c] : 0.0;
+        Uinv[e] = Xs[r][c];
+    }
+    if (t == 0 && bad) atomicAdd(flag, 1);
+}
+
+__global__ void k_get_diag(int n, const double *__restrict__ G, long long ldg, double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = G[i + (long long)i * ldg];
+}
+
+}  // namespace
+
+hipError_t rsqp_dense_work_alloc(RsqpDenseWork *w, long long mmax) {
+    rsqp_dense_work_free(w);
+    if (mmax < 1) mmax = 1;
+    const long long np = (mmax + NB - 1) / NB;
+    hipError_t e;
+    if ((e = hipMalloc((void **)&w->V, sizeof(double) * mmax * NB)) != hipSuccess) return e;
+    if ((e = hipMalloc((void **)&w->T, sizeof(double) * np * NB * NB)) != hipSuccess) return e;
+    if ((e = hipMalloc((void **)&w->W, sizeof(double) * mmax * NB)) != hipSuccess) return e;
+    if ((e = hipMalloc((void **)&w->tau, sizeof(double) * 2 * mmax)) != hipSuccess) return e;   // tau, rdiag
+    if ((e = hipMalloc((void **)&w->norm2, sizeof(double) * mmax)) != hipSuccess) return e;
+    if ((e = hipMalloc((void **)&w->dblk, sizeof(double) * 66 * NB * NB)) != hipSuccess) return e;   // S, Uinv + split-K slabs
+    if ((e = hipMalloc((void **)&w->flag, sizeof(int) * 4)) != hipSuccess) return e;
+    if ((e = hipMemset(w->flag, 0, sizeof(int) * 4)) != hipSuccess) return e;
+    w->mmax = mmax;
+    return hipSuccess;
+}
+
+void rsqp_dense_work_free(RsqpDenseWork *w) {
+    double *d[] = {w->V, w->T, w->W, w->tau, w->norm2, w->dblk};
+    for (double *p : d) if (p) (void)hipFree(p);
+    if (w->flag) (void)hipFree(w->flag);
+    *w = RsqpDenseWork();
+}
+
+#define DCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t rsqp_dgeqrf(int m, int n, double *B, long long ldb, double eps_li, RsqpDenseWork *w, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (m < n || m > w->mmax) return hipErrorInvalidValue;
+    double *rdiag = w->tau + w->mmax, *S = w->dblk, *ws = w->dblk + NB * NB;
+    hipLaunchKernelGGL(k_colnorm2, dim3(n), dim3(256), 0, st, m, B, ldb, w->norm2);
+    for (int k0 = 0, p = 0; k0 < n; k0 += NB, p++) {
+        const int jb = std::min(NB, n - k0), mt = m - k0, nt = n - k0 - jb;
+        for (int j = k0; j < k0 + jb; j++)
+            hipLaunchKernelGGL(k_qr_col, dim3(k0 + jb - j), dim3(256), 0, st, B, ldb, m, j, k0, w->V, w->mmax, w->tau, rdiag,
+                               w->norm2, eps_li, w->flag);
+        // S = V'V (jb x jb, long inner dimension: split K), T factor, reflectors back into B
+        DCHK(dgemm_ws(true, false, jb, jb, mt, 1.0, w->V, w->mmax, w->V, w->mmax, 0.0, S, jb, ws, 64LL * NB * NB, st));
+        hipLaunchKernelGGL(k_qr_T, dim3(1), dim3(256), 0, st, jb, S, w->tau + k0, w->T + (long long)p * NB * NB);
+        hipLaunchKernelGGL(k_panel_writeback, dim3((mt + 255) / 256, jb), dim3(256), 0, st, B, ldb, m, k0, jb, w->V, w->mmax, rdiag);
+        if (nt > 0) {
+            double *Ct = B + k0 + (long long)(k0 + jb) * ldb;
+            DCHK(rsqp_dgemm(true, false, jb, nt, mt, 1.0, w->V, w->mmax, Ct, ldb, 0.0, w->W, NB, st));      // W = V'C
+            hipLaunchKernelGGL(k_apply_T, dim3((nt + 63) / 64), dim3(64), 0, st, jb, nt, w->T + (long long)p * NB * NB, 1, w->W);
+            DCHK(rsqp_dgemm(false, false, mt, nt, jb, -1.0, w->V, w->mmax, w->W, NB, 1.0, Ct, ldb, st));   // C -= V (T'W)
+        }
+    }
+    return hipGetLastError();
+}
+
+hipError_t rsqp_dorgqr(int m, int n, const double *B, long long ldb, double *Q, long long ldq, RsqpDenseWork *w,
+                       hipStream_t st) {
+    if (m <= 0) return hipSuccess;
+    if (m > w->mmax) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_set_identity, dim3((m + 255) / 256, m), dim3(256), 0, st, m, Q, ldq);
+    const int np = (n + NB - 1) / NB;
+    for (int p = np - 1; p >= 0; p--) {
+        const int k0 = p * NB, jb = std::min(NB, n - k0), mt = m - k0;
+        hipLaunchKernelGGL(k_build_V, dim3((mt + 255) / 256, jb), dim3(256), 0, st, B, ldb, m, k0, jb, w->V, w->mmax);
+        double *Qs = Q + k0 + (long long)k0 * ldq;
+        DCHK(rsqp_dgemm(true, false, jb, mt, mt, 1.0, w->V, w->mmax, Qs, ldq, 0.0, w->W, NB, st));          // W = V'Q
+        hipLaunchKernelGGL(k_apply_T, dim3((mt + 63) / 64), dim3(64), 0, st, jb, mt, w->T + (long long)p * NB * NB, 0, w->W);
+        DCHK(rsqp_dgemm(false, false, mt, mt, jb, -1.0, w->V, w->mmax, w->W, NB, 1.0, Qs, ldq, st));       // Q -= V (T W)
+    }
+    return hipGetLastError();
+}
+
+// recursive doubling: after level s every aligned diagonal block of size 2s of X is the inverse
+// of the same block of R:  X12 = -X11 R12 X22
+hipError_t rsqp_dtrtri_upper(int n, const double *R, long long ldr, double *X, long long ldx, RsqpDenseWork *w,
+                             hipStream_t st) {
+    (void)w;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_zero_block, dim3((n + 255) / 256, n), dim3(256), 0, st, n, n, X, ldx);
+    hipLaunchKernelGGL(k_trinv_diag, dim3((n + NB - 1) / NB), dim3(64), 0, st, n, R, ldr, X, ldx);
+    if (n <= NB) return hipGetLastError();
+    // scratch for R12 X22: the strictly lower triangle of X is free; blocks of it are zeroed again afterwards
+    for (int s = NB; s < n; s *= 2) {
+        for (int a0 = 0; a0 + s < n; a0 += 2 * s) {
+            const int a1 = a0 + s, a2 = std::min(n, a1 + s), s2 = a2 - a1;
+            // tmp (s x s2) lives in the lower-left block X[a1:a2, a0:a1]' -- use its transpose slot X[a1.., a0..] of shape s2 x s
+            // instead keep it simple: tmp' = X22' R12' is not needed; store tmp in the lower block column-major with ld = ldx
+            double *tmp = X + a1 + (long long)a0 * ldx;     // s2 x s block (lower triangle), holds (R12 X22)' 
+            // (R12 X22)' = X22' R12'  ->  tmp (s2 x s) = X22' (s2 x s2) * R12' (s2 x s)
+            DCHK(rsqp_dgemm(true, true, s2, s, s2, 1.0, X + a1 + (long long)a1 * ldx, ldx, R + a0 + (long long)a1 * ldr, ldr, 0.0,
+                            tmp, ldx, st));
+            // X12 (s x s2) = -X11 (s x s) * tmp' (s x s2)
+            DCHK(rsqp_dgemm(false, true, s, s2, s, -1.0, X + a0 + (long long)a0 * ldx, ldx, tmp, ldx, 0.0,
+                            X + a0 + (long long)a1 * ldx, ldx, st));
+            hipLaunchKernelGGL(k_zero_block, dim3((s2 + 255) / 256, s), dim3(256), 0, st, s2, s, tmp, ldx);
+        }
+    }
+    return hipGetLastError();
+}
+
+hipError_t rsqp_dpotrf_upper(int n, double *G, long long ldg, double pd_rel, double pd_abs, RsqpDenseWork *w, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (n > w->mmax) return hipErrorInvalidValue;
+    double *Uinv = w->dblk;
+    hipLaunchKernelGGL(k_get_diag, dim3((n + 255) / 256), dim3(256), 0, st, n, G, ldg, w->norm2);
+    for (int k0 = 0; k0 < n; k0 += NB) {
+        const int jb = std::min(NB, n - k0), nt = n - k0 - jb;
+        double *Gd = G + k0 + (long long)k0 * ldg;
+        hipLaunchKernelGGL(k_potf2, dim3(1), dim3(64), 0, st, jb, Gd, ldg, w->norm2 + k0, pd_rel, pd_abs, Uinv, w->flag + 1);
+        if (nt > 0) {
+            double *G12 = G + k0 + (long long)(k0 + jb) * ldg;
+            // U12 = Ujj^-T G12  (jb x nt): via W, then copied back
+            DCHK(rsqp_dgemm(true, false, jb, nt, jb, 1.0, Uinv, NB, G12, ldg, 0.0, w->W, NB, st));
+            DCHK(hipMemcpy2DAsync(G12, sizeof(double) * ldg, w->W, sizeof(double) * NB, sizeof(double) * jb, nt, hipMemcpyDeviceToDevice, st));
+            // G22 -= U12' U12 (both triangles: the lower one is scratch and zeroed below)
+            DCHK(rsqp_dgemm(true, false, nt, nt, jb, -1.0, w->W, NB, w->W, NB, 1.0, G + (k0 + jb) + (long long)(k0 + jb) * ldg, ldg, st));
+        }
+    }
+    hipLaunchKernelGGL(k_zero_lower, dim3((n + 255) / 256, n), dim3(256), 0, st, n, G, ldg);
+    return hipGetLastError();
+}
+
+// =====================================================================================
+// host-pointer entry points (include/rsqp_hip.h): verification and benchmarking
+// =====================================================================================
+namespace {
+struct DevMem {
+    double *p = nullptr;
+    hipError_t alloc(size_t n) { return hipMalloc((void **)&p, sizeof(double) * std::max<size_t>(n, 1)); }
+    ~DevMem() { if (p) (void)hipFree(p); }
+};
+struct Stopwatch {
+    hipEvent_t a = nullptr, b = nullptr;
+    Stopwatch() { (void)hipEventCreate(&a); (void)hipEventCreate(&b); }
+    ~Stopwatch() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+    void start() { (void)hipEventRecord(a, nullptr); }
+    float stop() { (void)hipEventRecord(b, nullptr); (void)hipEventSynchronize(b); float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return ms; }
+};
+}  // namespace
+
+#define HCHK(call) do { if ((call) != hipSuccess) return -2; } while (0)
+
+extern "C" int rsqp_dense_gemm(int transA, int transB, int m, int n, int k, double alpha, const double *A, int lda,
+                               const double *B, int ldb, double beta, double *C, int ldc, int repeats, float *ms) {
+    if (m < 0 || n < 0 || k < 0 || !A || !B || !C) return -1;
+    const size_t na = (size_t)lda * (transA ? m : k), nb = (size_t)ldb * (transB ? k : n), nc = (size_t)ldc * n;
+    DevMem dA, dB, dC;
+    HCHK(dA.alloc(na)); HCHK(dB.alloc(nb)); HCHK(dC.alloc(nc));
+    HCHK(hipMemcpy(dA.p, A, sizeof(double) * na, hipMemcpyHostToDevice));
+    HCHK(hipMemcpy(dB.p, B, sizeof(double) * nb, hipMemcpyHostToDevice));
+    HCHK(hipMemcpy(dC.p, C, sizeof(double) * nc, hipMemcpyHostToDevice));
+    HCHK(rsqp_dgemm(transA != 0, transB != 0, m, n, k, alpha, dA.p, lda, dB.p, ldb, beta, dC.p, ldc, nullptr));
+    HCHK(hipDeviceSynchronize());
+    HCHK(hipMemcpy(C, dC.p, sizeof(double) * nc, hipMemcpyDeviceToHost));
+    if (ms && repeats > 0) {
+        Stopwatch sw;
+        sw.start();
+        for (int r = 0; r < repeats; r++) HCHK(rsqp_dgemm(transA != 0, transB != 0, m, n, k, alpha, dA.p, lda, dB.p, ldb, beta, dC.p, ldc, nullptr));
+        *ms = sw.stop() / repeats;
+    }
+    return 0;
+}
+
+extern "C" int rsqp_dense_qr(int m, int n, double *B, double *Q, double *Rinv, double eps_li, int *ndep, float *ms) {
+    if (m < n || n < 0 || !B) return -1;
+    DevMem dB, dQ, dX;
+    RsqpDenseWork w;
+    HCHK(dB.alloc((size_t)m * n)); HCHK(dQ.alloc((size_t)m * m)); HCHK(dX.alloc((size_t)n * n));
+    HCHK(rsqp_dense_work_alloc(&w, m));
+    HCHK(hipMemcpy(dB.p, B, sizeof(double) * (size_t)m * n, hipMemcpyHostToDevice));
+    Stopwatch sw;
+    sw.start();
+    hipError_t e = rsqp_dgeqrf(m, n, dB.p, m, eps_li, &w, nullptr);
+    if (e == hipSuccess) e = rsqp_dtrtri_upper(n, dB.p, m, dX.p, n, &w, nullptr);
+    if (e == hipSuccess) e = rsqp_dorgqr(m, n, dB.p, m, dQ.p, m, &w, nullptr);
+    const float t = sw.stop();
+    if (ms) *ms = t;
+    int flags[4] = {0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(flags, w.flag, sizeof(flags), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(B, dB.p, sizeof(double) * (size_t)m * n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && Q) e = hipMemcpy(Q, dQ.p, sizeof(double) * (size_t)m * m, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && Rinv) e = hipMemcpy(Rinv, dX.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost);
+    rsqp_dense_work_free(&w);
+    if (ndep) *ndep = flags[0];
+    return e == hipSuccess ? 0 : -2;
+}
+
+extern "C" int rsqp_dense_chol_inverse(int n, double *G, double *Ginv, double pd_rel, double pd_abs, int *not_pd, float *ms) {
+    if (n < 0 || !G) return -1;
+    DevMem dG, dX, dI;
+    RsqpDenseWork w;
+    HCHK(dG.alloc((size_t)n * n)); HCHK(dX.alloc((size_t)n * n)); HCHK(dI.alloc((size_t)n * n));
+    HCHK(rsqp_dense_work_alloc(&w, n));
+    HCHK(hipMemcpy(dG.p, G, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
+    Stopwatch sw;
+    sw.start();
+    hipError_t e = rsqp_dpotrf_upper(n, dG.p, n, pd_rel, pd_abs, &w, nullptr);
+    if (e == hipSuccess) e = rsqp_dtrtri_upper(n, dG.p, n, dX.p, n, &w, nullptr);
+    if (e == hipSuccess) e = rsqp_dgemm(false, true, n, n, n, 1.0, dX.p, n, dX.p, n, 0.0, dI.p, n, nullptr);   // U^-1 U^-T
+    const float t = sw.stop();
+    if (ms) *ms = t;
+    int flags[4] = {0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(flags, w.flag, sizeof(flags), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(G, dG.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && Ginv) e = hipMemcpy(Ginv, dI.p, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost);
+    rsqp_dense_work_free(&w);
+    if (not_pd) *not_pd = flags[1];
+    return e == hipSuccess ? 0 : -2;
+}

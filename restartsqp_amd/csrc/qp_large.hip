@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <vector>
 
 #include "rsqp_large.h"
@@ -753,6 +754,7 @@ struct RsqpLargeEngine::Impl {
     struct Prof { double ms = 0, bytes = 0; long long calls = 0; };
     Prof prof[8];
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     void pbegin() { if (profile) { if (!pe0) { (void)hipEventCreate(&pe0); (void)hipEventCreate(&pe1); } (void)hipEventRecord(pe0, st); } }
     void pend(int cls, double bytes) {
         if (!profile) return;
@@ -1224,6 +1226,7 @@ struct RsqpLargeEngine::Impl {
         status = QPS_PREPARINGAUXILIARYQP;
         infeasible = unbounded = 0;
         nFR = nAC = nZ = 0;
+        const double t_setup0 = now_s();
         // 1. bounds: Z = unit columns of the free variables (no constraint active yet)
         LCHK(hipMemcpyAsync(Sb, gb.data(), sizeof(int) * nV, hipMemcpyHostToDevice, st));
         hSb = gb;
@@ -1250,6 +1253,7 @@ struct RsqpLargeEngine::Impl {
             if (li) add_constraint(r, gc[r], false);
         }
         wz_enabled = true;
+        if (profile) { (void)hipStreamSynchronize(st); fprintf(stderr, "[rsqp profile] setup_aux: TQ part done, nFR %d nAC %d nZ %d, t=%.3f s\n", nFR, nAC, nZ, now_s() - t_setup0); }
         // 3. Wz = (Z'HZ)^-1 by bordering over the final null-space columns
         const int nZf = nZ;
         nZ = 0;
@@ -1265,6 +1269,7 @@ struct RsqpLargeEngine::Impl {
         hipLaunchKernelGGL(k_aux_v, g1(nV), dim3(NT), 0, st, nV, Sb, x, w1, y, w2, lbN, ubN, g, lb, ub);
         if (nC > 0) hipLaunchKernelGGL(k_aux_c, g1(nC), dim3(NT), 0, st, nC, Sc, Ax, lbAN, ubAN, lbA, ubA);
         status = QPS_AUXILIARYQPSOLVED;
+        if (profile) { (void)hipStreamSynchronize(st); fprintf(stderr, "[rsqp profile] setup_aux: done, t=%.3f s\n", now_s() - t_setup0); }
         return RET_OK;
     }
 };
