@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "rsqp_large.h"
+#include "rsqp_dense.h"
 
 namespace {
 
@@ -619,6 +620,44 @@ __global__ void __launch_bounds__(NT) k_norms_publish(const double *__restrict__
 }
 
 // Z[:, k] = e_{free[k]} (columns zero-filled beforehand)
+// blocked set-up: B[:, k] = free part of the row of candidate constraint cand[k] (compressed free coordinates)
+__global__ void k_build_B(const int *__restrict__ Arp, const int *__restrict__ Aci, const double *__restrict__ Arv,
+                          const int *__restrict__ cand, const int *__restrict__ fpos, double *__restrict__ B, long long ldb) {
+    const int r = cand[blockIdx.x];
+    double *col = B + (long long)blockIdx.x * ldb;
+    for (int k = Arp[r] + threadIdx.x; k < Arp[r + 1]; k += blockDim.x) {
+        const int p = fpos[Aci[k]];
+        if (p >= 0) col[p] = Arv[k];
+    }
+}
+// rows of the compressed orthogonal factor back to the variables: Y = Q[:, :n], Z = Q[:, n:]
+__global__ void k_scatter_Q(int m, int n, const double *__restrict__ Q, long long ldq, const int *__restrict__ freev,
+                            double *__restrict__ Y, double *__restrict__ Z, long long ld) {
+    const int c = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const double v = Q[i + (long long)c * ldq];
+    if (c < n) Y[freev[i] + (long long)c * ld] = v;
+    else Z[freev[i] + (long long)(c - n) * ld] = v;
+}
+// dst (n x n, ldd) = src' (src n x n, lds)
+__global__ void k_transpose(int n, const double *__restrict__ src, long long lds, double *__restrict__ dst, long long ldd) {
+    __shared__ double tile[32][33];
+    const int bi = blockIdx.x * 32, bj = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int i = bi + threadIdx.x, j = bj + r;
+        tile[r][threadIdx.x] = (i < n && j < n) ? src[i + (long long)j * lds] : 0.0;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int i = bj + threadIdx.x, j = bi + r;    // dst(i, j) = src(j, i)
+        if (i < n && j < n) dst[i + (long long)j * ldd] = tile[threadIdx.x][r];
+    }
+}
+__global__ void k_add_scaled(long long n, double a, const double *__restrict__ x, double *__restrict__ y) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i < n) y[i] += a * x[i];
+}
+
 __global__ void k_unit_cols(double *__restrict__ Z, long long ld, const int *__restrict__ freev, int n) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) Z[k * ld + freev[k]] = 1.0;
@@ -734,12 +773,20 @@ struct RsqpLargeEngine::Impl {
     bool dirty_products = true;
     bool wz_enabled = true;   // false while setup_aux builds Z/Y/Minv; Wz is bordered afterwards
     int since_refresh = 0;
+    // blocked (GEMM) set-up of a non-empty working set: dense_la.hip
+    RsqpDenseWork dw;
+    double *big = nullptr;    // 2 nV^2 scratch, allocated by the first blocked set-up
+    int *d_fpos = nullptr, *d_cand = nullptr, *d_freev = nullptr;
+    bool blocked_setup = getenv("RSQP_NO_BLOCKED_SETUP") == nullptr;
+    static constexpr int BLOCKED_MIN = 32;   // fewer active constraints: the sequential construction is as fast
 
     ~Impl() {
         double *dv[] = {Z, Y, Minv, Wz, x, g, lb, ub, gN, lbN, ubN, dx, w1, w2, w3, w4, w5, w6, wz1, wz2, wz3, Ax, lbA, ubA,
                         lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy};
         for (double *p : dv) if (p) (void)hipFree(p);
-        int *iv[] = {Sb, Sc, AC, posAC, pid, res_id};
+        if (big) (void)hipFree(big);
+        rsqp_dense_work_free(&dw);
+        int *iv[] = {Sb, Sc, AC, posAC, pid, res_id, d_fpos, d_cand, d_freev};
         for (int *p : iv) if (p) (void)hipFree(p);
         if (h_ctl) (void)hipHostFree(h_ctl);
         if (h_pinned) (void)hipHostFree(h_pinned);
@@ -1220,6 +1267,85 @@ struct RsqpLargeEngine::Impl {
         return rcode;
     }
 
+    // ---- blocked set-up (dense_la.hip) --------------------------------------------------------------
+    static constexpr int RET_FALLBACK = -77;
+    int ensure_big() {
+        if (big) return RET_OK;
+        LCHK(hipMalloc(reinterpret_cast<void **>(&big), sizeof(double) * 2 * (size_t)nV * nV));
+        return RET_OK;
+    }
+    // Y, Z, Minv for the candidate constraints `cand` (all taken: a linearly dependent one makes
+    // the caller fall back to the sequential construction, which skips it). Works in the compressed
+    // coordinates of the nFR free variables: B = A_cand,FR' = Q R, Y = Q[:, :n], Z = Q[:, n:],
+    // A_AC Y = R'  =>  Minv = R^-T.
+    int setup_tq_blocked(const std::vector<int> &gc, const std::vector<int> &freev, const std::vector<int> &cand) {
+        const int m = nFR, n = (int)cand.size();
+        if (ensure_big() != RET_OK) return RET_SETUP_FAILED;
+        std::vector<int> fpos(nV, -1);
+        for (int i = 0; i < m; i++) fpos[freev[i]] = i;
+        LCHK(hipMemcpyAsync(d_fpos, fpos.data(), sizeof(int) * nV, hipMemcpyHostToDevice, st));
+        LCHK(hipMemcpyAsync(d_cand, cand.data(), sizeof(int) * n, hipMemcpyHostToDevice, st));
+        LCHK(hipMemcpyAsync(d_freev, freev.data(), sizeof(int) * m, hipMemcpyHostToDevice, st));
+        double *B = Y;            // m x n, ld m (Y is rewritten at the end)
+        double *X = big;          // n x n  R^-1
+        double *Q = big + (size_t)nV * nV;   // m x m
+        LCHK(hipMemsetAsync(B, 0, sizeof(double) * (size_t)m * n, st));
+        LCHK(hipMemsetAsync(dw.flag, 0, sizeof(int) * 4, st));
+        hipLaunchKernelGGL(k_build_B, dim3(n), dim3(NT), 0, st, M.Arp, M.Aci, M.Arv, d_cand, d_fpos, B, (long long)m);
+        LCHK(rsqp_dgeqrf(m, n, B, m, RSQP_EPS_LI, &dw, st));
+        LCHK(hipMemcpyAsync(h_pinned_i, dw.flag, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+        LCHK(hipStreamSynchronize(st));
+        if (h_pinned_i[0] != 0) {   // dependent rows in the guess: start over, one constraint at a time
+            if (nZ > 0) {
+                LCHK(hipMemsetAsync(Z, 0, sizeof(double) * (size_t)ld * nZ, st));
+                hipLaunchKernelGGL(k_unit_cols, g1(nZ), dim3(NT), 0, st, Z, ld, d_freev, nZ);
+            }
+            return RET_FALLBACK;
+        }
+        LCHK(rsqp_dtrtri_upper(n, B, m, X, n, &dw, st));
+        hipLaunchKernelGGL(k_transpose, dim3((n + 31) / 32, (n + 31) / 32), dim3(32, 8), 0, st, n, X, (long long)n, Minv, ldm);
+        LCHK(rsqp_dorgqr(m, n, B, m, Q, m, &dw, st));
+        LCHK(hipMemsetAsync(Y, 0, sizeof(double) * (size_t)ld * n, st));
+        if (m > n) LCHK(hipMemsetAsync(Z, 0, sizeof(double) * (size_t)ld * (m - n), st));
+        hipLaunchKernelGGL(k_scatter_Q, dim3((m + NT - 1) / NT, m), dim3(NT), 0, st, m, n, Q, (long long)m, d_freev, Y, Z, ld);
+        // working-set bookkeeping
+        std::vector<int> hpos(nC, -1);
+        for (int k = 0; k < n; k++) { hAC[k] = cand[k]; hpos[cand[k]] = k; hSc[cand[k]] = gc[cand[k]]; }
+        LCHK(hipMemcpyAsync(AC, hAC.data(), sizeof(int) * n, hipMemcpyHostToDevice, st));
+        LCHK(hipMemcpyAsync(posAC, hpos.data(), sizeof(int) * nC, hipMemcpyHostToDevice, st));
+        LCHK(hipMemcpyAsync(Sc, hSc.data(), sizeof(int) * nC, hipMemcpyHostToDevice, st));
+        LCHK(hipStreamSynchronize(st));   // the host vectors above go out of scope
+        nAC = n;
+        nZ = m - n;
+        chk("setup_tq_blocked");
+        return RET_OK;
+    }
+    // Wz = (Z'(H + hreg I)Z)^-1 = U^-1 U^-T with Z'HZ = U'U; the pivots pass the same definiteness
+    // test as the bordering (wz_grow)
+    int setup_wz_blocked() {
+        if (ensure_big() != RET_OK) return RET_SETUP_FAILED;
+        double *HZ = big, *G = big + (size_t)nV * nV;
+        // H Z, column by column of Z in one batched launch
+        if (!M.haveH) LCHK(hipMemsetAsync(HZ, 0, sizeof(double) * (size_t)ld * nZ, st));
+        else if (M.denseH) LCHK(rsqp_dgemm(false, false, nV, nZ, nV, 1.0, M.denseH, nV, Z, ld, 0.0, HZ, ld, st));
+        else LCHK(rsqp_launch_spmv(M.blk_h, M.nblk_h, M.Hjc, M.Hir, M.Hval, Z, HZ, nZ, 0, 0, ld, ld, st));
+        if (M.hreg != 0.0) {
+            const long long tot = (long long)ld * nZ;
+            hipLaunchKernelGGL(k_add_scaled, dim3((unsigned)((tot + NT - 1) / NT)), dim3(NT), 0, st, tot, M.hreg, Z, HZ);
+        }
+        LCHK(rsqp_dgemm(true, false, nZ, nZ, nV, 1.0, Z, ld, HZ, ld, 0.0, G, nZ, st));
+        LCHK(hipMemsetAsync(dw.flag, 0, sizeof(int) * 4, st));
+        LCHK(rsqp_dpotrf_upper(nZ, G, nZ, RSQP_EPS_PD_REL, RSQP_EPS_PD_ABS, &dw, st));
+        LCHK(hipMemcpyAsync(h_pinned_i, dw.flag, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+        LCHK(hipStreamSynchronize(st));
+        if (h_pinned_i[1] != 0) return RET_SETUP_FAILED;   // not positive definite on the null space
+        double *Ui = HZ;   // nZ x nZ
+        LCHK(rsqp_dtrtri_upper(nZ, G, nZ, Ui, nZ, &dw, st));
+        LCHK(rsqp_dgemm(false, true, nZ, nZ, nZ, 1.0, Ui, nZ, Ui, nZ, 0.0, Wz, ld, st));
+        chk("setup_wz_blocked");
+        return RET_OK;
+    }
+
     // ---- auxiliary QP -------------------------------------------------------------------------
     // working-set guess on the host (hSb / hSc targets), x / y on the device already
     int setup_aux(const std::vector<int> &gb, const std::vector<int> &gc) {
@@ -1242,25 +1368,45 @@ struct RsqpLargeEngine::Impl {
             LCHK(hipMemcpyAsync(reinterpret_cast<int *>(dy), freev.data(), sizeof(int) * freev.size(), hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(k_unit_cols, g1(nZ), dim3(NT), 0, st, Z, ld, reinterpret_cast<const int *>(dy), nZ);
         }
-        // 2. constraints: reflections of Z only; the inverse reduced Hessian is built afterwards
-        wz_enabled = false;
+        // 2. constraints. Many of them (a hot start with new matrices, a warm start): blocked Householder
+        //    QR of A_AC,FR' on the matrix cores; otherwise one reflection of Z per constraint.
+        //    The inverse reduced Hessian is built afterwards in both cases.
         A_times(x, Ax);
-        for (int r = 0; r < nC; r++) {
-            if (gc[r] == 0) continue;
-            constraint_products(r);
-            bool li = false;
-            if (li_decision(&li) != RET_OK) { wz_enabled = true; return RET_SETUP_FAILED; }
-            if (li) add_constraint(r, gc[r], false);
+        std::vector<int> cand;
+        for (int r = 0; r < nC; r++) if (gc[r] != 0) cand.push_back(r);
+        bool tq_done = false;
+        if (blocked_setup && (int)cand.size() >= BLOCKED_MIN && (int)cand.size() <= nFR) {
+            const int rcb = setup_tq_blocked(gc, freev, cand);
+            if (rcb == RET_OK) tq_done = true;
+            else if (rcb != RET_FALLBACK) return rcb;
         }
-        wz_enabled = true;
-        if (profile) { (void)hipStreamSynchronize(st); fprintf(stderr, "[rsqp profile] setup_aux: TQ part done, nFR %d nAC %d nZ %d, t=%.3f s\n", nFR, nAC, nZ, now_s() - t_setup0); }
-        // 3. Wz = (Z'HZ)^-1 by bordering over the final null-space columns
-        const int nZf = nZ;
-        nZ = 0;
-        for (int k = 0; k < nZf; k++) {
-            int pd = 0;
-            if (wz_grow(&pd) != RET_OK) return RET_SETUP_FAILED;
-            if (!pd) return RET_SETUP_FAILED;
+        if (!tq_done) {
+            wz_enabled = false;
+            for (int r = 0; r < nC; r++) {
+                if (gc[r] == 0) continue;
+                constraint_products(r);
+                bool li = false;
+                if (li_decision(&li) != RET_OK) { wz_enabled = true; return RET_SETUP_FAILED; }
+                if (li) add_constraint(r, gc[r], false);
+            }
+            wz_enabled = true;
+        }
+        if (profile) { (void)hipStreamSynchronize(st); fprintf(stderr, "[rsqp profile] setup_aux: TQ part done (%s), nFR %d nAC %d nZ %d, t=%.3f s\n", tq_done ? "blocked QR" : "sequential", nFR, nAC, nZ, now_s() - t_setup0); }
+        // 3. Wz = (Z'HZ)^-1: blocked Cholesky + inverse, or bordering over the null-space columns
+        bool wz_done = false;
+        if (blocked_setup && nZ >= BLOCKED_MIN) {
+            const int rcw = setup_wz_blocked();
+            if (rcw == RET_OK) wz_done = true;
+            else return rcw;
+        }
+        if (!wz_done) {
+            const int nZf = nZ;
+            nZ = 0;
+            for (int k = 0; k < nZf; k++) {
+                int pd = 0;
+                if (wz_grow(&pd) != RET_OK) return RET_SETUP_FAILED;
+                if (!pd) return RET_SETUP_FAILED;
+            }
         }
         // multipliers: zero when inactive, clipped to the admissible sign
         hipLaunchKernelGGL(k_clip_y, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, Sc, y);
@@ -1303,7 +1449,9 @@ hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
     P.nblk_ratio = std::min(1024, std::max(1, (nV + nC + NT - 1) / NT));
     DA(pt, P.nblk_ratio); DA(res_t, 2);
     DA(Sb, nV); DA(Sc, nC); DA(AC, nC); DA(posAC, nC); DA(pid, P.nblk_ratio); DA(res_id, 2);
+    DA(d_fpos, nV); DA(d_cand, nC); DA(d_freev, nV);
 #undef DA
+    if ((e = rsqp_dense_work_alloc(&P.dw, nV)) != hipSuccess) return e;
     if ((e = hipHostMalloc(reinterpret_cast<void **>(&P.h_ctl), 64 * sizeof(double), hipHostMallocMapped)) != hipSuccess) return e;
     if ((e = hipHostGetDevicePointer(reinterpret_cast<void **>(&P.d_ctl), P.h_ctl, 0)) != hipSuccess) return e;
     if ((e = hipHostMalloc(reinterpret_cast<void **>(&P.h_pinned), 64 * sizeof(double))) != hipSuccess) return e;

@@ -171,3 +171,56 @@ def test_baseline_sparse_10k_sequence(capi):
         assert s.status == 20 and ok and nk < n // 10
         steps += 1
     assert steps == 2
+
+
+@pytest.mark.parametrize("kind", ["dense", "sparse"])
+def test_blocked_setup_matches_oracle(capi, oracle, kind):
+    """A solve that starts from a large working set (hotstart with new matrices, init with
+    x0 / y0 / guessed bounds) builds Y, Z, (A_AC Y)^-1 by blocked Householder QR and (Z'HZ)^-1 by
+    blocked Cholesky on the matrix cores (dense_la.hip) instead of one reflection per constraint.
+    Same bar as everywhere: working sets, status, nWSR identical to the oracle; x, y to 1e-9."""
+    rng = np.random.default_rng(5)
+    q = problems.dense_qp(300, 600, seed=11) if kind == "dense" else problems.sparse_qp(n=500, m=1000, nnz=10000, seed=12)
+    s = load(capi, q, engine=2)
+    n = s.solve(capi.MODE_COLD, 100000)
+    qp, rc, n_or = oracle_cold(oracle, q, 100000)
+    same_as_oracle(s, n, qp, n_or)
+    assert (s.working_set_raw()[1] != 0).sum() >= 32          # enough active constraints for the blocked path
+    q2 = problems.perturb(rng, q, 0.02)
+    A2 = q2.A_val * (1.0 + 0.01 * rng.normal(size=q2.A_val.shape))
+    for w, v in zip(range(5), (q2.g, q2.lb, q2.ub, q2.lbA, q2.ubA)):
+        s.set_vector(w, v)
+    s.set_A_csc(q2.A_jc, q2.A_ir, A2); s.set_H_csc(q2.H_jc, q2.H_ir, q2.H_val * 1.02)
+    n = s.solve(capi.MODE_HOT_MATRICES, 100000)
+    qp.set_A_csc(q2.A_jc, q2.A_ir, A2); qp.set_H_csc(q2.H_jc, q2.H_ir, q2.H_val * 1.02)
+    rc, n_or = qp.hotstart_matrices(q2.g, q2.lb, q2.ub, q2.lbA, q2.ubA, 100000)
+    same_as_oracle(s, n, qp, n_or)
+    ok, st, _, _ = s.test_optimality()
+    assert ok and st.KKT_error < 1e-8
+    x0, y0, gb = s.x, s.y, s.working_set_raw()[0]
+    q3 = problems.perturb(rng, q2, 0.02)
+    for w, v in zip(range(5), (q3.g, q3.lb, q3.ub, q3.lbA, q3.ubA)):
+        s.set_vector(w, v)
+    n = s.solve(capi.MODE_WARM_REINIT, 100000, x0, y0, gb)
+    rc, n_or = qp.init(q3.g, q3.lb, q3.ub, q3.lbA, q3.ubA, 100000, x0=x0, y0=y0, guess_b=gb)
+    same_as_oracle(s, n, qp, n_or)
+
+
+def test_blocked_setup_falls_back_on_dependent_guess(capi, oracle):
+    """Duplicate constraint rows in the guessed working set: the blocked QR reports the
+    dependence and the engine rebuilds the factorisation one constraint at a time (which skips
+    the dependent row) -- the result still matches the oracle."""
+    rng = np.random.default_rng(8)
+    q = problems.dense_qp(120, 200, seed=3)
+    A = q.dense_A(); A[150:200] = A[100:150]          # 50 duplicated rows
+    lbA, ubA = q.lbA.copy(), q.ubA.copy(); lbA[150:200] = lbA[100:150]; ubA[150:200] = ubA[100:150]
+    jc, ir, val = dense_to_csc(A)
+    q = QPData(q.nV, q.nC, q.H_jc, q.H_ir, q.H_val, jc, ir, val, q.g, q.lb, q.ub, lbA, ubA, name="dup")
+    s = load(capi, q, engine=2)
+    n = s.solve(capi.MODE_COLD, 100000)
+    qp, rc, n_or = oracle_cold(oracle, q, 100000)
+    same_as_oracle(s, n, qp, n_or)
+    x0, y0, gb = s.x, s.y, s.working_set_raw()[0]
+    n = s.solve(capi.MODE_WARM_REINIT, 100000, x0, y0, gb)    # constraints guessed from A x0: both copies look active
+    rc, n_or = qp.init(q.g, q.lb, q.ub, q.lbA, q.ubA, 100000, x0=x0, y0=y0, guess_b=gb)
+    same_as_oracle(s, n, qp, n_or)
