@@ -48,10 +48,11 @@ def pmc_traffic(substr, fetch_factor):
     are collected in separate runs and reported in KiB). MI355X_MICROARCH.md: on gfx950
     FETCH_SIZE counts half the bytes of wide coalesced streaming reads -> fetch_factor 2 for
     the streaming SpMV; WRITE_SIZE is exact. Returns None when no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic.json")
-    if not os.path.exists(path):
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+    if not paths:
         return None
-    d = json.load(open(path))
+    d = json.load(open(paths[-1]))   # the newest committed PMC pass
     for k, v in d.items():
         if substr in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             return fetch_factor * v["FETCH_SIZE"]["mean_per_dispatch"] * 1024 + v["WRITE_SIZE"]["mean_per_dispatch"] * 1024
@@ -116,21 +117,24 @@ def large_configs(capi, problems, hot_steps=6):
     ok, st, _, _ = s.test_optimality()
     out["sparse_10000x20000_cold"] = {"seconds": t, "nWSR": n, "ms_per_working_set_change": 1e3 * t / max(n, 1),
                                       "KKT_error": st.KKT_error, "certified": bool(ok)}
-    times, its, good = [], [], True
+    times, its, kinds, good = [], [], [], True
     for qk, changed in problems.sparse_sequence(q, nsteps=2 * hot_steps):
-        if changed:
-            continue     # VARIED steps re-factorise from scratch; reported separately when measured
         t = time.perf_counter()
         for w, v in zip(range(5), (qk.g, qk.lb, qk.ub, qk.lbA, qk.ubA)):
             s.set_vector(w, v)
-        nk = s.solve(capi.MODE_HOT_VECTORS, 400000)
+        if changed:      # QPhandler VARIED: new Jacobian values, hotstart(H, g, A, ...) re-factorises (blocked QR / Cholesky)
+            s.set_A_csc(qk.A_jc, qk.A_ir, qk.A_val)
+        nk = s.solve(capi.MODE_HOT_MATRICES if changed else capi.MODE_HOT_VECTORS, 400000)
         okk, stk, _, _ = s.test_optimality()          # QPhandler::solveQP = optimizeQP + certificate
-        times.append(time.perf_counter() - t); its.append(nk); good = good and bool(okk)
+        times.append(time.perf_counter() - t); its.append(nk); kinds.append(changed); good = good and bool(okk)
+    times, its, kinds = np.array(times), np.array(its), np.array(kinds)
     out["sparse_10000x20000_warm_sequence"] = {
         "qps": len(times), "wall_ms_per_sqp_iteration_mean": 1e3 * float(np.mean(times)),
         "wall_ms_per_sqp_iteration_median": 1e3 * float(np.median(times)), "nWSR_mean": float(np.mean(its)),
-        "all_certified": good, "note": "FIXED-matrix steps (hotstart on vectors) incl. host transfers and the KKT "
-                                       "certificate; VARIED steps re-factorise from scratch and are not included"}
+        "fixed_matrix_steps": {"qps": int((~kinds).sum()), "wall_ms_mean": 1e3 * float(times[~kinds].mean()), "nWSR_mean": float(its[~kinds].mean())},
+        "varied_matrix_steps": {"qps": int(kinds.sum()), "wall_ms_mean": 1e3 * float(times[kinds].mean()), "nWSR_mean": float(its[kinds].mean())},
+        "all_certified": good, "note": "alternating FIXED (hotstart on vectors) and VARIED (new Jacobian values: upload, blocked "
+                                       "re-factorisation, hotstart) steps, each incl. host transfers and the KKT certificate"}
     s.close()
     q = problems.dense_qp(600, 1200, seed=20260101)
     s = load(q)
@@ -278,9 +282,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "hs071-scale QP batch (derived hs071 first QP + seeded 1 %% perturbations, "
                                    "nV=8 x nC=2 via QPhandler [J I -I]), cold start, %d QPs/GPU per step" % B,
-                       "qps_per_gpu": B, "engine": "small_qp_kernel<64> (one wave per QP, LDS-resident)",
+                       "qps_per_gpu": B, "engine": "small_qp_kernel<16> (LDS-resident, 16 lanes per QP = 4 QPs per wave)",
                        "mean_nWSR": float(np.mean([r["nWSR"] for r in res])), "unsolved_or_kkt_fail": n_bad},
-            "roofline": {"kernel": "small_qp_kernel<64>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "small_qp_kernel<16>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic("small_qp_kernel", 1.0) if B == 16384 else None,
                          "traffic_note": "FETCH_SIZE uncorrected (narrow loads, uncalibrated) + WRITE_SIZE; the "

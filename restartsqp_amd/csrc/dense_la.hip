@@ -142,8 +142,8 @@ static hipError_t dgemm_ws(bool transA, bool transB, int m, int n, int k, double
     const int bx = (m + TM - 1) / TM, by = (n + TN - 1) / TN;
     // a long inner dimension over few output tiles: split K so that the chip has work
     int splits = 1;
-    if (ws && (long long)bx * by < 64 && k >= 1024) {
-        splits = (int)std::min<long long>(std::min<long long>(256 / ((long long)bx * by), k / 256), ws_cap / ((long long)m * n));
+    if (ws && (long long)bx * by < 200 && k >= 1024) {
+        splits = (int)std::min<long long>(std::min<long long>((511 + (long long)bx * by) / ((long long)bx * by), k / 256), ws_cap / ((long long)m * n));
         if (splits < 2) splits = 1;
     }
     int kc = k;
@@ -177,14 +177,20 @@ namespace {
 
 constexpr int NB = 64;
 
-__device__ __forceinline__ double block_sum256(double v, double *red) {
+template <int NTHR>
+__device__ __forceinline__ double block_sum(double v, double *red) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NTHR / 64; w++) s += red[w];
+    return s;
 }
+__device__ __forceinline__ double block_sum256(double v, double *red) { return block_sum<256>(v, red); }
+constexpr int QC = 1024;   // threads of the panel-column kernel (latency bound: 10 rows per thread at m = 10 000)
 
 __global__ void __launch_bounds__(256) k_colnorm2(int m, const double *__restrict__ B, long long ldb, double *__restrict__ out) {
     __shared__ double red[4];
@@ -199,15 +205,15 @@ __global__ void __launch_bounds__(256) k_colnorm2(int m, const double *__restric
 // column j (rows j..m-1) on its own -- the column is read-only during this launch -- and then
 // workgroup 0 stores it (explicit, unit diagonal) in V / tau / rdiag, workgroup b > 0 applies it
 // to panel column j + b.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(QC)
 k_qr_col(double *__restrict__ B, long long ldb, int m, int j, int k0, double *__restrict__ V, long long ldv,
          double *__restrict__ tau, double *__restrict__ rdiag, const double *__restrict__ norm2, double eps_li,
          int *__restrict__ flag) {
-    __shared__ double red[4];
+    __shared__ double red[QC / 64];
     const double *cj = B + (long long)j * ldb;
     double s = 0.0;
-    for (int i = j + 1 + threadIdx.x; i < m; i += 256) s += cj[i] * cj[i];
-    const double sigma = block_sum256(s, red);
+    for (int i = j + 1 + threadIdx.x; i < m; i += QC) s += cj[i] * cj[i];
+    const double sigma = block_sum<QC>(s, red);
     const double alpha = cj[j];
     double tj = 0.0, beta = alpha, scale = 0.0;
     if (sigma != 0.0) {
@@ -222,18 +228,18 @@ k_qr_col(double *__restrict__ B, long long ldb, int m, int j, int k0, double *__
             if (!(sqrt(alpha * alpha + sigma) > eps_li * sqrt(norm2[j]))) atomicAdd(flag, 1);
         }
         double *v = V + (long long)(j - k0) * ldv;
-        for (int i = k0 + threadIdx.x; i < m; i += 256) v[i - k0] = i < j ? 0.0 : (i == j ? 1.0 : cj[i] * scale);
+        for (int i = k0 + threadIdx.x; i < m; i += QC) v[i - k0] = i < j ? 0.0 : (i == j ? 1.0 : cj[i] * scale);
         return;
     }
     double *cc = B + (long long)(j + blockIdx.x) * ldb;
     double d = 0.0;
-    for (int i = j + 1 + threadIdx.x; i < m; i += 256) d += cj[i] * cc[i];
-    d = block_sum256(d, red);
+    for (int i = j + 1 + threadIdx.x; i < m; i += QC) d += cj[i] * cc[i];
+    d = block_sum<QC>(d, red);
     const double w = tj * (cc[j] + scale * d);
     __syncthreads();
     if (threadIdx.x == 0) cc[j] -= w;
     const double sw = scale * w;
-    for (int i = j + 1 + threadIdx.x; i < m; i += 256) cc[i] -= cj[i] * sw;
+    for (int i = j + 1 + threadIdx.x; i < m; i += QC) cc[i] -= cj[i] * sw;
 }
 
 // T factor of a panel (forward, columnwise: H_1 ... H_jb = I - V T V') from S = V'V and tau;
@@ -413,6 +419,8 @@ hipError_t rsqp_dense_work_alloc(RsqpDenseWork *w, long long mmax) {
     if ((e = hipMalloc((void **)&w->tau, sizeof(double) * 2 * mmax)) != hipSuccess) return e;   // tau, rdiag
     if ((e = hipMalloc((void **)&w->norm2, sizeof(double) * mmax)) != hipSuccess) return e;
     if ((e = hipMalloc((void **)&w->dblk, sizeof(double) * 66 * NB * NB)) != hipSuccess) return e;   // S, Uinv + split-K slabs
+    w->ws_cap = 4LL * NB * mmax;
+    if ((e = hipMalloc((void **)&w->ws, sizeof(double) * w->ws_cap)) != hipSuccess) return e;
     if ((e = hipMalloc((void **)&w->flag, sizeof(int) * 4)) != hipSuccess) return e;
     if ((e = hipMemset(w->flag, 0, sizeof(int) * 4)) != hipSuccess) return e;
     w->mmax = mmax;
@@ -420,7 +428,7 @@ hipError_t rsqp_dense_work_alloc(RsqpDenseWork *w, long long mmax) {
 }
 
 void rsqp_dense_work_free(RsqpDenseWork *w) {
-    double *d[] = {w->V, w->T, w->W, w->tau, w->norm2, w->dblk};
+    double *d[] = {w->V, w->T, w->W, w->tau, w->norm2, w->dblk, w->ws};
     for (double *p : d) if (p) (void)hipFree(p);
     if (w->flag) (void)hipFree(w->flag);
     *w = RsqpDenseWork();
@@ -436,7 +444,7 @@ hipError_t rsqp_dgeqrf(int m, int n, double *B, long long ldb, double eps_li, Rs
     for (int k0 = 0, p = 0; k0 < n; k0 += NB, p++) {
         const int jb = std::min(NB, n - k0), mt = m - k0, nt = n - k0 - jb;
         for (int j = k0; j < k0 + jb; j++)
-            hipLaunchKernelGGL(k_qr_col, dim3(k0 + jb - j), dim3(256), 0, st, B, ldb, m, j, k0, w->V, w->mmax, w->tau, rdiag,
+            hipLaunchKernelGGL(k_qr_col, dim3(k0 + jb - j), dim3(QC), 0, st, B, ldb, m, j, k0, w->V, w->mmax, w->tau, rdiag,
                                w->norm2, eps_li, w->flag);
         // S = V'V (jb x jb, long inner dimension: split K), T factor, reflectors back into B
         DCHK(dgemm_ws(true, false, jb, jb, mt, 1.0, w->V, w->mmax, w->V, w->mmax, 0.0, S, jb, ws, 64LL * NB * NB, st));
@@ -444,7 +452,7 @@ hipError_t rsqp_dgeqrf(int m, int n, double *B, long long ldb, double eps_li, Rs
         hipLaunchKernelGGL(k_panel_writeback, dim3((mt + 255) / 256, jb), dim3(256), 0, st, B, ldb, m, k0, jb, w->V, w->mmax, rdiag);
         if (nt > 0) {
             double *Ct = B + k0 + (long long)(k0 + jb) * ldb;
-            DCHK(rsqp_dgemm(true, false, jb, nt, mt, 1.0, w->V, w->mmax, Ct, ldb, 0.0, w->W, NB, st));      // W = V'C
+            DCHK(dgemm_ws(true, false, jb, nt, mt, 1.0, w->V, w->mmax, Ct, ldb, 0.0, w->W, NB, w->ws, w->ws_cap, st));   // W = V'C
             hipLaunchKernelGGL(k_apply_T, dim3((nt + 63) / 64), dim3(64), 0, st, jb, nt, w->T + (long long)p * NB * NB, 1, w->W);
             DCHK(rsqp_dgemm(false, false, mt, nt, jb, -1.0, w->V, w->mmax, w->W, NB, 1.0, Ct, ldb, st));   // C -= V (T'W)
         }
@@ -462,7 +470,7 @@ hipError_t rsqp_dorgqr(int m, int n, const double *B, long long ldb, double *Q, 
         const int k0 = p * NB, jb = std::min(NB, n - k0), mt = m - k0;
         hipLaunchKernelGGL(k_build_V, dim3((mt + 255) / 256, jb), dim3(256), 0, st, B, ldb, m, k0, jb, w->V, w->mmax);
         double *Qs = Q + k0 + (long long)k0 * ldq;
-        DCHK(rsqp_dgemm(true, false, jb, mt, mt, 1.0, w->V, w->mmax, Qs, ldq, 0.0, w->W, NB, st));          // W = V'Q
+        DCHK(dgemm_ws(true, false, jb, mt, mt, 1.0, w->V, w->mmax, Qs, ldq, 0.0, w->W, NB, w->ws, w->ws_cap, st));   // W = V'Q
         hipLaunchKernelGGL(k_apply_T, dim3((mt + 63) / 64), dim3(64), 0, st, jb, mt, w->T + (long long)p * NB * NB, 0, w->W);
         DCHK(rsqp_dgemm(false, false, mt, mt, jb, -1.0, w->V, w->mmax, w->W, NB, 1.0, Qs, ldq, st));       // Q -= V (T W)
     }

@@ -20,6 +20,8 @@ struct RsqpDenseWork {
     double *tau = nullptr;   // mmax
     double *norm2 = nullptr; // mmax        squared norms of the original columns
     double *dblk = nullptr;  // NB x NB     diagonal block scratch
+    double *ws = nullptr;    // split-K slabs of the tall-skinny products (V'C with a long inner dimension)
+    long long ws_cap = 0;
     int *flag = nullptr;     // [0] = number of dependent columns found, [1] = not positive definite
     long long mmax = 0;
 };

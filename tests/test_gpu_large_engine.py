@@ -154,7 +154,7 @@ def test_baseline_dense_2048x4096_certificate(capi):
 
 def test_baseline_sparse_10k_sequence(capi):
     """BASELINE config 4: n = 10 000, m = 20 000, 200 000 Jacobian non-zeros; cold start, then
-    warm-started QPs of the sequence (vector updates); every answer certified."""
+    warm-started QPs of the sequence (vector updates and new Jacobian values); every answer certified."""
     q = problems.sparse_qp()
     s = load(capi, q, engine=0)
     n = s.solve(capi.MODE_COLD, 200000)
@@ -162,15 +162,15 @@ def test_baseline_sparse_10k_sequence(capi):
     assert s.status == 20 and ok and st.KKT_error < 1e-8 and n > 1000
     steps = 0
     for qk, changed in problems.sparse_sequence(q, nsteps=4):
-        if changed:
-            continue
         for w, v in zip(range(5), (qk.g, qk.lb, qk.ub, qk.lbA, qk.ubA)):
             s.set_vector(w, v)
-        nk = s.solve(capi.MODE_HOT_VECTORS, 200000)
+        if changed:                                   # VARIED: new Jacobian values, blocked re-factorisation
+            s.set_A_csc(qk.A_jc, qk.A_ir, qk.A_val)
+        nk = s.solve(capi.MODE_HOT_MATRICES if changed else capi.MODE_HOT_VECTORS, 200000)
         ok, st, _, _ = s.test_optimality()
         assert s.status == 20 and ok and nk < n // 10
         steps += 1
-    assert steps == 2
+    assert steps == 4
 
 
 @pytest.mark.parametrize("kind", ["dense", "sparse"])
