@@ -150,6 +150,27 @@ def large_configs(capi, problems, hot_steps=6):
     return out
 
 
+def hs_batch_config(capi, problems, reps=50):
+    """BASELINE configs[4]: the batch of 512 independent hs0xx-scale QPs (mixed shapes, so the
+    problems sharing a wave diverge), whole on one GPU and as the 64-QP shard one of 8 GPUs gets.
+    Cold solve + fused KKT certificate per launch pair; device time by HIP events."""
+    out = {}
+    for nq in (512, 64):
+        probs = problems.hs_batch(nq)
+        b = capi.Batch(probs)
+        b.solve(capi.MODE_COLD, 1000)
+        b.timer_start()
+        for _ in range(reps):
+            b.solve(capi.MODE_COLD, 1000, sync=False)
+        ms = b.timer_stop_ms() / reps
+        ok, _ = b.test_optimality()
+        res = b.results()
+        out["%d_qps" % nq] = {"ms_per_batch": ms, "qp_solves_per_s": nq / (ms * 1e-3), "all_certified": bool(all(o == 1 for o in ok)),
+                              "mean_nWSR": float(np.mean([r["nWSR"] for r in res]))}
+        b.close()
+    return out
+
+
 def hs071_single_qp_latency(problems, iters=3000):
     """Wall-clock per SQP iteration of hs071 at the boundary, ONE QP at a time: the C++ host
     adapter (restartsqp_amd/csrc/host) replays QPhandler::update_delta + solveQP (hot start +
@@ -297,6 +318,7 @@ def main():
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
             line["roofline_spmv"] = spmv_roofline(capi, problems, args.spmv_batch, 5)
             line["hs071_single_qp"] = hs071_single_qp_latency(problems)
+            line["hs0xx_batch_512"] = hs_batch_config(capi, problems)
             if not args.no_large:
                 line["large_engine"] = large_configs(capi, problems)
         print(json.dumps(line))

@@ -158,27 +158,40 @@ struct Engine {
     }
 
     // ------------------------------------------------------------------ sparse products
-    __device__ __forceinline__ void A_times(const ldouble *v, ldouble *out) {
-        PFOR(r, nC) {
-            double s = 0.0;
-            for (int k = Arp[r]; k < Arp[r + 1]; k++) s += Arv[k] * v[Aci[k]];
-            out[r] = s;
+    // sum_k val[k] * v[idx[k]] over [k0, k1), accumulated in entry order. Four entries per trip:
+    // their index / value / gather loads are independent, so the LDS latencies overlap instead of
+    // chaining two round trips per entry.
+    template <class IP, class DP>
+    __device__ __forceinline__ static double sparse_dot(IP idx, DP val, const ldouble *v, int k0, int k1) {
+        double s = 0.0;
+        int k = k0;
+        for (; k + 4 <= k1; k += 4) {
+            const int c0 = idx[k], c1 = idx[k + 1], c2 = idx[k + 2], c3 = idx[k + 3];
+            const double a0 = val[k], a1 = val[k + 1], a2 = val[k + 2], a3 = val[k + 3];
+            const double v0 = v[c0], v1 = v[c1], v2 = v[c2], v3 = v[c3];
+            s += a0 * v0; s += a1 * v1; s += a2 * v2; s += a3 * v3;
         }
+        if (k + 2 <= k1) {
+            const int c0 = idx[k], c1 = idx[k + 1];
+            const double a0 = val[k], a1 = val[k + 1];
+            const double v0 = v[c0], v1 = v[c1];
+            s += a0 * v0; s += a1 * v1;
+            k += 2;
+        }
+        if (k < k1) s += val[k] * v[idx[k]];
+        return s;
+    }
+    __device__ __forceinline__ void A_times(const ldouble *v, ldouble *out) {
+        PFOR(r, nC) out[r] = sparse_dot(Aci, Arv, v, Arp[r], Arp[r + 1]);
         SYNC();
     }
     __device__ __forceinline__ void AT_times(const ldouble *yc, ldouble *out) {
-        PFOR(c, nV) {
-            double s = 0.0;
-            for (int k = Ajc[c]; k < Ajc[c + 1]; k++) s += Aval[k] * yc[Air[k]];
-            out[c] = s;
-        }
+        PFOR(c, nV) out[c] = sparse_dot(Air, Aval, yc, Ajc[c], Ajc[c + 1]);
         SYNC();
     }
     __device__ __forceinline__ void H_times(const ldouble *v, ldouble *out) {
         PFOR(c, nV) {
-            double s = 0.0;
-            if (haveH)
-                for (int k = Hjc[c]; k < Hjc[c + 1]; k++) s += Hval[k] * v[Hir[k]];
+            const double s = haveH ? sparse_dot(Hir, Hval, v, Hjc[c], Hjc[c + 1]) : 0.0;
             out[c] = s + hreg * v[c];
         }
         SYNC();
