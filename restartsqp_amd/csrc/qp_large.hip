@@ -620,6 +620,35 @@ __global__ void __launch_bounds__(NT) k_norms_publish(const double *__restrict__
 }
 
 // Z[:, k] = e_{free[k]} (columns zero-filled beforehand)
+// products of the sparse row r of A with the columns of two bases: out0 = M0' a_r (n0 columns),
+// out1 = M1' a_r (n1 columns). One thread per column, the row entries staged in LDS: the row has
+// a few dozen entries, so this gathers nnz * 64 B per column instead of streaming nV * 8 B.
+// (rows of fixed variables are zero in both bases: no masking needed)
+__global__ void __launch_bounds__(256)
+k_row_times_bases(const int *__restrict__ Arp, const int *__restrict__ Aci, const double *__restrict__ Arv, int r,
+                  const double *__restrict__ M0, int n0, double *__restrict__ out0, const double *__restrict__ M1, int n1,
+                  double *__restrict__ out1, long long l) {
+    __shared__ int sidx[256];
+    __shared__ double sval[256];
+    const int nb0 = (n0 + 255) / 256;
+    const bool first = (int)blockIdx.x < nb0;
+    const double *Mx = first ? M0 : M1;
+    const int ncols = first ? n0 : n1;
+    double *out = first ? out0 : out1;
+    const int c = (first ? blockIdx.x : blockIdx.x - nb0) * 256 + threadIdx.x;
+    const int k0 = Arp[r], k1 = Arp[r + 1];
+    const double *col = Mx + (long long)(c < ncols ? c : 0) * l;
+    double s = 0.0;
+    for (int base = k0; base < k1; base += 256) {
+        const int cnt = min(256, k1 - base);
+        __syncthreads();
+        if ((int)threadIdx.x < cnt) { sidx[threadIdx.x] = Aci[base + threadIdx.x]; sval[threadIdx.x] = Arv[base + threadIdx.x]; }
+        __syncthreads();
+        for (int e = 0; e < cnt; e++) s += sval[e] * col[sidx[e]];
+    }
+    if (c < ncols) out[c] = s;
+}
+
 // blocked set-up: B[:, k] = free part of the row of candidate constraint cand[k] (compressed free coordinates)
 __global__ void k_build_B(const int *__restrict__ Arp, const int *__restrict__ Aci, const double *__restrict__ Arv,
                           const int *__restrict__ cand, const int *__restrict__ fpos, double *__restrict__ B, long long ldb) {
@@ -946,8 +975,14 @@ struct RsqpLargeEngine::Impl {
     // products of constraint row r with the bases: w1 = a_FR, wz1 = Z'a, a1 = Y'a; scal[6]=|a|^2, scal[7]=|wZ|^2
     void constraint_products(int r) {
         row_of_A(r, w1, false);
-        gemv_t(Z, ld, nV, nZ, w1, wz1);
-        gemv_t(Y, ld, nV, nAC, w1, a1);
+        if (M.sparse_rows) {
+            const int nb = (nZ + 255) / 256 + (nAC + 255) / 256;
+            if (nb > 0)
+                hipLaunchKernelGGL(k_row_times_bases, dim3(nb), dim3(256), 0, st, M.Arp, M.Aci, M.Arv, r, Z, nZ, wz1, Y, nAC, a1, ld);
+        } else {
+            gemv_t(Z, ld, nV, nZ, w1, wz1);
+            gemv_t(Y, ld, nV, nAC, w1, a1);
+        }
         hipLaunchKernelGGL(k_norms_publish, dim3(1), dim3(NT), 0, st, w1, nV, wz1, nZ, scal, 6, 7, d_ctl);
     }
     void bound_products(int v) {

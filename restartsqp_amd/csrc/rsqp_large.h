@@ -10,6 +10,7 @@ struct RsqpLargeMatrices {
     const int *Arp = nullptr, *Aci = nullptr; const double *Arv = nullptr; const int4 *blk_r = nullptr; int nblk_r = 0;
     const int *Hjc = nullptr, *Hir = nullptr; const double *Hval = nullptr; const int4 *blk_h = nullptr; int nblk_h = 0;
     int haveH = 0;
+    int sparse_rows = 0;             // rows of A are sparse enough (fill < 1/8) for gathered row products
     double hreg = 0.0;               // H + hreg*I
     // optional dense column-major copies (null when the matrix is sparse)
     const double *denseA = nullptr;   // nC x nV, ld = nC
