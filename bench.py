@@ -307,7 +307,7 @@ def main():
                        "mean_nWSR": float(np.mean([r["nWSR"] for r in res])), "unsolved_or_kkt_fail": n_bad},
             "roofline": {"kernel": "small_qp_kernel<16>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic("small_qp_kernel", 1.0) if B == 16384 else None,
+                         "traffic": pmc_traffic("small_qp_kernel<16", 1.0) if B == 16384 else None,
                          "traffic_note": "FETCH_SIZE uncorrected (narrow loads, uncalibrated) + WRITE_SIZE; the "
                                          "writes are the 3.2 KB/QP engine image kept for hot starts",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_launch,
