@@ -205,28 +205,45 @@ def hs071_single_qp_latency(problems, iters=3000):
     return res
 
 
-def cpu_baseline(probs, seconds):
-    """Oracle (oracle/qp_oracle.c) timed on this host, one thread. Test infrastructure used as
-    the reported baseline only -- never on the measured GPU path."""
+def _cpu_worker(args):
+    """one process of the all-cores leg: the C oracle on its own copies of the sample QPs"""
+    probs, seconds = args
     import oracle as O
-    O.build()
     handles = []
     for q in probs:
         qp = O.OracleQP(q.nV, q.nC)
         qp.set_A_csc(q.A_jc, q.A_ir, q.A_val); qp.set_H_csc(q.H_jc, q.H_ir, q.H_val)
         handles.append(qp)
-    # time the C calls only (ctypes overhead included, python list handling excluded as far as possible)
-    n, t0 = 0, time.perf_counter()
+    reps, n, t0 = 50, 0, time.perf_counter()
     while True:
         for qp, q in zip(handles, probs):
-            qp.init(q.g, q.lb, q.ub, q.lbA, q.ubA, 1000)
-        n += len(probs)
+            qp.init_repeat(q.g, q.lb, q.ub, q.lbA, q.ubA, 1000, reps)     # C loop: no interpreter inside
+        n += reps * len(probs)
         t = time.perf_counter() - t0
         if t >= seconds:
-            break
-    return {"value": n / t, "unit": "QP solves/s", "cores": 1, "kind": "port",
-            "sample": "%d cold solves of the first %d QPs of the rank-0 batch in %.1f s (in-repo C oracle, "
-                      "gcc -O2, 1 thread; qpOASES 3.2.1 is not available)" % (n, len(probs), t)}
+            return n, t
+
+
+def cpu_baseline(probs, seconds):
+    """Oracle (oracle/qp_oracle.c) timed on this host: one thread (the reference's CPU path is
+    single-threaded), and -- for fairness -- one QP stream per core on all cores. Test
+    infrastructure used as the reported baseline only -- never on the measured GPU path."""
+    import oracle as O
+    O.build()
+    n, t = _cpu_worker((probs, seconds))
+    out = {"value": n / t, "unit": "QP solves/s", "cores": 1, "kind": "port",
+           "sample": "%d cold solves of the first %d QPs of the rank-0 batch in %.1f s (in-repo C oracle, gcc -O2, "
+                     "1 thread, solve loop in C; qpOASES 3.2.1 is not available)" % (n, len(probs), t)}
+    try:
+        import multiprocessing as mp
+        cores = len(os.sched_getaffinity(0))
+        with mp.get_context("fork").Pool(cores) as pool:
+            rs = pool.map(_cpu_worker, [(probs, max(1.0, seconds / 3))] * cores)
+        out["all_cores"] = {"value": sum(r[0] / r[1] for r in rs), "cores": cores,
+                            "note": "one independent QP stream per core (the reference itself has no threading)"}
+    except Exception as e:   # the all-cores figure is informational
+        out["all_cores"] = {"error": repr(e)}
+    return out
 
 
 def main():

@@ -47,6 +47,8 @@ def lib():
         L.orc_qp_init.argtypes = [C.c_void_p] + [c_dbl_p] * 5 + [c_int_p, c_dbl_p, c_dbl_p, c_int_p]
         L.orc_qp_hotstart.argtypes = [C.c_void_p] + [c_dbl_p] * 5 + [c_int_p]
         L.orc_qp_hotstart_matrices.argtypes = [C.c_void_p] + [c_dbl_p] * 5 + [c_int_p]
+        L.orc_qp_init_repeat.argtypes = [C.c_void_p] + [c_dbl_p] * 5 + [C.c_int, C.c_int]
+        L.orc_qp_init_repeat.restype = C.c_int
         L.orc_qp_set_regularisation.argtypes = [C.c_void_p, C.c_double]
         L.orc_qp_get_primal.argtypes = [C.c_void_p, c_dbl_p]
         L.orc_qp_get_dual.argtypes = [C.c_void_p, c_dbl_p]
@@ -262,6 +264,10 @@ class OracleQP:
         x0, y0, gb = _d(x0), _d(y0), _i(guess_b)
         rc = lib().orc_qp_init(self._h, *self._vecs(g, lb, ub, lbA, ubA), C.byref(n), _dp(x0), _dp(y0), _ip(gb))
         return rc, n.value
+
+    def init_repeat(self, g, lb, ub, lbA, ubA, nWSR, reps):
+        """`reps` cold solves in a C loop (timing only)"""
+        return lib().orc_qp_init_repeat(self._h, *self._vecs(g, lb, ub, lbA, ubA), nWSR, reps)
 
     def hotstart(self, g, lb, ub, lbA, ubA, nWSR):
         n = C.c_int(nWSR)

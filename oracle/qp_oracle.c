@@ -980,3 +980,15 @@ int orc_exitflag(const orc_qp *qp) {
     }
     return 30;
 }
+
+/* cold init repeated `reps` times inside C (bench.py's cpu_baseline: keeps the interpreter out of the
+ * timed loop). Returns the nWSR of the last solve. */
+int orc_qp_init_repeat(orc_qp *qp, const double *g, const double *lb, const double *ub, const double *lbA,
+                       const double *ubA, int nWSR_max, int reps) {
+    int n = 0;
+    for (int r = 0; r < reps; r++) {
+        n = nWSR_max;
+        orc_qp_init(qp, g, lb, ub, lbA, ubA, &n, 0, 0, 0);
+    }
+    return n;
+}

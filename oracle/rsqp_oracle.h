@@ -142,6 +142,9 @@ int orc_qp_set_H_csc(orc_qp *qp, const int *jc, const int *ir, const double *val
 int orc_qp_init(orc_qp *qp, const double *g, const double *lb, const double *ub,
                 const double *lbA, const double *ubA, int *nWSR, const double *x0,
                 const double *y0, const int *guess_b);
+/* the same cold init `reps` times in a C loop (timing aid of bench.py's cpu_baseline) */
+int orc_qp_init_repeat(orc_qp *qp, const double *g, const double *lb, const double *ub, const double *lbA,
+                       const double *ubA, int nWSR_max, int reps);
 /* SQProblem::hotstart(g,lb,ub,lbA,ubA,nWSR) -- src/qpOASESInterface.cpp:180, 191 */
 int orc_qp_hotstart(orc_qp *qp, const double *g, const double *lb, const double *ub,
                     const double *lbA, const double *ubA, int *nWSR);

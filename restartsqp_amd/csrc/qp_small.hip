@@ -165,6 +165,19 @@ struct Engine {
     __device__ __forceinline__ static double sparse_dot(IP idx, DP val, const ldouble *v, int k0, int k1) {
         double s = 0.0;
         int k = k0;
+        if constexpr (!MAT_LDS) {
+            // matrices in global memory (the image alone nearly fills the LDS): 8 entries per trip, so
+            // that 16 L2 round trips are in flight at once instead of 2
+            for (; k + 8 <= k1; k += 8) {
+                int c[8]; double a[8], w[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { c[u] = idx[k + u]; a[u] = val[k + u]; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) w[u] = v[c[u]];
+#pragma unroll
+                for (int u = 0; u < 8; u++) s += a[u] * w[u];
+            }
+        }
         for (; k + 4 <= k1; k += 4) {
             const int c0 = idx[k], c1 = idx[k + 1], c2 = idx[k + 2], c3 = idx[k + 3];
             const double a0 = val[k], a1 = val[k + 1], a2 = val[k + 2], a3 = val[k + 3];
