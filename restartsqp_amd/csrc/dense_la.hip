@@ -1,7 +1,7 @@
 // dense_la.hip -- dense f64 building blocks for gfx950 (see rsqp_dense.h).
 //
-//   * k_dgemm: LDS-tiled GEMM on v_mfma_f64_16x16x4_f64. Workgroup = 4 waves (2 x 2), tile TM x TN
-//     (64 / 128), K step 16. Both operand tiles are staged in LDS as [k][index] so that the
+//   * k_dgemm: LDS-tiled GEMM on v_mfma_f64_16x16x4_f64. Workgroup = 8 waves (2 x 4) on a 128 x 128
+//     tile or 4 waves (2 x 2) on 64-wide tiles, K step 16. Both operand tiles are staged in LDS as [k][index] so that the
 //     fragment of an MFMA (lane l: index l & 15, k = l >> 4) is one ds_read_b64 with 16 consecutive
 //     lanes on consecutive words; the next K tile is fetched into registers while the current one
 //     is multiplied. The roles of the two MFMA operands are swapped (D = B_frag x A_frag) so that
@@ -11,6 +11,7 @@
 //     columns are factored by small kernels, everything else is rsqp_dgemm.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 
 #include "rsqp_dense.h"
 
@@ -18,46 +19,49 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int GK = 16;    // K step of the GEMM
+constexpr int GK16 = 16;   // K step of the GEMM (32 for the 8-wave 128 x 128 tile)
 constexpr int GPAD = 4;   // LDS row padding (doubles): row stride = 8 words mod 64 banks
 
 // one operand tile (GK x T) -> registers. kcontig: element (kk, t) at X[kk + t * ld], else X[t + kk * ld]
-template <int T>
-__device__ __forceinline__ void load_tile(double (&r)[GK * T / 256], const double *X, long long ld, bool kcontig, int k0,
+template <int T, int NTHR, int GK>
+__device__ __forceinline__ void load_tile(double (&r)[GK * T / NTHR], const double *X, long long ld, bool kcontig, int k0,
                                           int t0, int kmax, int tmax) {
-    constexpr int E = GK * T / 256;
+    constexpr int E = GK * T / NTHR;
     const int tid = threadIdx.x;
 #pragma unroll
     for (int e = 0; e < E; e++) {
         int kk, t;
-        if (kcontig) { kk = tid & 15; t = (tid >> 4) + 16 * e; }
-        else { t = tid % T; kk = tid / T + (256 / T) * e; }
+        if (kcontig) { kk = tid & (GK - 1); t = tid / GK + (NTHR / GK) * e; }
+        else { t = tid % T; kk = tid / T + (NTHR / T) * e; }
         const int gk = k0 + kk, gt = t0 + t;
         double v = 0.0;
         if (gk < kmax && gt < tmax) v = kcontig ? X[gk + (long long)gt * ld] : X[gt + (long long)gk * ld];
         r[e] = v;
     }
 }
-template <int T>
-__device__ __forceinline__ void store_tile(const double (&r)[GK * T / 256], double (*S)[T + GPAD], bool kcontig) {
-    constexpr int E = GK * T / 256;
+template <int T, int NTHR, int GK>
+__device__ __forceinline__ void store_tile(const double (&r)[GK * T / NTHR], double (*S)[T + GPAD], bool kcontig) {
+    constexpr int E = GK * T / NTHR;
     const int tid = threadIdx.x;
 #pragma unroll
     for (int e = 0; e < E; e++) {
         int kk, t;
-        if (kcontig) { kk = tid & 15; t = (tid >> 4) + 16 * e; }
-        else { t = tid % T; kk = tid / T + (256 / T) * e; }
+        if (kcontig) { kk = tid & (GK - 1); t = tid / GK + (NTHR / GK) * e; }
+        else { t = tid % T; kk = tid / T + (NTHR / T) * e; }
         S[kk][t] = r[e];
     }
 }
 
-template <int TM, int TN>
-__global__ void __launch_bounds__(256)
+// NW waves as 2 (rows) x NW/2 (columns); MINW = resident waves per SIMD the register budget allows
+template <int TM, int TN, int NW, int MINW, int GK>
+__global__ void __launch_bounds__(NW * 64, MINW)
 k_dgemm(int ta, int tb, int m, int n, int kfull, int kc, double alpha, const double *__restrict__ A, long long lda,
         const double *__restrict__ B, long long ldb, double beta, double *__restrict__ C, long long ldc) {
-    __shared__ double As[GK][TM + GPAD];
-    __shared__ double Bs[GK][TN + GPAD];
-    constexpr int MI = TM / 32, NJ = TN / 32;   // 16x16 blocks per wave
+    extern __shared__ __attribute__((aligned(16))) double gemm_lds[];
+    double (*As)[TM + GPAD] = reinterpret_cast<double (*)[TM + GPAD]>(gemm_lds);
+    double (*Bs)[TN + GPAD] = reinterpret_cast<double (*)[TN + GPAD]>(gemm_lds + GK * (TM + GPAD));
+    constexpr int NTHR = NW * 64, WN = NW / 2;
+    constexpr int MI = TM / 32, NJ = TN / (16 * WN);   // 16x16 blocks per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int i0 = blockIdx.x * TM, j0 = blockIdx.y * TN;
@@ -70,16 +74,16 @@ k_dgemm(int ta, int tb, int m, int n, int kfull, int kc, double alpha, const dou
     for (int a = 0; a < NJ; a++)
 #pragma unroll
         for (int b = 0; b < MI; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
-    double ra[GK * TM / 256], rb[GK * TN / 256];
-    load_tile<TM>(ra, A, lda, akc, kbeg, i0, k, m);
-    load_tile<TN>(rb, B, ldb, bkc, kbeg, j0, k, n);
+    double ra[GK * TM / NTHR], rb[GK * TN / NTHR];
+    load_tile<TM, NTHR, GK>(ra, A, lda, akc, kbeg, i0, k, m);
+    load_tile<TN, NTHR, GK>(rb, B, ldb, bkc, kbeg, j0, k, n);
     for (int k0 = kbeg; k0 < k; k0 += GK) {
-        store_tile<TM>(ra, As, akc);
-        store_tile<TN>(rb, Bs, bkc);
+        store_tile<TM, NTHR, GK>(ra, As, akc);
+        store_tile<TN, NTHR, GK>(rb, Bs, bkc);
         __syncthreads();
         if (k0 + GK < k) {
-            load_tile<TM>(ra, A, lda, akc, k0 + GK, i0, k, m);
-            load_tile<TN>(rb, B, ldb, bkc, k0 + GK, j0, k, n);
+            load_tile<TM, NTHR, GK>(ra, A, lda, akc, k0 + GK, i0, k, m);
+            load_tile<TN, NTHR, GK>(rb, B, ldb, bkc, k0 + GK, j0, k, n);
         }
 #pragma unroll
         for (int k4 = 0; k4 < GK; k4 += 4) {
@@ -87,7 +91,7 @@ k_dgemm(int ta, int tb, int m, int n, int kfull, int kc, double alpha, const dou
 #pragma unroll
             for (int b = 0; b < MI; b++) af[b] = As[k4 + (lane >> 4)][wm * (TM / 2) + b * 16 + (lane & 15)];
 #pragma unroll
-            for (int a = 0; a < NJ; a++) bf[a] = Bs[k4 + (lane >> 4)][wn * (TN / 2) + a * 16 + (lane & 15)];
+            for (int a = 0; a < NJ; a++) bf[a] = Bs[k4 + (lane >> 4)][wn * (TN / WN) + a * 16 + (lane & 15)];
 #pragma unroll
             for (int a = 0; a < NJ; a++)
 #pragma unroll
@@ -103,7 +107,7 @@ k_dgemm(int ta, int tb, int m, int n, int kfull, int kc, double alpha, const dou
             const int i = i0 + wm * (TM / 2) + b * 16 + (lane & 15);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int j = j0 + wn * (TN / 2) + a * 16 + (lane >> 4) + 4 * r;
+                const int j = j0 + wn * (TN / WN) + a * 16 + (lane >> 4) + 4 * r;
                 if (i < m && j < n) {
                     double *c = C + i + (long long)j * ldc;
                     const double v = alpha * acc[a][b][r];
@@ -147,16 +151,33 @@ static hipError_t dgemm_ws(bool transA, bool transB, int m, int n, int k, double
         if (splits < 2) splits = 1;
     }
     int kc = k;
-    if (splits > 1) { kc = ((k + splits - 1) / splits + GK - 1) / GK * GK; splits = (k + kc - 1) / kc; }
+    if (splits > 1) { kc = ((k + splits - 1) / splits + 31) / 32 * 32; splits = (k + kc - 1) / kc; }
     dim3 grid(bx, by, splits);
     double *Cout = splits > 1 ? ws : C;
     const long long ldo = splits > 1 ? m : ldc;
     const double al = splits > 1 ? 1.0 : alpha, be = splits > 1 ? 0.0 : beta;
-#define GEMM_LAUNCH(a, b) hipLaunchKernelGGL((k_dgemm<a, b>), grid, dim3(256), 0, st, ta, tb, m, n, k, kc, al, A, lda, B, ldb, be, Cout, ldo)
-    if (TM == 128 && TN == 128) GEMM_LAUNCH(128, 128);
-    else if (TM == 64 && TN == 128) GEMM_LAUNCH(64, 128);
-    else if (TM == 128 && TN == 64) GEMM_LAUNCH(128, 64);
-    else GEMM_LAUNCH(64, 64);
+    static const int nw_big = getenv("RSQP_GEMM_WAVES") ? atoi(getenv("RSQP_GEMM_WAVES")) : 8;
+#define GEMM_LAUNCH(a, b, nw, mw, gk)                                                                              \
+    do {                                                                                                           \
+        const size_t lds_ = sizeof(double) * gk * ((a + GPAD) + (b + GPAD));                                       \
+        static bool set_ = false;                                                                                  \
+        if (!set_) {                                                                                               \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dgemm<a, b, nw, mw, gk>),                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                      \
+            set_ = true;                                                                                           \
+        }                                                                                                          \
+        hipLaunchKernelGGL((k_dgemm<a, b, nw, mw, gk>), grid, dim3(nw * 64), lds_, st, ta, tb, m, n, k, kc, al, A, \
+                           lda, B, ldb, be, Cout, ldo);                                                            \
+    } while (0)
+    if (TM == 128 && TN == 128) {
+        // measured on 4096^3: 8 waves (4 resident per SIMD, 122 VGPRs) 53.5 TFLOP/s; 4 waves x 2 resident
+        // 51.5; 4 waves x 1 resident (the compiler's default allocation) 37.8; K step 32 is slower (spills)
+        if (nw_big == 8) GEMM_LAUNCH(128, 128, 8, 4, 16);
+        else GEMM_LAUNCH(128, 128, 4, 2, 16);
+    }
+    else if (TM == 64 && TN == 128) GEMM_LAUNCH(64, 128, 4, 3, 16);
+    else if (TM == 128 && TN == 64) GEMM_LAUNCH(128, 64, 4, 3, 16);
+    else GEMM_LAUNCH(64, 64, 4, 4, 16);
 #undef GEMM_LAUNCH
     if (splits > 1) {
         const long long tot = (long long)m * n;
