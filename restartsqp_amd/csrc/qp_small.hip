@@ -33,16 +33,17 @@
 // A workgroup is ONE wave: LDS instructions of a wave execute in program order, so making a
 // write visible to the other lanes only needs the compiler to keep the order (no s_barrier,
 // which would also be illegal inside the per-problem divergent control flow of packed waves).
-#ifdef RSQP_SYNC_BARRIER  // diagnostic: only legal while all problems of a wave run in lockstep
-#define SYNC() __syncthreads()
-#else
-#define SYNC()                                               \
-    do {                                                     \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-        __builtin_amdgcn_wave_barrier();                     \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+// (L > 64: a problem owns several waves of its workgroup -- a real barrier.)
+#define SYNC()                                                   \
+    do {                                                         \
+        if constexpr (L > 64) {                                  \
+            __syncthreads();                                     \
+        } else {                                                 \
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+            __builtin_amdgcn_wave_barrier();                     \
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+        }                                                        \
     } while (0)
-#endif
 #define PFOR(i, n) for (int i = lane; i < (n); i += L)
 // LDS-qualified pointer types: guarantees ds_read / ds_write (a generic pointer would be
 // lowered to flat_load, which is several times slower and costs two registers)
@@ -102,6 +103,7 @@ struct Engine {
     ldouble *scal;  // 8 scalars for broadcasts
     lint *Sb, *Sc, *AC, *posAC;
     lint *iscal;    // 8 ints
+    static constexpr bool DENSE_MATS = false;
     // uniform over the L lanes of the problem
     int lane;
     int nFR, nAC, status, infeasible, unbounded, nflips;
@@ -126,7 +128,7 @@ struct Engine {
         y = p; p += nV + nC;
         dy = p; p += nV + nC;
         scal = p; p += 8;
-        lint *ip = (lint *)p;
+        lint *ip = (lint *)((ldouble *)base + rsqp_image_doubles(nV, nC));   // behind the explicit-inverse engine's extras
         Sb = ip; ip += nV;
         Sc = ip; ip += nC;
         AC = ip; ip += nC;
@@ -909,6 +911,7 @@ struct Engine {
         PFOR(i, nC) if (lbAN[i] > ubAN[i] + RSQP_EPS) bad += 1.0;
         return block_sum(bad) > 0.0;
     }
+    __device__ __forceinline__ void restore(int nFR_, int nAC_, int status_) { nFR = nFR_; nAC = nAC_; status = status_; }
 
     __device__ __forceinline__ double objective() {
         H_times(x, wv2);
@@ -916,6 +919,8 @@ struct Engine {
         return 0.5 * (a - hreg * c) + b;
     }
 };
+
+#include "qp_small_x.h"
 
 // ------------------------------------------------------------------------------------
 // bytes of LDS needed to stage the sparse matrices of one problem behind its image
@@ -926,17 +931,17 @@ __host__ __device__ inline long long mat_lds_bytes(int nV, int nC, int annz, int
 
 // L = lanes per problem (64 / L problems share one wave; each owns `stride` bytes of LDS),
 // W = minimum waves per SIMD the register allocator has to leave room for
-template <int L, bool MAT_LDS, int W>
-__global__ void __launch_bounds__(64, W)
+template <class ENG, int L, bool MAT_LDS, int W>
+__global__ void __launch_bounds__(L > 64 ? L : 64, W)
 small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
-    const int lane = L == 64 ? (int)threadIdx.x : (int)threadIdx.x & (L - 1);
-    const int grp = L == 64 ? 0 : (int)threadIdx.x / L;  // L == 64: everything below stays wave-uniform
-    const int q = blockIdx.x * (64 / L) + grp;
+    const int lane = L >= 64 ? (int)threadIdx.x : (int)threadIdx.x & (L - 1);
+    const int grp = L >= 64 ? 0 : (int)threadIdx.x / L;  // L >= 64: everything below stays workgroup-uniform
+    const int q = L >= 64 ? (int)blockIdx.x : blockIdx.x * (64 / L) + grp;
     if (q >= nq) return;  // no workgroup barrier anywhere below: idle groups may leave
     lchar *smem = (lchar *)smem_generic + grp * stride;
     const QPDesc d = P.desc[q];
-    Engine<L, MAT_LDS> E;
+    ENG E;
     E.lane = lane;
 #ifdef RSQP_STAMPS
     E.tlast = clock64();
@@ -950,7 +955,9 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
     const int *gAjc = P.Ajc + d.offAjc, *gAir = P.Air + d.offAnz, *gArp = P.Arp + d.offArp, *gAci = P.Aci + d.offAnz;
     const int *gHjc = P.Hjc + d.offHjc, *gHir = P.Hir + d.offHnz;
     const double *gAval = P.Aval + d.offAnz, *gArv = P.Arv + d.offAnz, *gHval = P.Hval + d.offHnz;
-    if constexpr (MAT_LDS) {
+    if constexpr (ENG::DENSE_MATS) {
+        E.stage_dense(smem + img_bytes, gAjc, gAir, gAval, gHjc, gHir, gHval);
+    } else if constexpr (MAT_LDS) {
         // stage CSC(A), CSR(A), CSC(H) behind the image
         const int annz = gAjc[d.nV], hnnz = d.haveH ? gHjc[d.nV] : 0;
         lint *ip0 = (lint *)(smem + img_bytes), *ip = ip0;
@@ -990,7 +997,7 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
         for (int k = lane; k < nd; k += L) simg[k] = img[k];
         for (int k = lane; k < ni; k += L) siimg[k] = iimg[k];
         SYNC();
-        E.nFR = E.iscal[1]; E.nAC = E.iscal[2]; E.status = E.iscal[3];
+        E.restore(E.iscal[1], E.iscal[2], E.iscal[3]);
         SYNC();
         if (E.status == QPS_NOTINITIALISED) mode = 0;
     }
@@ -1062,6 +1069,13 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     if (nq <= 0) return hipSuccess;
     const long long img = align16(rsqp_image_bytes(nVmax, nCmax));
     if (img > kMaxLds) return hipErrorInvalidValue;
+    // formulation: 0 = Givens / TQ (Engine), 1 = explicit inverses (EngineX, qp_small_x.h), which keeps
+    // DENSE copies of A and H in LDS. Measured per shape on the 512-QP hs0xx batch (ms, TQ vs explicit):
+    // 5x1 0.14 / 0.16, 8x2 0.045 / 0.051, 8x3 0.25 / 0.21, 12x4 0.49 / 0.42, 16x6 0.73 / 0.55,
+    // 23x6 1.26 / 1.01, 37x14 2.57 / 1.51, 69x28 10.8 / 4.1 -- the chains of the TQ form grow with nZ.
+    static const int forcedE = env_int("RSQP_SMALL_ENGINE", -1);
+    const int eng = forcedE == 0 || forcedE == 1 ? forcedE : (nVmax > 8 ? 1 : 0);
+    if (eng == 1 && mat_bytes_max >= 0) mat_bytes_max = 8LL * ((long long)nVmax * nVmax + (long long)nCmax * nVmax);
     const bool mat_lds = mat_bytes_max >= 0 && img + align16(mat_bytes_max) <= kMaxLds;
     // LDS of one problem; an odd number of 16-byte units spreads the problems that share a wave
     // over the banks
@@ -1085,24 +1099,33 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     // Packed builds with W=6 (80 VGPRs, ~180 spilled) returned wrong results and are not built.
     int waves = L == 64 ? (nVmax <= 16 ? 6 : 4) : 2;
     if (forcedW >= 2 && forcedW <= (L == 64 ? 6 : 4)) waves = forcedW;
-#define SQ_LAUNCH(LL, ML, W)                                                                                  \
+#define SQ_LAUNCH_E(ENG, LL, ML, W)                                                                           \
     do {                                                                                                      \
         static bool set_ = false;                                                                             \
         if (!set_) {                                                                                          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&small_qp_kernel<LL, ML, W>),            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&small_qp_kernel<ENG<LL, ML>, LL, ML, W>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);              \
             set_ = true;                                                                                      \
         }                                                                                                     \
-        hipLaunchKernelGGL((small_qp_kernel<LL, ML, W>), dim3(nblk), dim3(64), lds, stream, p, nq,            \
+        hipLaunchKernelGGL((small_qp_kernel<ENG<LL, ML>, LL, ML, W>), dim3(nblk), dim3(LL > 64 ? LL : 64), lds, stream, p, nq, \
                            (int)stride, mode, maxWSR);                                                        \
     } while (0)
+#define SQ_LAUNCH(LL, ML, W) SQ_LAUNCH_E(Engine, LL, ML, W)
 #define SQ_WAVES(LL)                                                                                          \
     switch (waves) {                                                                                          \
     case 3: SQ_LAUNCH(LL, true, 3); break;                                                                    \
     case 4: SQ_LAUNCH(LL, true, 4); break;                                                                    \
     default: SQ_LAUNCH(LL, true, 2); break;                                                                   \
     }
-    if (!mat_lds) {
+    static const int forcedWide = env_int("RSQP_SMALL_WIDE", -1);
+    const bool wide = forcedWide >= 0 ? forcedWide != 0 : nVmax > 32;
+    if (eng == 1) {
+        if (!mat_lds) SQ_LAUNCH_E(EngineX, 64, false, 3);
+        else if (L == 16) SQ_LAUNCH_E(EngineX, 16, true, 2);
+        else if (L == 32) SQ_LAUNCH_E(EngineX, 32, true, 2);
+        else if (wide) SQ_LAUNCH_E(EngineX, 256, true, 1);   // four waves per problem: the O(n^2) phases split over 256 lanes
+        else SQ_LAUNCH_E(EngineX, 64, true, 4);
+    } else if (!mat_lds) {
         SQ_LAUNCH(64, false, 3);
     } else if (L == 16) {
         SQ_WAVES(16)
@@ -1115,6 +1138,7 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
         default: SQ_LAUNCH(64, true, 4); break;
         }
     }
+#undef SQ_LAUNCH_E
 #undef SQ_WAVES
 #undef SQ_LAUNCH
     return hipGetLastError();

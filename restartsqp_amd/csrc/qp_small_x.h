@@ -1,0 +1,822 @@
+// qp_small_x.h -- included by qp_small.hip inside its anonymous namespace.
+//
+// EngineX: the LDS-resident engine in the EXPLICIT-INVERSE formulation of qp_large.hip
+// (orthonormal Z / Y, Minv = (A_AC,FR Y)^-1, Wz = (Z'HZ)^-1, one Householder reflection aimed at
+// the last column per working-set change, Sherman-Morrison / bordering updates of the inverses,
+// every solve a GEMV). Same homotopy, ratio tests, tie breaks and guards as Engine (the Givens /
+// TQ formulation) and the CPU restatement -- step directions do not depend on the bases -- but nothing in
+// an iteration is a sequential chain of length nZ: a Givens sweep or a triangular solve costs
+// ~300 cycles of LDS round trips per step, a GEMV of the same size a handful of pipelined loads
+// per lane. Used for problems with more than a few variables, where those chains dominate.
+// Formulas: see the kernels of qp_large.hip (k_house, k_wz_*, k_minv_border, k_house_unit,
+// k_house_free, k_sm_coef), which this file restates for one wave working in LDS.
+
+template <int L, bool MAT_LDS>
+struct EngineX {
+    typedef typename MatPtr<MAT_LDS>::I MI;
+    typedef typename MatPtr<MAT_LDS>::D MD;
+    int nV, nC, ld, ldy, sizeT, ldm, haveH;
+    double hreg;
+    MI Ajc, Air; MD Aval;
+    MI Arp, Aci; MD Arv;
+    MI Hjc, Hir; MD Hval;
+    static constexpr bool DENSE_MATS = MAT_LDS;   // A and H as dense column-major copies in LDS
+    ldouble *Ad, *Hd;                             // nC x nV (ld nC), nV x nV (ld nV)
+    ldouble *Z, *Wz, *Y, *Minv;
+    ldouble *x, *g, *lb, *ub, *gN, *lbN, *ubN, *dx, *w1, *w2, *w3, *w4, *w5, *w6, *wz1, *wz2, *wz3;
+    ldouble *Ax, *lbA, *ubA, *lbAN, *ubAN, *dAx, *c1, *c2, *c3;
+    ldouble *a1, *a2, *a3, *a4;
+    ldouble *y, *dy, *scal;
+    ldouble *wq, *wv4, *wc1;   // staging aliases used by the kernel wrapper (guess / x0 / guessed constraints)
+    lint *Sb, *Sc, *AC, *posAC, *iscal;
+    int lane;
+    int nFR, nAC, nZ, status, infeasible, unbounded, nflips;
+    long long tlast;
+
+    __device__ __forceinline__ void carve(lchar *base, int nV_, int nC_) {
+        nV = nV_; nC = nC_; ld = rsqp_ld(nV); sizeT = nV < nC ? nV : nC; ldm = sizeT | 1;
+        ldouble *p = (ldouble *)base;
+        Z = p; p += ld * nV;
+        Wz = p; p += ld * nV;
+        // Y shares Z's array: column j of Y is column nV-1-j of that array (nZ + nAC <= nV, so the two
+        // never meet); the T slot of the image (sizeT * ld doubles) holds Minv and the four a-vectors
+        Y = Z + (nV - 1) * ld; ldy = -ld;
+        ldouble *tslot = p; p += sizeT * ld;
+#define CARVE_V(name) name = p; p += nV
+        CARVE_V(x); CARVE_V(g); CARVE_V(lb); CARVE_V(ub); CARVE_V(gN); CARVE_V(lbN); CARVE_V(ubN);
+        CARVE_V(dx); CARVE_V(w1); CARVE_V(w2); CARVE_V(w3); CARVE_V(w4); CARVE_V(w5); CARVE_V(w6);
+        CARVE_V(wz1); CARVE_V(wz2); CARVE_V(wz3);
+#undef CARVE_V
+        p += nV;   // the image holds 18 vectors of nV
+#define CARVE_C(name) name = p; p += nC
+        CARVE_C(Ax); CARVE_C(lbA); CARVE_C(ubA); CARVE_C(lbAN); CARVE_C(ubAN); CARVE_C(dAx); CARVE_C(c1); CARVE_C(c2); CARVE_C(c3);
+#undef CARVE_C
+        y = p; p += nV + nC;
+        dy = p; p += nV + nC;
+        scal = p; p += 8;
+        Minv = tslot;                      // sizeT * ldm <= sizeT * ld
+        a1 = p; p += sizeT + 2; a2 = p; p += sizeT + 2; a3 = p; p += sizeT + 2; a4 = p; p += sizeT + 2;
+        lint *ip = (lint *)((ldouble *)base + rsqp_image_doubles(nV, nC));
+        Sb = ip; ip += nV;
+        Sc = ip; ip += nC;
+        AC = ip; ip += nC;
+        posAC = ip; ip += nC;
+        iscal = ip; ip += 8;
+        wq = wz1; wv4 = w4; wc1 = c1;
+        nZ = 0;
+    }
+
+    // dense copies of the matrices behind the image (hs0xx-scale problems: they are small, and a dense
+    // product is a run of independent loads where the compressed formats chain index -> value -> gather)
+    __device__ __forceinline__ void stage_dense(lchar *mem, const int *gAjc, const int *gAir, const double *gAval,
+                                                const int *gHjc, const int *gHir, const double *gHval) {
+        Ad = (ldouble *)mem;
+        Hd = Ad + nC * nV;
+        for (int k = lane; k < nC * nV + nV * nV; k += L) Ad[k] = 0.0;
+        SYNC();
+        PFOR(c, nV) {
+            for (int k = gAjc[c]; k < gAjc[c + 1]; k++) Ad[gAir[k] + c * nC] = gAval[k];
+            if (haveH)
+                for (int k = gHjc[c]; k < gHjc[c + 1]; k++) Hd[gHir[k] + c * nV] = gHval[k];
+        }
+        SYNC();
+    }
+
+    // ------------------------------------------------------------------ reductions
+    // butterflies over the lanes of the problem; with several waves (L > 64) the wave results meet
+    // in `scal` / `iscal[4..]` and are combined in wave order, so every lane ends with the same value
+    __device__ __forceinline__ double block_sum(double v) {
+#pragma unroll
+        for (int o = (L > 64 ? 64 : L) / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if constexpr (L > 64) {
+            __syncthreads();
+            if ((lane & 63) == 0) scal[lane >> 6] = v;
+            __syncthreads();
+            v = 0.0;
+#pragma unroll
+            for (int w = 0; w < L / 64; w++) v += scal[w];
+        }
+        return v;
+    }
+    __device__ __forceinline__ void block_argmin(double &t, int &id) {
+#pragma unroll
+        for (int o = (L > 64 ? 64 : L) / 2; o > 0; o >>= 1) {
+            double t2 = __shfl_xor(t, o);
+            int id2 = __shfl_xor(id, o);
+            if (t2 < t || (t2 == t && id2 < id)) { t = t2; id = id2; }
+        }
+        if constexpr (L > 64) {
+            __syncthreads();
+            if ((lane & 63) == 0) { scal[lane >> 6] = t; iscal[4 + (lane >> 6)] = id; }
+            __syncthreads();
+            t = scal[0]; id = iscal[4];
+#pragma unroll
+            for (int w = 1; w < L / 64; w++) {
+                const double t2 = scal[w]; const int id2 = iscal[4 + w];
+                if (t2 < t || (t2 == t && id2 < id)) { t = t2; id = id2; }
+            }
+        }
+    }
+    __device__ __forceinline__ double dot(const ldouble *a, const ldouble *b, int n) {
+        double s = 0.0;
+        PFOR(i, n) s += a[i] * b[i];
+        return block_sum(s);
+    }
+
+    // ------------------------------------------------------------------ dense building blocks (column-major)
+    // out[c] = sum_r M[c*l + r] * xv[r]      (lane per column). Eight rows per trip: their 16 LDS reads
+    // are issued before the first multiply, four independent partial sums.
+    __device__ __forceinline__ void gemv_t(const ldouble *M, int l, int nrows, int ncols, const ldouble *xv, ldouble *out) {
+        PFOR(c, ncols) {
+            const ldouble *col = M + c * l;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int r = 0;
+            for (; r + 8 <= nrows; r += 8) {
+                double m[8], xx[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { m[u] = col[r + u]; xx[u] = xv[r + u]; }
+                s0 += m[0] * xx[0]; s1 += m[1] * xx[1]; s2 += m[2] * xx[2]; s3 += m[3] * xx[3];
+                s0 += m[4] * xx[4]; s1 += m[5] * xx[5]; s2 += m[6] * xx[6]; s3 += m[7] * xx[7];
+            }
+            for (; r < nrows; r++) s0 += col[r] * xv[r];
+            out[c] = (s0 + s1) + (s2 + s3);
+        }
+        SYNC();
+    }
+    // out[r] = beta * base[r] + alpha * sum_c M[c*l + r] * wv[c]     (lane per row)
+    __device__ __forceinline__ void gemv_n(const ldouble *M, int l, int nrows, int ncols, const ldouble *wv, double alpha,
+                                           double beta, const ldouble *base, ldouble *out) {
+        PFOR(r, nrows) {
+            const ldouble *row = M + r;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int c = 0;
+            for (; c + 8 <= ncols; c += 8) {
+                double m[8], ww[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { m[u] = row[(c + u) * l]; ww[u] = wv[c + u]; }
+                s0 += m[0] * ww[0]; s1 += m[1] * ww[1]; s2 += m[2] * ww[2]; s3 += m[3] * ww[3];
+                s0 += m[4] * ww[4]; s1 += m[5] * ww[5]; s2 += m[6] * ww[6]; s3 += m[7] * ww[7];
+            }
+            for (; c < ncols; c++) s0 += row[c * l] * wv[c];
+            out[r] = (base ? beta * base[r] : 0.0) + alpha * ((s0 + s1) + (s2 + s3));
+        }
+        SYNC();
+    }
+    // M[c*l + r] += coef * t[r] * v[c]
+    __device__ __forceinline__ void ger(ldouble *M, int l, int nrows, int ncols, const ldouble *t, const ldouble *v, double coef) {
+        PFOR(r, nrows) {
+            ldouble *row = M + r;
+            const double tr = coef * t[r];
+            int c = 0;
+            for (; c + 8 <= ncols; c += 8) {
+                double m[8], vv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { m[u] = row[(c + u) * l]; vv[u] = v[c + u]; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) row[(c + u) * l] = m[u] + tr * vv[u];
+            }
+            for (; c < ncols; c++) row[c * l] += tr * v[c];
+        }
+        SYNC();
+    }
+    __device__ __forceinline__ void copyv(const ldouble *src, ldouble *dst, int n) {
+        PFOR(i, n) dst[i] = src[i];
+        SYNC();
+    }
+    __device__ __forceinline__ ldouble *Zc(int c) { return Z + c * ld; }
+    __device__ __forceinline__ ldouble *Yc(int c) { return Y + c * ldy; }
+
+    // ------------------------------------------------------------------ sparse products
+    template <class IP, class DP>
+    __device__ __forceinline__ static double sparse_dot(IP idx, DP val, const ldouble *v, int k0, int k1) {
+        double s = 0.0;
+        int k = k0;
+        for (; k + 4 <= k1; k += 4) {
+            const int i0 = idx[k], i1 = idx[k + 1], i2 = idx[k + 2], i3 = idx[k + 3];
+            const double b0 = val[k], b1 = val[k + 1], b2 = val[k + 2], b3 = val[k + 3];
+            const double v0 = v[i0], v1 = v[i1], v2 = v[i2], v3 = v[i3];
+            s += b0 * v0; s += b1 * v1; s += b2 * v2; s += b3 * v3;
+        }
+        for (; k < k1; k++) s += val[k] * v[idx[k]];
+        return s;
+    }
+    __device__ __forceinline__ void A_times(const ldouble *v, ldouble *out) {
+        if constexpr (DENSE_MATS) { gemv_n(Ad, nC, nC, nV, v, 1.0, 0.0, nullptr, out); return; }
+        PFOR(r, nC) out[r] = sparse_dot(Aci, Arv, v, Arp[r], Arp[r + 1]);
+        SYNC();
+    }
+    __device__ __forceinline__ void AT_times(const ldouble *yc, ldouble *out) {
+        if constexpr (DENSE_MATS) { gemv_t(Ad, nC, nC, nV, yc, out); return; }
+        PFOR(c, nV) out[c] = sparse_dot(Air, Aval, yc, Ajc[c], Ajc[c + 1]);
+        SYNC();
+    }
+    __device__ __forceinline__ void H_times(const ldouble *v, ldouble *out) {
+        if constexpr (DENSE_MATS) {
+            gemv_t(Hd, nV, nV, nV, v, out);        // H is symmetric: column sums = row sums
+            if (hreg != 0.0) { PFOR(c, nV) out[c] += hreg * v[c]; SYNC(); }
+            return;
+        }
+        PFOR(c, nV) {
+            const double s = haveH ? sparse_dot(Hir, Hval, v, Hjc[c], Hjc[c + 1]) : 0.0;
+            out[c] = s + hreg * v[c];
+        }
+        SYNC();
+    }
+    __device__ __forceinline__ void row_of_A(int i, ldouble *a, bool all) {
+        if constexpr (DENSE_MATS) {
+            PFOR(v, nV) a[v] = (all || Sb[v] == 0) ? Ad[i + v * nC] : 0.0;
+            SYNC();
+            return;
+        }
+        PFOR(v, nV) a[v] = 0.0;
+        SYNC();
+        for (int k = Arp[i] + lane; k < Arp[i + 1]; k += L) {
+            int c = Aci[k];
+            if (all || Sb[c] == 0) a[c] = Arv[k];
+        }
+        SYNC();
+    }
+
+    // ------------------------------------------------------------------ Householder onto the LAST component
+    // v = w, v[n-1] += sgn(w[n-1]) |w|; beta = 1 / (|w| (|w| + |w[n-1]|)); P = I - beta v v' maps w to sgi |w| e_last
+    __device__ __forceinline__ void house(const ldouble *w, int n, ldouble *v, double &alpha, double &beta, double &sgi) {
+        const double s = dot(w, w, n);
+        alpha = sqrt(s);
+        const double wl = n > 0 ? w[n - 1] : 0.0, sg = wl >= 0.0 ? 1.0 : -1.0;
+        SYNC();
+        PFOR(i, n) v[i] = w[i] + (i == n - 1 ? sg * alpha : 0.0);
+        beta = alpha > 0.0 ? 1.0 / (alpha * (alpha + fabs(wl))) : 0.0;
+        sgi = -sg;
+        SYNC();
+    }
+
+    // reflection of Z that puts the direction Z w (w = wz1, length nZ) into the last column; Wz follows
+    // and loses its last row / column. Returns |w| and the sign of the image.
+    __device__ __forceinline__ void z_reflect_and_shrink(bool wz_enabled, double &alpha, double &sgi) {
+        double beta;
+        house(wz1, nZ, wz2, alpha, beta, sgi);
+        gemv_n(Z, ld, nV, nZ, wz2, 1.0, 0.0, nullptr, w5);        // t = Z v
+        ger(Z, ld, nV, nZ, w5, wz2, -beta);                       // Z -= beta t v'
+        if (!wz_enabled) return;
+        gemv_n(Wz, ld, nZ, nZ, wz2, 1.0, 0.0, nullptr, wz3);      // s = Wz v
+        const double theta = dot(wz2, wz3, nZ);
+        const int l = nZ - 1;
+        const double vl = wz2[l], sl = wz3[l];
+        PFOR(a, nZ) w6[a] = Wz[l * ld + a] - beta * wz3[a] * vl - beta * wz2[a] * sl + beta * beta * theta * wz2[a] * vl;
+        SYNC();
+        const double w22 = w6[l];
+        PFOR(a, l) {
+            // one division per row (the HBM engine divides per element; same value up to rounding)
+            const double sa = beta * wz3[a], va = beta * wz2[a], vt = beta * beta * theta * wz2[a], cw = w6[a] / w22;
+            for (int b = 0; b < l; b++)
+                Wz[b * ld + a] += -sa * wz2[b] - va * wz3[b] + vt * wz2[b] - cw * w6[b];
+        }
+        SYNC();
+    }
+
+    // new row nAC: -(wY' Minv)/eta ; new column nAC: 0 ; corner 1/eta   (wY in a1)
+    __device__ __forceinline__ void minv_append(double eta) {
+        gemv_t(Minv, ldm, nAC, nAC, a1, a2);
+        PFOR(j, nAC + 1) {
+            if (j < nAC) { Minv[j * ldm + nAC] = -a2[j] / eta; Minv[nAC * ldm + j] = 0.0; }
+            else Minv[nAC * ldm + nAC] = 1.0 / eta;
+        }
+        SYNC();
+    }
+
+    // products of constraint row r with the bases: w1 = a_FR, wz1 = Z'a, a1 = Y'a (rows of fixed
+    // variables are zero in both bases, so the sparse row is used as it is)
+    __device__ __forceinline__ void constraint_products(int r, double &na2, double &wz2n) {
+        row_of_A(r, w1, false);
+        if constexpr (DENSE_MATS) {
+            gemv_t(Z, ld, nV, nZ, w1, wz1);
+            gemv_t(Y, ldy, nV, nAC, w1, a1);
+        } else {
+            const int k0 = Arp[r], k1 = Arp[r + 1];
+            PFOR(c, nZ) wz1[c] = sparse_dot(Aci, Arv, Zc(c), k0, k1);
+            PFOR(c, nAC) a1[c] = sparse_dot(Aci, Arv, Yc(c), k0, k1);
+            SYNC();
+        }
+        na2 = dot(w1, w1, nV);
+        wz2n = dot(wz1, wz1, nZ);
+    }
+    __device__ __forceinline__ void bound_products(int v, double &na2, double &wz2n) {
+        PFOR(c, nZ) wz1[c] = Z[c * ld + v];
+        PFOR(c, nAC) a1[c] = Y[c * ldy + v];
+        SYNC();
+        na2 = 1.0;
+        wz2n = dot(wz1, wz1, nZ);
+    }
+    __device__ __forceinline__ bool is_LI(double na2, double wz2n) {
+        return nZ > 0 && na2 > 0.0 && sqrt(wz2n) > RSQP_EPS_LI * sqrt(na2);
+    }
+
+    // prerequisites: constraint_products(r). skipZ: exchange / flip -- the row is orthogonal to all
+    // null-space columns but the last, which becomes the new Y column as it is
+    __device__ __forceinline__ void add_constraint(int r, int side, bool skipZ, bool wz_enabled) {
+        double eta;
+        if (!skipZ) {
+            double alpha, sgi;
+            z_reflect_and_shrink(wz_enabled, alpha, sgi);
+            copyv(Zc(nZ - 1), Yc(nAC), nV);
+            eta = sgi * alpha;
+        } else {
+            copyv(Zc(nZ - 1), Yc(nAC), nV);
+            eta = dot(w1, Zc(nZ - 1), nV);
+        }
+        nZ--;
+        minv_append(eta);
+        if (lane == 0) { AC[nAC] = r; posAC[r] = nAC; Sc[r] = side; }
+        nAC++;
+        SYNC();
+    }
+
+    // prerequisites: bound_products(v)
+    __device__ __forceinline__ void add_bound(int v, int side, bool skipZ) {
+        if (!skipZ) { double alpha, sgi; z_reflect_and_shrink(true, alpha, sgi); }
+        const ldouble *zs = Zc(nZ - 1);
+        nZ--;
+        // q~ = [qY ; q*], |q~| = 1: vt = q~ with last += sgn(q*); beta~ = 1/(1+|q*|); gamma = beta~/|q*|
+        const double qs = zs[v], sg = qs >= 0.0 ? 1.0 : -1.0, aq = fabs(qs);
+        const double beta = 1.0 / (1.0 + aq), gamma = beta / aq, vlast = qs + sg;
+        gemv_n(Y, ldy, nV, nAC, a1, 1.0, 0.0, nullptr, w5);        // t = Y vY
+        PFOR(i, nV) w5[i] += vlast * zs[i];                       //   + zs vlast
+        SYNC();
+        ger(Y, ldy, nV, nAC, w5, a1, -beta);                       // Y -= beta~ t vY'
+        gemv_t(Minv, ldm, nAC, nAC, a1, a2);
+        ger(Minv, ldm, nAC, nAC, a1, a2, gamma);                  // Minv += gamma vY (vY' Minv)
+        PFOR(c, nAC) Y[c * ldy + v] = 0.0;
+        PFOR(c, nZ) Z[c * ld + v] = 0.0;
+        if (lane == 0) Sb[v] = side;
+        nFR--;
+        SYNC();
+    }
+
+    // grow Wz by the null-space column Z[:, nZ]; false = not positive definite (nZ unchanged)
+    __device__ __forceinline__ bool wz_grow() {
+        const ldouble *z = Zc(nZ);
+        H_times(z, w2);
+        const double kappa = dot(z, w2, nV);
+        gemv_t(Z, ld, nV, nZ, w2, wz1);                            // k = Z'Hz
+        gemv_n(Wz, ld, nZ, nZ, wz1, 1.0, 0.0, nullptr, wz2);       // u = Wz k
+        const double ku = nZ > 0 ? dot(wz1, wz2, nZ) : 0.0;
+        const double rho2 = kappa - ku, thr = RSQP_EPS_PD_REL * (fabs(kappa) + fabs(ku)) + RSQP_EPS_PD_ABS;
+        if (!(rho2 > thr)) return false;
+        const double ir2 = 1.0 / rho2;
+        PFOR(a, nZ + 1) {
+            if (a < nZ) {
+                const double ua = wz2[a] / rho2;
+                for (int b = 0; b < nZ; b++) Wz[b * ld + a] += ua * wz2[b];
+                Wz[nZ * ld + a] = -ua;
+            } else {
+                for (int b = 0; b < nZ; b++) Wz[b * ld + nZ] = -(wz2[b] / rho2);
+                Wz[nZ * ld + nZ] = ir2;
+            }
+        }
+        nZ++;
+        SYNC();
+        return true;
+    }
+
+    // Y loses the column that carries constraint position k; it lands in Z[:, nZ]
+    __device__ __forceinline__ void remove_constraint_tq(int k) {
+        const int r = AC[k];
+        SYNC();
+        copyv(Minv + k * ldm, a1, nAC);                            // u = Minv[:, k]
+        double alpha, beta, sgi;
+        house(a1, nAC, a2, alpha, beta, sgi);
+        gemv_n(Y, ldy, nV, nAC, a2, 1.0, 0.0, nullptr, w5);         // t = Y v
+        ger(Y, ldy, nV, nAC, w5, a2, -beta);
+        gemv_t(Minv, ldm, nAC, nAC, a2, a3);                       // s' = v' Minv
+        ger(Minv, ldm, nAC, nAC, a2, a3, -beta);
+        copyv(Yc(nAC - 1), Zc(nZ), nV);
+        if (k != nAC - 1) {
+            copyv(Minv + (nAC - 1) * ldm, Minv + k * ldm, nAC);
+            if (lane == 0) { const int rl = AC[nAC - 1]; AC[k] = rl; posAC[rl] = k; }
+        }
+        if (lane == 0) { posAC[r] = -1; Sc[r] = 0; }
+        nAC--;
+        SYNC();
+    }
+
+    // variable v becomes free: the null space gains the column Z[:, nZ]
+    __device__ __forceinline__ void remove_bound_tq(int v) {
+        if (lane == 0) Sb[v] = 0;
+        nFR++;
+        ldouble *znew = Zc(nZ);
+        PFOR(i, nV) znew[i] = 0.0;
+        PFOR(j, nAC) a4[j] = 0.0;
+        SYNC();
+        if (nAC == 0) {
+            if (lane == 0) znew[v] = 1.0;
+            SYNC();
+            return;
+        }
+        if constexpr (DENSE_MATS) {
+            PFOR(j, nAC) a4[j] = Ad[AC[j] + v * nC];
+        } else {
+            for (int k = Ajc[v] + lane; k < Ajc[v + 1]; k += L) {
+                const int p = posAC[Air[k]];
+                if (p >= 0) a4[p] = Aval[k];
+            }
+        }
+        SYNC();
+        gemv_n(Minv, ldm, nAC, nAC, a4, 1.0, 0.0, nullptr, a1);    // c = Minv a_v
+        const double s = dot(a1, a1, nAC);
+        SYNC();
+        PFOR(i, nAC) a1[i] = -a1[i];                               // vY = -c
+        const double nu = sqrt(1.0 + s), beta = 1.0 / (nu * (nu + 1.0)), vlast = 1.0 + nu;
+        SYNC();
+        gemv_n(Y, ldy, nV, nAC, a1, 1.0, 0.0, nullptr, w5);         // t = Y vY + e_v vlast
+        if (lane == 0) w5[v] += vlast;
+        SYNC();
+        A_times(w5, c3);
+        PFOR(j, nAC) a2[j] = c3[AC[j]];                            // p = A_AC t
+        PFOR(i, nV) znew[i] = (i == v ? 1.0 : 0.0) - beta * w5[i] * vlast;
+        SYNC();
+        ger(Y, ldy, nV, nAC, w5, a1, -beta);
+        gemv_n(Minv, ldm, nAC, nAC, a2, 1.0, 0.0, nullptr, a3);    // q1 = Minv p
+        gemv_t(Minv, ldm, nAC, nAC, a1, a4);                       // q2' = vY' Minv
+        const double d = dot(a1, a3, nAC);
+        ger(Minv, ldm, nAC, nAC, a3, a4, beta / (1.0 - beta * d));
+    }
+
+    // ------------------------------------------------------------------ removal with definiteness guard
+    __device__ __forceinline__ int remove_with_guard(bool is_bound, int idx) {
+        double na2, wz2n;
+        if (is_bound) {
+            const int old = Sb[idx];
+            SYNC();
+            remove_bound_tq(idx);
+            if (lane == 0) y[idx] = 0.0;
+            SYNC();
+            if (wz_grow()) return RET_OK;
+            const bool cant = (old == -1 && ubN[idx] >= RSQP_INFTY) || (old == 1 && lbN[idx] <= -RSQP_INFTY);
+            nZ++;   // the candidate column is still Z[:, nZ]: treat it as the last null-space column
+            bound_products(idx, na2, wz2n);
+            add_bound(idx, cant ? old : -old, true);
+            if (cant) return RET_UNBOUNDED;
+            if (lane == 0) { if (old == -1) ub[idx] = x[idx]; else lb[idx] = x[idx]; }
+            nflips++;
+            SYNC();
+            return RET_OK;
+        } else {
+            const int old = Sc[idx], k = posAC[idx];
+            SYNC();
+            remove_constraint_tq(k);
+            if (lane == 0) y[nV + idx] = 0.0;
+            SYNC();
+            if (wz_grow()) return RET_OK;
+            const bool cant = (old == -1 && ubAN[idx] >= RSQP_INFTY) || (old == 1 && lbAN[idx] <= -RSQP_INFTY);
+            nZ++;
+            constraint_products(idx, na2, wz2n);
+            add_constraint(idx, cant ? old : -old, true, true);
+            if (cant) return RET_UNBOUNDED;
+            if (lane == 0) { if (old == -1) ubA[idx] = Ax[idx]; else lbA[idx] = Ax[idx]; }
+            nflips++;
+            SYNC();
+            return RET_OK;
+        }
+    }
+
+    // ------------------------------------------------------------------ exchange
+    // incoming row in w4 (all variables), its Y-products in a1. Finds the partner, shifts the duals.
+    __device__ __forceinline__ int ensure_LI(int side, double &y_new, int &pkind, int &pidx) {
+        PFOR(i, nC) c1[i] = 0.0;
+        SYNC();
+        gemv_t(Minv, ldm, nAC, nAC, a1, a2);                       // xi[j] = sum_i Minv[i][j] wY[i]
+        PFOR(j, nAC) c1[AC[j]] = a2[j];
+        SYNC();
+        AT_times(c1, w2);
+        PFOR(v, nV) w3[v] = Sb[v] != 0 ? w4[v] - w2[v] : 0.0;      // xiB
+        SYNC();
+        const double sgn = side == 1 ? -1.0 : 1.0;
+        double bt = RSQP_INFTY;
+        int bid = 0x7fffffff;
+        PFOR(i, nC) {
+            if (Sc[i] != 0) {
+                double xi = sgn * c1[i], yi = y[nV + i];
+                double num = Sc[i] == -1 ? yi : -yi, den = Sc[i] == -1 ? xi : -xi;
+                if (den > RSQP_EPS_DEN) {
+                    double t = (num > 0.0 ? num : 0.0) / den;
+                    if (t < bt || (t == bt && i < bid)) { bt = t; bid = i; }
+                }
+            }
+        }
+        PFOR(v, nV) {
+            if (Sb[v] != 0) {
+                double xi = sgn * w3[v], yi = y[v];
+                double num = Sb[v] == -1 ? yi : -yi, den = Sb[v] == -1 ? xi : -xi;
+                if (den > RSQP_EPS_DEN) {
+                    double t = (num > 0.0 ? num : 0.0) / den;
+                    if (t < bt || (t == bt && nC + v < bid)) { bt = t; bid = nC + v; }
+                }
+            }
+        }
+        block_argmin(bt, bid);
+        if (bid == 0x7fffffff) return RET_INFEASIBLE;
+        PFOR(i, nC) if (Sc[i] != 0) y[nV + i] -= bt * sgn * c1[i];
+        PFOR(v, nV) if (Sb[v] != 0) y[v] -= bt * sgn * w3[v];
+        SYNC();
+        y_new = sgn * bt;
+        pkind = bid < nC ? 1 : 2;
+        pidx = bid < nC ? bid : bid - nC;
+        return RET_OK;
+    }
+
+    __device__ __forceinline__ int change_active_set(const Blocking &b) {
+        if (b.kind == 1) return remove_with_guard(false, b.idx);
+        if (b.kind == 2) return remove_with_guard(true, b.idx);
+        if (b.kind == 3 || b.kind == 4) {
+            double ynew = 0.0, na2, wz2n;
+            bool full = true;
+            if (b.kind == 3) constraint_products(b.idx, na2, wz2n); else bound_products(b.idx, na2, wz2n);
+            if (!is_LI(na2, wz2n)) {
+                int pkind = 0, pidx = -1;
+                if (b.kind == 3) row_of_A(b.idx, w4, true);
+                else { PFOR(v, nV) w4[v] = v == b.idx ? 1.0 : 0.0; SYNC(); }
+                const int rc_ = ensure_LI(b.side, ynew, pkind, pidx);
+                if (rc_ != RET_OK) return rc_;
+                if (pkind == 1) {
+                    const int k = posAC[pidx];
+                    SYNC();
+                    remove_constraint_tq(k);
+                    if (lane == 0) y[nV + pidx] = 0.0;
+                } else {
+                    remove_bound_tq(pidx);
+                    if (lane == 0) y[pidx] = 0.0;
+                }
+                SYNC();
+                full = wz_grow();
+                if (!full) nZ++;   // keep the candidate column as the last null-space column
+                if (b.kind == 3) constraint_products(b.idx, na2, wz2n); else bound_products(b.idx, na2, wz2n);
+            }
+            if (b.kind == 3) {
+                add_constraint(b.idx, b.side, !full, true);
+                if (lane == 0) y[nV + b.idx] = ynew;
+            } else {
+                add_bound(b.idx, b.side, !full);
+                if (lane == 0) y[b.idx] = ynew;
+            }
+            SYNC();
+        }
+        return RET_OK;
+    }
+
+    // ------------------------------------------------------------------ auxiliary QP
+    __device__ __forceinline__ static double clampinf(double v) {
+        return v > RSQP_INFTY ? RSQP_INFTY : (v < -RSQP_INFTY ? -RSQP_INFTY : v);
+    }
+    __device__ __forceinline__ void store_targets(const double *g_, const double *lb_, const double *ub_,
+                                                  const double *lbA_, const double *ubA_) {
+        PFOR(v, nV) { gN[v] = g_[v]; lbN[v] = clampinf(lb_[v]); ubN[v] = clampinf(ub_[v]); }
+        PFOR(i, nC) { lbAN[i] = clampinf(lbA_[i]); ubAN[i] = clampinf(ubA_[i]); }
+        SYNC();
+    }
+    __device__ __forceinline__ bool bounds_inconsistent() {
+        double bad = 0.0;
+        PFOR(v, nV) if (lbN[v] > ubN[v] + RSQP_EPS) bad += 1.0;
+        PFOR(i, nC) if (lbAN[i] > ubAN[i] + RSQP_EPS) bad += 1.0;
+        return block_sum(bad) > 0.0;
+    }
+
+    // warm-start inputs staged by the caller: x0 in wv4 (= w4), y0 in dy, guessed bound status in wq
+    // (= wz1) and guessed constraint status in wc1 (= c1), as doubles
+    __device__ __forceinline__ int setup_aux(bool x0, bool y0, bool guess_b, bool guess_c) {
+        status = QPS_PREPARINGAUXILIARYQP;
+        infeasible = unbounded = 0;
+        PFOR(v, nV) {
+            double xv = x0 ? wv4[v] : 0.0;
+            int s;
+            if (guess_b) s = (int)wq[v];
+            else if (x0) s = xv <= lbN[v] + RSQP_BOUND_TOLERANCE ? -1 : (xv >= ubN[v] - RSQP_BOUND_TOLERANCE ? 1 : 0);
+            else if (y0) s = dy[v] > RSQP_EPS ? -1 : (dy[v] < -RSQP_EPS ? 1 : 0);
+            else s = -1;
+            if (s == -1 && lbN[v] <= -RSQP_INFTY) s = (ubN[v] < RSQP_INFTY && !x0 && !guess_b) ? 1 : 0;
+            if (s == 1 && ubN[v] >= RSQP_INFTY) s = 0;
+            wv4[v] = xv;
+            wq[v] = (double)s;
+        }
+        if (!y0) { PFOR(i, nV + nC) dy[i] = 0.0; }
+        if (!guess_c) { PFOR(i, nC) wc1[i] = 0.0; }
+        SYNC();
+        PFOR(v, nV) { x[v] = wv4[v]; Sb[v] = (int)wq[v]; }
+        PFOR(i, nV + nC) y[i] = dy[i];
+        for (int k = lane; k < ld * nV; k += L) { Z[k] = 0.0; Wz[k] = 0.0; }
+        for (int k = lane; k < sizeT * ldm; k += L) Minv[k] = 0.0;
+        PFOR(i, nC) { Sc[i] = 0; posAC[i] = -1; c2[i] = wc1[i]; }   // the guess moves out of c1 (scratch of the products)
+        SYNC();
+        if (lane == 0) {
+            int n = 0;
+            for (int v = 0; v < nV; v++)
+                if (Sb[v] == 0) Z[(n++) * ld + v] = 1.0;
+            iscal[0] = n;
+        }
+        SYNC();
+        nFR = nZ = iscal[0];
+        nAC = 0;
+        A_times(x, Ax);
+        for (int i = 0; i < nC; i++) {
+            int s = 0;
+            if (guess_c) s = (int)c2[i];
+            else if (x0) s = Ax[i] <= lbAN[i] + RSQP_BOUND_TOLERANCE ? -1 : (Ax[i] >= ubAN[i] - RSQP_BOUND_TOLERANCE ? 1 : 0);
+            else if (y0) s = y[nV + i] > RSQP_EPS ? -1 : (y[nV + i] < -RSQP_EPS ? 1 : 0);
+            if (s == -1 && lbAN[i] <= -RSQP_INFTY) s = 0;
+            if (s == 1 && ubAN[i] >= RSQP_INFTY) s = 0;
+            if (s != 0) {
+                double na2, wz2n;
+                constraint_products(i, na2, wz2n);
+                if (is_LI(na2, wz2n)) add_constraint(i, s, false, false);
+            }
+        }
+        // Wz = (Z'HZ)^-1 by bordering over the final null-space columns
+        const int nZf = nZ;
+        nZ = 0;
+        for (int k = 0; k < nZf; k++)
+            if (!wz_grow()) return RET_SETUP_FAILED;
+        PFOR(v, nV) {
+            double yv = y[v];
+            if (Sb[v] == 0 || (Sb[v] == -1 && yv < 0.0) || (Sb[v] == 1 && yv > 0.0)) y[v] = 0.0;
+        }
+        PFOR(i, nC) {
+            double yi = y[nV + i];
+            if (Sc[i] == 0 || (Sc[i] == -1 && yi < 0.0) || (Sc[i] == 1 && yi > 0.0)) y[nV + i] = 0.0;
+        }
+        SYNC();
+        AT_times(y + nV, w1);
+        H_times(x, w2);
+        PFOR(v, nV) {
+            double xv = x[v];
+            g[v] = w1[v] + y[v] - w2[v];
+            lb[v] = Sb[v] == -1 ? xv : fmin(lbN[v], xv - RSQP_BOUND_RELAXATION);
+            ub[v] = Sb[v] == 1 ? xv : fmax(ubN[v], xv + RSQP_BOUND_RELAXATION);
+        }
+        PFOR(i, nC) {
+            double ax = Ax[i];
+            lbA[i] = Sc[i] == -1 ? ax : fmin(lbAN[i], ax - RSQP_BOUND_RELAXATION);
+            ubA[i] = Sc[i] == 1 ? ax : fmax(ubAN[i], ax + RSQP_BOUND_RELAXATION);
+        }
+        SYNC();
+        status = QPS_AUXILIARYQPSOLVED;
+        return RET_OK;
+    }
+
+    // ------------------------------------------------------------------ step direction
+    __device__ __forceinline__ static double delta_of(double target, double cur) {
+        return (fabs(target) >= RSQP_INFTY && fabs(cur) >= RSQP_INFTY) ? 0.0 : target - cur;
+    }
+    __device__ __forceinline__ void step_direction() {
+        PFOR(v, nV) dx[v] = Sb[v] == -1 ? delta_of(lbN[v], lb[v]) : (Sb[v] == 1 ? delta_of(ubN[v], ub[v]) : 0.0);
+        PFOR(i, nV + nC) dy[i] = 0.0;
+        SYNC();
+        A_times(dx, c1);                                            // A dx_FX
+        H_times(dx, w2);
+        PFOR(j, nAC) {
+            const int r = AC[j];
+            a1[j] = (Sc[r] == -1 ? delta_of(lbAN[r], lbA[r]) : delta_of(ubAN[r], ubA[r])) - c1[r];   // bA
+        }
+        PFOR(v, nV) w1[v] = w2[v] + (gN[v] - g[v]);                 // tmpg
+        SYNC();
+        // range space: wY = Minv bA ; xY = Y wY
+        gemv_n(Minv, ldm, nAC, nAC, a1, 1.0, 0.0, nullptr, a2);
+        gemv_n(Y, ldy, nV, nAC, a2, 1.0, 0.0, nullptr, w3);
+        // null space: wZ = -Wz Z'(tmpg + H xY) ; dx_FR = xY + Z wZ
+        H_times(w3, w2);
+        PFOR(v, nV) w2[v] = 1.0 * w2[v] + 1.0 * w1[v];
+        SYNC();
+        gemv_t(Z, ld, nV, nZ, w2, wz1);
+        gemv_n(Wz, ld, nZ, nZ, wz1, -1.0, 0.0, nullptr, wz2);
+        gemv_n(Z, ld, nV, nZ, wz2, 1.0, 1.0, w3, w4);
+        PFOR(v, nV) if (Sb[v] == 0) dx[v] = w4[v];
+        SYNC();
+        // multipliers: dyAC = Minv' Y'(H dx + dg)
+        H_times(dx, w5);
+        PFOR(v, nV) w2[v] = w5[v] + (gN[v] - g[v]);
+        SYNC();
+        gemv_t(Y, ldy, nV, nAC, w2, a1);
+        gemv_t(Minv, ldm, nAC, nAC, a1, a2);
+        PFOR(j, nAC) dy[nV + AC[j]] = a2[j];
+        SYNC();
+        AT_times(dy + nV, w3);
+        PFOR(v, nV) dy[v] = Sb[v] != 0 ? w2[v] - w3[v] : 0.0;
+        A_times(dx, dAx);
+    }
+
+    // ------------------------------------------------------------------ ratio tests (as Engine)
+    __device__ __forceinline__ static void cand(double num, double den, int id, double &bt, int &bid) {
+        if (den >= RSQP_EPS_DEN) {
+            double t = (num > 0.0 ? num : 0.0) / den;
+            if (t < bt || (t == bt && id < bid)) { bt = t; bid = id; }
+        }
+    }
+    __device__ __forceinline__ Blocking ratio_tests() {
+        double bt = 1.0;
+        int bid = 0x7fffffff;
+        PFOR(i, nC) {
+            double Axi = Ax[i], dA = dAx[i];
+            if (Sc[i] != 0) {
+                double yi = y[nV + i], d = dy[nV + i];
+                if (Sc[i] == -1) cand(yi, -d, i, bt, bid); else cand(-yi, d, i, bt, bid);
+            } else {
+                if (lbAN[i] > -RSQP_INFTY) cand(Axi - lbA[i], delta_of(lbAN[i], lbA[i]) - dA, nC + nV + i, bt, bid);
+                if (ubAN[i] < RSQP_INFTY) cand(ubA[i] - Axi, dA - delta_of(ubAN[i], ubA[i]), 2 * nC + nV + i, bt, bid);
+            }
+        }
+        PFOR(v, nV) {
+            if (Sb[v] != 0) {
+                double yi = y[v], d = dy[v];
+                if (Sb[v] == -1) cand(yi, -d, nC + v, bt, bid); else cand(-yi, d, nC + v, bt, bid);
+            } else {
+                if (lbN[v] > -RSQP_INFTY) cand(x[v] - lb[v], delta_of(lbN[v], lb[v]) - dx[v], 3 * nC + nV + v, bt, bid);
+                if (ubN[v] < RSQP_INFTY) cand(ub[v] - x[v], dx[v] - delta_of(ubN[v], ub[v]), 3 * nC + 2 * nV + v, bt, bid);
+            }
+        }
+        if (!(bt < 1.0)) { bt = 1.0; bid = 0x7fffffff; }
+        block_argmin(bt, bid);
+        Blocking b;
+        b.tau = bt; b.kind = 0; b.idx = -1; b.side = 0;
+        if (bid != 0x7fffffff) {
+            if (bid < nC) { b.kind = 1; b.idx = bid; }
+            else if (bid < nC + nV) { b.kind = 2; b.idx = bid - nC; }
+            else if (bid < 2 * nC + nV) { b.kind = 3; b.idx = bid - nC - nV; b.side = -1; }
+            else if (bid < 3 * nC + nV) { b.kind = 3; b.idx = bid - 2 * nC - nV; b.side = 1; }
+            else if (bid < 3 * nC + 2 * nV) { b.kind = 4; b.idx = bid - 3 * nC - nV; b.side = -1; }
+            else { b.kind = 4; b.idx = bid - 3 * nC - 2 * nV; b.side = 1; }
+        }
+        return b;
+    }
+
+    // ------------------------------------------------------------------ homotopy (as Engine)
+    __device__ __forceinline__ void drift_correction() {
+        PFOR(v, nV) if (Sb[v] != 0) x[v] = Sb[v] == -1 ? lb[v] : ub[v];
+        SYNC();
+        A_times(x, Ax);
+        PFOR(i, nC) { if (Sc[i] == -1) lbA[i] = Ax[i]; else if (Sc[i] == 1) ubA[i] = Ax[i]; }
+        AT_times(y + nV, w1);
+        H_times(x, w2);
+        PFOR(v, nV) g[v] = w1[v] + y[v] - w2[v];
+        SYNC();
+    }
+    __device__ __forceinline__ int homotopy(int maxit, int &nWSR) {
+        int iter = 0, rcode = RET_OK;
+        status = QPS_PERFORMINGHOMOTOPY;
+        PFOR(v, nV) {
+            if (Sb[v] != -1 && lb[v] <= -RSQP_INFTY && lbN[v] > -RSQP_INFTY) lb[v] = fmin(lbN[v], x[v] - RSQP_BOUND_RELAXATION);
+            if (Sb[v] != 1 && ub[v] >= RSQP_INFTY && ubN[v] < RSQP_INFTY) ub[v] = fmax(ubN[v], x[v] + RSQP_BOUND_RELAXATION);
+        }
+        PFOR(i, nC) {
+            if (Sc[i] != -1 && lbA[i] <= -RSQP_INFTY && lbAN[i] > -RSQP_INFTY) lbA[i] = fmin(lbAN[i], Ax[i] - RSQP_BOUND_RELAXATION);
+            if (Sc[i] != 1 && ubA[i] >= RSQP_INFTY && ubAN[i] < RSQP_INFTY) ubA[i] = fmax(ubAN[i], Ax[i] + RSQP_BOUND_RELAXATION);
+        }
+        SYNC();
+        for (;;) {
+            STAMP(7);
+            step_direction();
+            STAMP(3);
+            Blocking b = ratio_tests();
+            STAMP(4);
+            double tau = b.tau;
+            bool done = b.kind == 0;
+            PFOR(v, nV) {
+                if (done) {
+                    g[v] = gN[v]; lb[v] = lbN[v]; ub[v] = ubN[v];
+                    x[v] = Sb[v] == -1 ? lb[v] : (Sb[v] == 1 ? ub[v] : x[v] + tau * dx[v]);
+                } else {
+                    x[v] += tau * dx[v];
+                    g[v] += tau * (gN[v] - g[v]);
+                    lb[v] += tau * delta_of(lbN[v], lb[v]);
+                    ub[v] += tau * delta_of(ubN[v], ub[v]);
+                }
+            }
+            PFOR(i, nV + nC) y[i] += tau * dy[i];
+            PFOR(i, nC) {
+                if (done) { lbA[i] = lbAN[i]; ubA[i] = ubAN[i]; }
+                else { lbA[i] += tau * delta_of(lbAN[i], lbA[i]); ubA[i] += tau * delta_of(ubAN[i], ubA[i]); }
+            }
+            SYNC();
+            A_times(x, Ax);
+            STAMP(5);
+            if (done) { status = QPS_SOLVED; break; }
+            if (iter >= maxit) { rcode = RET_MAX_NWSR; break; }
+            if (lane == 0) {
+                if (b.kind == 3) { if (b.side == -1) lbA[b.idx] = Ax[b.idx]; else ubA[b.idx] = Ax[b.idx]; }
+                else if (b.kind == 4) { if (b.side == -1) lb[b.idx] = x[b.idx]; else ub[b.idx] = x[b.idx]; }
+            }
+            SYNC();
+            rcode = change_active_set(b);
+            STAMP(6);
+            if (rcode == RET_INFEASIBLE) { infeasible = 1; break; }
+            if (rcode == RET_UNBOUNDED) { unbounded = 1; break; }
+            iter++;
+            drift_correction();
+        }
+        nWSR = iter;
+        return rcode;
+    }
+    __device__ __forceinline__ void restore(int nFR_, int nAC_, int status_) { nFR = nFR_; nAC = nAC_; nZ = nFR_ - nAC_; status = status_; }
+    __device__ __forceinline__ double objective() {
+        H_times(x, w2);
+        double a = dot(x, w2, nV), b = dot(gN, x, nV), c = dot(x, x, nV);
+        return 0.5 * (a - hreg * c) + b;
+    }
+};

@@ -13,7 +13,10 @@ from restartsqp_amd import capi, problems
 capi.LIB_PATH = lib
 L = capi.lib()
 L.rsqp_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-probs = problems.hs071_scale_batch(int(sys.argv[1]) if len(sys.argv) > 1 else 16384)
+if len(sys.argv) > 2:   # stamp_small_kernel.py <nV> <nC>: the problems of that shape in the 512-QP hs0xx batch
+    probs = [p for p in problems.hs_batch(512) if (p.nV, p.nC) == (int(sys.argv[1]), int(sys.argv[2]))]
+else:
+    probs = problems.hs071_scale_batch(int(sys.argv[1]) if len(sys.argv) > 1 else 16384)
 b = capi.Batch(probs)
 buf = (C.c_ulonglong * 16)()
 b.solve(capi.MODE_COLD, 1000)
@@ -27,4 +30,4 @@ names = {0: "prologue (zero image, stage matrices)", 2: "targets + setup_aux", 3
 tot = sum(buf[k] for k in names)
 for k, n in names.items():
     print("%-40s %9.0f cycles  %5.1f %%" % (n, buf[k] / reps, 100.0 * buf[k] / tot))
-print("total %.0f cycles per QP (block 0); kernel %.3f ms" % (tot / reps, b.last_solve_ms()))
+print("total %.0f cycles per QP (block 0); kernel %.3f ms; nWSR of QP 0: %d" % (tot / reps, b.last_solve_ms(), b.results()[0]["nWSR"]))
