@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerate the judged artefacts of a round on the GPU box:  bash tools/round_profiles.sh r01_f
 # writes gpurun_out/<tag>_bench.json, <tag>_kernel_stats_bench.csv, <tag>_pmc_hbm_traffic.json,
-# <tag>_kernel_stats_large_sparse.csv, <tag>_pmc_mfma_qr.json  (copy them into profiles/)
+# <tag>_kernel_stats_blocked_qr.csv  (copy them into profiles/)
 tag=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
@@ -15,7 +15,7 @@ echo "pmc hbm done"
 # blocked QR on the matrix cores: kernel stats + MFMA / VALU busy counters
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_qr -- python3 tools/qr_profile_run.py > gpurun_out/${tag}_qr_run.txt 2>/dev/null
 cp "$(find /tmp/prof_qr -name '*kernel_stats.csv' | head -1)" gpurun_out/${tag}_kernel_stats_blocked_qr.csv
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVES --kernel-trace --output-format csv -d /tmp/pmc_qr -- python3 tools/qr_profile_run.py > /dev/null 2>&1
-python tools/pmc_summary.py /tmp/pmc_qr > gpurun_out/${tag}_pmc_mfma_qr.json
+# MFMA / LDS counters of the GEMM alone (a PMC pass over the ~9000 launches of the QR takes minutes and
+# has hung once: not part of the default set) -- see scratch-free recipe in DESIGN.md section 6
 echo "qr done"
 ls -la gpurun_out | grep ${tag}
