@@ -251,7 +251,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch-per-gpu", type=int, default=16384)
+    ap.add_argument("--batch-per-gpu", type=int, default=65536)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--spmv-batch", type=int, default=256)
     ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline and roofline_spmv")
@@ -320,11 +320,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "hs071-scale QP batch (derived hs071 first QP + seeded 1 %% perturbations, "
                                    "nV=8 x nC=2 via QPhandler [J I -I]), cold start, %d QPs/GPU per step" % B,
-                       "qps_per_gpu": B, "engine": "small_qp_kernel<16> (LDS-resident, 16 lanes per QP = 4 QPs per wave)",
+                       "qps_per_gpu": B, "engine": "small_qp_kernel<Engine<8>> (LDS-resident, 8 lanes per QP = 8 QPs per wave)",
                        "mean_nWSR": float(np.mean([r["nWSR"] for r in res])), "unsolved_or_kkt_fail": n_bad},
-            "roofline": {"kernel": "small_qp_kernel<16>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "small_qp_kernel<Engine<8>>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic("small_qp_kernel<16", 1.0) if B == 16384 else None,
+                         "traffic": pmc_traffic("Engine<8", 1.0) if B == 65536 else None,
                          "traffic_note": "FETCH_SIZE uncorrected (narrow loads, uncalibrated) + WRITE_SIZE; the "
                                          "writes are the 3.2 KB/QP engine image kept for hot starts",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_launch,

@@ -940,7 +940,13 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
     const int q = L >= 64 ? (int)blockIdx.x : blockIdx.x * (64 / L) + grp;
     if (q >= nq) return;  // no workgroup barrier anywhere below: idle groups may leave
     lchar *smem = (lchar *)smem_generic + grp * stride;
-    const QPDesc d = P.desc[q];
+    QPDesc d = P.desc[q];
+    if constexpr (L < 64) {
+        // packed waves are only launched when every problem of the batch has nV, nC <= L: a loop over a
+        // vector of the engine is then a single predicated trip (no back edge, no counter)
+        __builtin_assume(d.nV <= L && d.nV >= 0);
+        __builtin_assume(d.nC <= L && d.nC >= 0);
+    }
     ENG E;
     E.lane = lane;
 #ifdef RSQP_STAMPS
@@ -1085,8 +1091,9 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     // mostly idle on hs0xx-scale problems, so 64 / L of them share a wave. Problems in one wave
     // follow their own control flow (exec masking); the LDS capacity bounds the problems in flight.
     static const int forcedL = env_int("RSQP_SMALL_LANES", -1), forcedW = env_int("RSQP_SMALL_WAVES", -1);
-    int L = nVmax <= 16 ? 16 : (nVmax <= 32 ? 32 : 64);
-    if (forcedL == 16 || forcedL == 32 || forcedL == 64) L = forcedL;
+    const int nmax = nVmax > nCmax ? nVmax : nCmax;
+    int L = nmax <= 8 ? 8 : (nmax <= 16 ? 16 : (nmax <= 32 ? 32 : 64));
+    if ((forcedL == 8 || forcedL == 16 || forcedL == 32 || forcedL == 64) && forcedL >= L) L = forcedL;   // never fewer lanes than entries
     if (!mat_lds) L = 64;
     while (L < 64 && (64 / L) * stride > kMaxLds) L *= 2;
     if (L == 64 && stride > kMaxLds) stride = mat_lds ? img + align16(mat_bytes_max) : img;
@@ -1095,7 +1102,8 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     // minimum resident waves per SIMD = register budget. One problem per wave keeps the uniform
     // state in SGPRs and runs best with 6 (small images) or 4 waves; packed waves hold that state
     // in VGPRs and need ~230 of them, so they run 2 waves/SIMD without spills (measured on
-    // 16 384 hs071-scale QPs: L=16 W=2 159 M solves/s, W=3 142 M, W=4 116 M; L=64 W=6 74 M).
+    // 16 384 hs071-scale QPs: L=16 W=2 159 M solves/s, W=3 142 M, W=4 116 M; L=64 W=6 74 M; with the
+    // single-trip loop hints L=16 187 M, and on 65 536 QPs L=8 219 M vs L=16 194 M).
     // Packed builds with W=6 (80 VGPRs, ~180 spilled) returned wrong results and are not built.
     int waves = L == 64 ? (nVmax <= 16 ? 6 : 4) : 2;
     if (forcedW >= 2 && forcedW <= (L == 64 ? 6 : 4)) waves = forcedW;
@@ -1127,6 +1135,8 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
         else SQ_LAUNCH_E(EngineX, 64, true, 4);
     } else if (!mat_lds) {
         SQ_LAUNCH(64, false, 3);
+    } else if (L == 8) {
+        SQ_LAUNCH(8, true, 2);
     } else if (L == 16) {
         SQ_WAVES(16)
     } else if (L == 32) {

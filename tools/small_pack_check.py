@@ -30,9 +30,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
 import numpy as np
 quick = "--quick" in sys.argv
 bad = 0
-for kind in (("hs", "random") if quick else ("hs071", "hs", "random")):
+for kind in (("hs071", "random") if quick else ("hs071", "hs", "random")):
     ref = None
-    for L, W in (((64, 4), (32, 2), (16, 2)) if quick else ((64, 4), (64, 6), (32, 2), (32, 4), (16, 2), (16, 3), (16, 4))):
+    variants = ((64, 4), (32, 2), (16, 2)) if quick else ((64, 4), (64, 6), (32, 2), (32, 4), (16, 2), (16, 3), (16, 4))
+    if kind == "hs071":
+        variants = variants + ((8, 2),)    # 8 lanes per problem: only batches with nV, nC <= 8
+    for L, W in variants:
         env = dict(os.environ, RSQP_SMALL_LANES=str(L), RSQP_SMALL_WAVES=str(W))
         out = "/tmp/pack_%s_%d_%d.npz" % (kind, L, W)
         r = subprocess.run([sys.executable, __file__, "--one", kind, out], env=env, capture_output=True, text=True, timeout=600)
