@@ -110,6 +110,11 @@ struct Engine {
     long long tlast;
 
     // ------------------------------------------------------------------ carve
+    // doubles of this formulation's image (<= rsqp_image_doubles, the size of the persistent copy)
+    __host__ __device__ static long long image_doubles(int nV, int nC) {
+        const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
+        return 2 * ld * nV + sT * ld + 15LL * nV + 8LL * nC + 2LL * (nV + nC) + 8;
+    }
     __device__ __forceinline__ void carve(lchar *base, int nV_, int nC_) {
         nV = nV_; nC = nC_; ld = rsqp_ld(nV); sizeT = nV < nC ? nV : nC;
         ldouble *p = (ldouble *)base;
@@ -120,15 +125,13 @@ struct Engine {
         CARVE_V(x); CARVE_V(g); CARVE_V(lb); CARVE_V(ub); CARVE_V(gN); CARVE_V(lbN); CARVE_V(ubN);
         CARVE_V(dx); CARVE_V(wq); CARVE_V(wv1); CARVE_V(wv2); CARVE_V(wv3); CARVE_V(wv4); CARVE_V(rc); CARVE_V(rs);
 #undef CARVE_V
-        p += 3 * nV;  // reserve (the image holds 18 vectors of nV)
 #define CARVE_C(name) name = p; p += nC
         CARVE_C(Ax); CARVE_C(lbA); CARVE_C(ubA); CARVE_C(lbAN); CARVE_C(ubAN); CARVE_C(dAx); CARVE_C(wc1); CARVE_C(wc2);
 #undef CARVE_C
-        p += nC;
         y = p; p += nV + nC;
         dy = p; p += nV + nC;
         scal = p; p += 8;
-        lint *ip = (lint *)((ldouble *)base + rsqp_image_doubles(nV, nC));   // behind the explicit-inverse engine's extras
+        lint *ip = (lint *)p;
         Sb = ip; ip += nV;
         Sc = ip; ip += nC;
         AC = ip; ip += nC;
@@ -931,7 +934,9 @@ __host__ __device__ inline long long mat_lds_bytes(int nV, int nC, int annz, int
 
 // L = lanes per problem (64 / L problems share one wave; each owns `stride` bytes of LDS),
 // W = minimum waves per SIMD the register allocator has to leave room for
-template <class ENG, int L, bool MAT_LDS, int W>
+// UNI: every problem of the batch has the same shape (P.uniV x P.uniC, kernel arguments): sizes, loop
+// bounds and LDS offsets are then wave-uniform scalars instead of per-lane values
+template <class ENG, int L, bool MAT_LDS, int W, bool UNI>
 __global__ void __launch_bounds__(L > 64 ? L : 64, W)
 small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
@@ -941,6 +946,7 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
     if (q >= nq) return;  // no workgroup barrier anywhere below: idle groups may leave
     lchar *smem = (lchar *)smem_generic + grp * stride;
     QPDesc d = P.desc[q];
+    if constexpr (UNI) { d.nV = P.uniV; d.nC = P.uniC; }
     if constexpr (L < 64) {
         // packed waves are only launched when every problem of the batch has nV, nC <= L: a loop over a
         // vector of the engine is then a single predicated trip (no back edge, no counter)
@@ -954,7 +960,7 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
     long long &tlast = E.tlast;
 #endif
     E.carve(smem, d.nV, d.nC);
-    const int nd = (int)rsqp_image_doubles(d.nV, d.nC), ni = (int)rsqp_image_ints(d.nV, d.nC);
+    const int nd = (int)ENG::image_doubles(d.nV, d.nC), ni = (int)rsqp_image_ints(d.nV, d.nC);
     const int img_bytes = (nd * 8 + ni * 4 + 15) & ~15;
     E.haveH = d.haveH;
     E.hreg = d.hreg;
@@ -1073,8 +1079,7 @@ static int env_int(const char *name, int dflt) {
 hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, long long mat_bytes_max, int mode,
                                 int maxWSR, hipStream_t stream) {
     if (nq <= 0) return hipSuccess;
-    const long long img = align16(rsqp_image_bytes(nVmax, nCmax));
-    if (img > kMaxLds) return hipErrorInvalidValue;
+    if (align16(rsqp_image_bytes(nVmax, nCmax)) > kMaxLds) return hipErrorInvalidValue;
     // formulation: 0 = Givens / TQ (Engine), 1 = explicit inverses (EngineX, qp_small_x.h), which keeps
     // DENSE copies of A and H in LDS. Measured per shape on the 512-QP hs0xx batch (ms, TQ vs explicit):
     // 5x1 0.14 / 0.16, 8x2 0.045 / 0.051, 8x3 0.25 / 0.21, 12x4 0.49 / 0.42, 16x6 0.73 / 0.55,
@@ -1082,6 +1087,9 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     static const int forcedE = env_int("RSQP_SMALL_ENGINE", -1);
     const int eng = forcedE == 0 || forcedE == 1 ? forcedE : (nVmax > 8 ? 1 : 0);
     if (eng == 1 && mat_bytes_max >= 0) mat_bytes_max = 8LL * ((long long)nVmax * nVmax + (long long)nCmax * nVmax);
+    // LDS image of the chosen formulation (the persistent copy in HBM is sized for the larger one)
+    const long long imgd = eng == 1 ? EngineX<64, true>::image_doubles(nVmax, nCmax) : Engine<64, true>::image_doubles(nVmax, nCmax);
+    const long long img = align16(8 * imgd + 4 * rsqp_image_ints(nVmax, nCmax));
     const bool mat_lds = mat_bytes_max >= 0 && img + align16(mat_bytes_max) <= kMaxLds;
     // LDS of one problem; an odd number of 16-byte units spreads the problems that share a wave
     // over the banks
@@ -1107,17 +1115,18 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     // Packed builds with W=6 (80 VGPRs, ~180 spilled) returned wrong results and are not built.
     int waves = L == 64 ? (nVmax <= 16 ? 6 : 4) : 2;
     if (forcedW >= 2 && forcedW <= (L == 64 ? 6 : 4)) waves = forcedW;
-#define SQ_LAUNCH_E(ENG, LL, ML, W)                                                                           \
+#define SQ_LAUNCH_U(ENG, LL, ML, W, U)                                                                        \
     do {                                                                                                      \
         static bool set_ = false;                                                                             \
         if (!set_) {                                                                                          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&small_qp_kernel<ENG<LL, ML>, LL, ML, W>), \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&small_qp_kernel<ENG<LL, ML>, LL, ML, W, U>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);              \
             set_ = true;                                                                                      \
         }                                                                                                     \
-        hipLaunchKernelGGL((small_qp_kernel<ENG<LL, ML>, LL, ML, W>), dim3(nblk), dim3(LL > 64 ? LL : 64), lds, stream, p, nq, \
+        hipLaunchKernelGGL((small_qp_kernel<ENG<LL, ML>, LL, ML, W, U>), dim3(nblk), dim3(LL > 64 ? LL : 64), lds, stream, p, nq, \
                            (int)stride, mode, maxWSR);                                                        \
     } while (0)
+#define SQ_LAUNCH_E(ENG, LL, ML, W) SQ_LAUNCH_U(ENG, LL, ML, W, false)
 #define SQ_LAUNCH(LL, ML, W) SQ_LAUNCH_E(Engine, LL, ML, W)
 #define SQ_WAVES(LL)                                                                                          \
     switch (waves) {                                                                                          \
@@ -1125,6 +1134,8 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     case 4: SQ_LAUNCH(LL, true, 4); break;                                                                    \
     default: SQ_LAUNCH(LL, true, 2); break;                                                                   \
     }
+    static const int forcedUni = env_int("RSQP_SMALL_UNIFORM", -1);
+    const bool uniform = p.uniV >= 0 && p.uniC >= 0 && forcedUni != 0;
     static const int forcedWide = env_int("RSQP_SMALL_WIDE", -1);
     const bool wide = forcedWide >= 0 ? forcedWide != 0 : nVmax > 32;
     if (eng == 1) {
@@ -1136,7 +1147,9 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     } else if (!mat_lds) {
         SQ_LAUNCH(64, false, 3);
     } else if (L == 8) {
-        SQ_LAUNCH(8, true, 2);
+        if (uniform) SQ_LAUNCH_U(Engine, 8, true, 2, true); else SQ_LAUNCH(8, true, 2);
+    } else if (L == 16 && uniform && waves == 2) {
+        SQ_LAUNCH_U(Engine, 16, true, 2, true);
     } else if (L == 16) {
         SQ_WAVES(16)
     } else if (L == 32) {
@@ -1149,6 +1162,7 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
         }
     }
 #undef SQ_LAUNCH_E
+#undef SQ_LAUNCH_U
 #undef SQ_WAVES
 #undef SQ_LAUNCH
     return hipGetLastError();

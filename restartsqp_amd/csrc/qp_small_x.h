@@ -33,6 +33,11 @@ struct EngineX {
     int nFR, nAC, nZ, status, infeasible, unbounded, nflips;
     long long tlast;
 
+    // doubles of this formulation's image (<= rsqp_image_doubles, the size of the persistent copy)
+    __host__ __device__ static long long image_doubles(int nV, int nC) {
+        const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
+        return 2 * ld * nV + sT * ld + 17LL * nV + 9LL * nC + 2LL * (nV + nC) + 8 + 4 * (sT + 2);
+    }
     __device__ __forceinline__ void carve(lchar *base, int nV_, int nC_) {
         nV = nV_; nC = nC_; ld = rsqp_ld(nV); sizeT = nV < nC ? nV : nC; ldm = sizeT | 1;
         ldouble *p = (ldouble *)base;
@@ -47,7 +52,6 @@ struct EngineX {
         CARVE_V(dx); CARVE_V(w1); CARVE_V(w2); CARVE_V(w3); CARVE_V(w4); CARVE_V(w5); CARVE_V(w6);
         CARVE_V(wz1); CARVE_V(wz2); CARVE_V(wz3);
 #undef CARVE_V
-        p += nV;   // the image holds 18 vectors of nV
 #define CARVE_C(name) name = p; p += nC
         CARVE_C(Ax); CARVE_C(lbA); CARVE_C(ubA); CARVE_C(lbAN); CARVE_C(ubAN); CARVE_C(dAx); CARVE_C(c1); CARVE_C(c2); CARVE_C(c3);
 #undef CARVE_C
@@ -56,7 +60,7 @@ struct EngineX {
         scal = p; p += 8;
         Minv = tslot;                      // sizeT * ldm <= sizeT * ld
         a1 = p; p += sizeT + 2; a2 = p; p += sizeT + 2; a3 = p; p += sizeT + 2; a4 = p; p += sizeT + 2;
-        lint *ip = (lint *)((ldouble *)base + rsqp_image_doubles(nV, nC));
+        lint *ip = (lint *)p;
         Sb = ip; ip += nV;
         Sc = ip; ip += nC;
         AC = ip; ip += nC;

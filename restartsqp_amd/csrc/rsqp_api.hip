@@ -289,6 +289,7 @@ QPPools pools_of(rsqp_solver *s) {
     p.x = s->d_x.p; p.y = s->d_y.p; p.ws_b = s->d_wsb.p; p.ws_c = s->d_wsc.p;
     p.status = s->d_status.p; p.ret = s->d_ret.p; p.nwsr = s->d_nwsr.p; p.nflips = s->d_nflips.p;
     p.obj = s->d_obj.p; p.state = s->d_state.p;
+    p.uniV = s->nV; p.uniC = s->nC;
     return p;
 }
 
@@ -904,7 +905,7 @@ extern "C" int rsqp_H_times(rsqp_solver *s, const double *p, double *result) {
 // batch of independent QPs
 // =====================================================================================
 struct rsqp_batch {
-    int nq = 0, device = 0, nVmax = 0, nCmax = 0;
+    int nq = 0, device = 0, nVmax = 0, nCmax = 0, uniV = -1, uniC = -1;
     long long sumV = 0, sumC = 0, sumAnz = 0, sumHnz = 0, mat_bytes_max = 0;
     bool haveH = false;
     std::vector<QPDesc> desc;
@@ -941,6 +942,7 @@ QPPools pools_of(rsqp_batch *b) {
     p.x = b->x.p; p.y = b->y.p; p.ws_b = b->ws_b.p; p.ws_c = b->ws_c.p;
     p.status = b->status.p; p.ret = b->ret.p; p.nwsr = b->nwsr.p; p.nflips = b->nflips.p;
     p.obj = b->obj.p; p.state = b->state.p;
+    p.uniV = b->uniV; p.uniC = b->uniC;
     return p;
 }
 }  // namespace
@@ -976,6 +978,8 @@ extern "C" int rsqp_batch_create(int nq, const int *nV, const int *nC, const int
         h_Aci.insert(h_Aci.end(), r.ci.begin(), r.ci.end());
         for (int v : r.perm) h_perm.push_back((int)offAnz + v);
         b->nVmax = std::max(b->nVmax, d.nV); b->nCmax = std::max(b->nCmax, d.nC);
+        if (q == 0) { b->uniV = d.nV; b->uniC = d.nC; }
+        else { if (b->uniV != d.nV) b->uniV = -1; if (b->uniC != d.nC) b->uniC = -1; }
         offV += d.nV; offC += d.nC; offAjc += d.nV + 1; offAnz += annz; offArp += d.nC + 1;
         b->mat_bytes_max = std::max(b->mat_bytes_max, rsqp_mat_lds_bytes(d.nV, d.nC, annz, b->haveH ? Hjc[offHjc + d.nV] : 0));
         if (b->haveH) {

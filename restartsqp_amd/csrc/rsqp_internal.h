@@ -39,6 +39,7 @@ struct QPPools {
     double *x, *y; int *ws_b, *ws_c;
     int *status, *ret, *nwsr, *nflips; double *obj;
     double *state;
+    int uniV, uniC;   // nV / nC of every problem when the batch is uniform in shape, else -1
 };
 
 // number of doubles / ints of the LDS (and persistent) image of one problem
