@@ -956,6 +956,7 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
     }
     ENG E;
     E.lane = lane;
+    if constexpr (L > 64) E.part = (ldouble *)(smem + stride) - L;   // the launcher reserves 8 L bytes at the end
 #ifdef RSQP_STAMPS
     E.tlast = clock64();
     long long &tlast = E.tlast;
@@ -1106,6 +1107,10 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     if (!mat_lds) L = 64;
     while (L < 64 && (64 / L) * stride > kMaxLds) L *= 2;
     if (L == 64 && stride > kMaxLds) stride = mat_lds ? img + align16(mat_bytes_max) : img;
+    static const int forcedWide0 = env_int("RSQP_SMALL_WIDE", -1);
+    const bool wide0 = eng == 1 && mat_lds && L == 64 && (forcedWide0 >= 0 ? forcedWide0 != 0 : nVmax > 32);
+    bool wide = false;
+    if (wide0 && stride + 2048 <= kMaxLds) { stride += 2048; wide = true; }   // one double per lane of the 4-wave build
     const int G = 64 / L, nblk = (nq + G - 1) / G;
     const size_t lds = (size_t)(G * stride);
     // minimum resident waves per SIMD = register budget. One problem per wave keeps the uniform
@@ -1135,8 +1140,6 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     case 4: SQ_LAUNCH(LL, true, 4); break;                                                                    \
     default: SQ_LAUNCH(LL, true, 2); break;                                                                   \
     }
-    static const int forcedWide = env_int("RSQP_SMALL_WIDE", -1);
-    const bool wide = forcedWide >= 0 ? forcedWide != 0 : nVmax > 32;
     if (eng == 1) {
         if (!mat_lds) SQ_LAUNCH_E(EngineX, 64, false, 3);
         else if (L == 16) SQ_LAUNCH_E(EngineX, 16, true, 2);

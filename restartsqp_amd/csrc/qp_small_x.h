@@ -27,6 +27,7 @@ struct EngineX {
     ldouble *Ax, *lbA, *ubA, *lbAN, *ubAN, *dAx, *c1, *c2, *c3;
     ldouble *a1, *a2, *a3, *a4;
     ldouble *y, *dy, *scal;
+    ldouble *part;             // L > 64: one double per lane for the split matrix phases (set by the kernel)
     ldouble *wq, *wv4, *wc1;   // staging aliases used by the kernel wrapper (guess / x0 / guessed constraints)
     lint *Sb, *Sc, *AC, *posAC, *iscal;
     int lane;
@@ -128,58 +129,102 @@ struct EngineX {
     }
 
     // ------------------------------------------------------------------ dense building blocks (column-major)
-    // out[c] = sum_r M[c*l + r] * xv[r]      (lane per column). Eight rows per trip: their 16 LDS reads
-    // are issued before the first multiply, four independent partial sums.
-    __device__ __forceinline__ void gemv_t(const ldouble *M, int l, int nrows, int ncols, const ldouble *xv, ldouble *out) {
-        PFOR(c, ncols) {
-            const ldouble *col = M + c * l;
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            int r = 0;
-            for (; r + 8 <= nrows; r += 8) {
-                double m[8], xx[8];
+    // Four waves per problem (L > 64): a matrix phase is split over (index, part) = (lane % n1,
+    // lane / n1): every part takes a contiguous slice of the inner dimension, partial sums meet in
+    // `part` (one double per lane) and are added in part order. false = this lane has no slice.
+    __device__ __forceinline__ bool split2d(int n1, int n2, int &i, int &j0, int &j1, int &nparts) {
+        nparts = L / n1;
+        if (nparts > n2) nparts = n2;
+        if (nparts < 1) nparts = 1;
+        const int p = lane / n1;
+        i = lane - p * n1;
+        const int chunk = (n2 + nparts - 1) / nparts;
+        j0 = p * chunk;
+        j1 = j0 + chunk < n2 ? j0 + chunk : n2;
+        return p < nparts;
+    }
+    __device__ __forceinline__ static double dot8(const ldouble *a, int sa, const ldouble *b, int j0, int j1) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int j = j0;
+        for (; j + 8 <= j1; j += 8) {
+            double m[8], xx[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) { m[u] = col[r + u]; xx[u] = xv[r + u]; }
-                s0 += m[0] * xx[0]; s1 += m[1] * xx[1]; s2 += m[2] * xx[2]; s3 += m[3] * xx[3];
-                s0 += m[4] * xx[4]; s1 += m[5] * xx[5]; s2 += m[6] * xx[6]; s3 += m[7] * xx[7];
-            }
-            for (; r < nrows; r++) s0 += col[r] * xv[r];
-            out[c] = (s0 + s1) + (s2 + s3);
+            for (int u = 0; u < 8; u++) { m[u] = a[(j + u) * sa]; xx[u] = b[j + u]; }
+            s0 += m[0] * xx[0]; s1 += m[1] * xx[1]; s2 += m[2] * xx[2]; s3 += m[3] * xx[3];
+            s0 += m[4] * xx[4]; s1 += m[5] * xx[5]; s2 += m[6] * xx[6]; s3 += m[7] * xx[7];
         }
+        for (; j < j1; j++) s0 += a[j * sa] * b[j];
+        return (s0 + s1) + (s2 + s3);
+    }
+    // out[c] = sum_r M[c*l + r] * xv[r]      (lane per column; eight rows per trip: their 16 LDS reads
+    // are issued before the first multiply, four independent partial sums)
+    __device__ __forceinline__ void gemv_t(const ldouble *M, int l, int nrows, int ncols, const ldouble *xv, ldouble *out) {
+        if constexpr (L > 64) {
+            if (ncols > 0 && ncols <= L / 2 && nrows >= 16) {
+                int c, r0, r1, np;
+                const bool on = split2d(ncols, nrows, c, r0, r1, np);
+                if (on) part[lane] = dot8(M + c * l, 1, xv, r0, r1);
+                SYNC();
+                if (lane < ncols) {
+                    double s = 0.0;
+                    for (int p = 0; p < np; p++) s += part[p * ncols + lane];
+                    out[lane] = s;
+                }
+                SYNC();
+                return;
+            }
+        }
+        PFOR(c, ncols) out[c] = dot8(M + c * l, 1, xv, 0, nrows);
         SYNC();
     }
     // out[r] = beta * base[r] + alpha * sum_c M[c*l + r] * wv[c]     (lane per row)
     __device__ __forceinline__ void gemv_n(const ldouble *M, int l, int nrows, int ncols, const ldouble *wv, double alpha,
                                            double beta, const ldouble *base, ldouble *out) {
-        PFOR(r, nrows) {
-            const ldouble *row = M + r;
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            int c = 0;
-            for (; c + 8 <= ncols; c += 8) {
-                double m[8], ww[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) { m[u] = row[(c + u) * l]; ww[u] = wv[c + u]; }
-                s0 += m[0] * ww[0]; s1 += m[1] * ww[1]; s2 += m[2] * ww[2]; s3 += m[3] * ww[3];
-                s0 += m[4] * ww[4]; s1 += m[5] * ww[5]; s2 += m[6] * ww[6]; s3 += m[7] * ww[7];
+        if constexpr (L > 64) {
+            if (nrows > 0 && nrows <= L / 2 && ncols >= 16) {
+                int r, c0, c1, np;
+                const bool on = split2d(nrows, ncols, r, c0, c1, np);
+                if (on) part[lane] = dot8(M + r, l, wv, c0, c1);
+                SYNC();
+                if (lane < nrows) {
+                    double s = 0.0;
+                    for (int p = 0; p < np; p++) s += part[p * nrows + lane];
+                    out[lane] = (base ? beta * base[lane] : 0.0) + alpha * s;
+                }
+                SYNC();
+                return;
             }
-            for (; c < ncols; c++) s0 += row[c * l] * wv[c];
-            out[r] = (base ? beta * base[r] : 0.0) + alpha * ((s0 + s1) + (s2 + s3));
         }
+        PFOR(r, nrows) out[r] = (base ? beta * base[r] : 0.0) + alpha * dot8(M + r, l, wv, 0, ncols);
         SYNC();
     }
     // M[c*l + r] += coef * t[r] * v[c]
     __device__ __forceinline__ void ger(ldouble *M, int l, int nrows, int ncols, const ldouble *t, const ldouble *v, double coef) {
-        PFOR(r, nrows) {
-            ldouble *row = M + r;
-            const double tr = coef * t[r];
-            int c = 0;
-            for (; c + 8 <= ncols; c += 8) {
-                double m[8], vv[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) { m[u] = row[(c + u) * l]; vv[u] = v[c + u]; }
-#pragma unroll
-                for (int u = 0; u < 8; u++) row[(c + u) * l] = m[u] + tr * vv[u];
+        int r = lane, c0 = 0, c1 = ncols, np = 1;
+        bool on = true;
+        if constexpr (L > 64) {
+            if (nrows > 0 && nrows <= L / 2) on = split2d(nrows, ncols, r, c0, c1, np);
+        }
+        if (L > 64 && np > 1) {
+            if (on) {
+                ldouble *row = M + r;
+                const double tr = coef * t[r];
+                for (int c = c0; c < c1; c++) row[c * l] += tr * v[c];
             }
-            for (; c < ncols; c++) row[c * l] += tr * v[c];
+        } else {
+            PFOR(rr, nrows) {
+                ldouble *row = M + rr;
+                const double tr = coef * t[rr];
+                int c = 0;
+                for (; c + 8 <= ncols; c += 8) {
+                    double m[8], vv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { m[u] = row[(c + u) * l]; vv[u] = v[c + u]; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) row[(c + u) * l] = m[u] + tr * vv[u];
+                }
+                for (; c < ncols; c++) row[c * l] += tr * v[c];
+            }
         }
         SYNC();
     }
@@ -269,11 +314,22 @@ struct EngineX {
         PFOR(a, nZ) w6[a] = Wz[l * ld + a] - beta * wz3[a] * vl - beta * wz2[a] * sl + beta * beta * theta * wz2[a] * vl;
         SYNC();
         const double w22 = w6[l];
-        PFOR(a, l) {
+        {
             // one division per row (the HBM engine divides per element; same value up to rounding)
-            const double sa = beta * wz3[a], va = beta * wz2[a], vt = beta * beta * theta * wz2[a], cw = w6[a] / w22;
-            for (int b = 0; b < l; b++)
-                Wz[b * ld + a] += -sa * wz2[b] - va * wz3[b] + vt * wz2[b] - cw * w6[b];
+            int a = lane, b0 = 0, b1 = l, np = 1;
+            bool on = lane < l;
+            if constexpr (L > 64) { if (l > 0 && l <= L / 2) on = split2d(l, l, a, b0, b1, np); }
+            if (np > 1) {
+                if (on) {
+                    const double sa = beta * wz3[a], va = beta * wz2[a], vt = beta * beta * theta * wz2[a], cw = w6[a] / w22;
+                    for (int b = b0; b < b1; b++) Wz[b * ld + a] += -sa * wz2[b] - va * wz3[b] + vt * wz2[b] - cw * w6[b];
+                }
+            } else {
+                PFOR(aa, l) {
+                    const double sa = beta * wz3[aa], va = beta * wz2[aa], vt = beta * beta * theta * wz2[aa], cw = w6[aa] / w22;
+                    for (int b = 0; b < l; b++) Wz[b * ld + aa] += -sa * wz2[b] - va * wz3[b] + vt * wz2[b] - cw * w6[b];
+                }
+            }
         }
         SYNC();
     }
