@@ -901,17 +901,17 @@ struct RsqpLargeEngine::Impl {
     void A_times(const double *in, double *out) {   // out[nC] = A in
         if (nC <= 0) return;
         if (M.denseA) gemv_n(M.denseA, nC, nC, nV, in, 1.0, 0.0, nullptr, out);
-        else rsqp_launch_spmv(M.blk_r, M.nblk_r, M.Arp, M.Aci, M.Arv, in, out, 1, 0, 0, 0, 0, st);
+        else (void)rsqp_launch_spmv(M.blk_r, M.nblk_r, M.Arp, M.Aci, M.Arv, in, out, 1, 0, 0, 0, 0, st);
     }
     void AT_times(const double *in, double *out) {  // out[nV] = A' in
         if (nC <= 0) fill(out, nV, 0.0);
         else if (M.denseA) gemv_t(M.denseA, nC, nC, nV, in, out);
-        else rsqp_launch_spmv(M.blk_c, M.nblk_c, M.Ajc, M.Air, M.Aval, in, out, 1, 0, 0, 0, 0, st);
+        else (void)rsqp_launch_spmv(M.blk_c, M.nblk_c, M.Ajc, M.Air, M.Aval, in, out, 1, 0, 0, 0, 0, st);
     }
     void H_times(const double *in, double *out) {
         if (!M.haveH) fill(out, nV, 0.0);
         else if (M.denseH) gemv_t(M.denseH, nV, nV, nV, in, out);
-        else rsqp_launch_spmv(M.blk_h, M.nblk_h, M.Hjc, M.Hir, M.Hval, in, out, 1, 0, 0, 0, 0, st);
+        else (void)rsqp_launch_spmv(M.blk_h, M.nblk_h, M.Hjc, M.Hir, M.Hval, in, out, 1, 0, 0, 0, 0, st);
         if (M.hreg != 0.0) hipLaunchKernelGGL(k_axpy, g1(nV), dim3(NT), 0, st, nV, M.hreg, in, out);
     }
     int read_scal(int s0, int n, double *out) {
