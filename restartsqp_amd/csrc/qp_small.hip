@@ -115,6 +115,11 @@ struct Engine {
         const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
         return 2 * ld * nV + sT * ld + 15LL * nV + 8LL * nC + 2LL * (nV + nC) + 8;
     }
+    // leading part of the image that survives a solve (factors, iterate, auxiliary data, multipliers)
+    __host__ __device__ static long long persist_doubles(int nV, int nC) {
+        const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
+        return 2 * ld * nV + sT * ld + 4LL * nV + 3LL * nC + (nV + nC);
+    }
     __device__ __forceinline__ void carve(lchar *base, int nV_, int nC_) {
         nV = nV_; nC = nC_; ld = rsqp_ld(nV); sizeT = nV < nC ? nV : nC;
         ldouble *p = (ldouble *)base;
@@ -122,13 +127,17 @@ struct Engine {
         R = p; p += ld * nV;
         T = p; p += sizeT * ld;
 #define CARVE_V(name) name = p; p += nV
-        CARVE_V(x); CARVE_V(g); CARVE_V(lb); CARVE_V(ub); CARVE_V(gN); CARVE_V(lbN); CARVE_V(ubN);
-        CARVE_V(dx); CARVE_V(wq); CARVE_V(wv1); CARVE_V(wv2); CARVE_V(wv3); CARVE_V(wv4); CARVE_V(rc); CARVE_V(rs);
-#undef CARVE_V
 #define CARVE_C(name) name = p; p += nC
-        CARVE_C(Ax); CARVE_C(lbA); CARVE_C(ubA); CARVE_C(lbAN); CARVE_C(ubAN); CARVE_C(dAx); CARVE_C(wc1); CARVE_C(wc2);
-#undef CARVE_C
+        // what a hot start needs (persist_doubles, written back to HBM) ...
+        CARVE_V(x); CARVE_V(g); CARVE_V(lb); CARVE_V(ub);
+        CARVE_C(Ax); CARVE_C(lbA); CARVE_C(ubA);
         y = p; p += nV + nC;
+        // ... and the per-solve scratch
+        CARVE_V(gN); CARVE_V(lbN); CARVE_V(ubN);
+        CARVE_V(dx); CARVE_V(wq); CARVE_V(wv1); CARVE_V(wv2); CARVE_V(wv3); CARVE_V(wv4); CARVE_V(rc); CARVE_V(rs);
+        CARVE_C(lbAN); CARVE_C(ubAN); CARVE_C(dAx); CARVE_C(wc1); CARVE_C(wc2);
+#undef CARVE_V
+#undef CARVE_C
         dy = p; p += nV + nC;
         scal = p; p += 8;
         lint *ip = (lint *)p;
@@ -963,6 +972,7 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
 #endif
     E.carve(smem, d.nV, d.nC);
     const int nd = (int)ENG::image_doubles(d.nV, d.nC), ni = (int)rsqp_image_ints(d.nV, d.nC);
+    const int np = (int)ENG::persist_doubles(d.nV, d.nC);   // what goes to / comes from HBM: [np doubles][ni ints]
     const int img_bytes = (nd * 8 + ni * 4 + 15) & ~15;
     E.haveH = d.haveH;
     E.hreg = d.hreg;
@@ -997,7 +1007,7 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
     }
     E.nflips = 0; E.infeasible = E.unbounded = 0; E.status = QPS_NOTINITIALISED; E.nFR = E.nAC = 0;
     double *img = P.state + d.offState;
-    int *iimg = reinterpret_cast<int *>(img + nd);
+    int *iimg = reinterpret_cast<int *>(img + np);
     ldouble *simg = (ldouble *)smem;
     lint *siimg = (lint *)(simg + nd);
 
@@ -1008,7 +1018,8 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
         SYNC();
     }
     if (mode != 0) {  // reload the image of the previous solve
-        for (int k = lane; k < nd; k += L) simg[k] = img[k];
+        for (int k = lane; k < np; k += L) simg[k] = img[k];
+        for (int k = np + lane; k < nd; k += L) simg[k] = 0.0;
         for (int k = lane; k < ni; k += L) siimg[k] = iimg[k];
         SYNC();
         E.restore(E.iscal[1], E.iscal[2], E.iscal[3]);
@@ -1058,7 +1069,7 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
         E.iscal[1] = E.nFR; E.iscal[2] = E.nAC; E.iscal[3] = E.status;
     }
     SYNC();
-    for (int k = lane; k < nd; k += L) img[k] = simg[k];
+    for (int k = lane; k < np; k += L) img[k] = simg[k];
     for (int k = lane; k < ni; k += L) iimg[k] = siimg[k];
     STAMP(9);
 }

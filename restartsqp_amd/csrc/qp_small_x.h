@@ -39,6 +39,11 @@ struct EngineX {
         const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
         return 2 * ld * nV + sT * ld + 17LL * nV + 9LL * nC + 2LL * (nV + nC) + 8 + 4 * (sT + 2);
     }
+    // leading part of the image that survives a solve (bases, inverses, iterate, auxiliary data, multipliers)
+    __host__ __device__ static long long persist_doubles(int nV, int nC) {
+        const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
+        return 2 * ld * nV + sT * ld + 4LL * nV + 3LL * nC + (nV + nC);
+    }
     __device__ __forceinline__ void carve(lchar *base, int nV_, int nC_) {
         nV = nV_; nC = nC_; ld = rsqp_ld(nV); sizeT = nV < nC ? nV : nC; ldm = sizeT | 1;
         ldouble *p = (ldouble *)base;
@@ -49,14 +54,18 @@ struct EngineX {
         Y = Z + (nV - 1) * ld; ldy = -ld;
         ldouble *tslot = p; p += sizeT * ld;
 #define CARVE_V(name) name = p; p += nV
-        CARVE_V(x); CARVE_V(g); CARVE_V(lb); CARVE_V(ub); CARVE_V(gN); CARVE_V(lbN); CARVE_V(ubN);
+#define CARVE_C(name) name = p; p += nC
+        // what a hot start needs (persist_doubles, written back to HBM) ...
+        CARVE_V(x); CARVE_V(g); CARVE_V(lb); CARVE_V(ub);
+        CARVE_C(Ax); CARVE_C(lbA); CARVE_C(ubA);
+        y = p; p += nV + nC;
+        // ... and the per-solve scratch
+        CARVE_V(gN); CARVE_V(lbN); CARVE_V(ubN);
         CARVE_V(dx); CARVE_V(w1); CARVE_V(w2); CARVE_V(w3); CARVE_V(w4); CARVE_V(w5); CARVE_V(w6);
         CARVE_V(wz1); CARVE_V(wz2); CARVE_V(wz3);
+        CARVE_C(lbAN); CARVE_C(ubAN); CARVE_C(dAx); CARVE_C(c1); CARVE_C(c2); CARVE_C(c3);
 #undef CARVE_V
-#define CARVE_C(name) name = p; p += nC
-        CARVE_C(Ax); CARVE_C(lbA); CARVE_C(ubA); CARVE_C(lbAN); CARVE_C(ubAN); CARVE_C(dAx); CARVE_C(c1); CARVE_C(c2); CARVE_C(c3);
 #undef CARVE_C
-        y = p; p += nV + nC;
         dy = p; p += nV + nC;
         scal = p; p += 8;
         Minv = tslot;                      // sizeT * ldm <= sizeT * ld
