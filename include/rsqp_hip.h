@@ -176,7 +176,9 @@ int rsqp_batch_sync(rsqp_batch *b);
 float rsqp_batch_last_solve_ms(rsqp_batch *b);
 /* HIP-event stopwatch on the batch's stream: start records an event, stop records a
  * second one, waits for it and returns the elapsed device time in ms (covers every
- * launch enqueued in between -- what bench.py divides by the step count). */
+ * launch enqueued in between -- what bench.py divides by the step count). While the stopwatch
+ * runs, rsqp_batch_solve does not record its own per-launch events (rsqp_batch_last_solve_ms keeps
+ * the value of the last solve outside a stopwatch interval). */
 int rsqp_batch_timer_start(rsqp_batch *b);
 float rsqp_batch_timer_stop_ms(rsqp_batch *b);
 /* results, concatenated like the inputs; any pointer may be NULL */

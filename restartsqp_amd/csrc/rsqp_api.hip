@@ -921,6 +921,7 @@ struct rsqp_batch {
     DevBuf<int> Wb, Wc, kV, kC;
     DevBuf<long long> koV, koC;
     float last_ms = 0.f;
+    bool timing = false;   // between timer_start and timer_stop: no per-launch events (they cost ~10 us of stream time each)
     ~rsqp_batch() {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -1050,10 +1051,10 @@ extern "C" int rsqp_batch_solve(rsqp_batch *b, int mode, int max_nWSR) {
     if (!b || mode < 0 || mode > 2 || max_nWSR < 0) return fail(RSQP_ERR_ARG, "rsqp_batch_solve");
     HIPCHK(hipSetDevice(b->device));
     QPPools p = pools_of(b);
-    HIPCHK(hipEventRecord(b->ev0, b->stream));
+    if (!b->timing) HIPCHK(hipEventRecord(b->ev0, b->stream));
     hipError_t e = rsqp_launch_small_qp(p, b->nq, b->nVmax, b->nCmax, b->mat_bytes_max, mode, max_nWSR, b->stream);
     if (e != hipSuccess) return fail(RSQP_ERR_DEVICE, std::string("QP kernel launch: ") + hipGetErrorString(e));
-    HIPCHK(hipEventRecord(b->ev1, b->stream));
+    if (!b->timing) HIPCHK(hipEventRecord(b->ev1, b->stream));
     return RSQP_OK;
 }
 
@@ -1076,11 +1077,13 @@ extern "C" int rsqp_batch_timer_start(rsqp_batch *b) {
     if (!b) return fail(RSQP_ERR_ARG, "null batch");
     HIPCHK(hipSetDevice(b->device));
     HIPCHK(hipEventRecord(b->ev2, b->stream));
+    b->timing = true;
     return RSQP_OK;
 }
 extern "C" float rsqp_batch_timer_stop_ms(rsqp_batch *b) {
     if (!b) return -1.f;
     float ms = -1.f;
+    b->timing = false;
     if (hipEventRecord(b->ev3, b->stream) != hipSuccess) return -1.f;
     if (hipEventSynchronize(b->ev3) != hipSuccess) return -1.f;
     if (hipEventElapsedTime(&ms, b->ev2, b->ev3) != hipSuccess) return -1.f;
