@@ -230,11 +230,35 @@ __global__ void __launch_bounds__(QC)
 k_qr_col(double *__restrict__ B, long long ldb, int m, int j, int k0, double *__restrict__ V, long long ldv,
          double *__restrict__ tau, double *__restrict__ rdiag, const double *__restrict__ norm2, double eps_li,
          int *__restrict__ flag) {
-    __shared__ double red[QC / 64];
+    __shared__ double red[QC / 64], red2[QC / 64];
     const double *cj = B + (long long)j * ldb;
-    double s = 0.0;
-    for (int i = j + 1 + threadIdx.x; i < m; i += QC) s += cj[i] * cj[i];
-    const double sigma = block_sum<QC>(s, red);
+    double *cc = B + (long long)(j + blockIdx.x) * ldb;
+    // one pass: the tail of column j and of this workgroup's column stay in registers (QR_REG rows
+    // per thread, i.e. m - j <= QR_REG * 1024; longer columns take the re-reading path)
+    constexpr int QR_REG = 12;
+    const bool inreg = m - j - 1 <= QR_REG * QC, mine = blockIdx.x != 0;
+    double vj[QR_REG], vc[QR_REG];
+    double s = 0.0, d = 0.0;
+    if (inreg) {
+#pragma unroll
+        for (int u = 0; u < QR_REG; u++) {
+            const int i = j + 1 + threadIdx.x + u * QC;
+            vj[u] = i < m ? cj[i] : 0.0;
+            vc[u] = (mine && i < m) ? cc[i] : 0.0;
+            s += vj[u] * vj[u];
+            d += vj[u] * vc[u];
+        }
+    } else {
+        for (int i = j + 1 + threadIdx.x; i < m; i += QC) { const double a = cj[i]; s += a * a; if (mine) d += a * cc[i]; }
+    }
+    // both sums through one pair of barriers
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); d += __shfl_xor(d, o); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; red2[threadIdx.x >> 6] = d; }
+    __syncthreads();
+    double sigma = 0.0, dsum = 0.0;
+#pragma unroll
+    for (int w = 0; w < QC / 64; w++) { sigma += red[w]; dsum += red2[w]; }
     const double alpha = cj[j];
     double tj = 0.0, beta = alpha, scale = 0.0;
     if (sigma != 0.0) {
@@ -243,24 +267,37 @@ k_qr_col(double *__restrict__ B, long long ldb, int m, int j, int k0, double *__
         tj = (beta - alpha) / beta;
         scale = 1.0 / (alpha - beta);
     }
-    if (blockIdx.x == 0) {
+    if (!mine) {
         if (threadIdx.x == 0) {
             tau[j] = tj; rdiag[j] = beta;
             if (!(sqrt(alpha * alpha + sigma) > eps_li * sqrt(norm2[j]))) atomicAdd(flag, 1);
         }
         double *v = V + (long long)(j - k0) * ldv;
-        for (int i = k0 + threadIdx.x; i < m; i += QC) v[i - k0] = i < j ? 0.0 : (i == j ? 1.0 : cj[i] * scale);
+        for (int i = k0 + threadIdx.x; i <= j && i < m; i += QC) v[i - k0] = i < j ? 0.0 : 1.0;
+        if (inreg) {
+#pragma unroll
+            for (int u = 0; u < QR_REG; u++) {
+                const int i = j + 1 + threadIdx.x + u * QC;
+                if (i < m) v[i - k0] = vj[u] * scale;
+            }
+        } else {
+            for (int i = j + 1 + threadIdx.x; i < m; i += QC) v[i - k0] = cj[i] * scale;
+        }
         return;
     }
-    double *cc = B + (long long)(j + blockIdx.x) * ldb;
-    double d = 0.0;
-    for (int i = j + 1 + threadIdx.x; i < m; i += QC) d += cj[i] * cc[i];
-    d = block_sum<QC>(d, red);
-    const double w = tj * (cc[j] + scale * d);
+    const double w = tj * (cc[j] + scale * dsum);
+    const double sw = scale * w;
+    if (inreg) {
+#pragma unroll
+        for (int u = 0; u < QR_REG; u++) {
+            const int i = j + 1 + threadIdx.x + u * QC;
+            if (i < m) cc[i] = vc[u] - vj[u] * sw;
+        }
+    } else {
+        for (int i = j + 1 + threadIdx.x; i < m; i += QC) cc[i] -= cj[i] * sw;
+    }
     __syncthreads();
     if (threadIdx.x == 0) cc[j] -= w;
-    const double sw = scale * w;
-    for (int i = j + 1 + threadIdx.x; i < m; i += QC) cc[i] -= cj[i] * sw;
 }
 
 // T factor of a panel (forward, columnwise: H_1 ... H_jb = I - V T V') from S = V'V and tau;
