@@ -340,36 +340,6 @@ __global__ void k_build_V(const double *__restrict__ B, long long ldb, int m, in
     V[(i - k0) + (long long)c * ldv] = i < k0 + c ? 0.0 : (i == k0 + c ? 1.0 : B[i + (long long)(k0 + c) * ldb]);
 }
 
-// W (jb x nt, ld NB) <- T' W (trans != 0) or T W; one thread per column, T in LDS
-__global__ void __launch_bounds__(64) k_apply_T(int jb, int nt, const double *__restrict__ T, int trans, double *__restrict__ W) {
-    __shared__ double Ts[NB][NB + 1];
-    for (int e = threadIdx.x; e < NB * NB; e += 64) Ts[e % NB][e / NB] = T[e];
-    __syncthreads();
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= nt) return;
-    double w[NB];
-    double *col = W + (long long)c * NB;
-#pragma unroll
-    for (int r = 0; r < NB; r++) w[r] = r < jb ? col[r] : 0.0;
-    if (trans) {
-#pragma unroll
-        for (int r = NB - 1; r >= 0; r--) {   // out[r] = sum_{c2 <= r} T[c2][r] w[c2]
-            double s = 0.0;
-#pragma unroll
-            for (int c2 = 0; c2 <= r; c2++) s += Ts[c2][r] * w[c2];
-            if (r < jb) col[r] = s;
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < NB; r++) {        // out[r] = sum_{c2 >= r} T[r][c2] w[c2]
-            double s = 0.0;
-#pragma unroll
-            for (int c2 = r; c2 < NB; c2++) s += Ts[r][c2] * w[c2];
-            if (r < jb) col[r] = s;
-        }
-    }
-}
-
 __global__ void k_set_identity(int m, double *__restrict__ Q, long long ldq) {
     const int j = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) Q[i + (long long)j * ldq] = i == j ? 1.0 : 0.0;
@@ -474,6 +444,7 @@ hipError_t rsqp_dense_work_alloc(RsqpDenseWork *w, long long mmax) {
     if ((e = hipMalloc((void **)&w->V, sizeof(double) * mmax * NB)) != hipSuccess) return e;
     if ((e = hipMalloc((void **)&w->T, sizeof(double) * np * NB * NB)) != hipSuccess) return e;
     if ((e = hipMalloc((void **)&w->W, sizeof(double) * mmax * NB)) != hipSuccess) return e;
+    if ((e = hipMalloc((void **)&w->W2, sizeof(double) * mmax * NB)) != hipSuccess) return e;
     if ((e = hipMalloc((void **)&w->tau, sizeof(double) * 2 * mmax)) != hipSuccess) return e;   // tau, rdiag
     if ((e = hipMalloc((void **)&w->norm2, sizeof(double) * mmax)) != hipSuccess) return e;
     if ((e = hipMalloc((void **)&w->dblk, sizeof(double) * 66 * NB * NB)) != hipSuccess) return e;   // S, Uinv + split-K slabs
@@ -486,7 +457,7 @@ hipError_t rsqp_dense_work_alloc(RsqpDenseWork *w, long long mmax) {
 }
 
 void rsqp_dense_work_free(RsqpDenseWork *w) {
-    double *d[] = {w->V, w->T, w->W, w->tau, w->norm2, w->dblk, w->ws};
+    double *d[] = {w->V, w->T, w->W, w->W2, w->tau, w->norm2, w->dblk, w->ws};
     for (double *p : d) if (p) (void)hipFree(p);
     if (w->flag) (void)hipFree(w->flag);
     *w = RsqpDenseWork();
@@ -511,8 +482,8 @@ hipError_t rsqp_dgeqrf(int m, int n, double *B, long long ldb, double eps_li, Rs
         if (nt > 0) {
             double *Ct = B + k0 + (long long)(k0 + jb) * ldb;
             DCHK(dgemm_ws(true, false, jb, nt, mt, 1.0, w->V, w->mmax, Ct, ldb, 0.0, w->W, NB, w->ws, w->ws_cap, st));   // W = V'C
-            hipLaunchKernelGGL(k_apply_T, dim3((nt + 63) / 64), dim3(64), 0, st, jb, nt, w->T + (long long)p * NB * NB, 1, w->W);
-            DCHK(rsqp_dgemm(false, false, mt, nt, jb, -1.0, w->V, w->mmax, w->W, NB, 1.0, Ct, ldb, st));   // C -= V (T'W)
+            DCHK(rsqp_dgemm(true, false, jb, nt, jb, 1.0, w->T + (long long)p * NB * NB, NB, w->W, NB, 0.0, w->W2, NB, st));   // T'W
+            DCHK(rsqp_dgemm(false, false, mt, nt, jb, -1.0, w->V, w->mmax, w->W2, NB, 1.0, Ct, ldb, st));   // C -= V (T'W)
         }
     }
     return hipGetLastError();
@@ -529,8 +500,8 @@ hipError_t rsqp_dorgqr(int m, int n, const double *B, long long ldb, double *Q, 
         hipLaunchKernelGGL(k_build_V, dim3((mt + 255) / 256, jb), dim3(256), 0, st, B, ldb, m, k0, jb, w->V, w->mmax);
         double *Qs = Q + k0 + (long long)k0 * ldq;
         DCHK(dgemm_ws(true, false, jb, mt, mt, 1.0, w->V, w->mmax, Qs, ldq, 0.0, w->W, NB, w->ws, w->ws_cap, st));   // W = V'Q
-        hipLaunchKernelGGL(k_apply_T, dim3((mt + 63) / 64), dim3(64), 0, st, jb, mt, w->T + (long long)p * NB * NB, 0, w->W);
-        DCHK(rsqp_dgemm(false, false, mt, mt, jb, -1.0, w->V, w->mmax, w->W, NB, 1.0, Qs, ldq, st));       // Q -= V (T W)
+        DCHK(rsqp_dgemm(false, false, jb, mt, jb, 1.0, w->T + (long long)p * NB * NB, NB, w->W, NB, 0.0, w->W2, NB, st));   // T W
+        DCHK(rsqp_dgemm(false, false, mt, mt, jb, -1.0, w->V, w->mmax, w->W2, NB, 1.0, Qs, ldq, st));       // Q -= V (T W)
     }
     return hipGetLastError();
 }

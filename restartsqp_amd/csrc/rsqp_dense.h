@@ -17,6 +17,7 @@ struct RsqpDenseWork {
     double *V = nullptr;     // mmax x NB   explicit panel reflectors (unit lower trapezoidal)
     double *T = nullptr;     // NB x NB     triangular factors of every panel, nb_panels * NB*NB
     double *W = nullptr;     // NB x mmax   V' C
+    double *W2 = nullptr;    // NB x mmax   T' W / T W
     double *tau = nullptr;   // mmax
     double *norm2 = nullptr; // mmax        squared norms of the original columns
     double *dblk = nullptr;  // NB x NB     diagonal block scratch
