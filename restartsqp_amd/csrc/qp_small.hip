@@ -50,6 +50,7 @@
 #define LDS __attribute__((address_space(3)))
 typedef LDS double ldouble;
 typedef LDS int lint;
+typedef LDS unsigned short lidx;   // staged matrix indices: every LDS-resident problem has < 65536 rows / entries
 typedef LDS char lchar;
 
 // diagnostic build only (-DRSQP_STAMPS, tools/stamp_small_kernel.py): cycles per phase of block 0
@@ -80,7 +81,7 @@ struct Blocking {
     int idx, side;
 };
 
-template <bool B> struct MatPtr { typedef const lint *I; typedef const ldouble *D; };
+template <bool B> struct MatPtr { typedef const lidx *I; typedef const ldouble *D; };
 template <> struct MatPtr<false> { typedef const int *I; typedef const double *D; };
 
 // MAT_LDS: the sparse matrices were staged into LDS behind the image (they fit for every
@@ -100,7 +101,6 @@ struct Engine {
     ldouble *x, *g, *lb, *ub, *gN, *lbN, *ubN, *dx, *wq, *wv1, *wv2, *wv3, *wv4, *rc, *rs;
     ldouble *Ax, *lbA, *ubA, *lbAN, *ubAN, *dAx, *wc1, *wc2;
     ldouble *y, *dy;
-    ldouble *scal;  // 8 scalars for broadcasts
     lint *Sb, *Sc, *AC, *posAC;
     lint *iscal;    // 8 ints
     static constexpr bool DENSE_MATS = false;
@@ -113,8 +113,9 @@ struct Engine {
     // doubles of this formulation's image (<= rsqp_image_doubles, the size of the persistent copy)
     __host__ __device__ static long long image_doubles(int nV, int nC) {
         const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
-        return 2 * ld * nV + sT * ld + 15LL * nV + 8LL * nC + 2LL * (nV + nC) + 8;
+        return 2 * ld * nV + sT * ld + 13LL * nV + 8LL * nC + 2LL * (nV + nC);
     }
+    __host__ __device__ static long long image_ints(int nV, int nC) { return nV + 3LL * nC + 4; }
     // leading part of the image that survives a solve (factors, iterate, auxiliary data, multipliers)
     __host__ __device__ static long long persist_doubles(int nV, int nC) {
         const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
@@ -134,18 +135,21 @@ struct Engine {
         y = p; p += nV + nC;
         // ... and the per-solve scratch
         CARVE_V(gN); CARVE_V(lbN); CARVE_V(ubN);
-        CARVE_V(dx); CARVE_V(wq); CARVE_V(wv1); CARVE_V(wv2); CARVE_V(wv3); CARVE_V(wv4); CARVE_V(rc); CARVE_V(rs);
+        CARVE_V(dx); CARVE_V(wq); CARVE_V(wv1); CARVE_V(wv2); CARVE_V(wv3); CARVE_V(wv4);
         CARVE_C(lbAN); CARVE_C(ubAN); CARVE_C(dAx); CARVE_C(wc1); CARVE_C(wc2);
 #undef CARVE_V
 #undef CARVE_C
         dy = p; p += nV + nC;
-        scal = p; p += 8;
+        // Givens coefficients of a sweep live in dx / dy: the step direction is dead from the homotopy
+        // step to the next step_direction(), which is when the working set changes (and in setup_aux,
+        // after y0 has been taken out of dy)
+        rc = dx; rs = dy;
         lint *ip = (lint *)p;
         Sb = ip; ip += nV;
         Sc = ip; ip += nC;
         AC = ip; ip += nC;
         posAC = ip; ip += nC;
-        iscal = ip; ip += 8;
+        iscal = ip; ip += 4;
     }
 
     // ------------------------------------------------------------------ reductions
@@ -937,8 +941,8 @@ struct Engine {
 // ------------------------------------------------------------------------------------
 // bytes of LDS needed to stage the sparse matrices of one problem behind its image
 __host__ __device__ inline long long mat_lds_bytes(int nV, int nC, int annz, int hnnz) {
-    long long ints = 2LL * (nV + 1) + (nC + 1) + 2LL * annz + hnnz, dbl = 2LL * annz + hnnz;
-    return ((ints * 4 + 7) & ~7LL) + dbl * 8;
+    long long idx = 2LL * (nV + 1) + (nC + 1) + 2LL * annz + hnnz, dbl = 2LL * annz + hnnz;   // 16-bit indices
+    return ((idx * 2 + 7) & ~7LL) + dbl * 8;
 }
 
 // L = lanes per problem (64 / L problems share one wave; each owns `stride` bytes of LDS),
@@ -971,9 +975,9 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
     long long &tlast = E.tlast;
 #endif
     E.carve(smem, d.nV, d.nC);
-    const int nd = (int)ENG::image_doubles(d.nV, d.nC), ni = (int)rsqp_image_ints(d.nV, d.nC);
+    const int nd = (int)ENG::image_doubles(d.nV, d.nC), ni = (int)ENG::image_ints(d.nV, d.nC);
     const int np = (int)ENG::persist_doubles(d.nV, d.nC);   // what goes to / comes from HBM: [np doubles][ni ints]
-    const int img_bytes = (nd * 8 + ni * 4 + 15) & ~15;
+    const int img_bytes = (nd * 8 + ni * 4 + 7) & ~7;   // the staged matrices follow 8-byte aligned
     E.haveH = d.haveH;
     E.hreg = d.hreg;
     const int *gAjc = P.Ajc + d.offAjc, *gAir = P.Air + d.offAnz, *gArp = P.Arp + d.offArp, *gAci = P.Aci + d.offAnz;
@@ -984,14 +988,14 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
     } else if constexpr (MAT_LDS) {
         // stage CSC(A), CSR(A), CSC(H) behind the image
         const int annz = gAjc[d.nV], hnnz = d.haveH ? gHjc[d.nV] : 0;
-        lint *ip0 = (lint *)(smem + img_bytes), *ip = ip0;
-        lint *lAjc = ip; ip += d.nV + 1;
-        lint *lArp = ip; ip += d.nC + 1;
-        lint *lHjc = ip; ip += d.nV + 1;
-        lint *lAir = ip; ip += annz;
-        lint *lAci = ip; ip += annz;
-        lint *lHir = ip; ip += hnnz;
-        ldouble *dp = (ldouble *)(smem + img_bytes + (((ip - ip0) * 4 + 7) & ~7));
+        LDS unsigned short *ip0 = (LDS unsigned short *)(smem + img_bytes), *ip = ip0;
+        LDS unsigned short *lAjc = ip; ip += d.nV + 1;
+        LDS unsigned short *lArp = ip; ip += d.nC + 1;
+        LDS unsigned short *lHjc = ip; ip += d.nV + 1;
+        LDS unsigned short *lAir = ip; ip += annz;
+        LDS unsigned short *lAci = ip; ip += annz;
+        LDS unsigned short *lHir = ip; ip += hnnz;
+        ldouble *dp = (ldouble *)(smem + img_bytes + (((ip - ip0) * 2 + 7) & ~7));
         ldouble *lAval = dp; dp += annz;
         ldouble *lArv = dp; dp += annz;
         ldouble *lHval = dp;
@@ -1102,12 +1106,13 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     if (eng == 1 && mat_bytes_max >= 0) mat_bytes_max = 8LL * ((long long)nVmax * nVmax + (long long)nCmax * nVmax);
     // LDS image of the chosen formulation (the persistent copy in HBM is sized for the larger one)
     const long long imgd = eng == 1 ? EngineX<64, true>::image_doubles(nVmax, nCmax) : Engine<64, true>::image_doubles(nVmax, nCmax);
-    const long long img = align16(8 * imgd + 4 * rsqp_image_ints(nVmax, nCmax));
-    const bool mat_lds = mat_bytes_max >= 0 && img + align16(mat_bytes_max) <= kMaxLds;
-    // LDS of one problem; an odd number of 16-byte units spreads the problems that share a wave
-    // over the banks
-    long long stride = img + (mat_lds ? align16(mat_bytes_max) : 0);
-    if (((stride >> 4) & 1) == 0) stride += 16;
+    const long long imgi = eng == 1 ? EngineX<64, true>::image_ints(nVmax, nCmax) : Engine<64, true>::image_ints(nVmax, nCmax);
+    const long long img = (8 * imgd + 4 * imgi + 7) & ~7LL;
+    const bool mat_lds = mat_bytes_max >= 0 && align16(img + mat_bytes_max) <= kMaxLds;
+    // LDS of one problem: image, then its staged matrices, 16-byte granular.
+    long long stride = align16(img + (mat_lds ? mat_bytes_max : 0));
+    // (an odd number of 16-byte units would spread the problems of a wave over the banks, but the LDS is
+    // allocated in 512-byte steps and the 8-lane build needs 8 x 2880 = 45 x 512 bytes for 7 workgroups per CU)
     // lanes per problem: the vectors of the engine have nV (+ nC) entries, a wave of 64 lanes is
     // mostly idle on hs0xx-scale problems, so 64 / L of them share a wave. Problems in one wave
     // follow their own control flow (exec masking); the LDS capacity bounds the problems in flight.
@@ -1117,7 +1122,7 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     if ((forcedL == 8 || forcedL == 16 || forcedL == 32 || forcedL == 64) && forcedL >= L) L = forcedL;   // never fewer lanes than entries
     if (!mat_lds) L = 64;
     while (L < 64 && (64 / L) * stride > kMaxLds) L *= 2;
-    if (L == 64 && stride > kMaxLds) stride = mat_lds ? img + align16(mat_bytes_max) : img;
+    if (L == 64 && stride > kMaxLds) stride = align16(mat_lds ? img + mat_bytes_max : img);
     static const int forcedWide0 = env_int("RSQP_SMALL_WIDE", -1);
     const bool wide0 = eng == 1 && mat_lds && L == 64 && (forcedWide0 >= 0 ? forcedWide0 != 0 : nVmax > 32);
     bool wide = false;

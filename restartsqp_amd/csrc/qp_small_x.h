@@ -44,6 +44,7 @@ struct EngineX {
         const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
         return 2 * ld * nV + sT * ld + 4LL * nV + 3LL * nC + (nV + nC);
     }
+    __host__ __device__ static long long image_ints(int nV, int nC) { return nV + 3LL * nC + 8; }
     __device__ __forceinline__ void carve(lchar *base, int nV_, int nC_) {
         nV = nV_; nC = nC_; ld = rsqp_ld(nV); sizeT = nV < nC ? nV : nC; ldm = sizeT | 1;
         ldouble *p = (ldouble *)base;
