@@ -49,7 +49,7 @@
 // lowered to flat_load, which is several times slower and costs two registers)
 #define LDS __attribute__((address_space(3)))
 typedef LDS double ldouble;
-typedef LDS int lint;
+typedef LDS short lint;   // working-set arrays in LDS: statuses in {-1,0,1}, indices < 32768 (HBM copies stay int)
 typedef LDS unsigned short lidx;   // staged matrix indices: every LDS-resident problem has < 65536 rows / entries
 typedef LDS char lchar;
 
@@ -113,7 +113,7 @@ struct Engine {
     // doubles of this formulation's image (<= rsqp_image_doubles, the size of the persistent copy)
     __host__ __device__ static long long image_doubles(int nV, int nC) {
         const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
-        return 2 * ld * nV + sT * ld + 13LL * nV + 8LL * nC + 2LL * (nV + nC);
+        return 2 * ld * nV + sT * ld + 12LL * nV + 8LL * nC + 2LL * (nV + nC);
     }
     __host__ __device__ static long long image_ints(int nV, int nC) { return nV + 3LL * nC + 4; }
     // leading part of the image that survives a solve (factors, iterate, auxiliary data, multipliers)
@@ -135,7 +135,8 @@ struct Engine {
         y = p; p += nV + nC;
         // ... and the per-solve scratch
         CARVE_V(gN); CARVE_V(lbN); CARVE_V(ubN);
-        CARVE_V(dx); CARVE_V(wq); CARVE_V(wv1); CARVE_V(wv2); CARVE_V(wv3); CARVE_V(wv4);
+        CARVE_V(dx); CARVE_V(wq); CARVE_V(wv1); CARVE_V(wv2); CARVE_V(wv3);
+        wv4 = wv3;   // the incoming row of an exchange / the staged x0: never alive together with wv3 (Cholesky work vector)
         CARVE_C(lbAN); CARVE_C(ubAN); CARVE_C(dAx); CARVE_C(wc1); CARVE_C(wc2);
 #undef CARVE_V
 #undef CARVE_C
@@ -977,7 +978,7 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
     E.carve(smem, d.nV, d.nC);
     const int nd = (int)ENG::image_doubles(d.nV, d.nC), ni = (int)ENG::image_ints(d.nV, d.nC);
     const int np = (int)ENG::persist_doubles(d.nV, d.nC);   // what goes to / comes from HBM: [np doubles][ni ints]
-    const int img_bytes = (nd * 8 + ni * 4 + 7) & ~7;   // the staged matrices follow 8-byte aligned
+    const int img_bytes = (nd * 8 + ni * 2 + 7) & ~7;   // the staged matrices follow 8-byte aligned
     E.haveH = d.haveH;
     E.hreg = d.hreg;
     const int *gAjc = P.Ajc + d.offAjc, *gAir = P.Air + d.offAnz, *gArp = P.Arp + d.offArp, *gAci = P.Aci + d.offAnz;
@@ -1107,7 +1108,7 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     // LDS image of the chosen formulation (the persistent copy in HBM is sized for the larger one)
     const long long imgd = eng == 1 ? EngineX<64, true>::image_doubles(nVmax, nCmax) : Engine<64, true>::image_doubles(nVmax, nCmax);
     const long long imgi = eng == 1 ? EngineX<64, true>::image_ints(nVmax, nCmax) : Engine<64, true>::image_ints(nVmax, nCmax);
-    const long long img = (8 * imgd + 4 * imgi + 7) & ~7LL;
+    const long long img = (8 * imgd + 2 * imgi + 7) & ~7LL;
     const bool mat_lds = mat_bytes_max >= 0 && align16(img + mat_bytes_max) <= kMaxLds;
     // LDS of one problem: image, then its staged matrices, 16-byte granular.
     long long stride = align16(img + (mat_lds ? mat_bytes_max : 0));

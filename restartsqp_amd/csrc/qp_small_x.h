@@ -99,7 +99,7 @@ struct EngineX {
 
     // ------------------------------------------------------------------ reductions
     // butterflies over the lanes of the problem; with several waves (L > 64) the wave results meet
-    // in `scal` / `iscal[4..]` and are combined in wave order, so every lane ends with the same value
+    // in `scal` and are combined in wave order, so every lane ends with the same value
     __device__ __forceinline__ double block_sum(double v) {
 #pragma unroll
         for (int o = (L > 64 ? 64 : L) / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -122,12 +122,12 @@ struct EngineX {
         }
         if constexpr (L > 64) {
             __syncthreads();
-            if ((lane & 63) == 0) { scal[lane >> 6] = t; iscal[4 + (lane >> 6)] = id; }
+            if ((lane & 63) == 0) { scal[lane >> 6] = t; scal[4 + (lane >> 6)] = (double)id; }   // ids exceed the 16-bit LDS integers
             __syncthreads();
-            t = scal[0]; id = iscal[4];
+            t = scal[0]; id = (int)scal[4];
 #pragma unroll
             for (int w = 1; w < L / 64; w++) {
-                const double t2 = scal[w]; const int id2 = iscal[4 + w];
+                const double t2 = scal[w]; const int id2 = (int)scal[4 + w];
                 if (t2 < t || (t2 == t && id2 < id)) { t = t2; id = id2; }
             }
         }
