@@ -45,6 +45,8 @@
         }                                                        \
     } while (0)
 #define PFOR(i, n) for (int i = lane; i < (n); i += L)
+// packed upper-Hessenberg R of the Givens / TQ engine: element (row r, column c), r <= c + 1
+#define RIX(c, r) ((c) * ((c) + 3) / 2 + (r))
 // LDS-qualified pointer types: guarantees ds_read / ds_write (a generic pointer would be
 // lowered to flat_load, which is several times slower and costs two registers)
 #define LDS __attribute__((address_space(3)))
@@ -113,19 +115,19 @@ struct Engine {
     // doubles of this formulation's image (<= rsqp_image_doubles, the size of the persistent copy)
     __host__ __device__ static long long image_doubles(int nV, int nC) {
         const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
-        return 2 * ld * nV + sT * ld + 12LL * nV + 8LL * nC + 2LL * (nV + nC);
+        return ld * nV + (long long)nV * (nV + 3) / 2 + sT * ld + 12LL * nV + 8LL * nC + 2LL * (nV + nC);
     }
     __host__ __device__ static long long image_ints(int nV, int nC) { return nV + 3LL * nC + 4; }
     // leading part of the image that survives a solve (factors, iterate, auxiliary data, multipliers)
     __host__ __device__ static long long persist_doubles(int nV, int nC) {
         const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
-        return 2 * ld * nV + sT * ld + 4LL * nV + 3LL * nC + (nV + nC);
+        return ld * nV + (long long)nV * (nV + 3) / 2 + sT * ld + 4LL * nV + 3LL * nC + (nV + nC);
     }
     __device__ __forceinline__ void carve(lchar *base, int nV_, int nC_) {
         nV = nV_; nC = nC_; ld = rsqp_ld(nV); sizeT = nV < nC ? nV : nC;
         ldouble *p = (ldouble *)base;
         Q = p; p += ld * nV;
-        R = p; p += ld * nV;
+        R = p; p += RIX(nV, 0);   // packed upper Hessenberg: column c holds rows 0 .. c + 1 (the sweeps create one sub-diagonal)
         T = p; p += sizeT * ld;
 #define CARVE_V(name) name = p; p += nV
 #define CARVE_C(name) name = p; p += nC
@@ -306,22 +308,22 @@ struct Engine {
         if (nZ < 2) return;
         PFOR(r, nZ) {
             int j0 = r > 0 ? r - 1 : 0;
-            double carry = R[j0 * ld + r];
+            double carry = R[RIX(j0, r)];
             for (int j = j0; j + 1 < nZ; j++) {
-                double b = R[(j + 1) * ld + r], c = rc[j], s = rs[j];
-                R[j * ld + r] = c * carry - s * b;
+                double b = R[RIX(j + 1, r)], c = rc[j], s = rs[j];
+                R[RIX(j, r)] = c * carry - s * b;
                 carry = s * carry + c * b;
             }
-            R[(nZ - 1) * ld + r] = carry;
+            R[RIX(nZ - 1, r)] = carry;
         }
         SYNC();
         for (int j = 0; j + 1 < nZ; j++) {
-            double diag = R[j * ld + j], sub = R[j * ld + j + 1];
+            double diag = R[RIX(j, j)], sub = R[RIX(j, j + 1)];
             if (sub != 0.0) {  // uniform: every lane read the same LDS words
                 double r = hypot(diag, sub), cc = diag / r, ss = sub / r;
                 SYNC();
                 for (int col = j + lane; col < nZ; col += L) {
-                    ldouble *pc = R + col * ld;
+                    ldouble *pc = R + RIX(col, 0);
                     double a = pc[j], b = pc[j + 1];
                     pc[j] = cc * a + ss * b;
                     pc[j + 1] = col == j ? 0.0 : -ss * a + cc * b;
@@ -407,16 +409,16 @@ struct Engine {
         SYNC();
         // R' r = rhs, column oriented
         for (int j = 0; j < zc; j++) {
-            double rj = wv3[j] / R[j * ld + j];
+            double rj = wv3[j] / R[RIX(j, j)];
             SYNC();
             if (lane == 0) wv3[j] = rj;
-            for (int k = j + 1 + lane; k < zc; k += L) wv3[k] -= R[k * ld + j] * rj;
+            for (int k = j + 1 + lane; k < zc; k += L) wv3[k] -= R[RIX(k, j)] * rj;
             SYNC();
         }
         double rr = dot(wv3, wv3, zc);
         double rho2 = zHz - rr;
         if (!(rho2 > RSQP_EPS_PD_REL * (fabs(zHz) + rr) + RSQP_EPS_PD_ABS)) return false;
-        PFOR(j, nV) R[zc * ld + j] = j < zc ? wv3[j] : (j == zc ? sqrt(rho2) : 0.0);
+        PFOR(j, zc + 2) R[RIX(zc, j)] = j < zc ? wv3[j] : (j == zc ? sqrt(rho2) : 0.0);   // rows 0 .. zc + 1 of the packed column
         SYNC();
         return true;
     }
@@ -530,7 +532,8 @@ struct Engine {
         SYNC();
         PFOR(v, nV) { x[v] = wv4[v]; Sb[v] = (int)wq[v]; }
         PFOR(i, nV + nC) y[i] = dy[i];
-        for (int k = lane; k < ld * nV; k += L) { Q[k] = 0.0; R[k] = 0.0; }
+        for (int k = lane; k < ld * nV; k += L) Q[k] = 0.0;
+        for (int k = lane; k < RIX(nV, 0); k += L) R[k] = 0.0;
         for (int k = lane; k < sizeT * ld; k += L) T[k] = 0.0;
         PFOR(i, nC) { Sc[i] = 0; posAC[i] = -1; }
         SYNC();
@@ -627,17 +630,17 @@ struct Engine {
         }
         SYNC();
         for (int j = 0; j < nZ; j++) {
-            double u = wq[j] / R[j * ld + j];
+            double u = wq[j] / R[RIX(j, j)];
             SYNC();
             if (lane == 0) wq[j] = u;
-            for (int k = j + 1 + lane; k < nZ; k += L) wq[k] -= R[k * ld + j] * u;
+            for (int k = j + 1 + lane; k < nZ; k += L) wq[k] -= R[RIX(k, j)] * u;
             SYNC();
         }
         for (int j = nZ - 1; j >= 0; j--) {
-            double w = wq[j] / R[j * ld + j];
+            double w = wq[j] / R[RIX(j, j)];
             SYNC();
             if (lane == 0) wq[j] = w;
-            for (int k = lane; k < j; k += L) wq[k] -= R[j * ld + k] * w;
+            for (int k = lane; k < j; k += L) wq[k] -= R[RIX(j, k)] * w;
             SYNC();
         }
         PFOR(v, nV) {
