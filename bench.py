@@ -326,7 +326,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic("Engine<8", 1.0) if B == 65536 else None,
                          "traffic_note": "FETCH_SIZE uncorrected (narrow loads, uncalibrated) + WRITE_SIZE; the "
-                                         "writes are the 2.0 KB/QP of engine state a hot start needs",
+                                         "writes are the 1.7 KB/QP of engine state a hot start needs",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "latency/LDS-bound kernel: HBM fraction is not its limiter"},
         }
