@@ -1,0 +1,41 @@
+"""Randomised check of the LDS engines against the CPU oracle (test infrastructure): mixed shapes
+incl. nV = 1, nC = 0, nC > nV; cold start, hot start on perturbed vectors. Usage (GPU box):
+  python tools/fuzz_small_vs_oracle.py [seed] [count]      (RSQP_SMALL_ENGINE=0|1 to force a formulation)"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from restartsqp_amd import capi, problems
+import oracle as O
+O.build()
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+rng = np.random.default_rng(seed)
+bad = 0
+for group, (vmax, cmax) in enumerate(((8, 8), (16, 16), (32, 40), (45, 50))):
+    probs = []
+    for k in range(count):
+        nV = int(rng.integers(1, vmax + 1)); nC = int(rng.integers(0, cmax + 1))
+        probs.append(problems.random_qp(rng, nV, nC, density=float(rng.uniform(0.2, 1.0))))
+    b = capi.Batch(probs)
+    b.solve(capi.MODE_COLD, 2000)
+    res = b.results()
+    pert = [problems.perturb(rng, p, 0.05) for p in probs]
+    b.set_vectors_from(pert)
+    b.solve(capi.MODE_HOT_VECTORS, 2000)
+    res2 = b.results()
+    for q, q2, r, r2 in zip(probs, pert, res, res2):
+        qp = O.OracleQP(q.nV, q.nC); qp.set_A_csc(q.A_jc, q.A_ir, q.A_val); qp.set_H_csc(q.H_jc, q.H_ir, q.H_val)
+        rc, n = qp.init(q.g, q.lb, q.ub, q.lbA, q.ubA, 2000)
+        ok = (r["status"] == qp.exitflag() and r["nWSR"] == n and np.array_equal(r["ws_b"], qp.ws_bounds) and np.array_equal(r["ws_c"], qp.ws_constraints)
+              and np.abs(r["x"] - qp.x).max() <= 1e-9 * max(1.0, np.abs(qp.x).max()) and np.abs(r["y"] - qp.y).max() <= 1e-9 * max(1.0, np.abs(qp.y).max()))
+        rc, n2 = qp.hotstart(q2.g, q2.lb, q2.ub, q2.lbA, q2.ubA, 2000)
+        ok2 = (r2["status"] == qp.exitflag() and r2["nWSR"] == n2 and np.array_equal(r2["ws_b"], qp.ws_bounds) and np.array_equal(r2["ws_c"], qp.ws_constraints)
+               and np.abs(r2["x"] - qp.x).max() <= 1e-9 * max(1.0, np.abs(qp.x).max()))
+        if not (ok and ok2):
+            bad += 1
+            if bad <= 5:
+                print("MISMATCH group", group, "shape", q.nV, q.nC, "cold", ok, "hot", ok2, "nWSR", r["nWSR"], n, r2["nWSR"], n2, "status", r["status"], r2["status"])
+    print("group %d (nV <= %d, nC <= %d): %d QPs checked, mismatches so far %d" % (group, vmax, cmax, len(probs), bad), flush=True)
+print("FUZZ", "FAILED" if bad else "OK")
+sys.exit(1 if bad else 0)
