@@ -595,12 +595,15 @@ struct Engine {
         PFOR(i, nV + nC) dy[i] = 0.0;
         SYNC();
         A_times(dx, wc2);
-        H_times(dx, wv2);
+        // without a null space (nZ == 0: every free direction is pinned by an active constraint -- the
+        // whole cold-start phase of hs0xx-scale problems) the projected-gradient part below is empty:
+        // its two Hessian products are skipped, nothing else depends on them
+        if (nZ > 0) H_times(dx, wv2);
         PFOR(i, nAC) {
             int r = AC[i];
             wc1[i] = (Sc[r] == -1 ? delta_of(lbAN[r], lbA[r]) : delta_of(ubAN[r], ubA[r])) - wc2[r];
         }
-        PFOR(v, nV) wv1[v] = (gN[v] - g[v]) + wv2[v];  // tmpg
+        if (nZ > 0) { PFOR(v, nV) wv1[v] = (gN[v] - g[v]) + wv2[v]; }  // tmpg
         PFOR(c, nFR) wq[c] = 0.0;
         SYNC();
         // range space: T wY = bA (column oriented)
@@ -619,9 +622,11 @@ struct Engine {
         }
         SYNC();
         // null space: R'R wZ = -Z'(tmpg + H xY)
-        H_times(wv3, wv2);
-        PFOR(v, nV) wv2[v] += wv1[v];
-        SYNC();
+        if (nZ > 0) {
+            H_times(wv3, wv2);
+            PFOR(v, nV) wv2[v] += wv1[v];
+            SYNC();
+        }
         PFOR(j, nZ) {
             const ldouble *qj = Q + j * ld;
             double s = 0.0;
@@ -1124,6 +1129,7 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     const int nmax = nVmax > nCmax ? nVmax : nCmax;
     int L = nmax <= 8 ? 8 : (nmax <= 16 ? 16 : (nmax <= 32 ? 32 : 64));
     if ((forcedL == 8 || forcedL == 16 || forcedL == 32 || forcedL == 64) && forcedL >= L) L = forcedL;   // never fewer lanes than entries
+    if (eng == 1 && L < 16) L = 16;   // the explicit-inverse build has no 8-lane instantiation
     if (!mat_lds) L = 64;
     while (L < 64 && (64 / L) * stride > kMaxLds) L *= 2;
     if (L == 64 && stride > kMaxLds) stride = align16(mat_lds ? img + mat_bytes_max : img);

@@ -740,23 +740,27 @@ struct EngineX {
         PFOR(i, nV + nC) dy[i] = 0.0;
         SYNC();
         A_times(dx, c1);                                            // A dx_FX
-        H_times(dx, w2);
+        if (nZ > 0) H_times(dx, w2);                                // (no null space: the projected-gradient part is empty)
         PFOR(j, nAC) {
             const int r = AC[j];
             a1[j] = (Sc[r] == -1 ? delta_of(lbAN[r], lbA[r]) : delta_of(ubAN[r], ubA[r])) - c1[r];   // bA
         }
-        PFOR(v, nV) w1[v] = w2[v] + (gN[v] - g[v]);                 // tmpg
+        if (nZ > 0) { PFOR(v, nV) w1[v] = w2[v] + (gN[v] - g[v]); }  // tmpg
         SYNC();
         // range space: wY = Minv bA ; xY = Y wY
         gemv_n(Minv, ldm, nAC, nAC, a1, 1.0, 0.0, nullptr, a2);
         gemv_n(Y, ldy, nV, nAC, a2, 1.0, 0.0, nullptr, w3);
         // null space: wZ = -Wz Z'(tmpg + H xY) ; dx_FR = xY + Z wZ
-        H_times(w3, w2);
-        PFOR(v, nV) w2[v] = 1.0 * w2[v] + 1.0 * w1[v];
-        SYNC();
-        gemv_t(Z, ld, nV, nZ, w2, wz1);
-        gemv_n(Wz, ld, nZ, nZ, wz1, -1.0, 0.0, nullptr, wz2);
-        gemv_n(Z, ld, nV, nZ, wz2, 1.0, 1.0, w3, w4);
+        if (nZ > 0) {
+            H_times(w3, w2);
+            PFOR(v, nV) w2[v] = 1.0 * w2[v] + 1.0 * w1[v];
+            SYNC();
+            gemv_t(Z, ld, nV, nZ, w2, wz1);
+            gemv_n(Wz, ld, nZ, nZ, wz1, -1.0, 0.0, nullptr, wz2);
+            gemv_n(Z, ld, nV, nZ, wz2, 1.0, 1.0, w3, w4);
+        } else {
+            copyv(w3, w4, nV);
+        }
         PFOR(v, nV) if (Sb[v] == 0) dx[v] = w4[v];
         SYNC();
         // multipliers: dyAC = Minv' Y'(H dx + dg)
