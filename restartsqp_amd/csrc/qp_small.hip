@@ -546,7 +546,8 @@ struct Engine {
         SYNC();
         nFR = iscal[0];
         nAC = 0;
-        A_times(x, Ax);
+        // products with x = 0 / y = 0 (a cold start) are zero vectors: no need to walk the matrices
+        if (x0) A_times(x, Ax); else { PFOR(i, nC) Ax[i] = 0.0; SYNC(); }
         for (int i = 0; i < nC; i++) {
             int s = 0;
             if (guess_c) s = (int)wc1[i];
@@ -565,8 +566,9 @@ struct Engine {
             if (Sc[i] == 0 || (Sc[i] == -1 && yi < 0.0) || (Sc[i] == 1 && yi > 0.0)) y[nV + i] = 0.0;
         }
         SYNC();
-        AT_times(y + nV, wv1);
-        H_times(x, wv2);
+        if (y0) AT_times(y + nV, wv1); else { PFOR(v, nV) wv1[v] = 0.0; }
+        if (x0) H_times(x, wv2); else { PFOR(v, nV) wv2[v] = 0.0; }
+        SYNC();
         PFOR(v, nV) {
             double xv = x[v];
             g[v] = wv1[v] + y[v] - wv2[v];
@@ -676,7 +678,7 @@ struct Engine {
             for (int cc = c + 1 + lane; cc < nFR; cc += L) wq[cc] -= ri[cc] * d;
             SYNC();
         }
-        AT_times(dy + nV, wv3);
+        if (nAC > 0) AT_times(dy + nV, wv3); else { PFOR(v, nV) wv3[v] = 0.0; SYNC(); }   // no active constraint: dy_C = 0
         PFOR(v, nV) dy[v] = Sb[v] != 0 ? wv2[v] - wv3[v] : 0.0;
         A_times(dx, dAx);
     }
@@ -782,7 +784,7 @@ struct Engine {
             for (int cc = c + 1 + lane; cc < nFR; cc += L) wq[cc] -= ri[cc] * d;
             SYNC();
         }
-        AT_times(wc2, wv2);
+        if (nAC > 0) AT_times(wc2, wv2); else { PFOR(v, nV) wv2[v] = 0.0; SYNC(); }   // xi_C = 0 without active constraints
         PFOR(v, nV) wv2[v] = Sb[v] != 0 ? wv4[v] - wv2[v] : 0.0;  // xiB
         SYNC();
         double sgn = side == 1 ? -1.0 : 1.0;
