@@ -118,6 +118,10 @@ struct Engine {
         return ld * nV + (long long)nV * (nV + 3) / 2 + sT * ld + 12LL * nV + 8LL * nC + 2LL * (nV + nC);
     }
     __host__ __device__ static long long image_ints(int nV, int nC) { return nV + 3LL * nC + 4; }
+    __host__ __device__ static long long factor_doubles(int nV, int nC) {   // Q, R, T: (re)initialised by setup_aux
+        const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
+        return ld * nV + (long long)nV * (nV + 3) / 2 + sT * ld;
+    }
     // leading part of the image that survives a solve (factors, iterate, auxiliary data, multipliers)
     __host__ __device__ static long long persist_doubles(int nV, int nC) {
         const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
@@ -998,7 +1002,7 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
         E.stage_dense(smem + img_bytes, gAjc, gAir, gAval, gHjc, gHir, gHval);
     } else if constexpr (MAT_LDS) {
         // stage CSC(A), CSR(A), CSC(H) behind the image
-        const int annz = gAjc[d.nV], hnnz = d.haveH ? gHjc[d.nV] : 0;
+        const int annz = d.annz >= 0 ? d.annz : gAjc[d.nV], hnnz = !d.haveH ? 0 : (d.hnnz >= 0 ? d.hnnz : gHjc[d.nV]);
         LDS unsigned short *ip0 = (LDS unsigned short *)(smem + img_bytes), *ip = ip0;
         LDS unsigned short *lAjc = ip; ip += d.nV + 1;
         LDS unsigned short *lArp = ip; ip += d.nC + 1;
@@ -1028,7 +1032,8 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
 
     int rcode = RET_OK, nWSR = 0;
     if (mode == 0) {
-        for (int k = lane; k < nd; k += L) simg[k] = 0.0;
+        // (the factor arrays at the head of the image are zeroed by setup_aux itself)
+        for (int k = (int)ENG::factor_doubles(d.nV, d.nC) + lane; k < nd; k += L) simg[k] = 0.0;
         for (int k = lane; k < ni; k += L) siimg[k] = 0;
         SYNC();
     }

@@ -39,6 +39,9 @@ struct EngineX {
         const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
         return 2 * ld * nV + sT * ld + 17LL * nV + 9LL * nC + 2LL * (nV + nC) + 8 + 4 * (sT + 2);
     }
+    __host__ __device__ static long long factor_doubles(int nV, int nC) {   // Z (+Y), Wz: (re)initialised by setup_aux
+        return 2LL * rsqp_ld(nV) * nV;
+    }
     // leading part of the image that survives a solve (bases, inverses, iterate, auxiliary data, multipliers)
     __host__ __device__ static long long persist_doubles(int nV, int nC) {
         const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;

@@ -264,6 +264,7 @@ int ensure_desc(rsqp_solver *s) {
     QPDesc d;
     std::memset(&d, 0, sizeof(d));
     d.nV = s->nV; d.nC = s->nC; d.haveH = (s->H.initialised && !s->lp_mode) ? 1 : 0;
+    d.annz = d.hnnz = -1;
     d.hreg = s->hreg;
     std::vector<QPDesc> hd(1, d);
     HIPCHK(s->d_desc.from(hd));
@@ -971,6 +972,7 @@ extern "C" int rsqp_batch_create(int nq, const int *nV, const int *nC, const int
         d.offState = offState;
         const int *jc = Ajc + offAjc;
         const int annz = jc[d.nV];
+        d.annz = annz; d.hnnz = b->haveH ? Hjc[offHjc + d.nV] : 0;
         for (int k = 0; k < annz; k++)
             if (Air[offAnz + k] < 0 || Air[offAnz + k] >= d.nC) return fail(RSQP_ERR_ARG, "rsqp_batch_create: A row index");
         CsrCopy r;

@@ -25,6 +25,7 @@ struct QPDesc {
     int offArp;           // A (CSR copy): Arp at offArp (nC+1 ints)
     int offHjc, offHnz;   // H (CSC, full symmetric)
     int haveH;
+    int annz, hnnz;       // entry counts of A and H when the host knows them (saves a dependent load), else -1
     double hreg;          // H + hreg*I (LP path: qpOASES regularises an all-zero Hessian)
     long long offState;   // persistent engine image (doubles) for hot starts
 };
