@@ -816,12 +816,10 @@ int run_certificate(rsqp_solver *s, rsqp_optimality_status *out, int *W_c, int *
     HIPCHK(hipSetDevice(s->device));
     int rc = flush_vectors(s);
     if (rc != RSQP_OK) return rc;
-    if (s->fits_small && s->A.initialised == (s->nC > 0)) {
-        // hs0xx-scale: all three products in one launch (one workgroup), results by zero-copy
+    const bool fused = s->fits_small && s->A.initialised == (s->nC > 0);
+    if (fused) {
+        // hs0xx-scale: the three products and the certificate in ONE launch (one workgroup), below
         if ((rc = ensure_desc(s)) != RSQP_OK) return rc;
-        QPPools p = pools_of(s);
-        if (rsqp_launch_small_products(p, 1, s->d_Ax.p, s->d_ATy.p, s->d_Hx.p, s->stream) != hipSuccess)
-            return fail(RSQP_ERR_DEVICE, "products launch failed");
     } else if (s->nC > 0) {
         if ((rc = spmv_csr(s, s->A, s->d_x.p, s->d_Ax.p)) != RSQP_OK) return rc;             // A x
         if ((rc = spmv_csc(s, s->A, s->d_y.p + s->nV, s->d_ATy.p)) != RSQP_OK) return rc;    // A'y_c
@@ -841,7 +839,11 @@ int run_certificate(rsqp_solver *s, rsqp_optimality_status *out, int *W_c, int *
     a.ub = s->d_vec[RSQP_VEC_UB].p; a.lbA = s->d_vec[RSQP_VEC_LBA].p; a.ubA = s->d_vec[RSQP_VEC_UBA].p;
     a.Ax = s->d_Ax.p; a.ATy = s->d_ATy.p; a.Hx = s->d_Hx.p;
     a.ws_b = s->d_wsb.p; a.ws_c = s->d_wsc.p; a.W_b = s->d_Wb.p; a.W_c = s->d_Wc.p; a.out = s->d_kkt.p;
-    if (rsqp_launch_kkt(a, 1, s->stream) != hipSuccess) return fail(RSQP_ERR_DEVICE, "kkt launch failed");
+    if (fused) {
+        QPPools p = pools_of(s);
+        if (rsqp_launch_small_certificate(p, a, 1, s->d_Ax.p, s->d_ATy.p, s->d_Hx.p, s->stream) != hipSuccess)
+            return fail(RSQP_ERR_DEVICE, "certificate launch failed");
+    } else if (rsqp_launch_kkt(a, 1, s->stream) != hipSuccess) return fail(RSQP_ERR_DEVICE, "kkt launch failed");
     HIPCHK(hipStreamSynchronize(s->stream));
     double o[6];
     HIPCHK(s->d_kkt.download(o, 6));
@@ -1125,15 +1127,14 @@ extern "C" int rsqp_batch_test_optimality(rsqp_batch *b, rsqp_optimality_status 
         HIPCHK(b->kV.from(kv)); HIPCHK(b->kC.from(kc)); HIPCHK(b->koV.from(ov)); HIPCHK(b->koC.from(oc));
     }
     QPPools p = pools_of(b);
-    if (rsqp_launch_small_products(p, b->nq, b->Ax.p, b->ATy.p, b->Hx.p, b->stream) != hipSuccess)
-        return fail(RSQP_ERR_DEVICE, "products launch failed");
     RsqpKktArgs a;
     std::memset(&a, 0, sizeof(a));
     a.nV = b->kV.p; a.nC = b->kC.p; a.offV = b->koV.p; a.offC = b->koC.p;
     a.x = b->x.p; a.y = b->y.p; a.g = b->g.p; a.lb = b->lb.p; a.ub = b->ub.p; a.lbA = b->lbA.p; a.ubA = b->ubA.p;
     a.Ax = b->Ax.p; a.ATy = b->ATy.p; a.Hx = b->Hx.p; a.ws_b = b->ws_b.p; a.ws_c = b->ws_c.p;
     a.W_b = b->Wb.p; a.W_c = b->Wc.p; a.out = b->kkt.p;
-    if (rsqp_launch_kkt(a, b->nq, b->stream) != hipSuccess) return fail(RSQP_ERR_DEVICE, "kkt launch failed");
+    if (rsqp_launch_small_certificate(p, a, b->nq, b->Ax.p, b->ATy.p, b->Hx.p, b->stream) != hipSuccess)
+        return fail(RSQP_ERR_DEVICE, "certificate launch failed");
     HIPCHK(hipStreamSynchronize(b->stream));
     std::vector<double> o(6 * (size_t)b->nq);
     HIPCHK(b->kkt.download(o.data(), o.size()));

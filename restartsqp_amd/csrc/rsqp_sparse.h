@@ -40,5 +40,5 @@ hipError_t rsqp_launch_gather(int n, const int *perm, const double *src, double 
 hipError_t rsqp_launch_densify(int nrow, int ncol, const int *jc, const int *ir, const double *val, double *dense,
                                hipStream_t stream);
 hipError_t rsqp_launch_kkt(const RsqpKktArgs &a, int nq, hipStream_t stream);
-hipError_t rsqp_launch_small_products(const QPPools &p, int nq, double *Ax, double *ATy, double *Hx,
-                                      hipStream_t stream);
+hipError_t rsqp_launch_small_certificate(const QPPools &p, const RsqpKktArgs &a, int nq, double *Ax, double *ATy,
+                                         double *Hx, hipStream_t stream);

@@ -357,9 +357,7 @@ __device__ inline void kkt_terms(int W, double yv, double val, double lo, double
     }
 }
 
-__global__ void __launch_bounds__(KKT_NT)
-kkt_kernel(RsqpKktArgs a) {
-    __shared__ double sh[4];
+__device__ __forceinline__ void kkt_body(const RsqpKktArgs &a, double *sh) {
     const int q = blockIdx.x;
     const int nV = a.nV ? a.nV[q] : a.nV1, nC = a.nC ? a.nC[q] : a.nC1;
     const long long oV = a.offV ? a.offV[q] : 0, oC = a.offC ? a.offC[q] : 0;
@@ -396,10 +394,14 @@ kkt_kernel(RsqpKktArgs a) {
         o[5] = fb;
     }
 }
+__global__ void __launch_bounds__(KKT_NT)
+kkt_kernel(RsqpKktArgs a) {
+    __shared__ double sh[4];
+    kkt_body(a, sh);
+}
 
 // products for a batch of SMALL problems: one workgroup per problem, lane per row/column
-__global__ void __launch_bounds__(KKT_NT)
-small_products_kernel(const QPDesc *desc, const int *Ajc, const int *Air, const double *Aval,
+__device__ __forceinline__ void small_products_body(const QPDesc *desc, const int *Ajc, const int *Air, const double *Aval,
                       const int *Arp, const int *Aci, const double *Arv, const int *Hjc, const int *Hir,
                       const double *Hval, const double *x, const double *y, double *Ax, double *ATy,
                       double *Hx) {
@@ -423,6 +425,19 @@ small_products_kernel(const QPDesc *desc, const int *Ajc, const int *Air, const 
         }
         Hx[d.offV + c] = h;
     }
+}
+// the three products and the certificate of a SMALL problem in one launch: the workgroup that
+// wrote Ax / A'y / Hx reads them back after a barrier
+__global__ void __launch_bounds__(KKT_NT)
+small_certificate_kernel(const QPDesc *desc, const int *Ajc, const int *Air, const double *Aval,
+                         const int *Arp, const int *Aci, const double *Arv, const int *Hjc, const int *Hir,
+                         const double *Hval, const double *x, const double *y, double *Ax, double *ATy,
+                         double *Hx, RsqpKktArgs a) {
+    __shared__ double sh[4];
+    small_products_body(desc, Ajc, Air, Aval, Arp, Aci, Arv, Hjc, Hir, Hval, x, y, Ax, ATy, Hx);
+    __threadfence_block();
+    __syncthreads();
+    kkt_body(a, sh);
 }
 
 }  // namespace
@@ -564,9 +579,10 @@ hipError_t rsqp_launch_kkt(const RsqpKktArgs &a, int nq, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t rsqp_launch_small_products(const QPPools &p, int nq, double *Ax, double *ATy, double *Hx,
-                                      hipStream_t stream) {
-    hipLaunchKernelGGL(small_products_kernel, dim3(nq), dim3(KKT_NT), 0, stream, p.desc, p.Ajc, p.Air, p.Aval,
-                       p.Arp, p.Aci, p.Arv, p.Hjc, p.Hir, p.Hval, p.x, p.y, Ax, ATy, Hx);
+hipError_t rsqp_launch_small_certificate(const QPPools &p, const RsqpKktArgs &a, int nq, double *Ax, double *ATy,
+                                         double *Hx, hipStream_t stream) {
+    hipLaunchKernelGGL(small_certificate_kernel, dim3(nq), dim3(KKT_NT), 0, stream, p.desc, p.Ajc, p.Air, p.Aval,
+                       p.Arp, p.Aci, p.Arv, p.Hjc, p.Hir, p.Hval, p.x, p.y, Ax, ATy, Hx, a);
     return hipGetLastError();
 }
+
