@@ -1,9 +1,9 @@
 """Randomised check of the LDS engines against the CPU oracle (test infrastructure): mixed shapes
 incl. nV = 1, nC = 0, nC > nV; cold start, hot start on perturbed vectors. Usage (GPU box):
-  python tools/fuzz_small_vs_oracle.py [seed] [count]      (RSQP_SMALL_ENGINE=0|1 to force a formulation)"""
+  python tests/checks/fuzz_small_vs_oracle.py [seed] [count]      (RSQP_SMALL_ENGINE=0|1 to force a formulation)"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from restartsqp_amd import capi, problems
 import oracle as O

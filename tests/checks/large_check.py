@@ -1,7 +1,7 @@
 """HBM-resident engine vs oracle on small / mid-size problems (development aid)."""
 import glob, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import oracle as O
 from restartsqp_amd import capi, problems

@@ -449,9 +449,9 @@ def test_both_formulations_pass_the_parity_suite(engine):
 def test_fuzz_mixed_shapes_against_oracle():
     """Randomised shapes (nV = 1, nC = 0, nC > nV included) in four size classes, so that every packing
     of the LDS engines (8 / 16 / 32 lanes per problem, one and four waves) and both formulations see
-    cold and hot starts: working sets, status, nWSR bit-exact, x / y to 1e-9 (tools/fuzz_small_vs_oracle.py)."""
+    cold and hot starts: working sets, status, nWSR bit-exact, x / y to 1e-9 (tests/checks/fuzz_small_vs_oracle.py)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_small_vs_oracle.py"), "7", "120"],
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "checks", "fuzz_small_vs_oracle.py"), "7", "120"],
                        capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0 and "FUZZ OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
