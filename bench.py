@@ -330,7 +330,7 @@ def main():
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "latency/LDS-bound kernel: HBM fraction is not its limiter"},
         }
-        if not args.no_extras:
+        if not args.no_extras and world == 1:   # extras (CPU baseline, secondary rooflines, large configs): N = 1 only
             line["cpu_baseline"] = cpu_baseline(probs[:256], args.cpu_seconds)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
             line["roofline_spmv"] = spmv_roofline(capi, problems, args.spmv_batch, 5)
