@@ -224,3 +224,14 @@ def test_blocked_setup_falls_back_on_dependent_guess(capi, oracle):
     n = s.solve(capi.MODE_WARM_REINIT, 100000, x0, y0, gb)    # constraints guessed from A x0: both copies look active
     rc, n_or = qp.init(q.g, q.lb, q.ub, q.lbA, q.ubA, 100000, x0=x0, y0=y0, guess_b=gb)
     same_as_oracle(s, n, qp, n_or)
+
+
+def test_fuzz_against_oracle():
+    """Random dense and sparse problems of 50-160 variables on the HBM-resident engine: cold start, hot
+    start on vectors, hot start with new matrices (blocked set-up), warm re-initialisation -- working
+    sets, status, nWSR identical to the oracle, x / y to 1e-9 (tests/checks/fuzz_large_vs_oracle.py)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "checks", "fuzz_large_vs_oracle.py"), "5", "6"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and "FUZZ OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
