@@ -1463,7 +1463,8 @@ RsqpLargeEngine::~RsqpLargeEngine() { delete p_; }
 
 long long RsqpLargeEngine::bytes_needed(int nV, int nC) {
     const long long nA = std::min(nV, nC);
-    return 8LL * (2LL * nV * nV + (long long)nV * nA + nA * nA + 40LL * (nV + nC));
+    // Z, Wz, Y, Minv, vectors + the scratch of the blocked set-up (2 nV^2, allocated on first use) and its panels
+    return 8LL * (4LL * nV * nV + (long long)nV * nA + nA * nA + 40LL * (nV + nC) + 9LL * 64 * nV);
 }
 
 hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
