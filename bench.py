@@ -231,7 +231,15 @@ def cpu_baseline(probs, seconds):
     import oracle as O
     O.build()
     n, t = _cpu_worker((probs, seconds))
-    out = {"value": n / t, "unit": "QP solves/s", "cores": 1, "kind": "port",
+    model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    out = {"value": n / t, "unit": "QP solves/s", "cores": 1, "kind": "port", "host_cpu": model, "host_nproc": os.cpu_count(),
            "sample": "%d cold solves of the first %d QPs of the rank-0 batch in %.1f s (in-repo C oracle, gcc -O2, "
                      "1 thread, solve loop in C; qpOASES 3.2.1 is not available)" % (n, len(probs), t)}
     try:
