@@ -689,10 +689,10 @@ struct Engine {
 
     // ------------------------------------------------------------------ ratio tests
     __device__ __forceinline__ static void cand(double num, double den, int id, double &bt, int &bid) {
-        if (den >= RSQP_EPS_DEN) {
-            double t = (num > 0.0 ? num : 0.0) / den;
-            if (t < bt || (t == bt && id < bid)) { bt = t; bid = id; }
-        }
+        // the quotient does not wait for the comparison with the running minimum (two candidates of a
+        // lane divide back to back); a rejected denominator only wastes a division
+        const double t = (num > 0.0 ? num : 0.0) / den;
+        if (den >= RSQP_EPS_DEN && (t < bt || (t == bt && id < bid))) { bt = t; bid = id; }
     }
     // candidate ids: [0,nC) active constr. duals, [nC,nC+nV) fixed-variable duals,
     // then inactive constr. lower / upper, then free variables lower / upper
@@ -873,9 +873,11 @@ struct Engine {
         SYNC();
         A_times(x, Ax);
         PFOR(i, nC) { if (Sc[i] == -1) lbA[i] = Ax[i]; else if (Sc[i] == 1) ubA[i] = Ax[i]; }
-        AT_times(y + nV, wv1);
-        H_times(x, wv2);
-        PFOR(v, nV) g[v] = wv1[v] + y[v] - wv2[v];
+        PFOR(v, nV) {   // A'y_C and H x of variable v in one pass, then the gradient from stationarity
+            const double aty = sparse_dot(Air, Aval, y + nV, Ajc[v], Ajc[v + 1]);
+            const double hx = (haveH ? sparse_dot(Hir, Hval, x, Hjc[v], Hjc[v + 1]) : 0.0) + hreg * x[v];
+            g[v] = aty + y[v] - hx;
+        }
         SYNC();
     }
 
