@@ -81,6 +81,8 @@ const char *rsqp_last_error(void);
  * plain-QP ctor (:54-94). device < 0 selects the current device. */
 int rsqp_create(int nV, int nC, int device, rsqp_solver **out);
 void rsqp_destroy(rsqp_solver *s);
+int rsqp_get_nV(const rsqp_solver *s);
+int rsqp_get_nC(const rsqp_solver *s);
 /* engine selection: 0 = automatic (the LDS-resident kernel when the problem image fits the
  * 160 KiB of one CU, the HBM-resident engine otherwise), 1 = LDS-resident, 2 = HBM-resident.
  * Both run entirely on the GPU; there is no CPU path. Call before the first solve. */
@@ -153,6 +155,28 @@ int rsqp_A_transposed_times(rsqp_solver *s, const double *p, double *result); /*
 int rsqp_H_times(rsqp_solver *s, const double *p, double *result);
 
 /* ------------------------------------------------------------------------------------ */
+/* on-disk QP formats of the reference (host only, no GPU needed)                         */
+/* ------------------------------------------------------------------------------------ */
+/* WriteQPDataToFile (QPsolverInterface.hpp:182-184; called for every failed QP, QPhandler.cpp:569-571):
+ *   RSQP_DUMP_QPOASES  qpOASESInterface.cpp:791-814 + SpHbMat.cpp:568-578:
+ *                      lb[nV] lbA[nC] ub[nV] ubA[nC] g[nV]; A: ir[nnz] jc[nV+1] val[nnz]; H likewise
+ *   RSQP_DUMP_QORE     QOREInterface.cpp:582-598 + SpHbMat.cpp:556-567 (the layout of test/unsolved_QP_data):
+ *                      nV nC nnzA nnzH; lb[nV+nC] ub[nV+nC] g[nV]; A, H as CSR: rowptr, col, val
+ * one number per line, doubles "%23.16e" (Vector.cpp:212-215). Matrices are given / kept as CSC. */
+enum { RSQP_DUMP_QPOASES = 0, RSQP_DUMP_QORE = 1 };
+int rsqp_write_qp_dump(const char *path, int layout, int nV, int nC, const double *lb, const double *ub,
+                       const double *lbA, const double *ubA, const double *g, const int *A_jc, const int *A_ir,
+                       const double *A_val, const int *H_jc, const int *H_ir, const double *H_val);
+/* the same for the data currently held by a solver handle (matrix values are read back from the device) */
+int rsqp_write_qp_data(const rsqp_solver *s, const char *path, int layout);
+/* reader of the QORE layout (test/QPsolvers_testers.cpp:48-150); matrices come back as CSC
+ * (convert_csr_to_csc, :18-29). First call the _sizes function, then pass arrays of
+ * lb, ub, g: nV; lbA, ubA: nC; A_jc, H_jc: nV+1; A_ir, A_val: nnzA; H_ir, H_val: nnzH. */
+int rsqp_read_qore_dump_sizes(const char *path, int *nV, int *nC, int *nnzA, int *nnzH);
+int rsqp_read_qore_dump(const char *path, double *lb, double *ub, double *lbA, double *ubA, double *g,
+                        int *A_jc, int *A_ir, double *A_val, int *H_jc, int *H_ir, double *H_val);
+
+/* ------------------------------------------------------------------------------------ */
 /* a batch of independent QPs (north_star: CUTEst sweeps / parameter scans)              */
 /* ------------------------------------------------------------------------------------ */
 /* nq problems of individual size; nV[q], nC[q], and per problem CSC matrices given as
@@ -200,6 +224,11 @@ void rsqp_spmv_plan_destroy(rsqp_spmv_plan *p);
 int rsqp_spmv_plan_upload(rsqp_spmv_plan *p, const double *vals, const double *xin, int transposed);
 int rsqp_spmv_plan_run(rsqp_spmv_plan *p, int transposed, int repeats, float *ms_per_launch);
 int rsqp_spmv_plan_download(rsqp_spmv_plan *p, double *out, int transposed);
+/* which kernel rsqp_spmv_plan_run launches for this product: 0 = csx_stream_spmv (entry-order sums,
+ * bit-exact vs SpHbMat.cpp:659-737), 35 = csx_ldsvec_spmv_pipe2<4,3>, 38 = csx_ldsvec_spmv_pipe2<2,4>
+ * (other codes: tuning variants of sparse.hip). *idx16 (may be NULL) = 1 when the 16-bit index copies
+ * (instantiation <.., unsigned short>) are used, 0 for <.., int>. */
+int rsqp_spmv_plan_variant(const rsqp_spmv_plan *p, int transposed, int *idx16);
 
 /* ------------------------------------------------------------------------------------ */
 /* dense f64 building blocks of the HBM-resident engine (MFMA GEMM, blocked QR, Cholesky) */

@@ -37,6 +37,12 @@ SYMBOLS = {
     "rsqp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "rsqp_destroy": (None, [C.c_void_p]),
     "rsqp_set_options": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "rsqp_get_nV": (C.c_int, [C.c_void_p]),
+    "rsqp_get_nC": (C.c_int, [C.c_void_p]),
+    "rsqp_write_qp_dump": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, ip, ip, dp, ip, ip, dp]),
+    "rsqp_write_qp_data": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "rsqp_read_qore_dump_sizes": (C.c_int, [C.c_char_p, ip, ip, ip, ip]),
+    "rsqp_read_qore_dump": (C.c_int, [C.c_char_p, dp, dp, dp, dp, dp, ip, ip, dp, ip, ip, dp]),
     "rsqp_set_engine": (C.c_int, [C.c_void_p, C.c_int]),
     "rsqp_get_engine": (C.c_int, [C.c_void_p]),
     "rsqp_set_A_triplet": (C.c_int, [C.c_void_p, C.c_int, ip, ip, dp, C.c_int, ip, ip, ip, dp]),
@@ -81,6 +87,7 @@ SYMBOLS = {
     "rsqp_spmv_plan_upload": (C.c_int, [C.c_void_p, dp, dp, C.c_int]),
     "rsqp_spmv_plan_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "rsqp_spmv_plan_download": (C.c_int, [C.c_void_p, dp, C.c_int]),
+    "rsqp_spmv_plan_variant": (C.c_int, [C.c_void_p, C.c_int, ip]),
 }
 
 
@@ -140,6 +147,32 @@ def device_count():
     return lib().rsqp_device_count()
 
 
+DUMP_QPOASES, DUMP_QORE = 0, 1
+
+
+def write_qp_dump(path, qp, layout=DUMP_QORE):
+    """WriteQPDataToFile in the reference's layouts (host only): `qp` has the QPData fields."""
+    a = [_d(qp.lb), _d(qp.ub), _d(qp.lbA), _d(qp.ubA), _d(qp.g)]
+    Ajc, Air, Aval = _i(qp.A_jc), _i(qp.A_ir), _d(qp.A_val)
+    Hjc, Hir, Hval = _i(qp.H_jc), _i(qp.H_ir), _d(qp.H_val)
+    check(lib().rsqp_write_qp_dump(os.fsencode(path), layout, qp.nV, qp.nC, *[_dp(v) for v in a], _ip(Ajc), _ip(Air),
+                                   _dp(Aval), _ip(Hjc), _ip(Hir), _dp(Hval)))
+
+
+def read_qore_dump(path):
+    """C reader of the QORE dump layout -> dict of arrays (CSC matrices)."""
+    n = [C.c_int(0) for _ in range(4)]
+    check(lib().rsqp_read_qore_dump_sizes(os.fsencode(path), *[C.byref(v) for v in n]))
+    nV, nC, nnzA, nnzH = (v.value for v in n)
+    d = dict(nV=nV, nC=nC, lb=np.zeros(nV), ub=np.zeros(nV), lbA=np.zeros(nC), ubA=np.zeros(nC), g=np.zeros(nV),
+             A_jc=np.zeros(nV + 1, np.int32), A_ir=np.zeros(nnzA, np.int32), A_val=np.zeros(nnzA),
+             H_jc=np.zeros(nV + 1, np.int32), H_ir=np.zeros(nnzH, np.int32), H_val=np.zeros(nnzH))
+    check(lib().rsqp_read_qore_dump(os.fsencode(path), _dp(d["lb"]), _dp(d["ub"]), _dp(d["lbA"]), _dp(d["ubA"]), _dp(d["g"]),
+                                    _ip(d["A_jc"]), _ip(d["A_ir"]), _dp(d["A_val"]), _ip(d["H_jc"]), _ip(d["H_ir"]),
+                                    _dp(d["H_val"])))
+    return d
+
+
 class Solver:
     """Thin RAII wrapper over one ``rsqp_solver`` handle."""
 
@@ -155,6 +188,10 @@ class Solver:
             self._h = None
 
     __del__ = close
+
+    def write_qp_data(self, path, layout=DUMP_QPOASES):
+        """WriteQPDataToFile for the data held by this handle."""
+        check(lib().rsqp_write_qp_data(self._h, os.fsencode(path), layout))
 
     def set_engine(self, engine):
         """0 automatic, 1 LDS-resident kernel, 2 HBM-resident engine."""
@@ -388,6 +425,12 @@ class SpmvPlan:
         ms = C.c_float(0)
         check(lib().rsqp_spmv_plan_run(self._h, int(transposed), repeats, C.byref(ms)))
         return ms.value
+
+    def variant(self, transposed=False):
+        """(kernel code, uses 16-bit indices) of the product -- see rsqp_spmv_plan_variant."""
+        i16 = C.c_int(0)
+        v = check(lib().rsqp_spmv_plan_variant(self._h, int(transposed), C.byref(i16)))
+        return v, bool(i16.value)
 
     def download(self, transposed=False):
         out = np.zeros(self.nbatch * (self.ncol if transposed else self.nrow))

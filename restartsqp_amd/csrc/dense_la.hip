@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "rsqp_dense.h"
+#include "rsqp_internal.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -160,12 +161,8 @@ static hipError_t dgemm_ws(bool transA, bool transB, int m, int n, int k, double
 #define GEMM_LAUNCH(a, b, nw, mw, gk)                                                                              \
     do {                                                                                                           \
         const size_t lds_ = sizeof(double) * gk * ((a + GPAD) + (b + GPAD));                                       \
-        static bool set_ = false;                                                                                  \
-        if (!set_) {                                                                                               \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dgemm<a, b, nw, mw, gk>),                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                      \
-            set_ = true;                                                                                           \
-        }                                                                                                          \
+        static std::atomic<unsigned long long> set_{0};                                                            \
+        rsqp_allow_full_lds(reinterpret_cast<const void *>(&k_dgemm<a, b, nw, mw, gk>), set_, (int)lds_);          \
         hipLaunchKernelGGL((k_dgemm<a, b, nw, mw, gk>), grid, dim3(nw * 64), lds_, st, ta, tb, m, n, k, kc, al, A, \
                            lda, B, ldb, be, Cout, ldo);                                                            \
     } while (0)

@@ -11,8 +11,27 @@ void HipQPInterface::check(int rc, const char *what) const {
     throw QP_INTERNAL_ERROR(msg);
 }
 
-HipQPInterface::HipQPInterface(NLPInfo nlp_info, QPType, std::shared_ptr<const Options> options, int device)
-    : HipQPInterface(nlp_info.nVar + 2 * nlp_info.nCon, nlp_info.nCon, options, device) {}
+HipQPInterface::HipQPInterface(NLPInfo nlp_info, QPType, std::shared_ptr<const Options> options,
+                               Ipopt::SmartPtr<Ipopt::Journalist> jnlst, int device)
+    : HipQPInterface(nlp_info.nVar + 2 * nlp_info.nCon, nlp_info.nCon, options, device) {
+    jnlst_ = jnlst;
+}
+
+// src/qpOASESInterface.cpp:54-94: sizes from A, data handed over once; the reference wraps the CSC arrays of
+// H and A in qpOASES matrix objects (:77-90), here they go to the device
+HipQPInterface::HipQPInterface(std::shared_ptr<SpHbMat> H, std::shared_ptr<SpHbMat> A, std::shared_ptr<Vector> g,
+                               std::shared_ptr<Vector> lb, std::shared_ptr<Vector> ub, std::shared_ptr<Vector> lbA,
+                               std::shared_ptr<Vector> ubA, std::shared_ptr<Options> options, int device)
+    : HipQPInterface(A->ColNum(), A->RowNum(), options, device) {
+    if (H->isCompressedRow() || A->isCompressedRow())
+        throw QP_INTERNAL_ERROR("HipQPInterface: H and A must be compressed-column (as for qpOASES)");
+    if (H->RowNum() != nVar_QP_ || H->ColNum() != nVar_QP_ || g->Dim() != nVar_QP_ || lb->Dim() != nVar_QP_ ||
+        ub->Dim() != nVar_QP_ || lbA->Dim() != nConstr_QP_ || ubA->Dim() != nConstr_QP_)
+        throw QP_INTERNAL_ERROR("HipQPInterface: inconsistent dimensions");
+    set_A_csc(A->ColIndex(), A->RowIndex(), A->MatVal());
+    set_H_csc(H->ColIndex(), H->RowIndex(), H->MatVal());
+    set_g(g); set_lb(lb); set_ub(ub); set_lbA(lbA); set_ubA(ubA);
+}
 
 HipQPInterface::HipQPInterface(int nVar_QP, int nConstr_QP, std::shared_ptr<const Options> options, int device)
     : nVar_QP_(nVar_QP), nConstr_QP_(nConstr_QP), options_(options), x_qp_(nVar_QP), y_qp_(nVar_QP + nConstr_QP) {
@@ -27,6 +46,42 @@ void HipQPInterface::set_A_csc(const int *jc, const int *ir, const double *val) 
 }
 void HipQPInterface::set_H_csc(const int *jc, const int *ir, const double *val) {
     check(rsqp_set_H_csc(solver_, jc, ir, val), "rsqp_set_H_csc");
+}
+
+const std::shared_ptr<Vector> &HipQPInterface::refresh(int which, std::shared_ptr<Vector> &v) const {
+    if (!v) v = std::make_shared<Vector>(which <= RSQP_VEC_UB ? nVar_QP_ : nConstr_QP_);
+    check(rsqp_get_vector(solver_, which, v->values()), "rsqp_get_vector");
+    return v;
+}
+
+// host mirror of the device CSC (values read back) with the products bound to the device copy
+std::shared_ptr<const SpHbMat> HipQPInterface::mirror(bool isA) const {
+    const int nnz = isA ? rsqp_get_A_nnz(solver_) : rsqp_get_H_nnz(solver_);
+    auto M = std::make_shared<SpHbMat>(isA ? nConstr_QP_ : nVar_QP_, nVar_QP_, false);
+    M->ColIndex_.assign(nVar_QP_ + 1, 0);
+    if (nnz >= 0) {
+        M->RowIndex_.resize(nnz); M->MatVal_.resize(nnz); M->order_.resize(nnz);
+        check(isA ? rsqp_get_A_csc(solver_, M->ColIndex_.data(), M->RowIndex_.data(), M->MatVal_.data(), M->order_.data())
+                  : rsqp_get_H_csc(solver_, M->ColIndex_.data(), M->RowIndex_.data(), M->MatVal_.data(), M->order_.data()),
+              "rsqp_get_*_csc");
+    }
+    rsqp_solver *h = solver_;
+    if (isA) {
+        M->times_ = [h](const double *p, double *r) { if (rsqp_A_times(h, p, r) < 0) throw QP_INTERNAL_ERROR(rsqp_last_error()); };
+        M->ttimes_ = [h](const double *p, double *r) { if (rsqp_A_transposed_times(h, p, r) < 0) throw QP_INTERNAL_ERROR(rsqp_last_error()); };
+    } else {   // symmetric: both products are the same
+        M->times_ = M->ttimes_ = [h](const double *p, double *r) { if (rsqp_H_times(h, p, r) < 0) throw QP_INTERNAL_ERROR(rsqp_last_error()); };
+    }
+    return M;
+}
+std::shared_ptr<const SpHbMat> HipQPInterface::getA() const { return mirror(true); }
+std::shared_ptr<const SpHbMat> HipQPInterface::getH() const { return mirror(false); }
+
+void HipQPInterface::WriteQPDataToFile(Ipopt::EJournalLevel, Ipopt::EJournalCategory, const std::string filename) {
+    check(rsqp_write_qp_data(solver_, ("qpOASES" + filename).c_str(), RSQP_DUMP_QPOASES), "rsqp_write_qp_data");
+}
+void HipQPInterface::WriteQPDataToFileQORE(const std::string filename) {
+    check(rsqp_write_qp_data(solver_, ("QORE_" + filename).c_str(), RSQP_DUMP_QORE), "rsqp_write_qp_data");
 }
 
 void HipQPInterface::fetch_solution() {

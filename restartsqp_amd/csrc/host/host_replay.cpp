@@ -9,12 +9,214 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <vector>
 
 #include "HipQPInterface.hpp"
 
 using namespace rsqp;
 
+namespace {
+
+const double INF_REF = 1.0e18;  // include/sqphot/Utils.hpp:35
+
+// hs071 (test/CUTE_examples/hs071.nl) in closed form: what SQPTNLP hands to Algorithm
+struct Hs071 {
+    double x[4], c[2], grad[4];
+    std::shared_ptr<SpTripletMat> J, H;
+    static constexpr double x_l[4] = {1, 1, 1, 1}, x_u[4] = {5, 5, 5, 5};
+    static constexpr double c_l[2] = {25, 40};
+    double c_u[2] = {std::numeric_limits<double>::infinity(), 40};
+    explicit Hs071(const double *xk) {
+        for (int i = 0; i < 4; i++) x[i] = xk[i];
+        const double x1 = x[0], x2 = x[1], x3 = x[2], x4 = x[3];
+        c[0] = x1 * x2 * x3 * x4; c[1] = x1 * x1 + x2 * x2 + x3 * x3 + x4 * x4;
+        grad[0] = x4 * (2 * x1 + x2 + x3); grad[1] = x1 * x4; grad[2] = x1 * x4 + 1.0; grad[3] = x1 * (x1 + x2 + x3);
+        J = std::make_shared<SpTripletMat>();
+        J->RowNum = 2; J->ColNum = 4;
+        J->RowIndex = {1, 1, 1, 1, 2, 2, 2, 2}; J->ColIndex = {1, 2, 3, 4, 1, 2, 3, 4};
+        J->MatVal = {x2 * x3 * x4, x1 * x3 * x4, x1 * x2 * x4, x1 * x2 * x3, 2 * x1, 2 * x2, 2 * x3, 2 * x4};
+        H = std::make_shared<SpTripletMat>();   // Hessian of f (zero multipliers), lower triangle row by row
+        H->RowNum = H->ColNum = 4; H->isSymmetric = true;
+        H->RowIndex = {1, 2, 2, 3, 3, 3, 4, 4, 4, 4}; H->ColIndex = {1, 1, 2, 1, 2, 3, 1, 2, 3, 4};
+        H->MatVal = {2 * x4, x4, 0, x4, 0, 0, 2 * x1 + x2 + x3, x1, x1, 0};
+    }
+};
+constexpr double Hs071::x_l[4], Hs071::x_u[4], Hs071::c_l[2];
+
+// the caller side of the boundary: QPhandler's formulas (reference src/QPhandler.cpp), restated so that
+// the adapter sees the call storm Algorithm produces (per-element virtual setters)
+struct Handler {
+    int n, m;
+    int irow[2], jcol[2], size[2];
+    double value[2];
+    IdentityInfo I;
+    std::shared_ptr<HipQPInterface> solver;
+    Handler(NLPInfo info, QPType t, std::shared_ptr<const Options> opt, Ipopt::SmartPtr<Ipopt::Journalist> jnlst)
+        : n(info.nVar), m(info.nCon) {
+        irow[0] = irow[1] = 1; jcol[0] = n + 1; jcol[1] = n + m + 1; size[0] = size[1] = m; value[0] = 1.0; value[1] = -1.0;
+        I = IdentityInfo{2, irow, jcol, size, value};                                  // QPhandler.cpp:41-51
+        solver = std::make_shared<HipQPInterface>(info, t, opt, jnlst);                // :58-76
+    }
+    void set_bounds(double delta, const double *x_l, const double *x_u, const double *x_k, const double *c_l,
+                    const double *c_u, const double *c_k) {                             // :167-201
+        for (int i = 0; i < m; i++) { solver->set_lbA(i, c_l[i] - c_k[i]); solver->set_ubA(i, c_u[i] - c_k[i]); }
+        for (int i = 0; i < n; i++) {
+            solver->set_lb(i, std::fmax(x_l[i] - x_k[i], -delta));
+            solver->set_ub(i, std::fmin(x_u[i] - x_k[i], delta));
+        }
+        for (int i = 0; i < 2 * m; i++) solver->set_ub(n + i, INF_REF);
+    }
+    void update_bounds(double delta, const double *x_l, const double *x_u, const double *x_k, const double *c_l,
+                       const double *c_k) {                                             // :342-368 (ubA is not refreshed)
+        for (int i = 0; i < m; i++) solver->set_lbA(i, c_l[i] - c_k[i]);
+        for (int i = 0; i < n; i++) {
+            solver->set_lb(i, std::fmax(x_l[i] - x_k[i], -delta));
+            solver->set_ub(i, std::fmin(x_u[i] - x_k[i], delta));
+        }
+    }
+    void set_g(const double *grad, double rho) { for (int i = 0; i < n + 2 * m; i++) solver->set_g(i, i < n ? grad[i] : rho); }  // :272-297
+    void set_g(double rho) { for (int i = n; i < n + 2 * m; i++) solver->set_g(i, rho); }                                       // :657-660 (LP)
+    void update_penalty(double rho) { for (int i = n; i < n + 2 * m; i++) solver->set_g(i, rho); }                               // :430-441
+    void update_grad(const double *grad) { for (int i = 0; i < n; i++) solver->set_g(i, grad[i]); }                              // :450-463
+    void set_A(std::shared_ptr<const SpTripletMat> J) { solver->set_A(J, I); }
+    void set_H(std::shared_ptr<const SpTripletMat> H) { solver->set_H(H); }
+    void solveQP(std::shared_ptr<Stats> stats) {                                        // :470-499
+        solver->optimizeQP(stats);
+        std::vector<ActiveType> Wc(m), Wb(n + 2 * m);
+        if (!solver->test_optimality(Wc.data(), Wb.data())) throw QP_NOT_OPTIMAL("KKT certificate failed");
+    }
+    void solveLP(std::shared_ptr<Stats> stats) { solver->optimizeLP(stats); }           // QPhandler.hpp:66-68
+    double get_infea_measure_model() {                                                  // :592-594
+        const double *x = solver->get_optimal_solution();
+        double s = 0.0;
+        for (int i = n; i < n + 2 * m; i++) s += std::fabs(x[i]);
+        return s;
+    }
+    void report(const char *tag, std::shared_ptr<Stats> stats) {
+        const double *x = solver->get_optimal_solution();
+        std::printf("%s status %d qp_iter %d obj %.15g infea_model %.15g x", tag, solver->get_status(), stats->qp_iter,
+                    solver->get_obj_value(), get_infea_measure_model());
+        for (int i = 0; i < n + 2 * m; i++) std::printf(" %.15g", x[i]);
+        std::printf("\n");
+    }
+};
+
+// Algorithm::update_penalty_parameter (reference src/Algorithm.cpp:886-1028: setupLP + solveLP on the LP
+// handler, then update_penalty + solveQP on the QP handler, repeatedly) followed by
+// Algorithm::second_order_correction (:1144-1211: update_grad(H p + g), update_bounds at x_trial, solveQP,
+// and the restore calls). Two handler objects -- LP and QP (Algorithm.cpp:561-562) -- live side by side.
+int penalty_soc_trace() {
+    NLPInfo info{2, 4, 8, 10};
+    auto options = std::make_shared<Options>();
+    auto stats = std::make_shared<Stats>();
+    // hs071 with c2 relaxed to c2 >= 40 (the reference's update_bounds never refreshes ubA, QPhandler.cpp:358-360,
+    // so an equality cannot be replayed through an SOC step), at a point that violates both constraints;
+    // delta is small enough that the linearised constraints cannot be met: the slacks stay positive
+    const double x0[4] = {1, 2, 2, 1};
+    Hs071 nlp(x0);
+    nlp.c_u[1] = std::numeric_limits<double>::infinity();
+    const double delta = 0.25;
+    double rho = 1.0;
+    Handler myQP(info, QP, options, nullptr), myLP(info, LP, options, nullptr);
+    myQP.set_A(nlp.J); myQP.set_H(nlp.H);
+    myQP.set_bounds(delta, nlp.x_l, nlp.x_u, nlp.x, nlp.c_l, nlp.c_u, nlp.c);
+    myQP.set_g(nlp.grad, rho);
+    myQP.solveQP(stats);
+    myQP.report("qp rho=1", stats);
+    // setupLP (:700-704) + solveLP
+    myLP.set_bounds(delta, nlp.x_l, nlp.x_u, nlp.x, nlp.c_l, nlp.c_u, nlp.c);
+    myLP.set_g(rho);
+    myLP.set_A(nlp.J);
+    myLP.solveLP(stats);
+    myLP.report("lp rho=1", stats);
+    // the loop of :933-960 for two trial values
+    for (int k = 0; k < 2; k++) {
+        rho *= 10.0;
+        myQP.update_penalty(rho);
+        myQP.solveQP(stats);
+        myQP.report(k == 0 ? "qp rho=10" : "qp rho=100", stats);
+    }
+    // second-order correction: p = x_qp[0..4), g := H p + grad, bounds at x_trial = x + p
+    double p[4], Hp[4] = {0, 0, 0, 0}, xt[4];
+    for (int i = 0; i < 4; i++) p[i] = myQP.solver->get_optimal_solution()[i];
+    for (size_t e = 0; e < nlp.H->MatVal.size(); e++) {
+        const int r = nlp.H->RowIndex[e] - 1, c = nlp.H->ColIndex[e] - 1;
+        Hp[r] += nlp.H->MatVal[e] * p[c];
+        if (r != c) Hp[c] += nlp.H->MatVal[e] * p[r];
+    }
+    for (int i = 0; i < 4; i++) { Hp[i] += nlp.grad[i]; xt[i] = nlp.x[i] + p[i]; }
+    Hs071 trial(xt);
+    myQP.update_grad(Hp);
+    myQP.update_bounds(delta, nlp.x_l, nlp.x_u, trial.x, nlp.c_l, trial.c);
+    myQP.solveQP(stats);
+    myQP.report("qp soc", stats);
+    myQP.update_grad(nlp.grad);                                                // step rejected: restore (:1204-1208)
+    myQP.update_bounds(delta, nlp.x_l, nlp.x_u, nlp.x, nlp.c_l, nlp.c);
+    myQP.solveQP(stats);
+    myQP.report("qp restored", stats);
+    // the next penalty update reuses the LP object: hot start with a new gradient (rho) and a re-set Jacobian
+    myLP.set_bounds(delta, nlp.x_l, nlp.x_u, nlp.x, nlp.c_l, nlp.c_u, nlp.c);
+    myLP.set_g(rho);
+    myLP.set_A(nlp.J);
+    myLP.solveLP(stats);
+    myLP.report("lp rho=100", stats);
+    return 0;
+}
+
+// plain-QP ctor with data (reference src/qpOASESInterface.cpp:54-94, as test/QPsolvers_testers.cpp:220 uses
+// it on the dumps of test/unsolved_QP_data), the data getters QPhandler::get_active_set reads
+// (src/QPhandler.cpp:596-650) and WriteQPDataToFile in both layouts
+int dump_replay(const char *path, const char *outname) {
+    int nV, nC, annz, hnnz;
+    if (rsqp_read_qore_dump_sizes(path, &nV, &nC, &annz, &hnnz) != RSQP_OK) { std::printf("cannot read %s\n", path); return 4; }
+    auto lb = std::make_shared<Vector>(nV), ub = std::make_shared<Vector>(nV), g = std::make_shared<Vector>(nV);
+    auto lbA = std::make_shared<Vector>(nC), ubA = std::make_shared<Vector>(nC);
+    std::vector<int> Ajc(nV + 1), Air(annz), Hjc(nV + 1), Hir(hnnz);
+    std::vector<double> Aval(annz), Hval(hnnz);
+    if (rsqp_read_qore_dump(path, lb->values(), ub->values(), lbA->values(), ubA->values(), g->values(), Ajc.data(), Air.data(),
+                            Aval.data(), Hjc.data(), Hir.data(), Hval.data()) != RSQP_OK) { std::printf("bad dump %s\n", path); return 4; }
+    auto A = std::make_shared<SpHbMat>(nC, nV, Ajc.data(), Air.data(), Aval.data());
+    auto H = std::make_shared<SpHbMat>(nV, nV, Hjc.data(), Hir.data(), Hval.data());
+    HipQPInterface qp(H, A, g, lb, ub, lbA, ubA, std::make_shared<Options>());
+    auto stats = std::make_shared<Stats>();
+    bool solved = true;
+    try { qp.optimizeQP(stats); } catch (const QP_NOT_OPTIMAL &) { solved = false; }
+    std::printf("dump status %d qp_iter %d solved %d obj %.15g\n", qp.get_status(), stats->qp_iter, solved ? 1 : 0, qp.get_obj_value());
+    // QPhandler::get_active_set, qpOASES branch (incl. its getUbA-twice quirk, QPhandler.cpp:641-642)
+    const double sqrt_m_eps = 1.4901161193847656e-08;
+    auto x = std::make_shared<Vector>(nV), Ax = std::make_shared<Vector>(nC);
+    x->copy_vector(qp.get_optimal_solution());
+    qp.getA()->times(x, Ax);
+    auto l = qp.getLb(), u = qp.getUb();
+    std::printf("A_b");
+    for (int i = 0; i < nV; i++) {
+        const bool lo = std::fabs(x->values(i) - l->values(i)) < sqrt_m_eps, hi = std::fabs(u->values(i) - x->values(i)) < sqrt_m_eps;
+        std::printf(" %d", lo ? (hi ? ACTIVE_BOTH_SIDE : ACTIVE_BELOW) : (hi ? ACTIVE_ABOVE : INACTIVE));
+    }
+    auto la = qp.getUbA(), ua = qp.getUbA();
+    std::printf("\nA_c");
+    for (int i = 0; i < nC; i++) {
+        const bool lo = std::fabs(Ax->values(i) - la->values(i)) < sqrt_m_eps, hi = std::fabs(ua->values(i) - Ax->values(i)) < sqrt_m_eps;
+        std::printf(" %d", lo ? (hi ? ACTIVE_BOTH_SIDE : ACTIVE_BELOW) : (hi ? ACTIVE_ABOVE : INACTIVE));
+    }
+    std::printf("\nAx");
+    for (int i = 0; i < nC; i++) std::printf(" %.15g", Ax->values(i));
+    std::printf("\ngetG %d getH_nnz %d getA_nnz %d\n", qp.getG()->Dim(), qp.getH()->EntryNum(), qp.getA()->EntryNum());
+    qp.WriteQPDataToFile(Ipopt::J_LAST_LEVEL, Ipopt::J_USER1, outname);   // QPhandler::WriteQPData (:569-571)
+    qp.WriteQPDataToFileQORE(outname);
+    return 0;
+}
+
+}  // namespace
+
 int main(int argc, char **argv) {
+    try {
+        if (argc > 1 && std::strcmp(argv[1], "--penalty") == 0) return penalty_soc_trace();
+        if (argc > 3 && std::strcmp(argv[1], "--dump") == 0) return dump_replay(argv[2], argv[3]);
+    } catch (const std::exception &e) {
+        std::printf("EXCEPTION %s\n", e.what());
+        return 2;
+    }
     const int bench_iters = (argc > 2 && std::strcmp(argv[1], "--bench") == 0) ? std::atoi(argv[2]) : 0;
     const double INF = 1.0e18;  // include/sqphot/Utils.hpp:35
     NLPInfo info{2, 4, 8, 10};

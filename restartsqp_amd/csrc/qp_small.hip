@@ -1158,12 +1158,8 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     if (forcedW >= 2 && forcedW <= (L == 64 ? 6 : 4)) waves = forcedW;
 #define SQ_LAUNCH_U(ENG, LL, ML, W, U)                                                                        \
     do {                                                                                                      \
-        static bool set_ = false;                                                                             \
-        if (!set_) {                                                                                          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&small_qp_kernel<ENG<LL, ML>, LL, ML, W, U>), \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);              \
-            set_ = true;                                                                                      \
-        }                                                                                                     \
+        static std::atomic<unsigned long long> set_{0};                                                       \
+        rsqp_allow_full_lds(reinterpret_cast<const void *>(&small_qp_kernel<ENG<LL, ML>, LL, ML, W, U>), set_, (int)kMaxLds); \
         hipLaunchKernelGGL((small_qp_kernel<ENG<LL, ML>, LL, ML, W, U>), dim3(nblk), dim3(LL > 64 ? LL : 64), lds, stream, p, nq, \
                            (int)stride, mode, maxWSR);                                                        \
     } while (0)

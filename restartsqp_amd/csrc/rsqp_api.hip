@@ -391,6 +391,8 @@ extern "C" int rsqp_set_engine(rsqp_solver *s, int engine) {
     return RSQP_OK;
 }
 extern "C" int rsqp_get_engine(const rsqp_solver *s) { return s ? s->engine : -1; }
+extern "C" int rsqp_get_nV(const rsqp_solver *s) { return s ? s->nV : -1; }
+extern "C" int rsqp_get_nC(const rsqp_solver *s) { return s ? s->nC : -1; }
 
 extern "C" int rsqp_set_options(rsqp_solver *s, int qp_maxiter, int lp_maxiter) {
     if (!s || qp_maxiter < 0 || lp_maxiter < 0) return fail(RSQP_ERR_ARG, "rsqp_set_options");
@@ -471,7 +473,9 @@ int set_csc(rsqp_solver *s, DevMatrix &M, int nrow, int ncol, const int *jc, con
     if (!s || !jc || (jc[ncol] > 0 && (!ir || !val))) return fail(RSQP_ERR_ARG, "rsqp_set_*_csc");
     if (s->firstQPsolved && !*flag) *flag = true;
     const int nnz = jc[ncol];
-    if (M.initialised && nnz == M.nnz && !M.from_triplet) {  // same pattern: refresh values
+    // same pattern (compared entry by entry, not just by count): refresh values
+    if (M.initialised && nnz == M.nnz && !M.from_triplet && M.nrow == nrow && M.ncol == ncol &&
+        std::equal(jc, jc + ncol + 1, M.h_jc.begin()) && std::equal(ir, ir + nnz, M.h_ir.begin())) {
         HIPCHK(M.val.upload(val, nnz));
         if (M.have_csr && rsqp_launch_gather(M.nnz, M.perm.p, M.val.p, M.rval.p, s->stream) != hipSuccess)
             return fail(RSQP_ERR_DEVICE, "gather launch failed");
@@ -487,6 +491,8 @@ int set_csc(rsqp_solver *s, DevMatrix &M, int nrow, int ncol, const int *jc, con
         for (int k = jc[c]; k < jc[c + 1]; k++)
             if (ir[k] < 0 || ir[k] >= nrow) return fail(RSQP_ERR_ARG, "rsqp_set_*_csc: row index out of range");
     }
+    // a new pattern on an initialised matrix: everything derived from the old one (CSR copy, SpMV
+    // blocks, host mirror) is rebuilt; the dirty flag set above makes optimizeQP re-factorise
     M.from_triplet = false;
     int rc = upload_matrix(M, cs, want_csr);
     s->desc_ready = false;
@@ -658,7 +664,12 @@ int handle_error(rsqp_solver *s, int *total) {
 
 extern "C" int rsqp_optimize_qp(rsqp_solver *s, int *nWSR_used) {
     if (!s) return fail(RSQP_ERR_ARG, "null solver");
-    if (s->lp_mode) { s->lp_mode = false; s->hreg = 0.0; s->desc_ready = false; }
+    if (s->lp_mode) {
+        // an LP was solved on this handle before (the reference keeps separate LP and QP objects,
+        // Algorithm.cpp:561-562): the stored factors belong to H = regVal*I, so start over
+        s->lp_mode = false; s->hreg = 0.0; s->desc_ready = false;
+        s->firstQPsolved = false; s->old_status = s->new_status = 0;
+    }
     int nWSR = s->qp_maxiter, total = 0, rc;
     if (!s->firstQPsolved) {
         rc = rsqp_solve(s, RSQP_MODE_COLD, &nWSR, nullptr, nullptr, nullptr);
@@ -724,17 +735,26 @@ int handle_error_lp(rsqp_solver *s, int *total) {
 
 extern "C" int rsqp_optimize_lp(rsqp_solver *s, int *nWSR_used) {
     if (!s) return fail(RSQP_ERR_ARG, "null solver");
-    double ng = 0.0;
-    for (double v : s->h_vec[RSQP_VEC_G]) ng += v * v;
-    ng = std::sqrt(ng);
-    const double reg = (ng > 0.0 ? ng : 1.0) * 1.0e3 * RSQP_EPS;   // qpOASES: getNorm(g) * epsRegularisation
-    if (!s->lp_mode || reg != s->hreg) { s->lp_mode = true; s->hreg = reg; s->desc_ready = false; }
+    if (!s->lp_mode) {   // a QP was solved on this handle before: its factors belong to another Hessian
+        s->lp_mode = true; s->firstQPsolved = false; s->old_status = s->new_status = 0;
+    }
+    // qpOASES fixes regVal = getNorm(g) * epsRegularisation when the problem is initialised and keeps it
+    // across hot starts (the factors stored in the engine were built with it); a later init -- the first
+    // solve, a status flip, handle_error -- computes it afresh from the gradient of that call
+    auto set_reg_for_init = [s]() {
+        double ng = 0.0;
+        for (double v : s->h_vec[RSQP_VEC_G]) ng += v * v;
+        ng = std::sqrt(ng);
+        s->hreg = (ng > 0.0 ? ng : 1.0) * 1.0e3 * RSQP_EPS;
+        s->desc_ready = false;
+    };
     int nWSR = s->lp_maxiter, total = 0, rc;
     if (!s->firstQPsolved) {
+        set_reg_for_init();
         rc = rsqp_solve(s, RSQP_MODE_COLD, &nWSR, nullptr, nullptr, nullptr);
         if (rc != RSQP_OK) return rc;
         if (solved(s)) s->firstQPsolved = true;
-        else if ((rc = handle_error_lp(s, &total)) != RSQP_OK) return rc;
+        else { set_reg_for_init(); if ((rc = handle_error_lp(s, &total)) != RSQP_OK) return rc; }
     } else {
         const int cur = (s->upd_A || s->upd_H) ? 2 : 1;
         if (s->old_status == 0) s->old_status = cur;
@@ -750,16 +770,18 @@ extern "C" int rsqp_optimize_lp(rsqp_solver *s, int *nWSR_used) {
         else if (s->new_status == 2 && s->old_status == 2)
             rc = rsqp_solve(s, RSQP_MODE_HOT_MATRICES, &nWSR, nullptr, nullptr, nullptr);
         else {   // :266-270: plain re-init on a status flip
+            set_reg_for_init();
             rc = rsqp_solve(s, RSQP_MODE_COLD, &nWSR, nullptr, nullptr, nullptr);
             s->new_status = s->old_status = 0;
         }
         if (rc != RSQP_OK) return rc;
         s->upd_A = s->upd_H = s->upd_bounds = s->upd_g = false;
-        if (!solved(s) && (rc = handle_error_lp(s, &total)) != RSQP_OK) return rc;
+        if (!solved(s)) { set_reg_for_init(); if ((rc = handle_error_lp(s, &total)) != RSQP_OK) return rc; }
     }
     total += nWSR;
     if (solved(s)) {
         // one regularisation step: min (reg/2)|x - x_k|^2 + g'x  <=>  gradient g - reg*x_k
+        const double reg = s->hreg;
         std::vector<double> gmod = s->h_vec[RSQP_VEC_G];
         for (int i = 0; i < s->nV; i++) gmod[i] -= reg * s->h_x[i];
         rc = flush_vectors(s);
@@ -1291,6 +1313,12 @@ extern "C" int rsqp_spmv_plan_run(rsqp_spmv_plan *p, int transposed, int repeats
     HIPCHK(hipEventElapsedTime(&ms, p->ev0, p->ev1));
     if (ms_per_launch) *ms_per_launch = ms / repeats;
     return RSQP_OK;
+}
+
+extern "C" int rsqp_spmv_plan_variant(const rsqp_spmv_plan *p, int transposed, int *idx16) {
+    if (!p) return fail(RSQP_ERR_ARG, "null plan");
+    if (idx16) *idx16 = p->use16 ? 1 : 0;
+    return transposed ? p->variant_t : p->variant_n;
 }
 
 extern "C" int rsqp_spmv_plan_download(rsqp_spmv_plan *p, double *out, int transposed) {

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #define RSQP_INFTY 1.0e20           // qpOASES INFTY
 #define RSQP_EPS 2.221e-16          // qpOASES EPS
 #define RSQP_EPS_DEN (1.0e3 * RSQP_EPS)
@@ -55,6 +57,18 @@ __host__ __device__ inline long long rsqp_image_ints(int nV, int nC) { return nV
 __host__ __device__ inline long long rsqp_image_bytes(int nV, int nC) {
     long long b = rsqp_image_doubles(nV, nC) * 8 + rsqp_image_ints(nV, nC) * 4;
     return (b + 15) & ~15LL;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: set it once per
+// (kernel, device) -- `mask` is the kernel's own bitmask of devices already done (thread-safe)
+inline void rsqp_allow_full_lds(const void *fn, std::atomic<unsigned long long> &mask, int bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(mask.load(std::memory_order_acquire) & bit)) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        mask.fetch_or(bit, std::memory_order_release);
+    }
 }
 
 // launchers (defined in the .hip files)

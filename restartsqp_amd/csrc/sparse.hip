@@ -467,12 +467,8 @@ hipError_t rsqp_launch_spmv_ldsvec(int variant, int nminor, int nslices, const i
     if (lds > 160 * 1024) return hipErrorInvalidValue;
 #define LV_LAUNCH(G, U)                                                                                        \
     do {                                                                                                       \
-        static bool set_ = false;                                                                              \
-        if (!set_) {                                                                                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_ldsvec_spmv<G, U>),                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
-            set_ = true;                                                                                       \
-        }                                                                                                      \
+        static std::atomic<unsigned long long> set_{0};                                                        \
+        rsqp_allow_full_lds(reinterpret_cast<const void *>(&csx_ldsvec_spmv<G, U>), set_, 160 * 1024);         \
         hipLaunchKernelGGL((csx_ldsvec_spmv<G, U>), dim3(nbatch * nslices), dim3(LV_NT), lds, stream, nminor,  \
                            nslices, slice, ptr, idx, val, in, out, ptr_stride, nnz_stride, in_stride,          \
                            out_stride);                                                                        \
@@ -488,12 +484,8 @@ hipError_t rsqp_launch_spmv_ldsvec(int variant, int nminor, int nslices, const i
     case 8: LV_LAUNCH(2, 4); break;
 #define LP_LAUNCH(G, U, N)                                                                                        \
     do {                                                                                                       \
-        static bool set_ = false;                                                                              \
-        if (!set_) {                                                                                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_ldsvec_spmv_pipe<G, U, N>),             \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
-            set_ = true;                                                                                       \
-        }                                                                                                      \
+        static std::atomic<unsigned long long> set_{0};                                                        \
+        rsqp_allow_full_lds(reinterpret_cast<const void *>(&csx_ldsvec_spmv_pipe<G, U, N>), set_, 160 * 1024); \
         hipLaunchKernelGGL((csx_ldsvec_spmv_pipe<G, U, N>), dim3(nbatch * nslices), dim3(LV_NT), lds, stream,     \
                            nminor, nslices, slice, ptr, idx, val, in, out, ptr_stride, nnz_stride, in_stride,  \
                            out_stride);                                                                        \
@@ -515,22 +507,14 @@ hipError_t rsqp_launch_spmv_ldsvec(int variant, int nminor, int nslices, const i
 #define L2_LAUNCH(G, U)                                                                                        \
     do {                                                                                                       \
         if (idx16) {                                                                                           \
-            static bool set_ = false;                                                                          \
-            if (!set_) {                                                                                       \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_ldsvec_spmv_pipe2<G, U, unsigned short>), \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);             \
-                set_ = true;                                                                                   \
-            }                                                                                                  \
+            static std::atomic<unsigned long long> set_{0};                                                    \
+            rsqp_allow_full_lds(reinterpret_cast<const void *>(&csx_ldsvec_spmv_pipe2<G, U, unsigned short>), set_, 160 * 1024); \
             hipLaunchKernelGGL((csx_ldsvec_spmv_pipe2<G, U, unsigned short>), dim3(nbatch * nslices),          \
                                dim3(LV_NT), lds, stream, nminor, nslices, slice, ptr, idx16, val, in, out,     \
                                ptr_stride, nnz_stride, in_stride, out_stride);                                 \
         } else {                                                                                               \
-            static bool set_ = false;                                                                          \
-            if (!set_) {                                                                                       \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_ldsvec_spmv_pipe2<G, U, int>),   \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);             \
-                set_ = true;                                                                                   \
-            }                                                                                                  \
+            static std::atomic<unsigned long long> set_{0};                                                    \
+            rsqp_allow_full_lds(reinterpret_cast<const void *>(&csx_ldsvec_spmv_pipe2<G, U, int>), set_, 160 * 1024); \
             hipLaunchKernelGGL((csx_ldsvec_spmv_pipe2<G, U, int>), dim3(nbatch * nslices), dim3(LV_NT), lds,   \
                                stream, nminor, nslices, slice, ptr, idx, val, in, out, ptr_stride, nnz_stride, \
                                in_stride, out_stride);                                                         \

@@ -156,10 +156,9 @@ class HipQPInterface:
         self._s.reset_constraints()
 
     def WriteQPDataToFile(self, level, category, filename):
-        """qpOASES-layout dump (:791-814)."""
-        from .qpdump import QPData, write_qpoases_dump
-        A = self._s.get_A_csc()
-        H = self._s.get_H_csc()
-        write_qpoases_dump("qpOASES" + filename, QPData(self.nVar_QP_, self.nConstr_QP_, H[0], H[1], H[2], A[0], A[1],
-                                                        A[2], self.getG(), self.getLb(), self.getUb(), self.getLbA(),
-                                                        self.getUbA()))
+        """qpOASES-layout dump "qpOASES" + filename (:791-814), written by the C ABI (rsqp_write_qp_data)."""
+        self._s.write_qp_data("qpOASES" + filename, capi.DUMP_QPOASES)
+
+    def WriteQPDataToFileQORE(self, filename):
+        """the QORE layout of the same data (src/QOREInterface.cpp:582-598): "QORE_" + filename"""
+        self._s.write_qp_data("QORE_" + filename, capi.DUMP_QORE)

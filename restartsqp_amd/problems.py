@@ -206,3 +206,25 @@ def sparse_sequence(q, nsteps=50, seed=20260102):
             nxt.A_val = cur.A_val * (1.0 + 0.01 * rng.normal(size=cur.A_val.shape))
         cur = nxt
         yield cur, changed
+
+
+# ------------------------------------------------------------------------------------
+# the reference's second set of real QP inputs (test/unsolved_QPs/*.hpp)
+# ------------------------------------------------------------------------------------
+def unsolved_qps(path=None):
+    """The nine QP data headers of reference test/unsolved_QPs (qpOASES CSC layout) from the JSON fixture
+    tests/golden/unsolved_qps.json (made by tests/golden/make_unsolved_qp_fixtures.py). Returns
+    [(QPData, expected_status or None)]. All are non-convex and most carry a NON-SYMMETRIC H (the dumper of
+    that reference revision permuted the mirrored values); the arrays are passed on exactly as recorded."""
+    import json
+    import os
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "unsolved_qps.json")
+    f = lambda a: np.array([float(v) for v in a], dtype=np.float64)
+    i = lambda a: np.array(a, dtype=np.int32)
+    out = []
+    for name, q in json.load(open(path))["qps"].items():
+        out.append((QPData(q["nV"], q["nC"], i(q["H_jc"]), i(q["H_ir"]), f(q["H_val"]), i(q["A_jc"]), i(q["A_ir"]),
+                           f(q["A_val"]), f(q["g"]), f(q["lb"]), f(q["ub"]), f(q["lbA"]), f(q["ubA"]), name=name),
+                    q.get("expected_status")))
+    return out
