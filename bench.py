@@ -9,19 +9,26 @@ independent hs071-scale QPs (the derived hs071 first QP and seeded 1 % perturbat
 launch of the LDS-resident active-set kernel, inputs already resident in HBM. Shards are
 independent (no data-path collective) -> weak scaling; `value` = QPs of all ranks / max time.
 
+`--gpus N` with N > 1 and no torchrun environment: bench.py starts the N ranks itself (a child
+`python -m torch.distributed.run`, before anything touches the GPU) and exits with its code.
+
 The JSON line also carries
   roofline       -- the dominant kernel of the timed region (the batched QP kernel): algorithmic
                     HBM bytes per launch / its HIP-event duration. The kernel is LDS/latency
                     bound, so the fraction is small by nature; see DESIGN.md.
+  kernel_ms_stats -- median / quartiles of >= 200 individually timed launches (HIP events).
+  with_gather    -- (N > 1) the same step followed by the only collective of the path: the
+                    all-gather of fixed-stride result records over RCCL; throughput and latency.
   roofline_spmv  -- the n=10k x m=20k, 200k-nnz Jacobian product A'y (SpHbMat::transposed_times)
                     batched over distinct matrices (> 2x the 256 MiB Infinity Cache), the
                     kernel BASELINE.json's roofline target names; measured outside the timed region.
-  cpu_baseline   -- the CPU oracle (a port: qpOASES cannot be built here) on one host core,
-                    bounded sample of the same workload.
+  cpu_baseline   -- the CPU oracle (a port: qpOASES cannot be built here) built -O3 -march=native on
+                    this host, one pinned core, bounded sample of the same workload.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+NO_BUILD = False
 
 
 def qp_algorithmic_bytes(q):
@@ -47,16 +55,23 @@ def pmc_traffic(substr, fetch_factor):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
     are collected in separate runs and reported in KiB). MI355X_MICROARCH.md: on gfx950
     FETCH_SIZE counts half the bytes of wide coalesced streaming reads -> fetch_factor 2 for
-    the streaming SpMV; WRITE_SIZE is exact. Returns None when no profile is committed."""
+    the streaming SpMV; WRITE_SIZE is exact. Returns (bytes, file) or (None, None)."""
     import glob
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
     if not paths:
-        return None
+        return None, None
     d = json.load(open(paths[-1]))   # the newest committed PMC pass
     for k, v in d.items():
         if substr in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            return fetch_factor * v["FETCH_SIZE"]["mean_per_dispatch"] * 1024 + v["WRITE_SIZE"]["mean_per_dispatch"] * 1024
-    return None
+            b = fetch_factor * v["FETCH_SIZE"]["mean_per_dispatch"] * 1024 + v["WRITE_SIZE"]["mean_per_dispatch"] * 1024
+            return b, os.path.basename(paths[-1])
+    return None, None
+
+
+def quartiles(ms):
+    a = np.sort(np.asarray(ms, dtype=np.float64))
+    return {"n": int(len(a)), "median": float(np.median(a)), "q1": float(np.percentile(a, 25)),
+            "q3": float(np.percentile(a, 75)), "min": float(a[0]), "max": float(a[-1])}
 
 
 def spmv_roofline(capi, problems, nbatch, repeats):
@@ -70,35 +85,64 @@ def spmv_roofline(capi, problems, nbatch, repeats):
     for name, tr, bytes_one in (("ATy_csc", True, 12 * nnz + 4 * (n + 1) + 8 * n + 8 * m),
                                 ("Ax_csr", False, 12 * nnz + 4 * (m + 1) + 8 * m + 8 * n)):
         plan.run(tr, 2)
-        ms = plan.run(tr, repeats)
-        gbs = bytes_one * nbatch / (ms * 1e-3) / 1e9
-        out[name] = {"ms_per_launch": ms, "bytes_per_launch": bytes_one * nbatch, "achieved": gbs}
+        ms = [plan.run(tr, 1) for _ in range(max(repeats, 20))]
+        st = quartiles(ms)
+        gbs = bytes_one * nbatch / (st["median"] * 1e-3) / 1e9
+        out[name] = {"ms_per_launch": st["median"], "ms_stats": st, "bytes_per_launch": bytes_one * nbatch, "achieved": gbs,
+                     "kernel_variant": plan.variant(tr)[0], "idx16": plan.variant(tr)[1]}
     best = out["ATy_csc"]
     # bytes the kernel actually streams: the plan keeps 16-bit copies of the index arrays when
     # both dimensions are < 65536 (10 B instead of 12 B per entry)
     streamed = (10 * nnz + 4 * (n + 1) + 8 * n + 8 * m) * nbatch
-    res = {"kernel": "csx_ldsvec_spmv_pipe2 (A'y on CSC = SpHbMat::transposed_times; input vector resident in LDS)",
+    traffic, tfile = pmc_traffic("csx_ldsvec_spmv_pipe2<4, 3", 2.0) if nbatch == 256 else (None, None)
+    res = {"kernel": "csx_ldsvec_spmv_pipe2<4,3,ushort> (A'y on CSC = SpHbMat::transposed_times; input vector resident in LDS; "
+                     "parity: tests/test_gpu_parity.py::test_roofline_spmv_kernels_match_the_oracle)",
            "bound": "hbm", "achieved": best["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": best["achieved"] / HBM_PEAK_GBS,
-           "traffic": pmc_traffic("csx_ldsvec_spmv_pipe2<4, 3", 2.0) if nbatch == 256 else None,
-           "matrices_per_launch": nbatch,
+           "frac": best["achieved"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tfile,
+           "matrices_per_launch": nbatch, "kernel_variant": best["kernel_variant"],
            "bytes_per_matrix": 12 * nnz + 4 * (n + 1) + 8 * n + 8 * m, "ms_per_launch": best["ms_per_launch"],
+           "ms_stats": best["ms_stats"],
            "streamed_bytes_per_launch_est": streamed, "raw_stream_GBs_est": streamed / (best["ms_per_launch"] * 1e-3) / 1e9,
-           "Ax_csr_GBs": out["Ax_csr"]["achieved"], "Ax_csr_frac": out["Ax_csr"]["achieved"] / HBM_PEAK_GBS}
+           "Ax_csr_GBs": out["Ax_csr"]["achieved"], "Ax_csr_frac": out["Ax_csr"]["achieved"] / HBM_PEAK_GBS,
+           "Ax_csr_kernel_variant": out["Ax_csr"]["kernel_variant"]}
     plan.close()
     return res
 
 
-def large_configs(capi, problems, hot_steps=6):
+def value_refresh_roofline(capi, problems):
+    """SpHbMat::setMatVal on the device at the QPhandler shape of the sparse configuration
+    ([J I -I]: 200 000 Jacobian entries + 40 000 identity entries; SURVEY 8(d): 20 B per entry)."""
+    from restartsqp_amd.sqptypes import IdentityInfo
+    n, m, nnz = 10000, 20000, 200000
+    jc, ir, rng = problems.sparse_pattern(n, m, nnz)
+    cols = np.repeat(np.arange(n), np.diff(jc))
+    s = capi.Solver(n + 2 * m, m)
+    s.set_engine(2)
+    ident = IdentityInfo([1, 1], [n + 1, n + m + 1], [m, m], [1.0, -1.0]).blocks()
+    s.set_A_triplet(ir + 1, cols + 1, rng.normal(size=nnz), ident)
+    s.set_A_triplet(ir + 1, cols + 1, rng.normal(size=nnz), ident)      # value refresh: stages the triplet values
+    ms_s, ms_g = s.time_value_refresh(200)
+    s.close()
+    bs, bg = 20.0 * nnz, 20.0 * (nnz + 2 * m)
+    return {"scatter_values": {"entries": nnz, "algorithmic_bytes": bs, "ms_per_launch": ms_s, "achieved": bs / (ms_s * 1e-3) / 1e9,
+                               "frac": bs / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "gather_values": {"entries": nnz + 2 * m, "algorithmic_bytes": bg, "ms_per_launch": ms_g,
+                              "achieved": bg / (ms_g * 1e-3) / 1e9, "frac": bg / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "unit": "GB/s", "peak": HBM_PEAK_GBS, "bound": "hbm",
+            "note": "4.8 MB per launch = 0.6 us at peak: a single refresh is launch-latency bound, not HBM bound"}
+
+
+def large_configs(capi, problems, seq_steps=50):
     """BASELINE configs 3 and 4 on the HBM-resident engine (outside the timed region): cold
-    solve of the dense 2048 x 4096 QP, cold solve + warm-started sequence of the sparse
-    10 000 x 20 000 QP ("wall-clock per SQP iteration, n=10k sparse"), and a mid-size dense QP
-    solved by both the GPU engine and the CPU oracle."""
+    solve of the dense 2048 x 4096 QP, cold solve + the 50-QP warm-started sequence of the sparse
+    10 000 x 20 000 QP through rsqp_optimize_qp ("wall-clock per SQP iteration, n=10k sparse"), and a
+    mid-size dense QP solved by both the GPU engine and the CPU oracle."""
     import oracle as O
     out = {}
 
     def load(q):
         s = capi.Solver(q.nV, q.nC)
+        s.set_options(qp_maxiter=400000)
         s.set_A_csc(q.A_jc, q.A_ir, q.A_val); s.set_H_csc(q.H_jc, q.H_ir, q.H_val)
         for w, v in zip(range(5), (q.g, q.lb, q.ub, q.lbA, q.ubA)):
             s.set_vector(w, v)
@@ -110,21 +154,32 @@ def large_configs(capi, problems, hot_steps=6):
     ok, st, _, _ = s.test_optimality()
     out["dense_2048x4096_cold"] = {"seconds": t, "nWSR": n, "ms_per_working_set_change": 1e3 * t / max(n, 1),
                                    "KKT_error": st.KKT_error, "certified": bool(ok)}
+    gold = os.path.join(ROOT, "tests", "golden", "oracle_large_dense_2048x4096.json")
+    if os.path.exists(gold):
+        g = json.load(open(gold))
+        wb, wc = s.working_set_raw()
+        out["dense_2048x4096_cold"].update({
+            "oracle_nWSR": g["nWSR"], "same_working_set_as_oracle": bool(np.array_equal(wb, g["ws_b"]) and np.array_equal(wc, g["ws_c"])),
+            "max_abs_dx_vs_oracle": float(np.abs(s.x - np.array(g["x"])).max()),
+            "oracle_seconds_build_container_1_core": g["oracle_seconds_build_container"]})
+    prof = s.engine_profile()
+    if prof:
+        out["dense_2048x4096_cold"]["kernels"] = prof
     s.close()
     q = problems.sparse_qp()
     s = load(q)
-    t = time.perf_counter(); n = s.solve(capi.MODE_COLD, 400000); t = time.perf_counter() - t
+    t = time.perf_counter(); n = s.optimize_qp(); t = time.perf_counter() - t
     ok, st, _, _ = s.test_optimality()
     out["sparse_10000x20000_cold"] = {"seconds": t, "nWSR": n, "ms_per_working_set_change": 1e3 * t / max(n, 1),
-                                      "KKT_error": st.KKT_error, "certified": bool(ok)}
+                                      "KKT_error": st.KKT_error, "certified": bool(ok), "entry": "rsqp_optimize_qp"}
     times, its, kinds, good = [], [], [], True
-    for qk, changed in problems.sparse_sequence(q, nsteps=2 * hot_steps):
+    for qk, changed in problems.sparse_sequence(q, nsteps=seq_steps):
         t = time.perf_counter()
         for w, v in zip(range(5), (qk.g, qk.lb, qk.ub, qk.lbA, qk.ubA)):
             s.set_vector(w, v)
-        if changed:      # QPhandler VARIED: new Jacobian values, hotstart(H, g, A, ...) re-factorises (blocked QR / Cholesky)
+        if changed:      # QPhandler VARIED: new Jacobian values
             s.set_A_csc(qk.A_jc, qk.A_ir, qk.A_val)
-        nk = s.solve(capi.MODE_HOT_MATRICES if changed else capi.MODE_HOT_VECTORS, 400000)
+        nk = s.optimize_qp()                          # the FIXED / VARIED dispatch of qpOASESInterface.cpp:137-224 decides the mode
         okk, stk, _, _ = s.test_optimality()          # QPhandler::solveQP = optimizeQP + certificate
         times.append(time.perf_counter() - t); its.append(nk); kinds.append(changed); good = good and bool(okk)
     times, its, kinds = np.array(times), np.array(its), np.array(kinds)
@@ -133,8 +188,13 @@ def large_configs(capi, problems, hot_steps=6):
         "wall_ms_per_sqp_iteration_median": 1e3 * float(np.median(times)), "nWSR_mean": float(np.mean(its)),
         "fixed_matrix_steps": {"qps": int((~kinds).sum()), "wall_ms_mean": 1e3 * float(times[~kinds].mean()), "nWSR_mean": float(its[~kinds].mean())},
         "varied_matrix_steps": {"qps": int(kinds.sum()), "wall_ms_mean": 1e3 * float(times[kinds].mean()), "nWSR_mean": float(its[kinds].mean())},
-        "all_certified": good, "note": "alternating FIXED (hotstart on vectors) and VARIED (new Jacobian values: upload, blocked "
-                                       "re-factorisation, hotstart) steps, each incl. host transfers and the KKT certificate"}
+        "all_certified": good, "entry": "rsqp_optimize_qp",
+        "note": "BASELINE configs[3]: 50 QPs, alternating FIXED (new vectors) and VARIED (new Jacobian values) steps through "
+                "optimizeQP's dispatch: a FIXED<->VARIED flip re-initialises from (x, y, bounds) (qpOASESInterface.cpp:199-207), "
+                "each step incl. host transfers and the KKT certificate"}
+    prof = s.engine_profile()
+    if prof:
+        out["sparse_10000x20000_warm_sequence"]["kernels"] = prof
     s.close()
     q = problems.dense_qp(600, 1200, seed=20260101)
     s = load(q)
@@ -150,24 +210,35 @@ def large_configs(capi, problems, hot_steps=6):
     return out
 
 
-def hs_batch_config(capi, problems, reps=50):
+def hs_batch_config(capi, problems, parallel, reps=50, cpu_seconds=4.0):
     """BASELINE configs[4]: the batch of 512 independent hs0xx-scale QPs (mixed shapes, so the
-    problems sharing a wave diverge), whole on one GPU and as the 64-QP shard one of 8 GPUs gets.
-    Cold solve + fused KKT certificate per launch pair; device time by HIP events."""
+    problems sharing a wave diverge), whole on one GPU and as the 64-QP shard one of 8 GPUs gets
+    (parallel.balanced_shards: largest first, dealt round-robin). Cold solve per launch; device time by
+    HIP events. CPU figure: the oracle on the same 512 QPs, one core and all cores."""
     out = {}
-    for nq in (512, 64):
-        probs = problems.hs_batch(nq)
+    all_probs = problems.hs_batch(512)
+    order = parallel.balanced_order(all_probs)
+    shard0 = parallel.balanced_shards(all_probs, 8)[0]
+    for tag, idx in (("512_qps", order), ("64_qps_shard_of_8_gpus", shard0)):
+        probs = [all_probs[k] for k in idx]
         b = capi.Batch(probs)
         b.solve(capi.MODE_COLD, 1000)
-        b.timer_start()
+        ms = []
         for _ in range(reps):
-            b.solve(capi.MODE_COLD, 1000, sync=False)
-        ms = b.timer_stop_ms() / reps
+            b.solve(capi.MODE_COLD, 1000, sync=True)
+            ms.append(b.last_solve_ms())
+        st = quartiles(ms)
         ok, _ = b.test_optimality()
         res = b.results()
-        out["%d_qps" % nq] = {"ms_per_batch": ms, "qp_solves_per_s": nq / (ms * 1e-3), "all_certified": bool(all(o == 1 for o in ok)),
-                              "mean_nWSR": float(np.mean([r["nWSR"] for r in res]))}
+        out[tag] = {"ms_per_batch": st["median"], "ms_stats": st, "qp_solves_per_s": len(probs) / (st["median"] * 1e-3),
+                    "all_certified": bool(all(o == 1 for o in ok)), "mean_nWSR": float(np.mean([r["nWSR"] for r in res])),
+                    "order": "largest first (parallel.balanced_order)"}
         b.close()
+    cpu = cpu_batch_baseline(all_probs, cpu_seconds)
+    out["cpu_baseline"] = cpu
+    out["speedup_vs_cpu_1_core"] = out["512_qps"]["qp_solves_per_s"] / cpu["value"]
+    if "value" in cpu.get("all_cores", {}):
+        out["speedup_vs_cpu_all_cores"] = out["512_qps"]["qp_solves_per_s"] / cpu["all_cores"]["value"]
     return out
 
 
@@ -176,10 +247,10 @@ def hs071_single_qp_latency(problems, iters=3000):
     adapter (restartsqp_amd/csrc/host) replays QPhandler::update_delta + solveQP (hot start +
     mandatory KKT certificate). A single 8-variable QP is launch/sync-latency bound on any GPU;
     the CPU oracle does the same work in a few microseconds -- reported for honesty."""
-    import subprocess
     import oracle as O
     host = os.path.join(ROOT, "restartsqp_amd", "csrc", "host")
-    subprocess.check_call(["make", "-s", "-C", host, "host_replay"])
+    if not NO_BUILD:
+        subprocess.check_call(["make", "-s", "-C", host, "host_replay"])
     out = subprocess.run([os.path.join(host, "host_replay"), "--bench", str(iters)], capture_output=True, text=True,
                          timeout=300).stdout
     res = {}
@@ -205,16 +276,26 @@ def hs071_single_qp_latency(problems, iters=3000):
     return res
 
 
+def _pin(core):
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, {allowed[core % len(allowed)]})
+    except (AttributeError, OSError):
+        pass
+
+
 def _cpu_worker(args):
-    """one process of the all-cores leg: the C oracle on its own copies of the sample QPs"""
-    probs, seconds = args
+    """one process of a CPU leg: the C oracle on its own copies of the sample QPs, pinned to one core"""
+    probs, seconds, core = args
+    _pin(core)
     import oracle as O
     handles = []
     for q in probs:
         qp = O.OracleQP(q.nV, q.nC)
         qp.set_A_csc(q.A_jc, q.A_ir, q.A_val); qp.set_H_csc(q.H_jc, q.H_ir, q.H_val)
         handles.append(qp)
-    reps, n, t0 = 50, 0, time.perf_counter()
+    small = max(q.nV for q in probs) <= 16
+    reps, n, t0 = (50 if small else 1), 0, time.perf_counter()
     while True:
         for qp, q in zip(handles, probs):
             qp.init_repeat(q.g, q.lb, q.ub, q.lbA, q.ubA, 1000, reps)     # C loop: no interpreter inside
@@ -224,13 +305,7 @@ def _cpu_worker(args):
             return n, t
 
 
-def cpu_baseline(probs, seconds):
-    """Oracle (oracle/qp_oracle.c) timed on this host: one thread (the reference's CPU path is
-    single-threaded, SURVEY 8(d)), and -- for fairness -- one QP stream per core on all cores. Test
-    infrastructure used as the reported baseline only -- never on the measured GPU path."""
-    import oracle as O
-    O.build()
-    n, t = _cpu_worker((probs, seconds))
+def _host_info():
     model = ""
     try:
         for ln in open("/proc/cpuinfo"):
@@ -239,37 +314,92 @@ def cpu_baseline(probs, seconds):
                 break
     except OSError:
         pass
-    out = {"value": n / t, "unit": "QP solves/s", "cores": 1, "kind": "port", "host_cpu": model, "host_nproc": os.cpu_count(),
-           "sample": "%d cold solves of the first %d QPs of the rank-0 batch in %.1f s (in-repo C oracle, gcc -O2, "
-                     "1 thread, solve loop in C; qpOASES 3.2.1 is not available)" % (n, len(probs), t)}
+    return model
+
+
+def _all_cores(probs, seconds):
     try:
         import multiprocessing as mp
         cores = len(os.sched_getaffinity(0))
         with mp.get_context("fork").Pool(cores) as pool:
-            rs = pool.map(_cpu_worker, [(probs, max(1.0, seconds / 3))] * cores)
-        out["all_cores"] = {"value": sum(r[0] / r[1] for r in rs), "cores": cores,
-                            "note": "one independent QP stream per core (the reference itself has no threading)"}
+            rs = pool.map(_cpu_worker, [(probs, seconds, c) for c in range(cores)])
+        return {"value": sum(r[0] / r[1] for r in rs), "cores": cores,
+                "note": "one independent QP stream per core, each pinned (the reference itself has no threading)"}
     except Exception as e:   # the all-cores figure is informational
-        out["all_cores"] = {"error": repr(e)}
+        return {"error": repr(e)}
+
+
+def cpu_baseline(probs, seconds):
+    """Oracle (oracle/qp_oracle.c) timed on this host: one pinned thread (the reference's CPU path is
+    single-threaded, SURVEY 8(d)), and -- for fairness -- one QP stream per core on all cores. Test
+    infrastructure used as the reported baseline only -- never on the measured GPU path."""
+    runs = [_run_worker_in_child(probs, seconds / 3.0) for _ in range(3)]
+    rates = [n / t for n, t in runs]
+    n = sum(r[0] for r in runs); t = sum(r[1] for r in runs)
+    out = {"value": float(np.median(rates)), "unit": "QP solves/s", "cores": 1, "kind": "port", "host_cpu": _host_info(),
+           "host_nproc": os.cpu_count(), "runs": rates,
+           "sample": "%d cold solves of the first %d QPs of the rank-0 batch in %.1f s (3 runs, median; in-repo C oracle, "
+                     "gcc -O3 -march=native built on this host, 1 thread pinned to a core, solve loop in C; qpOASES 3.2.1 "
+                     "is not available)" % (n, len(probs), t)}
+    out["all_cores"] = _all_cores(probs, max(1.0, seconds / 3))
     return out
 
 
+def cpu_batch_baseline(probs, seconds):
+    """the same for the 512-QP mixed batch of BASELINE configs[4] (whole batches, cold)"""
+    n, t = _run_worker_in_child(probs, seconds)
+    out = {"value": n / t, "unit": "QP solves/s", "cores": 1, "kind": "port",
+           "sample": "%d cold solves (%.1f passes over the 512 mixed hs0xx QPs) in %.1f s, 1 pinned core" % (n, n / len(probs), t)}
+    out["all_cores"] = _all_cores(probs, max(1.0, seconds / 2))
+    return out
+
+
+def _run_worker_in_child(probs, seconds):
+    """time the one-core leg in a forked child (pinning stays local to it)"""
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(1) as pool:
+        return pool.map(_cpu_worker, [(probs, seconds, 0)])[0]
+
+
+def spawn_ranks(args):
+    """--gpus N without a torchrun environment: start the N rank processes as a child job"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
+    global NO_BUILD
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch-per-gpu", type=int, default=65536)
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--spmv-batch", type=int, default=256)
-    ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline and roofline_spmv")
+    ap.add_argument("--stat-launches", type=int, default=200, help="individually timed launches for median / IQR")
+    ap.add_argument("--no-extras", action="store_true", help="skip cpu_baseline and the secondary measurements")
     ap.add_argument("--no-large", action="store_true", help="skip the dense 2048x4096 / sparse 10k configurations")
+    ap.add_argument("--no-build", action="store_true",
+                    help="never run hipcc / make (profiled runs: build first, outside rocprofv3 -- tools/*.sh)")
+    ap.add_argument("--keep-state", type=int, default=0,
+                    help="1: every cold solve also writes the hot-start image (1.7 KB/QP) back to HBM")
     args = ap.parse_args()
+    NO_BUILD = args.no_build
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        import torch
+        have = torch.cuda.device_count()          # does not initialise the GPU
+        if have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, have))
+        raise SystemExit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import torch
@@ -282,17 +412,19 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
 
-    from restartsqp_amd import build, capi, problems
-    build.build_lib()
+    from restartsqp_amd import build, capi, parallel, problems
+    if not NO_BUILD:
+        build.build_lib()
     if capi.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
 
     B = args.batch_per_gpu
     probs = problems.hs071_scale_batch(B, seed=20260103 + rank)
     batch = capi.Batch(probs, device=local_rank)
+    batch.set_keep_state(bool(args.keep_state))
 
     def sync():
-        batch and capi.check(capi.lib().rsqp_batch_sync(batch._h))
+        capi.check(capi.lib().rsqp_batch_sync(batch._h))
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -312,16 +444,56 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # launch-by-launch statistics (each launch bracketed by its own HIP events; outside the timed region)
+    per_launch = []
+    for _ in range(args.stat_launches):
+        batch.solve(capi.MODE_COLD, 1000, sync=True)
+        per_launch.append(batch.last_solve_ms())
+
+    # the one collective of the path: all-gather of the fixed-stride result records (RCCL), N > 1 only
+    gather = None
+    if dist is not None:
+        stride = batch.record_stride
+        rec = torch.zeros(B * stride, dtype=torch.float64, device="cuda")
+        allrec = torch.zeros(world * B * stride, dtype=torch.float64, device="cuda")
+        ksteps = max(5, min(args.steps, 50))
+        for timed in (False, True):
+            sync()
+            tg0, only = time.perf_counter(), 0.0
+            for _ in range(ksteps):
+                batch.solve(capi.MODE_COLD, 1000, sync=False)
+                batch.pack_records_dev(rec.data_ptr())
+                capi.check(capi.lib().rsqp_batch_sync(batch._h))
+                tc = time.perf_counter()
+                dist.all_gather_into_tensor(allrec, rec)
+                torch.cuda.synchronize()
+                only += time.perf_counter() - tc
+            sync()
+            tg = time.perf_counter() - tg0
+        tt = torch.tensor([tg, only], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tg, only = (float(v) for v in tt.tolist())
+        got = allrec.view(world * B, stride)
+        gather = {"steps": ksteps, "ms_per_step": 1e3 * tg / ksteps, "value": world * B * ksteps / tg, "unit": "QP solves/s",
+                  "all_gather_ms": 1e3 * only / ksteps, "record_bytes": 8 * stride, "bytes_gathered_per_rank": 8 * world * B * stride,
+                  "ranks_seen": int((got[::B, 0] == 20).sum().item()),
+                  "note": "solve + device-side record packing + all_gather_into_tensor over RCCL; not part of `value`"}
+
     # correctness guard: every QP solved, certificate green (outside the timed region)
     res = batch.results()
     ok, kkt = batch.test_optimality()
     n_bad = sum(1 for r, o in zip(res, ok) if r["status"] != 20 or o != 1)
+    if dist is not None:
+        tb = torch.tensor([n_bad], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        n_bad = int(tb.item())
 
     if rank == 0:
         total = world * B * args.steps
         k_ms = kernel_ms_total / args.steps   # average launch duration over the timed region
         bytes_launch = float(sum(qp_algorithmic_bytes(q) for q in probs))
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9
+        traffic, tfile = pmc_traffic("Engine<8", 1.0) if B == 65536 else (None, None)
         line = {
             "metric": "QP-subproblem solves/sec", "value": total / elapsed, "unit": "QP solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -329,21 +501,28 @@ def main():
             "config": {"workload": "hs071-scale QP batch (derived hs071 first QP + seeded 1 %% perturbations, "
                                    "nV=8 x nC=2 via QPhandler [J I -I]), cold start, %d QPs/GPU per step" % B,
                        "qps_per_gpu": B, "engine": "small_qp_kernel<Engine<8>> (LDS-resident, 8 lanes per QP = 8 QPs per wave)",
+                       "keep_state": bool(args.keep_state),
                        "mean_nWSR": float(np.mean([r["nWSR"] for r in res])), "unsolved_or_kkt_fail": n_bad},
             "roofline": {"kernel": "small_qp_kernel<Engine<8>>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic("Engine<8", 1.0) if B == 65536 else None,
-                         "traffic_note": "FETCH_SIZE uncorrected (narrow loads, uncalibrated) + WRITE_SIZE; the "
-                                         "writes are the 1.7 KB/QP of engine state a hot start needs",
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tfile,
+                         "traffic_note": "from the committed rocprofv3 --pmc passes of this command (FETCH_SIZE uncorrected: "
+                                         "narrow loads; + WRITE_SIZE), not measured in this run",
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_launch,
-                         "note": "latency/LDS-bound kernel: HBM fraction is not its limiter"},
+                         "note": "latency/LDS-bound kernel: HBM fraction is not its limiter; see roofline_issue in DESIGN.md 6"},
+            "kernel_ms_stats": quartiles(per_launch),
         }
+        if gather is not None:
+            line["with_gather"] = gather
         if not args.no_extras and world == 1:   # extras (CPU baseline, secondary rooflines, large configs): N = 1 only
+            import oracle as O
+            if not NO_BUILD:
+                O.use_native_build()
             line["cpu_baseline"] = cpu_baseline(probs[:256], args.cpu_seconds)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
-            line["roofline_spmv"] = spmv_roofline(capi, problems, args.spmv_batch, 5)
+            line["roofline_spmv"] = spmv_roofline(capi, problems, args.spmv_batch, 40)
+            line["roofline_value_refresh"] = value_refresh_roofline(capi, problems)
             line["hs071_single_qp"] = hs071_single_qp_latency(problems)
-            line["hs0xx_batch_512"] = hs_batch_config(capi, problems)
+            line["hs0xx_batch_512"] = hs_batch_config(capi, problems, parallel)
             if not args.no_large:
                 line["large_engine"] = large_configs(capi, problems)
         print(json.dumps(line))

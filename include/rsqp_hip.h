@@ -81,6 +81,12 @@ const char *rsqp_last_error(void);
  * plain-QP ctor (:54-94). device < 0 selects the current device. */
 int rsqp_create(int nV, int nC, int device, rsqp_solver **out);
 void rsqp_destroy(rsqp_solver *s);
+/* measurement only (bench.py): per-kernel-class accounting of the HBM-resident engine. Profiling brackets
+ * every launch of a class with HIP events (serialises the stream). rsqp_get_engine_profile returns the number
+ * of classes n (0: the handle has no HBM engine) and fills out4n[4k..4k+3] = {calls, ms, algorithmic bytes, 0}. */
+int rsqp_set_engine_profiling(rsqp_solver *s, int on);
+int rsqp_get_engine_profile(const rsqp_solver *s, double *out4n, int n);
+int rsqp_engine_profile_names(const char **names, int n);
 int rsqp_get_nV(const rsqp_solver *s);
 int rsqp_get_nC(const rsqp_solver *s);
 /* engine selection: 0 = automatic (the LDS-resident kernel when the problem image fits the
@@ -117,6 +123,10 @@ int rsqp_get_H_csc(const rsqp_solver *s, int *jc, int *ir, double *val, int *ord
 int rsqp_set_vector(rsqp_solver *s, int which, const double *v);
 int rsqp_set_entry(rsqp_solver *s, int which, int location, double value);
 int rsqp_get_vector(const rsqp_solver *s, int which, double *v);
+/* device time (ms per launch, HIP events) of the two kernels behind a value refresh of A --
+ * SpHbMat::setMatVal (SpHbMat.cpp:368-380): the scatter through `order` (20 B per entry) and the
+ * refresh of the CSR copy -- on the values staged by the last rsqp_set_A_triplet */
+int rsqp_time_value_refresh(rsqp_solver *s, int repeats, float *ms_scatter, float *ms_gather);
 /* reset_constraints (qpOASESInterface.cpp:897-902) */
 int rsqp_reset_constraints(rsqp_solver *s);
 
@@ -196,6 +206,11 @@ int rsqp_batch_set_matrix_values(rsqp_batch *b, const double *Aval, const double
  * stream; rsqp_batch_sync() waits. */
 int rsqp_batch_solve(rsqp_batch *b, int mode, int max_nWSR);
 int rsqp_batch_sync(rsqp_batch *b);
+/* keep != 0 (default): every solve writes the state a hot start needs (factors, iterate, multipliers,
+ * working set: what a qpOASES SQProblem object keeps between init / hotstart calls) back to HBM.
+ * keep == 0: batches that are only ever solved from a cold start (parameter scans) skip that write
+ * (1.7 KB per hs071-scale QP); a hot start after such a solve silently becomes a cold start. */
+int rsqp_batch_set_keep_state(rsqp_batch *b, int keep);
 /* device time of the last rsqp_batch_solve in milliseconds (HIP events on its stream) */
 float rsqp_batch_last_solve_ms(rsqp_batch *b);
 /* HIP-event stopwatch on the batch's stream: start records an event, stop records a
@@ -210,6 +225,13 @@ int rsqp_batch_get_results(rsqp_batch *b, double *x, double *y, int *ws_b, int *
                            int *nWSR, double *obj);
 /* fused KKT certificate for every problem of the batch (one launch) */
 int rsqp_batch_test_optimality(rsqp_batch *b, rsqp_optimality_status *out /* nq */, int *ok /* nq */);
+/* fixed-stride result records written to DEVICE memory, for the gather of a sharded batch over RCCL
+ * (the path has no other exchange). Per problem, stride = 4 + 3 nVmax + 2 nCmax doubles:
+ *   {Exitflag, nWSR, objective, KKT_error (0 before rsqp_batch_test_optimality), x[nVmax],
+ *    y_bounds[nVmax], y_constraints[nCmax], ws_b[nVmax], ws_c[nCmax]}   (qpOASESInterface.cpp:290-357).
+ * rec_dev: caller-owned device buffer of nq * stride doubles; enqueued on the batch's stream. */
+int rsqp_batch_record_stride(const rsqp_batch *b);
+int rsqp_batch_pack_records_dev(rsqp_batch *b, double *rec_dev);
 
 /* ------------------------------------------------------------------------------------ */
 /* batched sparse products, device resident -- the SpMV the roofline target names        */

@@ -29,6 +29,20 @@ def build(force=False):
     return so
 
 
+def use_native_build():
+    """bench.py's cpu_baseline only: rebuild the oracle with -O3 -march=native on THIS host (into
+    oracle/_native/, git- and gpurun-ignored) and make it the library lib() loads. Call before the first use."""
+    global _LIB_PATH
+    if _LIB is not None:
+        raise RuntimeError("oracle library already loaded")
+    subprocess.check_call(["make", "-s", "-B", "-C", _HERE, "_native/liboracle_native.so"])
+    _LIB_PATH = os.path.join(_HERE, "_native", "liboracle_native.so")
+    return _LIB_PATH
+
+
+_LIB_PATH = None
+
+
 class OptimalityStatus(C.Structure):
     _fields_ = [("primal_violation", C.c_double), ("dual_violation", C.c_double),
                 ("compl_violation", C.c_double), ("stationarity_violation", C.c_double),
@@ -38,7 +52,7 @@ class OptimalityStatus(C.Structure):
 def lib():
     global _LIB
     if _LIB is None:
-        L = C.CDLL(build())
+        L = C.CDLL(_LIB_PATH or build())
         L.orc_qp_create.restype = C.c_void_p
         L.orc_qp_create.argtypes = [C.c_int, C.c_int]
         L.orc_qp_destroy.argtypes = [C.c_void_p]

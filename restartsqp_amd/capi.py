@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librsqp_hip.so")
+LIB_PATH = os.environ.get("RSQP_LIB") or os.path.join(_HERE, "lib", "librsqp_hip.so")   # RSQP_LIB: tuning builds (tools/)
 
 OK = 0
 ERR_ARG, ERR_DEVICE, ERR_TOO_LARGE, ERR_WORKING_SET = -1, -2, -3, -4
@@ -43,6 +43,9 @@ SYMBOLS = {
     "rsqp_write_qp_data": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "rsqp_read_qore_dump_sizes": (C.c_int, [C.c_char_p, ip, ip, ip, ip]),
     "rsqp_read_qore_dump": (C.c_int, [C.c_char_p, dp, dp, dp, dp, dp, ip, ip, dp, ip, ip, dp]),
+    "rsqp_set_engine_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "rsqp_get_engine_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "rsqp_engine_profile_names": (C.c_int, [C.c_void_p, C.c_int]),
     "rsqp_set_engine": (C.c_int, [C.c_void_p, C.c_int]),
     "rsqp_get_engine": (C.c_int, [C.c_void_p]),
     "rsqp_set_A_triplet": (C.c_int, [C.c_void_p, C.c_int, ip, ip, dp, C.c_int, ip, ip, ip, dp]),
@@ -77,11 +80,15 @@ SYMBOLS = {
     "rsqp_batch_set_matrix_values": (C.c_int, [C.c_void_p, dp, dp]),
     "rsqp_batch_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rsqp_batch_sync": (C.c_int, [C.c_void_p]),
+    "rsqp_batch_set_keep_state": (C.c_int, [C.c_void_p, C.c_int]),
     "rsqp_batch_last_solve_ms": (C.c_float, [C.c_void_p]),
     "rsqp_batch_timer_start": (C.c_int, [C.c_void_p]),
     "rsqp_batch_timer_stop_ms": (C.c_float, [C.c_void_p]),
     "rsqp_batch_get_results": (C.c_int, [C.c_void_p, dp, dp, ip, ip, ip, ip, dp]),
     "rsqp_batch_test_optimality": (C.c_int, [C.c_void_p, C.c_void_p, ip]),
+    "rsqp_batch_record_stride": (C.c_int, [C.c_void_p]),
+    "rsqp_batch_pack_records_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rsqp_time_value_refresh": (C.c_int, [C.c_void_p, C.c_int, fp, fp]),
     "rsqp_spmv_plan_create": (C.c_int, [C.c_int, C.c_int, ip, ip, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "rsqp_spmv_plan_destroy": (None, [C.c_void_p]),
     "rsqp_spmv_plan_upload": (C.c_int, [C.c_void_p, dp, dp, C.c_int]),
@@ -192,6 +199,34 @@ class Solver:
     def write_qp_data(self, path, layout=DUMP_QPOASES):
         """WriteQPDataToFile for the data held by this handle."""
         check(lib().rsqp_write_qp_data(self._h, os.fsencode(path), layout))
+
+    def set_engine_profiling(self, on=True):
+        check(lib().rsqp_set_engine_profiling(self._h, int(bool(on))))
+
+    def engine_profile(self):
+        """per-kernel-class device time / algorithmic bytes of the HBM-resident engine since its creation
+        (rsqp_get_engine_profile), or None when the handle runs the LDS-resident engine"""
+        n = lib().rsqp_get_engine_profile(self._h, None, 0)
+        if n <= 0:
+            return None
+        buf = (C.c_double * (4 * n))()
+        names = (C.c_char_p * n)()
+        lib().rsqp_get_engine_profile(self._h, C.cast(buf, C.c_void_p), n)
+        lib().rsqp_engine_profile_names(C.cast(names, C.c_void_p), n)
+        out = {}
+        for k in range(n):
+            calls, ms, byts, peak = buf[4 * k], buf[4 * k + 1], buf[4 * k + 2], buf[4 * k + 3]
+            if calls > 0:
+                out[names[k].decode()] = {"calls": int(calls), "ms_total": ms, "us_per_call": 1e3 * ms / calls,
+                                          "algorithmic_bytes": byts, "achieved": byts / (ms * 1e-3) / 1e9 if ms > 0 else None,
+                                          "unit": "GB/s", "peak": 8000.0, "bound": "hbm",
+                                          "frac": byts / (ms * 1e-3) / 1e9 / 8000.0 if ms > 0 else None}
+        return out
+
+    def time_value_refresh(self, repeats=50):
+        a, b = C.c_float(0), C.c_float(0)
+        check(lib().rsqp_time_value_refresh(self._h, repeats, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def set_engine(self, engine):
         """0 automatic, 1 LDS-resident kernel, 2 HBM-resident engine."""
@@ -373,6 +408,9 @@ class Batch:
         if sync:
             check(lib().rsqp_batch_sync(self._h))
 
+    def set_keep_state(self, keep):
+        check(lib().rsqp_batch_set_keep_state(self._h, int(bool(keep))))
+
     def last_solve_ms(self):
         return lib().rsqp_batch_last_solve_ms(self._h)
 
@@ -394,6 +432,15 @@ class Batch:
             out.append(dict(x=x[v0:v1], y=y[yo:yo + (v1 - v0) + (c1 - c0)], ws_b=wb[v0:v1], ws_c=wc[c0:c1],
                             status=int(st[q]), nWSR=int(nw[q]), obj=float(obj[q])))
         return out
+
+    @property
+    def record_stride(self):
+        return lib().rsqp_batch_record_stride(self._h)
+
+    def pack_records_dev(self, dev_ptr):
+        """fixed-stride result records (parallel.pack_records layout) into device memory at `dev_ptr`
+        (nq * record_stride doubles, e.g. a torch tensor's data_ptr()); asynchronous on the batch's stream"""
+        check(lib().rsqp_batch_pack_records_dev(self._h, C.c_void_p(dev_ptr)))
 
     def test_optimality(self):
         st = (OptimalityStatus * self.nq)()

@@ -1606,6 +1606,16 @@ int RsqpLargeEngine::status_word() const {
 }
 int RsqpLargeEngine::nflips() const { return p_->nflips; }
 hipError_t RsqpLargeEngine::last_error() const { return p_->err_; }
+const char *RsqpLargeEngine::profile_name(int k) {
+    static const char *nm[PROFILE_CLASSES] = {"gemv_n", "gemv_t", "ger", "wz_shrink", "wz_grow", "spmv", "", ""};
+    return k >= 0 && k < PROFILE_CLASSES ? nm[k] : "";
+}
+void RsqpLargeEngine::profile_enable(bool on) { p_->profile = on; }
+void RsqpLargeEngine::profile_get(double *out) const {
+    for (int k = 0; k < PROFILE_CLASSES; k++) {
+        out[4 * k] = (double)p_->prof[k].calls; out[4 * k + 1] = p_->prof[k].ms; out[4 * k + 2] = p_->prof[k].bytes; out[4 * k + 3] = 0.0;
+    }
+}
 double RsqpLargeEngine::objective() {
     Impl &P = *p_;
     P.H_times(P.x, P.w2);

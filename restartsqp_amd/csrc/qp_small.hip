@@ -964,12 +964,16 @@ __host__ __device__ inline long long mat_lds_bytes(int nV, int nC, int annz, int
 
 // L = lanes per problem (64 / L problems share one wave; each owns `stride` bytes of LDS),
 // W = minimum waves per SIMD the register allocator has to leave room for
-// UNI: every problem of the batch has the same shape (P.uniV x P.uniC, kernel arguments): sizes, loop
-// bounds and LDS offsets are then wave-uniform scalars instead of per-lane values. Measured: 221 VGPRs
-// instead of 256 but 214 vs 226 M solves/s on 65 536 hs071-scale QPs -- not instantiated.
-template <class ENG, int L, bool MAT_LDS, int W, bool UNI>
+// SHAPE = NVC * 256 + NCC > 0: every problem of the batch has the shape NVC x NCC, known at COMPILE time
+// (parameter scans / the hs071-scale batch: 8 x 2 through the QPhandler formulation). Sizes, loop bounds and
+// the offsets of the LDS image are then constants: every vector of the engine sits at an immediate offset of
+// ONE per-lane base address instead of in a register of its own, and every loop over a vector is straight-line.
+// (Passing the uniform shape as kernel ARGUMENTS instead -- wave-uniform scalars -- measured 221 VGPRs instead
+// of 256 but 214 vs 226 M solves/s on 65 536 hs071-scale QPs: not built.)
+template <class ENG, int L, bool MAT_LDS, int W, int SHAPE>
 __global__ void __launch_bounds__(L > 64 ? L : 64, W)
 small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
+    constexpr int NVC = SHAPE >> 8, NCC = SHAPE & 255;
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     const int lane = L >= 64 ? (int)threadIdx.x : (int)threadIdx.x & (L - 1);
     const int grp = L >= 64 ? 0 : (int)threadIdx.x / L;  // L >= 64: everything below stays workgroup-uniform
@@ -977,7 +981,7 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
     if (q >= nq) return;  // no workgroup barrier anywhere below: idle groups may leave
     lchar *smem = (lchar *)smem_generic + grp * stride;
     QPDesc d = P.desc[q];
-    if constexpr (UNI) { d.nV = P.uniV; d.nC = P.uniC; }
+    if constexpr (SHAPE > 0) { d.nV = NVC; d.nC = NCC; }
     if constexpr (L < 64) {
         // packed waves are only launched when every problem of the batch has nV, nC <= L: a loop over a
         // vector of the engine is then a single predicated trip (no back edge, no counter)
@@ -1091,8 +1095,12 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
         E.iscal[1] = E.nFR; E.iscal[2] = E.nAC; E.iscal[3] = E.status;
     }
     SYNC();
-    for (int k = lane; k < np; k += L) img[k] = simg[k];
-    for (int k = lane; k < ni; k += L) iimg[k] = siimg[k];
+    if (P.keep_state) {
+        for (int k = lane; k < np; k += L) img[k] = simg[k];
+        for (int k = lane; k < ni; k += L) iimg[k] = siimg[k];
+    } else if (lane == 0) {
+        iimg[(int)(E.iscal - siimg) + 3] = QPS_NOTINITIALISED;
+    }
     STAMP(9);
 }
 
@@ -1163,7 +1171,7 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
         hipLaunchKernelGGL((small_qp_kernel<ENG<LL, ML>, LL, ML, W, U>), dim3(nblk), dim3(LL > 64 ? LL : 64), lds, stream, p, nq, \
                            (int)stride, mode, maxWSR);                                                        \
     } while (0)
-#define SQ_LAUNCH_E(ENG, LL, ML, W) SQ_LAUNCH_U(ENG, LL, ML, W, false)
+#define SQ_LAUNCH_E(ENG, LL, ML, W) SQ_LAUNCH_U(ENG, LL, ML, W, 0)
 #define SQ_LAUNCH(LL, ML, W) SQ_LAUNCH_E(Engine, LL, ML, W)
 #define SQ_WAVES(LL)                                                                                          \
     switch (waves) {                                                                                          \
@@ -1171,6 +1179,22 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     case 4: SQ_LAUNCH(LL, true, 4); break;                                                                    \
     default: SQ_LAUNCH(LL, true, 2); break;                                                                   \
     }
+#ifdef RSQP_SMALL_EXPERIMENT
+    // quick-turnaround build for tuning (tools/small_experiment.sh): only the 8-lane Givens / TQ kernel
+    {
+        static const int shp = env_int("RSQP_SMALL_SHAPE", 0);
+        const bool fixed = shp != 0 && p.uniV == 8 && p.uniC == 2;
+#ifdef RSQP_EXP_L16W6
+        // the build the launcher refuses (qp_small.hip "Packed builds with W=6"): 16 lanes per problem, 6 waves per
+        // SIMD = 80 VGPRs with ~180 spilled values; kept reachable only here, for the root-cause hunt
+        if (L == 16 && eng == 0 && mat_lds) { SQ_LAUNCH_U(Engine, 16, true, 6, 0); return hipGetLastError(); }
+#endif
+        if (L != 8 || eng != 0 || !mat_lds) return hipErrorInvalidValue;
+        if (fixed) { switch (waves) { case 3: SQ_LAUNCH_U(Engine, 8, true, 3, 8 * 256 + 2); break; case 4: SQ_LAUNCH_U(Engine, 8, true, 4, 8 * 256 + 2); break; default: SQ_LAUNCH_U(Engine, 8, true, 2, 8 * 256 + 2); } }
+        else { switch (waves) { case 3: SQ_LAUNCH_U(Engine, 8, true, 3, 0); break; case 4: SQ_LAUNCH_U(Engine, 8, true, 4, 0); break; default: SQ_LAUNCH_U(Engine, 8, true, 2, 0); } }
+        return hipGetLastError();
+    }
+#else
     if (eng == 1) {
         if (!mat_lds) SQ_LAUNCH_E(EngineX, 64, false, 3);
         else if (L == 16) SQ_LAUNCH_E(EngineX, 16, true, 2);
@@ -1180,7 +1204,13 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     } else if (!mat_lds) {
         SQ_LAUNCH(64, false, 3);
     } else if (L == 8) {
-        SQ_LAUNCH(8, true, 2);
+        // uniform hs071-scale batches (8 x 2 through the QPhandler formulation; parameter scans of one NLP
+        // iterate) run the build with the shape as a compile-time constant: 160 instead of 253 VGPRs, no
+        // per-vector address registers, straight-line vector loops (+3 % on 65 536 QPs; the occupancy of both
+        // builds is capped at 2 waves per SIMD by the 20 KB of LDS a wave of 8 problems needs)
+        static const int noshape = env_int("RSQP_SMALL_NOSHAPE", 0);
+        if (p.uniV == 8 && p.uniC == 2 && !noshape) SQ_LAUNCH_U(Engine, 8, true, 2, 8 * 256 + 2);
+        else SQ_LAUNCH(8, true, 2);
     } else if (L == 16) {
         SQ_WAVES(16)
     } else if (L == 32) {
@@ -1192,6 +1222,7 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
         default: SQ_LAUNCH(64, true, 4); break;
         }
     }
+#endif
 #undef SQ_LAUNCH_E
 #undef SQ_LAUNCH_U
 #undef SQ_WAVES

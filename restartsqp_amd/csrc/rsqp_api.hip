@@ -206,7 +206,7 @@ struct rsqp_solver {
     int engine = 1;
     bool fits_small = true;
     RsqpLargeEngine *large = nullptr;
-    bool large_ready = false;
+    bool large_ready = false, profile_large = false;
     DevBuf<double> denseA, denseH;   // dense copies for the HBM-resident engine (dense matrices only)
     ~rsqp_solver() {
         delete large;
@@ -291,6 +291,7 @@ QPPools pools_of(rsqp_solver *s) {
     p.status = s->d_status.p; p.ret = s->d_ret.p; p.nwsr = s->d_nwsr.p; p.nflips = s->d_nflips.p;
     p.obj = s->d_obj.p; p.state = s->d_state.p;
     p.uniV = s->nV; p.uniC = s->nC;
+    p.keep_state = 1;
     return p;
 }
 
@@ -391,6 +392,22 @@ extern "C" int rsqp_set_engine(rsqp_solver *s, int engine) {
     return RSQP_OK;
 }
 extern "C" int rsqp_get_engine(const rsqp_solver *s) { return s ? s->engine : -1; }
+// measurement only: per-kernel-class device time of the HBM-resident engine (bench.py)
+extern "C" int rsqp_set_engine_profiling(rsqp_solver *s, int on) {
+    if (!s) return fail(RSQP_ERR_ARG, "null solver");
+    s->profile_large = on != 0;
+    if (s->large) s->large->profile_enable(s->profile_large);
+    return RSQP_OK;
+}
+extern "C" int rsqp_get_engine_profile(const rsqp_solver *s, double *out4n, int n) {
+    if (!s || !s->large) return 0;
+    if (out4n && n >= RsqpLargeEngine::PROFILE_CLASSES) s->large->profile_get(out4n);
+    return RsqpLargeEngine::PROFILE_CLASSES;
+}
+extern "C" int rsqp_engine_profile_names(const char **names, int n) {
+    for (int k = 0; names && k < n && k < RsqpLargeEngine::PROFILE_CLASSES; k++) names[k] = RsqpLargeEngine::profile_name(k);
+    return RsqpLargeEngine::PROFILE_CLASSES;
+}
 extern "C" int rsqp_get_nV(const rsqp_solver *s) { return s ? s->nV : -1; }
 extern "C" int rsqp_get_nC(const rsqp_solver *s) { return s ? s->nC : -1; }
 
@@ -559,7 +576,7 @@ extern "C" int rsqp_reset_constraints(rsqp_solver *s) {
 
 namespace {
 int solve_large(rsqp_solver *s, int mode, int *nWSR, const double *x0, const double *y0, const int *guess_b) {
-    if (!s->large) s->large = new RsqpLargeEngine();
+    if (!s->large) { s->large = new RsqpLargeEngine(); if (s->profile_large) s->large->profile_enable(true); }
     if (!s->large_ready) {
         size_t free_b = 0, total_b = 0;
         HIPCHK(hipMemGetInfo(&free_b, &total_b));
@@ -946,6 +963,7 @@ struct rsqp_batch {
     DevBuf<int> Wb, Wc, kV, kC;
     DevBuf<long long> koV, koC;
     float last_ms = 0.f;
+    bool keep_state = true;
     bool timing = false;   // between timer_start and timer_stop: no per-launch events (they cost ~10 us of stream time each)
     ~rsqp_batch() {
         if (ev0) (void)hipEventDestroy(ev0);
@@ -969,6 +987,7 @@ QPPools pools_of(rsqp_batch *b) {
     p.status = b->status.p; p.ret = b->ret.p; p.nwsr = b->nwsr.p; p.nflips = b->nflips.p;
     p.obj = b->obj.p; p.state = b->state.p;
     p.uniV = b->uniV; p.uniC = b->uniC;
+    p.keep_state = b->keep_state ? 1 : 0;
     return p;
 }
 }  // namespace
@@ -1084,6 +1103,12 @@ extern "C" int rsqp_batch_solve(rsqp_batch *b, int mode, int max_nWSR) {
     return RSQP_OK;
 }
 
+extern "C" int rsqp_batch_set_keep_state(rsqp_batch *b, int keep) {
+    if (!b) return fail(RSQP_ERR_ARG, "null batch");
+    b->keep_state = keep != 0;
+    return RSQP_OK;
+}
+
 extern "C" int rsqp_batch_sync(rsqp_batch *b) {
     if (!b) return fail(RSQP_ERR_ARG, "null batch");
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -1168,6 +1193,85 @@ extern "C" int rsqp_batch_test_optimality(rsqp_batch *b, rsqp_optimality_status 
         }
         if (ok) ok[q] = o[6 * q + 5] != 0.0 ? RSQP_ERR_WORKING_SET : (o[6 * q + 4] > 1.0e-6 ? 0 : 1);
     }
+    return RSQP_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// fixed-stride result records on the device: what a rank contributes to the gather of a sharded batch
+// (SURVEY 8(e)). Layout = restartsqp_amd/parallel.py pack_records:
+//   {exitflag, nWSR, objective, KKT_error, x[nVmax], y_bounds[nVmax], y_constr[nCmax], ws_b[nVmax], ws_c[nCmax]}
+// One thread per record entry; unused tail entries of a smaller problem are zero.
+// ---------------------------------------------------------------------------------
+namespace {
+__global__ void pack_records_kernel(int nq, int nVmax, int nCmax, const QPDesc *__restrict__ desc,
+                                    const double *__restrict__ x, const double *__restrict__ y,
+                                    const int *__restrict__ ws_b, const int *__restrict__ ws_c,
+                                    const int *__restrict__ status, const int *__restrict__ nwsr,
+                                    const double *__restrict__ obj, const double *__restrict__ kkt,
+                                    double *__restrict__ rec) {
+    const int stride = 4 + 3 * nVmax + 2 * nCmax;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)nq * stride) return;
+    const int q = (int)(t / stride), e = (int)(t % stride);
+    const QPDesc d = desc[q];
+    double v = 0.0;
+    if (e < 4) {
+        if (e == 0) {   // exitflag_of(): qpOASESInterface::get_status (src/qpOASESInterface.cpp:332-357)
+            const int sw = status[q];
+            v = sw >= 200 ? RSQP_QPERROR_UNBOUNDED : (sw >= 100 ? RSQP_QPERROR_INFEASIBLE : (sw == QPS_SOLVED ? RSQP_QP_OPTIMAL : RSQP_QPERROR_NOTINITIALISED + sw));
+        } else if (e == 1) v = nwsr[q];
+        else if (e == 2) v = obj[q];
+        else v = kkt ? kkt[6 * q + 4] : 0.0;
+    } else {
+        int o = e - 4;
+        if (o < nVmax) { if (o < d.nV) v = x[d.offV + o]; }
+        else if ((o -= nVmax) < nVmax) { if (o < d.nV) v = y[d.offV + d.offC + o]; }
+        else if ((o -= nVmax) < nCmax) { if (o < d.nC) v = y[d.offV + d.offC + d.nV + o]; }
+        else if ((o -= nCmax) < nVmax) { if (o < d.nV) v = ws_b[d.offV + o]; }
+        else { o -= nVmax; if (o < d.nC) v = ws_c[d.offC + o]; }
+    }
+    rec[t] = v;
+}
+}  // namespace
+
+extern "C" int rsqp_batch_record_stride(const rsqp_batch *b) {
+    return b ? 4 + 3 * b->nVmax + 2 * b->nCmax : -1;
+}
+
+extern "C" int rsqp_batch_pack_records_dev(rsqp_batch *b, double *rec_dev) {
+    if (!b || !rec_dev) return fail(RSQP_ERR_ARG, "rsqp_batch_pack_records_dev");
+    HIPCHK(hipSetDevice(b->device));
+    const long long tot = (long long)b->nq * rsqp_batch_record_stride(b);
+    hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, b->stream, b->nq, b->nVmax,
+                       b->nCmax, b->d_desc.p, b->x.p, b->y.p, b->ws_b.p, b->ws_c.p, b->status.p, b->nwsr.p, b->obj.p,
+                       b->kkt.p /* null until the certificate has run */, rec_dev);
+    HIPCHK(hipGetLastError());
+    return RSQP_OK;
+}
+
+// setMatVal on the device (SpHbMat.cpp:368-393): time `repeats` launches of the scatter through `order`
+// and of the CSR-copy gather on the values already staged by rsqp_set_A_triplet (no host transfer inside)
+extern "C" int rsqp_time_value_refresh(rsqp_solver *s, int repeats, float *ms_scatter, float *ms_gather) {
+    if (!s || repeats <= 0 || !s->A.initialised || !s->A.from_triplet) return fail(RSQP_ERR_ARG, "rsqp_time_value_refresh");
+    HIPCHK(hipSetDevice(s->device));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    DevMatrix &M = s->A;
+    for (int pass = 0; pass < 2; pass++) {
+        float *out = pass == 0 ? ms_scatter : ms_gather;
+        HIPCHK(hipEventRecord(e0, s->stream));
+        for (int r = 0; r < repeats; r++) {
+            hipError_t e = pass == 0 ? rsqp_launch_scatter(M.n_triplet, M.order.p, nullptr, M.tv.p, M.val.p, s->stream)
+                                     : rsqp_launch_gather(M.nnz, M.perm.p, M.val.p, M.rval.p, s->stream);
+            if (e != hipSuccess) return fail(RSQP_ERR_DEVICE, "value refresh launch failed");
+        }
+        HIPCHK(hipEventRecord(e1, s->stream));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        if (out) *out = ms / repeats;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return RSQP_OK;
 }
 

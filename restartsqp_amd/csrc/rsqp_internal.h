@@ -43,6 +43,9 @@ struct QPPools {
     int *status, *ret, *nwsr, *nflips; double *obj;
     double *state;
     int uniV, uniC;   // nV / nC of every problem when the batch is uniform in shape, else -1
+    int keep_state;   // 1: write the hot-start part of the engine image back to HBM at the end of a solve (what the
+                      //    SQProblem object keeps between calls); 0: cold-start-only batches skip that write --
+                      //    the image is marked "not initialised", a later hot start falls back to a cold start
 };
 
 // number of doubles / ints of the LDS (and persistent) image of one problem

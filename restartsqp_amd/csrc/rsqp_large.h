@@ -37,6 +37,12 @@ public:
     int nflips() const;
     double objective();
     hipError_t last_error() const;
+    // per-kernel-class accounting (HIP events around every launch of the class: serialises the stream, so
+    // only for measurement runs). Classes: names(); get() fills {calls, ms, algorithmic bytes, 0} per class.
+    static constexpr int PROFILE_CLASSES = 8;
+    static const char *profile_name(int k);
+    void profile_enable(bool on);
+    void profile_get(double *out4n) const;
     struct Impl;
 private:
     Impl *p_;

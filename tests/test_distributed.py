@@ -29,6 +29,21 @@ def test_balanced_order_is_permutation():
     assert sorted(perm.tolist()) == list(range(37))
 
 
+def test_balanced_shards_spread_the_expensive_problems():
+    """BASELINE configs[4]: 512 mixed hs0xx QPs on 8 GPUs. Contiguous blocks put whatever the input order
+    holds on a rank; the balanced deal gives every rank the same number of the largest (69 x 28) members."""
+    ps = problems.hs_batch(512)
+    shards = parallel.balanced_shards(ps, 8)
+    assert sorted(np.concatenate(shards).tolist()) == list(range(512)) and all(len(s) == 64 for s in shards)
+    big = [sum(1 for k in s if ps[k].nV == 69) for s in shards]
+    assert max(big) - min(big) <= 1 and sum(big) == sum(1 for p in ps if p.nV == 69)
+    cost = [sum(ps[k].nV * max(ps[k].nC, 1) for k in s) for s in shards]
+    assert max(cost) - min(cost) <= 69 * 28      # within one largest member (14 of them do not divide by 8)
+    for s in shards:    # largest first inside a shard too
+        c = [ps[k].nV * max(ps[k].nC, 1) for k in s]
+        assert c == sorted(c, reverse=True)
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -49,10 +64,24 @@ def _worker(rank, world, port, q):
             kkt.append(0.0)
         return res, kkt
 
-    out = parallel.solve_sharded(probs, solve_fn, dist)
     ref, _ = solve_fn(probs)
-    ok = all(np.array_equal(a["x"], b["x"]) and np.array_equal(a["y"], b["y"]) and a["nWSR"] == b["nWSR"] and
-             np.array_equal(a["ws_b"], b["ws_b"]) and np.array_equal(a["ws_c"], b["ws_c"]) for a, b in zip(out, ref))
+    same = lambda out, ref: all(
+        np.array_equal(a["x"], b["x"]) and np.array_equal(a["y"], b["y"]) and a["nWSR"] == b["nWSR"] and
+        np.array_equal(a["ws_b"], b["ws_b"]) and np.array_equal(a["ws_c"], b["ws_c"]) for a, b in zip(out, ref))
+    out = parallel.solve_sharded(probs, solve_fn, dist)
+    ok = same(out, ref)
+    # heterogeneous batch dealt largest-first round-robin: same answers, problem by problem
+    ok = ok and same(parallel.solve_sharded(probs, solve_fn, dist, balance=True), ref)
+    # parameter scan: only rank 0 knows the base problem; the broadcast hands it to rank 1
+    base = problems.random_qp(np.random.default_rng(3), 9, 5) if rank == 0 else None
+    if rank == 0:
+        base.lbA[0] = -np.inf       # infinities survive the broadcast
+    member = lambda b, k: problems.perturb(np.random.default_rng(1000 + k), b)
+    scan = parallel.parameter_scan(base, 11, member, solve_fn, dist)
+    full = problems.random_qp(np.random.default_rng(3), 9, 5)
+    full.lbA[0] = -np.inf
+    ref_scan, _ = solve_fn([member(full, k) for k in range(11)])
+    ok = ok and same(scan, ref_scan) and len(scan) == 11
     q.put((rank, ok, len(out)))
     dist.barrier()
     dist.destroy_process_group()

@@ -4,9 +4,12 @@
 # <tag>_kernel_stats_blocked_qr.csv  (copy them into profiles/)
 tag=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+# everything is built BEFORE the first rocprofv3 line (hipcc / make / g++ must never run as children of a profiled,
+# GPU-initialised process); the profiled bench.py runs get --no-build
+python3 __graft_entry__.py > /dev/null || exit 1
 python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 bench.py --no-large --cpu-seconds 1 > gpurun_out/${tag}_bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 bench.py --no-build --no-large --cpu-seconds 1 --steps 20 --warmup 3 --stat-launches 20 > gpurun_out/${tag}_bench_under_rocprof.json 2>/dev/null
 # bench.py starts the C++ host program for the single-QP latency leg: one stats file per process, keep the parent's (largest)
 cp "$(find /tmp/prof_bench -name '*kernel_stats.csv' -printf '%s %p\n' | sort -n | tail -1 | cut -d' ' -f2-)" gpurun_out/${tag}_kernel_stats_bench.csv
 echo "stats done"
