@@ -27,6 +27,7 @@
 //   * the image is written back to HBM at the end of a solve and reloaded by the next
 //     hot start (qpOASES keeps the same data inside the SQProblem object).
 #include <cstdlib>
+#include <type_traits>
 
 #include "rsqp_internal.h"
 
@@ -83,12 +84,27 @@ struct Blocking {
     int idx, side;
 };
 
+// The target vectors gN / lbN / ubN are only ever read by the lane that owns the entry (and by two uniform-index
+// reads in the flipping guard). Builds whose shape is a compile-time constant (nV <= L: one entry per lane) keep
+// them in a REGISTER per lane instead of 3 nV doubles of LDS -- which is what brings the hs071-scale image to
+// 2368 B = 64 (mod 256): the four problems of a 32-lane LDS access group then sit on disjoint banks.
+struct LdsVec {
+    ldouble *p;
+    __device__ __forceinline__ ldouble &operator[](int i) const { return p[i]; }
+    template <int L> __device__ __forceinline__ double bcast(int i) const { return p[i]; }
+};
+struct RegVec {
+    double r;
+    __device__ __forceinline__ double &operator[](int) { return r; }                 // index == owning lane by construction
+    __device__ __forceinline__ const double &operator[](int) const { return r; }
+    template <int L> __device__ __forceinline__ double bcast(int i) const { return __shfl(r, i, L); }   // i uniform over the problem
+};
 template <bool B> struct MatPtr { typedef const lidx *I; typedef const ldouble *D; };
 template <> struct MatPtr<false> { typedef const int *I; typedef const double *D; };
 
 // MAT_LDS: the sparse matrices were staged into LDS behind the image (they fit for every
 // hs0xx-scale problem); otherwise they are read from global memory (L2).
-template <int L, bool MAT_LDS>
+template <int L, bool MAT_LDS, bool REGV = false>
 struct Engine {
     typedef typename MatPtr<MAT_LDS>::I MI;
     typedef typename MatPtr<MAT_LDS>::D MD;
@@ -100,7 +116,9 @@ struct Engine {
     MI Hjc, Hir; MD Hval;
     // LDS image
     ldouble *Q, *R, *T;
-    ldouble *x, *g, *lb, *ub, *gN, *lbN, *ubN, *dx, *wq, *wv1, *wv2, *wv3, *wv4, *rc, *rs;
+    ldouble *x, *g, *lb, *ub, *dx, *wq, *wv1, *wv2, *wv3, *wv4, *rc, *rs;
+    typedef typename std::conditional<REGV, RegVec, LdsVec>::type TV;
+    TV gN, lbN, ubN;
     ldouble *Ax, *lbA, *ubA, *lbAN, *ubAN, *dAx, *wc1, *wc2;
     ldouble *y, *dy;
     lint *Sb, *Sc, *AC, *posAC;
@@ -115,7 +133,7 @@ struct Engine {
     // doubles of this formulation's image (<= rsqp_image_doubles, the size of the persistent copy)
     __host__ __device__ static long long image_doubles(int nV, int nC) {
         const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
-        return ld * nV + (long long)nV * (nV + 3) / 2 + sT * ld + 12LL * nV + 8LL * nC + 2LL * (nV + nC);
+        return ld * nV + (long long)nV * (nV + 3) / 2 + sT * ld + (REGV ? 9LL : 12LL) * nV + 8LL * nC + 2LL * (nV + nC);
     }
     __host__ __device__ static long long image_ints(int nV, int nC) { return nV + 3LL * nC + 4; }
     __host__ __device__ static long long factor_doubles(int nV, int nC) {   // Q, R, T: (re)initialised by setup_aux
@@ -140,7 +158,7 @@ struct Engine {
         CARVE_C(Ax); CARVE_C(lbA); CARVE_C(ubA);
         y = p; p += nV + nC;
         // ... and the per-solve scratch
-        CARVE_V(gN); CARVE_V(lbN); CARVE_V(ubN);
+        if constexpr (!REGV) { CARVE_V(gN.p); CARVE_V(lbN.p); CARVE_V(ubN.p); }
         CARVE_V(dx); CARVE_V(wq); CARVE_V(wv1); CARVE_V(wv2); CARVE_V(wv3);
         wv4 = wv3;   // the incoming row of an exchange / the staged x0: never alive together with wv3 (Cholesky work vector)
         CARVE_C(lbAN); CARVE_C(ubAN); CARVE_C(dAx); CARVE_C(wc1); CARVE_C(wc2);
@@ -743,7 +761,7 @@ struct Engine {
             if (lane == 0) y[idx] = 0.0;
             SYNC();
             if (chol_append(zc)) return RET_OK;
-            if ((old == -1 && ubN[idx] >= RSQP_INFTY) || (old == 1 && lbN[idx] <= -RSQP_INFTY)) {
+            if ((old == -1 && ubN.template bcast<L>(idx) >= RSQP_INFTY) || (old == 1 && lbN.template bcast<L>(idx) <= -RSQP_INFTY)) {
                 add_bound(idx, old, false, true);
                 return RET_UNBOUNDED;
             }
@@ -948,7 +966,9 @@ struct Engine {
 
     __device__ __forceinline__ double objective() {
         H_times(x, wv2);
-        double a = dot(x, wv2, nV), b = dot(gN, x, nV), c = dot(x, x, nV);
+        double bs = 0.0;
+        PFOR(i, nV) bs += gN[i] * x[i];
+        double a = dot(x, wv2, nV), b = block_sum(bs), c = dot(x, x, nV);
         return 0.5 * (a - hreg * c) + b;
     }
 };
@@ -1130,8 +1150,13 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     static const int forcedE = env_int("RSQP_SMALL_ENGINE", -1);
     const int eng = forcedE == 0 || forcedE == 1 ? forcedE : (nVmax > 8 ? 1 : 0);
     if (eng == 1 && mat_bytes_max >= 0) mat_bytes_max = 8LL * ((long long)nVmax * nVmax + (long long)nCmax * nVmax);
+    // uniform hs071-scale batches (8 x 2 through the QPhandler formulation; parameter scans of one NLP iterate) run
+    // the build with the shape as a compile-time constant and the target vectors in registers (see RegVec)
+    static const int noshape = env_int("RSQP_SMALL_NOSHAPE", 0);
+    const bool shape82 = eng == 0 && p.uniV == 8 && p.uniC == 2 && !noshape && mat_bytes_max >= 0;
     // LDS image of the chosen formulation (the persistent copy in HBM is sized for the larger one)
-    const long long imgd = eng == 1 ? EngineX<64, true>::image_doubles(nVmax, nCmax) : Engine<64, true>::image_doubles(nVmax, nCmax);
+    const long long imgd = eng == 1 ? EngineX<64, true>::image_doubles(nVmax, nCmax)
+                                    : (shape82 ? Engine<8, true, true>::image_doubles(nVmax, nCmax) : Engine<64, true>::image_doubles(nVmax, nCmax));
     const long long imgi = eng == 1 ? EngineX<64, true>::image_ints(nVmax, nCmax) : Engine<64, true>::image_ints(nVmax, nCmax);
     const long long img = (8 * imgd + 2 * imgi + 7) & ~7LL;
     const bool mat_lds = mat_bytes_max >= 0 && align16(img + mat_bytes_max) <= kMaxLds;
@@ -1153,7 +1178,28 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     static const int forcedWide0 = env_int("RSQP_SMALL_WIDE", -1);
     const bool wide0 = eng == 1 && mat_lds && L == 64 && (forcedWide0 >= 0 ? forcedWide0 != 0 : nVmax > 32);
     bool wide = false;
-    if (wide0 && stride + 2048 <= kMaxLds) { stride += 2048; wide = true; }   // one double per lane of the 4-wave build
+    // several waves per problem: four (256 lanes, one wave per SIMD). The kernel keeps ~430 values live per lane
+    // (256 VGPRs + AGPRs), so an eight-wave build (RSQP_SMALL_WIDE_LANES=512, tuning builds only) spills 233 of them.
+    // With one wave per SIMD every wave instruction costs its full 4+ cycles: the four-wave kernel is bound by the
+    // instruction count per wave (~350 per 69 x 69 product stage), not by LDS bandwidth or barriers.
+#if defined(RSQP_SMALL_EXPERIMENT) && RSQP_SMALL_EXPERIMENT == 2
+    static const int wideL = env_int("RSQP_SMALL_WIDE_LANES", 256) == 512 ? 512 : 256;
+#else
+    constexpr int wideL = 256;
+#endif
+    if (wide0 && stride + 8 * wideL <= kMaxLds) { stride += 8 * wideL; wide = true; }   // one double per lane of the wide build
+    // bank spread of packed waves: a 32-lane LDS access group holds 32 / L problems, each touching 2 L consecutive
+    // banks of the 64 (ds_read_b64: bank = dword address mod 64; stores: 16-lane groups, mod 32). Their images must
+    // therefore start 2 L dwords apart modulo 64, i.e. stride = 8 L (mod 256) bytes -- with stride = 0 (mod 256)
+    // every vector access of an 8-lane build is a 4-way conflict (measured: 54 % of the LDS-array cycles, LDS busy
+    // 73 % of the kernel). The stride is padded to the next such value when that does not cost a resident workgroup.
+    if (L < 64) {
+        static const int nospread = env_int("RSQP_SMALL_NOSPREAD", 0);
+        long long s1 = stride;
+        while ((s1 & 255) != ((8 * L) & 255)) s1 += 16;
+        auto wgs = [&](long long st) { const long long a = (((64 / L) * st) + 511) / 512 * 512; return a > 0 ? kMaxLds / a : 0; };
+        if (!nospread && wgs(s1) == wgs(stride) && (64 / L) * s1 <= kMaxLds) stride = s1;
+    }
     const int G = 64 / L, nblk = (nq + G - 1) / G;
     const size_t lds = (size_t)(G * stride);
     // minimum resident waves per SIMD = register budget. One problem per wave keeps the uniform
@@ -1171,6 +1217,14 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
         hipLaunchKernelGGL((small_qp_kernel<ENG<LL, ML>, LL, ML, W, U>), dim3(nblk), dim3(LL > 64 ? LL : 64), lds, stream, p, nq, \
                            (int)stride, mode, maxWSR);                                                        \
     } while (0)
+    // compile-time shape NV x NC, target vectors in registers
+#define SQ_LAUNCH_SHAPE(LL, W, NV, NC)                                                                        \
+    do {                                                                                                      \
+        static std::atomic<unsigned long long> set_{0};                                                       \
+        rsqp_allow_full_lds(reinterpret_cast<const void *>(&small_qp_kernel<Engine<LL, true, true>, LL, true, W, NV * 256 + NC>), set_, (int)kMaxLds); \
+        hipLaunchKernelGGL((small_qp_kernel<Engine<LL, true, true>, LL, true, W, NV * 256 + NC>), dim3(nblk), dim3(64), lds, stream, p, nq, \
+                           (int)stride, mode, maxWSR);                                                        \
+    } while (0)
 #define SQ_LAUNCH_E(ENG, LL, ML, W) SQ_LAUNCH_U(ENG, LL, ML, W, 0)
 #define SQ_LAUNCH(LL, ML, W) SQ_LAUNCH_E(Engine, LL, ML, W)
 #define SQ_WAVES(LL)                                                                                          \
@@ -1179,18 +1233,26 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     case 4: SQ_LAUNCH(LL, true, 4); break;                                                                    \
     default: SQ_LAUNCH(LL, true, 2); break;                                                                   \
     }
-#ifdef RSQP_SMALL_EXPERIMENT
+#if defined(RSQP_SMALL_EXPERIMENT) && RSQP_SMALL_EXPERIMENT == 2
+    // quick-turnaround build for tuning (tools/small_experiment.sh -DRSQP_SMALL_EXPERIMENT=2): only the four-wave
+    // explicit-inverse kernel (mid-size problems, BASELINE configs[4])
+    {
+        if (!(eng == 1 && wide)) return hipErrorInvalidValue;
+        if (wideL == 512) SQ_LAUNCH_E(EngineX, 512, true, 1);
+        else SQ_LAUNCH_E(EngineX, 256, true, 1);
+        return hipGetLastError();
+    }
+#elif defined(RSQP_SMALL_EXPERIMENT)
     // quick-turnaround build for tuning (tools/small_experiment.sh): only the 8-lane Givens / TQ kernel
     {
-        static const int shp = env_int("RSQP_SMALL_SHAPE", 0);
-        const bool fixed = shp != 0 && p.uniV == 8 && p.uniC == 2;
+        const bool fixed = shape82;
 #ifdef RSQP_EXP_L16W6
         // the build the launcher refuses (qp_small.hip "Packed builds with W=6"): 16 lanes per problem, 6 waves per
         // SIMD = 80 VGPRs with ~180 spilled values; kept reachable only here, for the root-cause hunt
         if (L == 16 && eng == 0 && mat_lds) { SQ_LAUNCH_U(Engine, 16, true, 6, 0); return hipGetLastError(); }
 #endif
         if (L != 8 || eng != 0 || !mat_lds) return hipErrorInvalidValue;
-        if (fixed) { switch (waves) { case 3: SQ_LAUNCH_U(Engine, 8, true, 3, 8 * 256 + 2); break; case 4: SQ_LAUNCH_U(Engine, 8, true, 4, 8 * 256 + 2); break; default: SQ_LAUNCH_U(Engine, 8, true, 2, 8 * 256 + 2); } }
+        if (fixed) { switch (waves) { case 3: SQ_LAUNCH_SHAPE(8, 3, 8, 2); break; case 4: SQ_LAUNCH_SHAPE(8, 4, 8, 2); break; default: SQ_LAUNCH_SHAPE(8, 2, 8, 2); } }
         else { switch (waves) { case 3: SQ_LAUNCH_U(Engine, 8, true, 3, 0); break; case 4: SQ_LAUNCH_U(Engine, 8, true, 4, 0); break; default: SQ_LAUNCH_U(Engine, 8, true, 2, 0); } }
         return hipGetLastError();
     }
@@ -1204,12 +1266,9 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     } else if (!mat_lds) {
         SQ_LAUNCH(64, false, 3);
     } else if (L == 8) {
-        // uniform hs071-scale batches (8 x 2 through the QPhandler formulation; parameter scans of one NLP
-        // iterate) run the build with the shape as a compile-time constant: 160 instead of 253 VGPRs, no
-        // per-vector address registers, straight-line vector loops (+3 % on 65 536 QPs; the occupancy of both
-        // builds is capped at 2 waves per SIMD by the 20 KB of LDS a wave of 8 problems needs)
-        static const int noshape = env_int("RSQP_SMALL_NOSHAPE", 0);
-        if (p.uniV == 8 && p.uniC == 2 && !noshape) SQ_LAUNCH_U(Engine, 8, true, 2, 8 * 256 + 2);
+        // shape build: 160 instead of 253 VGPRs, no per-vector address registers, straight-line vector loops; the
+        // occupancy of both builds is capped at 2 waves per SIMD by the LDS a wave of 8 problems needs
+        if (shape82) SQ_LAUNCH_SHAPE(8, 2, 8, 2);
         else SQ_LAUNCH(8, true, 2);
     } else if (L == 16) {
         SQ_WAVES(16)
@@ -1223,6 +1282,7 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
         }
     }
 #endif
+#undef SQ_LAUNCH_SHAPE
 #undef SQ_LAUNCH_E
 #undef SQ_LAUNCH_U
 #undef SQ_WAVES

@@ -11,6 +11,102 @@
 // Formulas: see the kernels of qp_large.hip (k_house, k_wz_*, k_minv_border, k_house_unit,
 // k_house_free, k_sm_coef), which this file restates for one wave working in LDS.
 
+// ---- products of the several-waves-per-problem build, as real (non-inlined) functions: the explicit-inverse engine
+// issues ~30 matrix-vector products per working-set change; inlined, the four-wave kernel was 260 KB of code -- four
+// times the 64 KB instruction cache two CUs share -- and ran at the speed of its instruction fetches.
+#ifndef RSQP_XINLINE
+#define RSQP_XINLINE __forceinline__
+#endif
+#define WSYNC()                                                  \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+    } while (0)
+// a / b for 0 <= a < 4096, 1 <= b <= 256 without the ~40-instruction integer-division sequence (there is no
+// hardware divide; the lane -> (output, slice) maps below are evaluated on every product): (a + 0.5) / b is at
+// least 0.5 / 256 away from an integer, far beyond the error of a float reciprocal
+__device__ __forceinline__ int fdiv_small(int a, int b) { return (int)(((float)a + 0.5f) * __frcp_rn((float)b)); }
+// strided dot: sum_{j = j0, j0 + st, ... < n} a[j * sa] * b[j], four independent partial sums
+__device__ __forceinline__ double xdots(const ldouble *a, int sa, const ldouble *b, int j0, int st, int n) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const int da = st * sa;
+    const ldouble *pa = a + j0 * sa, *pb = b + j0;
+    int left = j0 < n ? (st == 1 ? n - j0 : fdiv_small(n - j0 + st - 1, st)) : 0;        // terms of this slice
+    for (; left >= 8; left -= 8) {                         // 16 LDS reads in flight
+        double m[8], x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { m[u] = pa[u * da]; x[u] = pb[u * st]; }
+        s0 += m[0] * x[0]; s1 += m[1] * x[1]; s2 += m[2] * x[2]; s3 += m[3] * x[3];
+        s0 += m[4] * x[4]; s1 += m[5] * x[5]; s2 += m[6] * x[6]; s3 += m[7] * x[7];
+        pa += 8 * da; pb += 8 * st;
+    }
+    if (left >= 4) {
+        double m[4], x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { m[u] = pa[u * da]; x[u] = pb[u * st]; }
+        s0 += m[0] * x[0]; s1 += m[1] * x[1]; s2 += m[2] * x[2]; s3 += m[3] * x[3];
+        pa += 4 * da; pb += 4 * st; left -= 4;
+    }
+    for (; left > 0; left--) { s0 += pa[0] * pb[0]; pa += da; pb += st; }
+    return (s0 + s1) + (s2 + s3);
+}
+// The outputs of a product are dealt to the waves [w0, w0 + nw) in runs of opw = ceil(nout / nw); inside a wave
+// P = 64 / opw lanes share an output, each summing an interleaved slice of the inner dimension; the slices meet in
+// `part` behind a wave-scope fence (LDS operations of one wave execute in order) and are added in slice order
+// by the first lane of the output. Waves outside [w0, w0 + nw) skip the call, so independent products given
+// disjoint wave ranges run side by side; the caller closes the group with ONE workgroup barrier.
+// TR: out[c] = sum_r M[c*l + r] xv[r] (nout = ncols, inner = nrows); else out[r] = beta base[r] + alpha sum_c M[c*l + r] xv[c]
+template <bool TR>
+__device__ RSQP_XINLINE void xgemv_w(const ldouble *M, int l, int nrows, int ncols, const ldouble *xv, double alpha,
+                                     double beta, const ldouble *base, ldouble *out, int w0, int nw, ldouble *part, int lane) {
+    const int w = (lane >> 6) - w0, li = lane & 63;
+    if (w < 0 || w >= nw) return;
+    const int nout = TR ? ncols : nrows, ninner = TR ? nrows : ncols;
+    if (nout <= 0) return;
+    const int opw = nw == 1 ? nout : fdiv_small(nout + nw - 1, nw);
+    ldouble *pw = part + (lane & ~63);
+    if (opw > 64 || ninner < 8) {            // a lane owns whole outputs (several when the run exceeds the wave)
+        for (int o = li; o < opw; o += 64) {
+            const int og = w * opw + o;
+            if (og < nout) {
+                const double t = TR ? xdots(M + og * l, 1, xv, 0, 1, ninner) : xdots(M + og, l, xv, 0, 1, ninner);
+                out[og] = TR ? t : (base ? beta * base[og] : 0.0) + alpha * t;
+            }
+        }
+        return;
+    }
+    int P = fdiv_small(64, opw);
+    if (P > 8) P = 8;
+    const int p = fdiv_small(li, opw), o = li - p * opw, og = w * opw + o;
+    const bool on = p < P && og < nout;
+    if (on) pw[li] = TR ? xdots(M + og * l, 1, xv, p, P, ninner) : xdots(M + og, l, xv, p, P, ninner);
+    WSYNC();
+    if (on && p == 0) {
+        double t = pw[o];
+        for (int k = 1; k < P; k++) t += pw[k * opw + o];
+        out[og] = TR ? t : (base ? beta * base[og] : 0.0) + alpha * t;
+    }
+}
+// M[c*l + r] += coef * t[r] * v[c], the nrows x ncols elements dealt over nl lanes (rows fastest)
+__device__ RSQP_XINLINE void xger_w(ldouble *M, int l, int nrows, int ncols, const ldouble *t, const ldouble *v, double coef,
+                                    int nl, int lane) {
+    if (nrows <= 0 || ncols <= 0) return;
+    int np = nrows <= nl ? fdiv_small(nl, nrows) : 0;
+    if (np < 1) {            // more rows than lanes: lane per row, all columns
+        for (int r = lane; r < nrows; r += nl) {
+            const double tr = coef * t[r];
+            for (int c = 0; c < ncols; c++) M[c * l + r] += tr * v[c];
+        }
+        return;
+    }
+    if (np > ncols) np = ncols;
+    const int pp = fdiv_small(lane, nrows), r = lane - pp * nrows;
+    if (pp >= np) return;
+    const double tr = coef * t[r];
+    for (int c = pp; c < ncols; c += np) M[c * l + r] += tr * v[c];
+}
+
 template <int L, bool MAT_LDS>
 struct EngineX {
     typedef typename MatPtr<MAT_LDS>::I MI;
@@ -37,7 +133,7 @@ struct EngineX {
     // doubles of this formulation's image (<= rsqp_image_doubles, the size of the persistent copy)
     __host__ __device__ static long long image_doubles(int nV, int nC) {
         const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
-        return 2 * ld * nV + sT * ld + 17LL * nV + 9LL * nC + 2LL * (nV + nC) + 8 + 4 * (sT + 2);
+        return 2 * ld * nV + sT * ld + 17LL * nV + 9LL * nC + 2LL * (nV + nC) + 16 + 4 * (sT + 2);
     }
     __host__ __device__ static long long factor_doubles(int nV, int nC) {   // Z (+Y), Wz: (re)initialised by setup_aux
         return 2LL * rsqp_ld(nV) * nV;
@@ -71,7 +167,7 @@ struct EngineX {
 #undef CARVE_V
 #undef CARVE_C
         dy = p; p += nV + nC;
-        scal = p; p += 8;
+        scal = p; p += 16;
         Minv = tslot;                      // sizeT * ldm <= sizeT * ld
         a1 = p; p += sizeT + 2; a2 = p; p += sizeT + 2; a3 = p; p += sizeT + 2; a4 = p; p += sizeT + 2;
         lint *ip = (lint *)p;
@@ -125,17 +221,26 @@ struct EngineX {
         }
         if constexpr (L > 64) {
             __syncthreads();
-            if ((lane & 63) == 0) { scal[lane >> 6] = t; scal[4 + (lane >> 6)] = (double)id; }   // ids exceed the 16-bit LDS integers
+            if ((lane & 63) == 0) { scal[lane >> 6] = t; scal[8 + (lane >> 6)] = (double)id; }   // ids exceed the 16-bit LDS integers
             __syncthreads();
-            t = scal[0]; id = (int)scal[4];
+            t = scal[0]; id = (int)scal[8];
 #pragma unroll
             for (int w = 1; w < L / 64; w++) {
-                const double t2 = scal[w]; const int id2 = (int)scal[4 + w];
+                const double t2 = scal[w]; const int id2 = (int)scal[8 + w];
                 if (t2 < t || (t2 == t && id2 < id)) { t = t2; id = id2; }
             }
         }
     }
     __device__ __forceinline__ double dot(const ldouble *a, const ldouble *b, int n) {
+        if constexpr (L > 64) {
+            // several waves per problem: every wave forms the whole sum by itself from the (already published) LDS
+            // operands -- same arithmetic in each of them, so all lanes agree and no workgroup barrier is needed
+            double s = 0.0;
+            for (int i = lane & 63; i < n; i += 64) s += a[i] * b[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            return s;
+        }
         double s = 0.0;
         PFOR(i, n) s += a[i] * b[i];
         return block_sum(s);
@@ -146,12 +251,12 @@ struct EngineX {
     // lane / n1): every part takes a contiguous slice of the inner dimension, partial sums meet in
     // `part` (one double per lane) and are added in part order. false = this lane has no slice.
     __device__ __forceinline__ bool split2d(int n1, int n2, int &i, int &j0, int &j1, int &nparts) {
-        nparts = L / n1;
+        nparts = fdiv_small(L, n1);
         if (nparts > n2) nparts = n2;
         if (nparts < 1) nparts = 1;
-        const int p = lane / n1;
+        const int p = fdiv_small(lane, n1);
         i = lane - p * n1;
-        const int chunk = (n2 + nparts - 1) / nparts;
+        const int chunk = fdiv_small(n2 + nparts - 1, nparts);
         j0 = p * chunk;
         j1 = j0 + chunk < n2 ? j0 + chunk : n2;
         return p < nparts;
@@ -169,23 +274,21 @@ struct EngineX {
         for (; j < j1; j++) s0 += a[j * sa] * b[j];
         return (s0 + s1) + (s2 + s3);
     }
+    // ---- several waves per problem (L > 64): one workgroup barrier per product or group of independent products (xgemv_w)
+    static constexpr int NW = L > 64 ? L / 64 : 1;
+    template <bool TR>
+    __device__ __forceinline__ void gemv_w(const ldouble *M, int l, int nrows, int ncols, const ldouble *xv, double alpha,
+                                           double beta, const ldouble *base, ldouble *out, int w0, int nw) {
+        xgemv_w<TR>(M, l, nrows, ncols, xv, alpha, beta, base, out, w0, nw, part, lane);
+    }
+
     // out[c] = sum_r M[c*l + r] * xv[r]      (lane per column; eight rows per trip: their 16 LDS reads
     // are issued before the first multiply, four independent partial sums)
     __device__ __forceinline__ void gemv_t(const ldouble *M, int l, int nrows, int ncols, const ldouble *xv, ldouble *out) {
         if constexpr (L > 64) {
-            if (ncols > 0 && ncols <= L / 2 && nrows >= 16) {
-                int c, r0, r1, np;
-                const bool on = split2d(ncols, nrows, c, r0, r1, np);
-                if (on) part[lane] = dot8(M + c * l, 1, xv, r0, r1);
-                SYNC();
-                if (lane < ncols) {
-                    double s = 0.0;
-                    for (int p = 0; p < np; p++) s += part[p * ncols + lane];
-                    out[lane] = s;
-                }
-                SYNC();
-                return;
-            }
+            gemv_w<true>(M, l, nrows, ncols, xv, 1.0, 0.0, nullptr, out, 0, NW);
+            SYNC();
+            return;
         }
         PFOR(c, ncols) out[c] = dot8(M + c * l, 1, xv, 0, nrows);
         SYNC();
@@ -194,36 +297,17 @@ struct EngineX {
     __device__ __forceinline__ void gemv_n(const ldouble *M, int l, int nrows, int ncols, const ldouble *wv, double alpha,
                                            double beta, const ldouble *base, ldouble *out) {
         if constexpr (L > 64) {
-            if (nrows > 0 && nrows <= L / 2 && ncols >= 16) {
-                int r, c0, c1, np;
-                const bool on = split2d(nrows, ncols, r, c0, c1, np);
-                if (on) part[lane] = dot8(M + r, l, wv, c0, c1);
-                SYNC();
-                if (lane < nrows) {
-                    double s = 0.0;
-                    for (int p = 0; p < np; p++) s += part[p * nrows + lane];
-                    out[lane] = (base ? beta * base[lane] : 0.0) + alpha * s;
-                }
-                SYNC();
-                return;
-            }
+            gemv_w<false>(M, l, nrows, ncols, wv, alpha, beta, base, out, 0, NW);
+            SYNC();
+            return;
         }
         PFOR(r, nrows) out[r] = (base ? beta * base[r] : 0.0) + alpha * dot8(M + r, l, wv, 0, ncols);
         SYNC();
     }
     // M[c*l + r] += coef * t[r] * v[c]
     __device__ __forceinline__ void ger(ldouble *M, int l, int nrows, int ncols, const ldouble *t, const ldouble *v, double coef) {
-        int r = lane, c0 = 0, c1 = ncols, np = 1;
-        bool on = true;
         if constexpr (L > 64) {
-            if (nrows > 0 && nrows <= L / 2) on = split2d(nrows, ncols, r, c0, c1, np);
-        }
-        if (L > 64 && np > 1) {
-            if (on) {
-                ldouble *row = M + r;
-                const double tr = coef * t[r];
-                for (int c = c0; c < c1; c++) row[c * l] += tr * v[c];
-            }
+            xger_w(M, l, nrows, ncols, t, v, coef, L, lane);
         } else {
             PFOR(rr, nrows) {
                 ldouble *row = M + rr;
@@ -284,6 +368,36 @@ struct EngineX {
         }
         SYNC();
     }
+    // independent products of one stage, side by side on disjoint waves (several waves per problem, dense copies)
+    static constexpr bool FUSED = L > 64 && MAT_LDS;
+    // outA = A v, outH = (H + hreg I) v
+    __device__ __forceinline__ void AH_times(const ldouble *v, ldouble *outA, ldouble *outH) {
+        if constexpr (FUSED) {
+            const int wa = nC > 0 ? 1 : 0;
+            gemv_w<false>(Ad, nC, nC, nV, v, 1.0, 0.0, nullptr, outA, 0, wa);
+            gemv_w<true>(Hd, nV, nV, nV, v, 1.0, 0.0, nullptr, outH, wa, NW - wa);
+            SYNC();
+            if (hreg != 0.0) { PFOR(c, nV) outH[c] += hreg * v[c]; SYNC(); }
+        } else {
+            A_times(v, outA);
+            H_times(v, outH);
+        }
+    }
+    // Ax = A xv, aty = A' yc, hx = (H + hreg I) xv
+    __device__ __forceinline__ void AAtH_times(const ldouble *xv, const ldouble *yc, ldouble *outA, ldouble *aty, ldouble *hx) {
+        if constexpr (FUSED) {
+            const int wa = nC > 0 ? 1 : 0;
+            gemv_w<false>(Ad, nC, nC, nV, xv, 1.0, 0.0, nullptr, outA, 0, wa);
+            gemv_w<true>(Ad, nC, nC, nV, yc, 1.0, 0.0, nullptr, aty, wa, 1);       // inner dimension nC: short sums
+            gemv_w<true>(Hd, nV, nV, nV, xv, 1.0, 0.0, nullptr, hx, wa + 1, NW - wa - 1);
+            SYNC();
+            if (hreg != 0.0) { PFOR(c, nV) hx[c] += hreg * xv[c]; SYNC(); }
+        } else {
+            A_times(xv, outA);
+            AT_times(yc, aty);
+            H_times(xv, hx);
+        }
+    }
     __device__ __forceinline__ void row_of_A(int i, ldouble *a, bool all) {
         if constexpr (DENSE_MATS) {
             PFOR(v, nV) a[v] = (all || Sb[v] == 0) ? Ad[i + v * nC] : 0.0;
@@ -317,10 +431,19 @@ struct EngineX {
     __device__ __forceinline__ void z_reflect_and_shrink(bool wz_enabled, double &alpha, double &sgi) {
         double beta;
         house(wz1, nZ, wz2, alpha, beta, sgi);
+        if constexpr (FUSED) {
+            const int wt = wz_enabled ? NW / 2 : NW;
+            gemv_w<false>(Z, ld, nV, nZ, wz2, 1.0, 0.0, nullptr, w5, 0, wt);                        // t = Z v
+            if (wz_enabled) gemv_w<false>(Wz, ld, nZ, nZ, wz2, 1.0, 0.0, nullptr, wz3, wt, NW - wt); // s = Wz v
+            SYNC();
+            ger(Z, ld, nV, nZ, w5, wz2, -beta);                   // Z -= beta t v'
+            if (!wz_enabled) return;
+        } else {
         gemv_n(Z, ld, nV, nZ, wz2, 1.0, 0.0, nullptr, w5);        // t = Z v
         ger(Z, ld, nV, nZ, w5, wz2, -beta);                       // Z -= beta t v'
         if (!wz_enabled) return;
         gemv_n(Wz, ld, nZ, nZ, wz2, 1.0, 0.0, nullptr, wz3);      // s = Wz v
+        }
         const double theta = dot(wz2, wz3, nZ);
         const int l = nZ - 1;
         const double vl = wz2[l], sl = wz3[l];
@@ -361,7 +484,14 @@ struct EngineX {
     // variables are zero in both bases, so the sparse row is used as it is)
     __device__ __forceinline__ void constraint_products(int r, double &na2, double &wz2n) {
         row_of_A(r, w1, false);
-        if constexpr (DENSE_MATS) {
+        if constexpr (FUSED) {
+            int wz = nAC == 0 ? NW : (nZ == 0 ? 0 : fdiv_small(NW * nZ + ((nZ + nAC) >> 1), nZ + nAC));
+            if (nZ > 0 && wz < 1) wz = 1;
+            if (nAC > 0 && wz > NW - 1) wz = NW - 1;
+            gemv_w<true>(Z, ld, nV, nZ, w1, 1.0, 0.0, nullptr, wz1, 0, wz);
+            gemv_w<true>(Y, ldy, nV, nAC, w1, 1.0, 0.0, nullptr, a1, wz, NW - wz);
+            SYNC();
+        } else if constexpr (DENSE_MATS) {
             gemv_t(Z, ld, nV, nZ, w1, wz1);
             gemv_t(Y, ldy, nV, nAC, w1, a1);
         } else {
@@ -742,8 +872,10 @@ struct EngineX {
         PFOR(v, nV) dx[v] = Sb[v] == -1 ? delta_of(lbN[v], lb[v]) : (Sb[v] == 1 ? delta_of(ubN[v], ub[v]) : 0.0);
         PFOR(i, nV + nC) dy[i] = 0.0;
         SYNC();
-        A_times(dx, c1);                                            // A dx_FX
-        if (nZ > 0) H_times(dx, w2);                                // (no null space: the projected-gradient part is empty)
+        STAMP(10);
+        if (nZ > 0) AH_times(dx, c1, w2);                           // A dx_FX and H dx_FX
+        else A_times(dx, c1);                                       // (no null space: the projected-gradient part is empty)
+        STAMP(11);
         PFOR(j, nAC) {
             const int r = AC[j];
             a1[j] = (Sc[r] == -1 ? delta_of(lbAN[r], lbA[r]) : delta_of(ubAN[r], ubA[r])) - c1[r];   // bA
@@ -751,8 +883,10 @@ struct EngineX {
         if (nZ > 0) { PFOR(v, nV) w1[v] = w2[v] + (gN[v] - g[v]); }  // tmpg
         SYNC();
         // range space: wY = Minv bA ; xY = Y wY
+        STAMP(12);
         gemv_n(Minv, ldm, nAC, nAC, a1, 1.0, 0.0, nullptr, a2);
         gemv_n(Y, ldy, nV, nAC, a2, 1.0, 0.0, nullptr, w3);
+        STAMP(13);
         // null space: wZ = -Wz Z'(tmpg + H xY) ; dx_FR = xY + Z wZ
         if (nZ > 0) {
             H_times(w3, w2);
@@ -764,10 +898,12 @@ struct EngineX {
         } else {
             copyv(w3, w4, nV);
         }
+        STAMP(14);
         PFOR(v, nV) if (Sb[v] == 0) dx[v] = w4[v];
         SYNC();
+        STAMP(15);
         // multipliers: dyAC = Minv' Y'(H dx + dg)
-        H_times(dx, w5);
+        AH_times(dx, dAx, w5);                                      // A dx (for the ratio tests) rides along with H dx
         PFOR(v, nV) w2[v] = w5[v] + (gN[v] - g[v]);
         SYNC();
         gemv_t(Y, ldy, nV, nAC, w2, a1);
@@ -776,7 +912,7 @@ struct EngineX {
         SYNC();
         AT_times(dy + nV, w3);
         PFOR(v, nV) dy[v] = Sb[v] != 0 ? w2[v] - w3[v] : 0.0;
-        A_times(dx, dAx);
+        SYNC();
     }
 
     // ------------------------------------------------------------------ ratio tests (as Engine)
@@ -827,10 +963,8 @@ struct EngineX {
     __device__ __forceinline__ void drift_correction() {
         PFOR(v, nV) if (Sb[v] != 0) x[v] = Sb[v] == -1 ? lb[v] : ub[v];
         SYNC();
-        A_times(x, Ax);
+        AAtH_times(x, y + nV, Ax, w1, w2);
         PFOR(i, nC) { if (Sc[i] == -1) lbA[i] = Ax[i]; else if (Sc[i] == 1) ubA[i] = Ax[i]; }
-        AT_times(y + nV, w1);
-        H_times(x, w2);
         PFOR(v, nV) g[v] = w1[v] + y[v] - w2[v];
         SYNC();
     }
