@@ -68,6 +68,32 @@ def pmc_traffic(substr, fetch_factor):
     return None, None
 
 
+def pmc_issue_roofline(substr, n_cus=256, n_simd=1024, n_xcd=8):
+    """What actually bounds the LDS-resident QP kernel ("achieved LDS / VALU utilisation"), from the
+    committed rocprofv3 --pmc passes of `bench.py --no-extras` (tools/pmc_small.sh): LDS-array busy cycles
+    (SQ_LDS_IDX_ACTIVE, of which SQ_LDS_BANK_CONFLICT are conflict cycles) per CU-cycle and VALU issue cycles
+    (SQ_ACTIVE_INST_VALU, in units of 4 cycles) per SIMD-cycle; kernel cycles = GRBM_GUI_ACTIVE / XCDs."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_small_L8.json")))
+    if not paths:
+        return None
+    d = json.load(open(paths[-1]))
+    for k, v in d.items():
+        if substr in k and "SQ_LDS_IDX_ACTIVE" in v and "GRBM_GUI_ACTIVE" in v:
+            g = lambda c: v[c]["mean_per_dispatch"] if c in v else None
+            cyc = g("GRBM_GUI_ACTIVE") / n_xcd
+            lds = g("SQ_LDS_IDX_ACTIVE") / (cyc * n_cus)
+            out = {"bound": "lds", "kernel": k[:80], "achieved": lds, "peak": 1.0, "unit": "LDS-array busy cycles per CU cycle",
+                   "frac": lds, "lds_bank_conflict_share": g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE"),
+                   "valu_issue_frac": 4.0 * g("SQ_ACTIVE_INST_VALU") / (cyc * n_simd) if g("SQ_ACTIVE_INST_VALU") else None,
+                   "kernel_cycles": cyc, "waves": g("SQ_WAVES"), "insts_valu": g("SQ_INSTS_VALU"), "insts_salu": g("SQ_INSTS_SALU"),
+                   "insts_lds": g("SQ_INSTS_LDS"), "wait_inst_any_over_wave_cycles": (g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"))
+                   if g("SQ_WAIT_INST_ANY") and g("SQ_WAVE_CYCLES") else None,
+                   "source": os.path.basename(paths[-1])}
+            return out
+    return None
+
+
 def quartiles(ms):
     a = np.sort(np.asarray(ms, dtype=np.float64))
     return {"n": int(len(a)), "median": float(np.median(a)), "q1": float(np.percentile(a, 25)),
@@ -162,9 +188,6 @@ def large_configs(capi, problems, seq_steps=50):
             "oracle_nWSR": g["nWSR"], "same_working_set_as_oracle": bool(np.array_equal(wb, g["ws_b"]) and np.array_equal(wc, g["ws_c"])),
             "max_abs_dx_vs_oracle": float(np.abs(s.x - np.array(g["x"])).max()),
             "oracle_seconds_build_container_1_core": g["oracle_seconds_build_container"]})
-    prof = s.engine_profile()
-    if prof:
-        out["dense_2048x4096_cold"]["kernels"] = prof
     s.close()
     q = problems.sparse_qp()
     s = load(q)
@@ -192,9 +215,20 @@ def large_configs(capi, problems, seq_steps=50):
         "note": "BASELINE configs[3]: 50 QPs, alternating FIXED (new vectors) and VARIED (new Jacobian values) steps through "
                 "optimizeQP's dispatch: a FIXED<->VARIED flip re-initialises from (x, y, bounds) (qpOASESInterface.cpp:199-207), "
                 "each step incl. host transfers and the KKT certificate"}
+    # per-kernel rooflines of the HBM-resident engine: two more steps of the sequence (outside every timing above) with the
+    # engine's own accounting on -- HIP events around every launch of a kernel class, algorithmic bytes per call
+    s.set_engine_profiling(True)
+    for qk, changed in problems.sparse_sequence(q, nsteps=2, seed=20260199):
+        for w, v in zip(range(5), (qk.g, qk.lb, qk.ub, qk.lbA, qk.ubA)):
+            s.set_vector(w, v)
+        if changed:
+            s.set_A_csc(qk.A_jc, qk.A_ir, qk.A_val)
+        s.optimize_qp()
     prof = s.engine_profile()
     if prof:
-        out["sparse_10000x20000_warm_sequence"]["kernels"] = prof
+        out["roofline_large_engine_kernels"] = {
+            "workload": "sparse 10 000 x 20 000, one FIXED and one VARIED step of the warm-started sequence", "kernels": prof,
+            "note": "achieved = algorithmic bytes (8 B x rows x cols for a product, 16 B for a rank-1 update) / HIP-event time per call"}
     s.close()
     q = problems.dense_qp(600, 1200, seed=20260101)
     s = load(q)
@@ -511,6 +545,9 @@ def main():
                          "note": "latency/LDS-bound kernel: HBM fraction is not its limiter; see roofline_issue in DESIGN.md 6"},
             "kernel_ms_stats": quartiles(per_launch),
         }
+        issue = pmc_issue_roofline("small_qp_kernel<Engine<8") if B == 65536 else None
+        if issue:
+            line["roofline_lds"] = issue
         if gather is not None:
             line["with_gather"] = gather
         if not args.no_extras and world == 1:   # extras (CPU baseline, secondary rooflines, large configs): N = 1 only

@@ -64,6 +64,7 @@ def lib():
         L.orc_qp_init_repeat.argtypes = [C.c_void_p] + [c_dbl_p] * 5 + [C.c_int, C.c_int]
         L.orc_qp_init_repeat.restype = C.c_int
         L.orc_qp_set_regularisation.argtypes = [C.c_void_p, C.c_double]
+        L.orc_qp_set_guess_constraints_from_y0.argtypes = [C.c_void_p, C.c_int]
         L.orc_qp_get_primal.argtypes = [C.c_void_p, c_dbl_p]
         L.orc_qp_get_dual.argtypes = [C.c_void_p, c_dbl_p]
         L.orc_qp_get_objective.restype = C.c_double
@@ -268,6 +269,10 @@ class OracleQP:
 
     def set_regularisation(self, reg):
         lib().orc_qp_set_regularisation(self._h, float(reg))
+
+    def set_guess_constraints_from_y0(self, on=True):
+        """warm init without guessed constraints: sides from sign(y0) (the HIP engine's rule) instead of A x0"""
+        lib().orc_qp_set_guess_constraints_from_y0(self._h, int(bool(on)))
 
     def _vecs(self, g, lb, ub, lbA, ubA):
         self._keep = [_d(g), _d(lb), _d(ub), _d(lbA), _d(ubA)]

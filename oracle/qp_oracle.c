@@ -67,6 +67,8 @@ struct orc_qp {
     int status, infeasible, unbounded, nflips;
     int sizeT;
     double hreg; /* H + hreg*I: qpOASES treats an all-zero Hessian (LP) as regVal*I */
+    int guess_c_from_y0; /* 0: the reference's rule for init(.., xOpt, yOpt, guessedBounds) -- constraints clipped
+                            at A x0; 1: the HIP engine's rule -- constraint sides from the signs of y0 (see setup_aux) */
 };
 
 static double clampinf(double v) {
@@ -466,10 +468,11 @@ static int setup_aux(orc_qp *qp, const double *x0, const double *y0, const int *
     for (int i = 0; i < nC; i++) {
         int s = 0;
         if (guess_c) s = guess_c[i];
+        else if (y0 && (!x0 || qp->guess_c_from_y0)) s = y0[nV + i] > ORC_EPS ? -1 : (y0[nV + i] < -ORC_EPS ? 1 : 0);
         else if (x0) {
             if (qp->Ax[i] <= qp->lbAN[i] + BOUND_TOLERANCE) s = -1;
             else if (qp->Ax[i] >= qp->ubAN[i] - BOUND_TOLERANCE) s = 1;
-        } else if (y0) s = y0[nV + i] > ORC_EPS ? -1 : (y0[nV + i] < -ORC_EPS ? 1 : 0);
+        }
         if (s == -1 && qp->lbAN[i] <= -ORC_INFTY) s = 0;
         if (s == 1 && qp->ubAN[i] >= ORC_INFTY) s = 0;
         if (s != 0 && constraint_is_LI(qp, i)) add_constraint(qp, i, s, 0, 0);
@@ -944,6 +947,7 @@ int orc_qp_hotstart_matrices(orc_qp *qp, const double *g, const double *lb, cons
 }
 
 void orc_qp_set_regularisation(orc_qp *qp, double reg) { qp->hreg = reg; }
+void orc_qp_set_guess_constraints_from_y0(orc_qp *qp, int on) { qp->guess_c_from_y0 = on != 0; }
 
 void orc_qp_get_primal(const orc_qp *qp, double *x) { memcpy(x, qp->x, sizeof(double) * (size_t)qp->nV); }
 void orc_qp_get_dual(const orc_qp *qp, double *y) {

@@ -156,6 +156,12 @@ int orc_qp_hotstart_matrices(orc_qp *qp, const double *g, const double *lb, cons
 /* H := H + reg*I for every later solve (qpOASES regularises an all-zero Hessian, i.e. the LP of
  * optimizeLP, src/qpOASESInterface.cpp:227-284); the objective excludes the reg term */
 void orc_qp_set_regularisation(orc_qp *qp, double reg);
+/* init(.., x0, y0, guessedBounds) without guessed constraints (the FIXED <-> VARIED flip of
+ * src/qpOASESInterface.cpp:199-207). 0 (default) = the reference's path: qpOASES derives no constraint
+ * from y0 when x0 is given as well, the working set restarts from the constraints x0 happens to sit on.
+ * 1 = what the HIP engine does: constraint sides from the signs of y0 (the working set of the previous
+ * solve). Same KKT point on a strictly convex QP, far fewer working-set changes. */
+void orc_qp_set_guess_constraints_from_y0(orc_qp *qp, int on);
 void orc_qp_get_primal(const orc_qp *qp, double *x);
 void orc_qp_get_dual(const orc_qp *qp, double *y);       /* nV bound mult., then nC */
 double orc_qp_get_objective(const orc_qp *qp);

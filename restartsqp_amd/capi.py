@@ -37,6 +37,7 @@ SYMBOLS = {
     "rsqp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "rsqp_destroy": (None, [C.c_void_p]),
     "rsqp_set_options": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "rsqp_set_reinit_guess": (C.c_int, [C.c_void_p, C.c_int]),
     "rsqp_get_nV": (C.c_int, [C.c_void_p]),
     "rsqp_get_nC": (C.c_int, [C.c_void_p]),
     "rsqp_write_qp_dump": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, ip, ip, dp, ip, ip, dp]),
@@ -235,6 +236,10 @@ class Solver:
     @property
     def engine(self):
         return lib().rsqp_get_engine(self._h)
+
+    def set_reinit_guess(self, from_y0=True):
+        """warm re-initialisation without guessed constraints: sides from sign(y0) (default) or, as qpOASES, from A x0"""
+        check(lib().rsqp_set_reinit_guess(self._h, int(bool(from_y0))))
 
     def set_options(self, qp_maxiter=1000, lp_maxiter=100):
         check(lib().rsqp_set_options(self._h, qp_maxiter, lp_maxiter))

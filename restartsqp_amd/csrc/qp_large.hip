@@ -51,19 +51,34 @@ __device__ inline double block_sum(double v, double *sh) {
 // (ld and the column bases are even for every matrix of this engine, so the double2 loads are
 // 16-byte aligned; an odd tail row is handled separately.)
 constexpr int GT_COLS = 4;
-__global__ void __launch_bounds__(NT) k_gemv_t(const double *__restrict__ M, long long ld, int nrows, int ncols,
-                                               const double *__restrict__ x, double *__restrict__ out) {
-    __shared__ double sh[4];
-    const int c0 = blockIdx.x * GT_COLS;
+// one transposed product with optional fused element-wise work:
+//   x-prologue  x[r] := x[r] + (xa[r] - xb[r])       (the residual H dx + (gN - g) of the multiplier step)
+//   epilogue    out[c] := acc + addv[c]               (tmpg + H xY), written to out[omap[c]] when omap is given
+//               (scatter of the active-constraint multipliers to their constraint indices)
+struct GtTask {
+    const double *M; long long ld; int nrows, ncols;
+    const double *x, *xa, *xb, *addv; const int *omap; double *out;
+};
+__device__ inline void gemv_t_body(const GtTask &t, int blk, double *sh) {
+    const double *__restrict__ M = t.M;
+    const double *__restrict__ x = t.x;
+    const long long ld = t.ld;
+    const int nrows = t.nrows, ncols = t.ncols;
+    const int c0 = blk * GT_COLS;
     double s[GT_COLS];
 #pragma unroll
     for (int k = 0; k < GT_COLS; k++) s[k] = 0.0;
     const bool vec = ((ld & 1) == 0) && ((reinterpret_cast<unsigned long long>(M) & 15) == 0) &&
-                     ((reinterpret_cast<unsigned long long>(x) & 15) == 0);
+                     ((reinterpret_cast<unsigned long long>(x) & 15) == 0) &&
+                     (!t.xa || (((reinterpret_cast<unsigned long long>(t.xa) | reinterpret_cast<unsigned long long>(t.xb)) & 15) == 0));
     if (vec) {
         const int n2 = nrows >> 1;
         for (int r = threadIdx.x; r < n2; r += NT) {
-            const double2 xv = reinterpret_cast<const double2 *>(x)[r];
+            double2 xv = reinterpret_cast<const double2 *>(x)[r];
+            if (t.xa) {
+                const double2 a = reinterpret_cast<const double2 *>(t.xa)[r], b = reinterpret_cast<const double2 *>(t.xb)[r];
+                xv.x += a.x - b.x; xv.y += a.y - b.y;
+            }
 #pragma unroll
             for (int k = 0; k < GT_COLS; k++) {
                 const int c = c0 + k < ncols ? c0 + k : ncols - 1;
@@ -72,15 +87,17 @@ __global__ void __launch_bounds__(NT) k_gemv_t(const double *__restrict__ M, lon
             }
         }
         if ((nrows & 1) && threadIdx.x == 0) {
+            const int r = nrows - 1;
+            const double xv = x[r] + (t.xa ? t.xa[r] - t.xb[r] : 0.0);
 #pragma unroll
             for (int k = 0; k < GT_COLS; k++) {
                 const int c = c0 + k < ncols ? c0 + k : ncols - 1;
-                s[k] += M[c * ld + nrows - 1] * x[nrows - 1];
+                s[k] += M[c * ld + r] * xv;
             }
         }
     } else {
         for (int r = threadIdx.x; r < nrows; r += NT) {
-            const double xv = x[r];
+            const double xv = x[r] + (t.xa ? t.xa[r] - t.xb[r] : 0.0);
 #pragma unroll
             for (int k = 0; k < GT_COLS; k++) {
                 const int c = c0 + k < ncols ? c0 + k : ncols - 1;
@@ -90,9 +107,22 @@ __global__ void __launch_bounds__(NT) k_gemv_t(const double *__restrict__ M, lon
     }
 #pragma unroll
     for (int k = 0; k < GT_COLS; k++) {
-        const double t = block_sum(s[k], sh);
-        if (threadIdx.x == 0 && c0 + k < ncols) out[c0 + k] = t;
+        const double v = block_sum(s[k], sh);
+        if (threadIdx.x == 0 && c0 + k < ncols) {
+            const int c = c0 + k;
+            t.out[t.omap ? t.omap[c] : c] = t.addv ? v + t.addv[c] : v;
+        }
     }
+}
+__global__ void __launch_bounds__(NT) k_gemv_t(GtTask t) {
+    __shared__ double sh[4];
+    gemv_t_body(t, blockIdx.x, sh);
+}
+// two independent transposed products in one launch (blocks [0, nb0) work on t0, the rest on t1)
+__global__ void __launch_bounds__(NT) k_gemv_t2(GtTask t0, int nb0, GtTask t1) {
+    __shared__ double sh[4];
+    if ((int)blockIdx.x < nb0) gemv_t_body(t0, blockIdx.x, sh);
+    else gemv_t_body(t1, blockIdx.x - nb0, sh);
 }
 
 // out = beta*base + alpha * M w, column-major M. A workgroup owns 64 consecutive rows (one
@@ -181,6 +211,76 @@ __global__ void __launch_bounds__(NT) k_gemv_n_reduce(const double *__restrict__
         out[r] = (base ? beta * base[r] : 0.0) + alpha * ((sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]));
 }
 
+// Single-launch form of out = beta*base + alpha * M w for matrices that are launch-bound rather than HBM-bound
+// (nrows <= 8192: the two-kernel form above costs a second ~4 us launch for the reduction). A workgroup owns 16
+// consecutive rows (8 lanes x 16-byte loads = one 128-byte line per column) and ALL columns, dealt to 32 column
+// groups; the 32 partial sums of a row meet in LDS and are added in group order (deterministic). 128 workgroups
+// x 256 threads x 8 loads in flight keep ~4 MB on the wire for a 2048 x 2048 matrix.
+// Optional epilogue (the step direction's "dx on the free variables", k_merge_free): mdst[r] = out[r] where mSb[r] == 0.
+template <bool VEC>
+__global__ void __launch_bounds__(NT) k_gemv_n1(const double *__restrict__ M, long long ld, int nrows, int ncols,
+                                                const double *__restrict__ w, double alpha, double beta,
+                                                const double *__restrict__ base, double *__restrict__ out,
+                                                const int *__restrict__ mSb, double *__restrict__ mdst) {
+    constexpr int RPL = VEC ? 2 : 1;
+    __shared__ double sh[32][8 * RPL + 1];
+    const int rl = threadIdx.x & 7, cg = threadIdx.x >> 3;
+    const int r = (blockIdx.x * 8 + rl) * RPL;
+    double a0 = 0.0, a1 = 0.0;
+    if (VEC) {
+        if (r + 1 < nrows) {
+            double2 s0 = {0, 0}, s1 = {0, 0}, s2 = {0, 0}, s3 = {0, 0};
+            int c = cg;
+            for (; c + 96 < ncols; c += 128) {
+                const double2 m0 = *reinterpret_cast<const double2 *>(M + c * ld + r);
+                const double2 m1 = *reinterpret_cast<const double2 *>(M + (c + 32) * ld + r);
+                const double2 m2 = *reinterpret_cast<const double2 *>(M + (c + 64) * ld + r);
+                const double2 m3 = *reinterpret_cast<const double2 *>(M + (c + 96) * ld + r);
+                const double w0 = w[c], w1 = w[c + 32], w2 = w[c + 64], w3 = w[c + 96];
+                s0.x += m0.x * w0; s0.y += m0.y * w0; s1.x += m1.x * w1; s1.y += m1.y * w1;
+                s2.x += m2.x * w2; s2.y += m2.y * w2; s3.x += m3.x * w3; s3.y += m3.y * w3;
+            }
+            for (; c < ncols; c += 32) {
+                const double2 m0 = *reinterpret_cast<const double2 *>(M + c * ld + r);
+                s0.x += m0.x * w[c]; s0.y += m0.y * w[c];
+            }
+            a0 = (s0.x + s1.x) + (s2.x + s3.x);
+            a1 = (s0.y + s1.y) + (s2.y + s3.y);
+        } else if (r < nrows) {
+            for (int c = cg; c < ncols; c += 32) a0 += M[c * ld + r] * w[c];
+        }
+        sh[cg][2 * rl] = a0; sh[cg][2 * rl + 1] = a1;
+    } else {
+        if (r < nrows) {
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int c = cg;
+            for (; c + 96 < ncols; c += 128) {
+                s0 += M[c * ld + r] * w[c];
+                s1 += M[(c + 32) * ld + r] * w[c + 32];
+                s2 += M[(c + 64) * ld + r] * w[c + 64];
+                s3 += M[(c + 96) * ld + r] * w[c + 96];
+            }
+            for (; c < ncols; c += 32) s0 += M[c * ld + r] * w[c];
+            a0 = (s0 + s1) + (s2 + s3);
+        }
+        sh[cg][rl] = a0;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 8 * RPL) {
+        const int rr = blockIdx.x * 8 * RPL + threadIdx.x;
+        if (rr < nrows) {
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+            for (int g = 0; g < 32; g += 4) {
+                t0 += sh[g][threadIdx.x]; t1 += sh[g + 1][threadIdx.x]; t2 += sh[g + 2][threadIdx.x]; t3 += sh[g + 3][threadIdx.x];
+            }
+            const double v = (base ? beta * base[rr] : 0.0) + alpha * ((t0 + t1) + (t2 + t3));
+            out[rr] = v;
+            if (mSb && mSb[rr] == 0) mdst[rr] = v;
+        }
+    }
+}
+
 // M[c*ld + r] += coef * t[r] * v[c]   (coef = scal[ci] * cs)
 __global__ void __launch_bounds__(NT) k_ger(double *__restrict__ M, long long ld, int nrows, int ncols,
                                             const double *__restrict__ t, const double *__restrict__ v,
@@ -245,13 +345,19 @@ __global__ void __launch_bounds__(NT) k_house(const double *__restrict__ w, int 
 //   Wt = P Wz P ;  Wz' = Wt_11 - Wt_12 Wt_12' / Wt_22
 // with s = Wz v, theta = v's:  Wt[a][b] = Wz[a][b] - beta s_a v_b - beta v_a s_b + beta^2 theta v_a v_b
 // col[a] = Wt[a][last] is prepared by k_wz_lastcol; then one pass over the leading block.
-__global__ void k_wz_lastcol(const double *__restrict__ Wz, long long ld, int nZ, const double *__restrict__ s,
-                             const double *__restrict__ v, const double *__restrict__ scal, int sb, int st,
+// (theta = v's is formed here, by every workgroup in the same order; workgroup 0 publishes it in scal[st])
+__global__ void __launch_bounds__(NT) k_wz_lastcol(const double *__restrict__ Wz, long long ld, int nZ, const double *__restrict__ s,
+                             const double *__restrict__ v, double *__restrict__ scal, int sb, int st,
                              double *__restrict__ col) {
+    __shared__ double sh[4];
+    double th = 0.0;
+    for (int i = threadIdx.x; i < nZ; i += NT) th += v[i] * s[i];
+    th = block_sum(th, sh);
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[st] = th;
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= nZ) return;
     const int l = nZ - 1;
-    const double beta = scal[sb], theta = scal[st];
+    const double beta = scal[sb], theta = th;
     col[a] = Wz[(long long)l * ld + a] - beta * s[a] * v[l] - beta * v[a] * s[l] + beta * beta * theta * v[a] * v[l];
 }
 __global__ void __launch_bounds__(NT) k_wz_shrink(double *__restrict__ Wz, long long ld, int nZ,
@@ -539,6 +645,91 @@ __global__ void k_rerelax(int n, const int *__restrict__ S, const double *__rest
 }
 
 // ---- fused helpers (fewer launches per working-set change) -------------------------------
+// At n <= 4096 the engine is bound by the NUMBER of launches (every kernel, however small, occupies the stream for
+// 2.5 - 5 us: rocprofv3 of the dense 2048 x 4096 cold start showed 51 launches = 259 us per working-set change, 37 %
+// of it in element-wise and single-thread kernels), so neighbouring element-wise steps share a launch.
+// step direction: bA[j] = delta b(AC[j]) - (A dx_FX)[AC[j]]  and  tmpg = H dx_FX + (gN - g)
+__global__ void k_sd_prep(int nAC, const int *__restrict__ AC, const int *__restrict__ Sc, const double *__restrict__ lbA,
+                          const double *__restrict__ ubA, const double *__restrict__ lbAN, const double *__restrict__ ubAN,
+                          const double *__restrict__ Adx, double *__restrict__ bA, int nV, const double *__restrict__ Hdxfx,
+                          const double *__restrict__ gN, const double *__restrict__ g, double *__restrict__ tmpg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nAC) {
+        const int r = AC[i];
+        bA[i] = (Sc[r] == -1 ? delta_of(lbAN[r], lbA[r]) : delta_of(ubAN[r], ubA[r])) - Adx[r];
+    }
+    if (i < nV) tmpg[i] = Hdxfx[i] + (gN[i] - g[i]);
+}
+// dy on the fixed variables: (H dx + (gN - g)) - A'dy_C, zero on the free ones
+__global__ void k_dy_fixed2(int nV, const int *__restrict__ Sb, const double *__restrict__ Hdx, const double *__restrict__ gN,
+                            const double *__restrict__ g, const double *__restrict__ ATdy, double *__restrict__ dy) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nV) dy[v] = Sb[v] != 0 ? (Hdx[v] + (gN[v] - g[v])) - ATdy[v] : 0.0;
+}
+// the whole homotopy step in one launch: variables, constraints, multipliers, and -- fix != 0 -- the blocking
+// bound / constraint put exactly on its new side (fkind 3: constraint fidx, 4: variable fidx)
+__global__ void k_step_all(int nV, int nC, double tau, int done, const int *__restrict__ Sb, double *__restrict__ x,
+                           double *__restrict__ g, double *__restrict__ lb, double *__restrict__ ub,
+                           const double *__restrict__ gN, const double *__restrict__ lbN, const double *__restrict__ ubN,
+                           const double *__restrict__ dx, const double *__restrict__ ATdy, double *__restrict__ ATy,
+                           const double *__restrict__ Hdx, double *__restrict__ Hx, double *__restrict__ lbA,
+                           double *__restrict__ ubA, const double *__restrict__ lbAN, const double *__restrict__ ubAN,
+                           const double *__restrict__ dAx, double *__restrict__ Ax, const double *__restrict__ dy,
+                           double *__restrict__ y, int fix, int fkind, int fidx, int fside) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nV) {
+        const int v = i;
+        if (done) {
+            g[v] = gN[v]; lb[v] = lbN[v]; ub[v] = ubN[v];
+            x[v] = Sb[v] == -1 ? lb[v] : (Sb[v] == 1 ? ub[v] : x[v] + tau * dx[v]);
+        } else {
+            x[v] += tau * dx[v];
+            g[v] += tau * (gN[v] - g[v]);
+            lb[v] += tau * delta_of(lbN[v], lb[v]);
+            ub[v] += tau * delta_of(ubN[v], ub[v]);
+            ATy[v] += tau * ATdy[v];
+            Hx[v] += tau * Hdx[v];
+            if (fix && fkind == 4 && v == fidx) { if (fside == -1) lb[v] = x[v]; else ub[v] = x[v]; }
+        }
+    }
+    if (i < nC) {
+        if (done) { lbA[i] = lbAN[i]; ubA[i] = ubAN[i]; }
+        else {
+            lbA[i] += tau * delta_of(lbAN[i], lbA[i]);
+            ubA[i] += tau * delta_of(ubAN[i], ubA[i]);
+            Ax[i] += tau * dAx[i];
+            if (fix && fkind == 3 && i == fidx) { if (fside == -1) lbA[i] = Ax[i]; else ubA[i] = Ax[i]; }
+        }
+    }
+    if (i < nV + nC) y[i] += tau * dy[i];
+}
+// products of variable v with the bases -- rows v of Z and Y -- and the norms of the independence test, one workgroup
+__global__ void __launch_bounds__(NT) k_bound_products(const double *__restrict__ Z, const double *__restrict__ Y, long long ld,
+                                                       int v, int nZ, int nAC, double *__restrict__ wz1, double *__restrict__ a1,
+                                                       double *__restrict__ scal, int s1, int s2, double *__restrict__ ctl) {
+    __shared__ double sh[4];
+    double q = 0.0;
+    for (int c = threadIdx.x; c < nZ; c += NT) { const double t = Z[c * ld + v]; wz1[c] = t; q += t * t; }
+    for (int c = threadIdx.x; c < nAC; c += NT) a1[c] = Y[c * ld + v];
+    q = block_sum(q, sh);
+    if (threadIdx.x == 0) { scal[s1] = 1.0; scal[s2] = q; ctl[2] = 1.0; ctl[3] = q; }
+}
+// a variable joins the fixed set: rows v of both bases are cleared, the working set updated
+__global__ void k_clean_bound(double *__restrict__ Y, double *__restrict__ Z, long long ld, int v, int nAC, int nZ,
+                              int *__restrict__ Sb, int side) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < nAC) Y[c * ld + v] = 0.0;
+    if (c < nZ) Z[c * ld + v] = 0.0;
+    if (c == 0) Sb[v] = side;
+}
+// working-set bookkeeping of a removed constraint (position k, constraint r; the last position moves into k)
+__global__ void k_ws_remove_c(int *AC, int *posAC, int *Sc, int k, int last, int r, double *y, int yidx) {
+    if (k != last) { const int rl = AC[last]; AC[k] = rl; posAC[rl] = k; }
+    posAC[r] = -1; Sc[r] = 0;
+    if (y) y[yidx] = 0.0;
+}
+__global__ void k_free_bound_ws(int *Sb, int v, double *y) { Sb[v] = 0; if (y) y[v] = 0.0; }
+
 // dx on the fixed variables (zero elsewhere) and dy := 0, one launch over nV + nC
 __global__ void k_dx_fixed_zero_dy(int nV, int nC, const int *__restrict__ Sb, const double *__restrict__ lb,
                                    const double *__restrict__ ub, const double *__restrict__ lbN,
@@ -695,11 +886,15 @@ __global__ void k_unit_cols(double *__restrict__ Z, long long ld, const int *__r
 inline dim3 g1(int n) { return dim3((unsigned)((n + NT - 1) / NT)); }
 
 // ---- small single-thread / utility kernels -----------------------------------------------
+// eta_from_house: eta = image sign * alpha of the last Householder vector (scal[2] * scal[0]), else scal[es];
+// thread nAC also records the new working-set entry (constraint r at position nAC, side)
 __global__ void k_minv_border(double *Minv, long long ldm, int nAC, const double *row,
-                                                     const double *scal, int es) {
+                                                     const double *scal, int es, int eta_from_house, int *AC, int *posAC,
+                                                     int *Sc, int r, int side) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > nAC) return;
-    const double eta = scal[es];
+    const double eta = eta_from_house ? scal[2] * scal[0] : scal[es];
+    if (j == nAC) { AC[nAC] = r; posAC[r] = nAC; Sc[r] = side; }
     if (j < nAC) {
         Minv[(long long)j * ldm + nAC] = -row[j] / eta;   // new row nAC
         Minv[(long long)nAC * ldm + j] = 0.0;             // new column nAC
@@ -710,8 +905,8 @@ __global__ void k_minv_border(double *Minv, long long ldm, int nAC, const double
 __global__ void k_eta_from_house(double *scal) { scal[5] = scal[2] * scal[0]; }
 // a1[0..nAC) = qY, a1[nAC] = q*: unit vector. vt = q~ with last += sgn(q*); beta~ = 1/(1+|q*|),
 // gamma = beta~/(1 - beta~ |qY|^2) = beta~/|q*|
-__global__ void k_house_unit(double *a1, int nAC, double *scal) {
-    const double qs = a1[nAC], sg = qs >= 0.0 ? 1.0 : -1.0, aq = fabs(qs);
+__global__ void k_house_unit(double *a1, int nAC, double *scal, const double *zs, int v) {
+    const double qs = zs[v], sg = qs >= 0.0 ? 1.0 : -1.0, aq = fabs(qs);   // q* = zs[v]
     const double beta = 1.0 / (1.0 + aq);
     a1[nAC] = qs + sg;
     scal[8] = beta;
@@ -741,8 +936,18 @@ __global__ void k_newcol_free(int nV, int v, const double *t, const double *scal
     if (i < nV) znew[i] = (i == v ? 1.0 : 0.0) - scal[8] * t[i] * scal[10];
 }
 __global__ void k_sm_coef(double *scal) { scal[16] = scal[8] / (1.0 - scal[8] * scal[15]); }
-__global__ void k_rho2(double *scal, double *ctl) {
-    const double kappa = scal[11], ku = scal[12];
+// kappa = z'(H z), ku = k'u (both dots formed here), rho2 = kappa - ku and its threshold
+__global__ void __launch_bounds__(NT) k_rho2(double *scal, double *ctl, const double *__restrict__ z, const double *__restrict__ Hz,
+                                             int nV, const double *__restrict__ kv, const double *__restrict__ uv, int nZ) {
+    __shared__ double sh[4];
+    double p = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nV; i += NT) p += z[i] * Hz[i];
+    for (int i = threadIdx.x; i < nZ; i += NT) q += kv[i] * uv[i];
+    p = block_sum(p, sh);
+    q = block_sum(q, sh);
+    if (threadIdx.x != 0) return;
+    scal[11] = p; scal[12] = q;
+    const double kappa = p, ku = q;
     scal[13] = kappa - ku;
     scal[14] = RSQP_EPS_PD_REL * (fabs(kappa) + fabs(ku)) + RSQP_EPS_PD_ABS;
     ctl[4] = scal[13]; ctl[5] = scal[14];
@@ -807,6 +1012,7 @@ struct RsqpLargeEngine::Impl {
     double *big = nullptr;    // 2 nV^2 scratch, allocated by the first blocked set-up
     int *d_fpos = nullptr, *d_cand = nullptr, *d_freev = nullptr;
     bool blocked_setup = getenv("RSQP_NO_BLOCKED_SETUP") == nullptr;
+    bool reinit_from_y0 = true;
     static constexpr int BLOCKED_MIN = 32;   // fewer active constraints: the sequential construction is as fast
 
     ~Impl() {
@@ -850,23 +1056,50 @@ struct RsqpLargeEngine::Impl {
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { fprintf(stderr, "[rsqp large] %s: %s (nV=%d nC=%d nZ=%d nAC=%d)\n", what, hipGetErrorString(e), nV, nC, nZ, nAC); debug = false; }
     }
-    void gemv_t(const double *Mx, long long l, int nrows, int ncols, const double *xv, double *out) {
+    static GtTask gt_task(const double *Mx, long long l, int nrows, int ncols, const double *xv, double *out) {
+        GtTask t;
+        t.M = Mx; t.ld = l; t.nrows = nrows; t.ncols = ncols; t.x = xv; t.xa = t.xb = t.addv = nullptr; t.omap = nullptr; t.out = out;
+        return t;
+    }
+    void gemv_t_task(const GtTask &t) {
         pbegin();
-        if (ncols > 0)
-            hipLaunchKernelGGL(k_gemv_t, dim3((ncols + GT_COLS - 1) / GT_COLS), dim3(NT), 0, st, Mx, l, nrows, ncols, xv, out);
-        pend(1, 8.0 * nrows * (double)ncols + 8.0 * nrows + 8.0 * ncols);
+        if (t.ncols > 0) hipLaunchKernelGGL(k_gemv_t, dim3((t.ncols + GT_COLS - 1) / GT_COLS), dim3(NT), 0, st, t);
+        pend(1, 8.0 * t.nrows * (double)t.ncols + 8.0 * t.nrows + 8.0 * t.ncols);
         chk("gemv_t");
     }
+    void gemv_t(const double *Mx, long long l, int nrows, int ncols, const double *xv, double *out) {
+        gemv_t_task(gt_task(Mx, l, nrows, ncols, xv, out));
+    }
+    // two independent products, one launch
+    void gemv_t_pair(const GtTask &t0, const GtTask &t1) {
+        if (t0.ncols <= 0) { gemv_t_task(t1); return; }
+        if (t1.ncols <= 0) { gemv_t_task(t0); return; }
+        pbegin();
+        const int nb0 = (t0.ncols + GT_COLS - 1) / GT_COLS, nb1 = (t1.ncols + GT_COLS - 1) / GT_COLS;
+        hipLaunchKernelGGL(k_gemv_t2, dim3(nb0 + nb1), dim3(NT), 0, st, t0, nb0, t1);
+        pend(1, 8.0 * t0.nrows * (double)t0.ncols + 8.0 * t1.nrows * (double)t1.ncols);
+        chk("gemv_t_pair");
+    }
     // out = beta*base + alpha * M w
+    // mSb / mdst: optional epilogue mdst[r] = out[r] where mSb[r] == 0 (k_merge_free fused into the product)
     void gemv_n(const double *Mx, long long l, int nrows, int ncols, const double *wv, double alpha, double beta,
-                const double *base, double *out) {
+                const double *base, double *out, const int *mSb = nullptr, double *mdst = nullptr) {
         if (nrows <= 0) return;
         if (ncols <= 0) {
             if (base && beta != 0.0) hipLaunchKernelGGL(k_axpby, g1(nrows), dim3(NT), 0, st, nrows, beta, base, 0.0, (const double *)nullptr, out);
             else hipLaunchKernelGGL(k_fill, g1(nrows), dim3(NT), 0, st, out, nrows, 0.0);
+            if (mSb) hipLaunchKernelGGL(k_merge_free, g1(nrows), dim3(NT), 0, st, nrows, mSb, out, mdst);
             return;
         }
         pbegin();
+        if (nrows <= 8192 || mSb) {   // launch-bound sizes: one kernel, no partials (k_gemv_n1)
+            const bool vec1 = ((l & 1) == 0) && ((reinterpret_cast<unsigned long long>(Mx) & 15) == 0);
+            if (vec1) hipLaunchKernelGGL(k_gemv_n1<true>, dim3((nrows + 15) / 16), dim3(NT), 0, st, Mx, l, nrows, ncols, wv, alpha, beta, base, out, mSb, mdst);
+            else hipLaunchKernelGGL(k_gemv_n1<false>, dim3((nrows + 7) / 8), dim3(NT), 0, st, Mx, l, nrows, ncols, wv, alpha, beta, base, out, mSb, mdst);
+            pend(0, 8.0 * nrows * (double)ncols + 8.0 * nrows + 8.0 * ncols);
+            chk("gemv_n1");
+            return;
+        }
         // chunks: enough workgroups to fill the 256 CUs a few times, as few partials as possible
         const bool vec = ((l & 1) == 0) && ((reinterpret_cast<unsigned long long>(Mx) & 15) == 0) && nrows >= 128;
         const int rb = vec ? (nrows + 127) / 128 : (nrows + 63) / 64;
@@ -908,11 +1141,19 @@ struct RsqpLargeEngine::Impl {
         else if (M.denseA) gemv_t(M.denseA, nC, nC, nV, in, out);
         else (void)rsqp_launch_spmv(M.blk_c, M.nblk_c, M.Ajc, M.Air, M.Aval, in, out, 1, 0, 0, 0, 0, st);
     }
-    void H_times(const double *in, double *out) {
+    // out = (H + hreg I) in [+ add]
+    void H_times(const double *in, double *out, const double *add = nullptr) {
+        if (M.haveH && M.denseH && M.hreg == 0.0) {       // the sum rides in the product's epilogue
+            GtTask t = gt_task(M.denseH, nV, nV, nV, in, out);
+            t.addv = add;
+            gemv_t_task(t);
+            return;
+        }
         if (!M.haveH) fill(out, nV, 0.0);
         else if (M.denseH) gemv_t(M.denseH, nV, nV, nV, in, out);
         else (void)rsqp_launch_spmv(M.blk_h, M.nblk_h, M.Hjc, M.Hir, M.Hval, in, out, 1, 0, 0, 0, 0, st);
         if (M.hreg != 0.0) hipLaunchKernelGGL(k_axpy, g1(nV), dim3(NT), 0, st, nV, M.hreg, in, out);
+        if (add) hipLaunchKernelGGL(k_axpby, g1(nV), dim3(NT), 0, st, nV, 1.0, out, 1.0, add, out);
     }
     int read_scal(int s0, int n, double *out) {
         LCHK(hipMemcpyAsync(h_pinned, scal + s0, sizeof(double) * n, hipMemcpyDeviceToHost, st));
@@ -935,8 +1176,7 @@ struct RsqpLargeEngine::Impl {
         ger(Z, ld, nV, nZ, w5, wz2, 1, -1.0);                                            // Z -= beta t v'
         if (!wz_enabled) return;
         gemv_n(Wz, ld, nZ, nZ, wz2, 1.0, 0.0, nullptr, wz3);                             // s = Wz v
-        dot(wz2, wz3, nZ, 4);                                                            // theta
-        hipLaunchKernelGGL(k_wz_lastcol, g1(nZ), dim3(NT), 0, st, Wz, ld, nZ, wz3, wz2, scal, 1, 4, w6);
+        hipLaunchKernelGGL(k_wz_lastcol, g1(nZ), dim3(NT), 0, st, Wz, ld, nZ, wz3, wz2, scal, 1, 4, w6);   // theta = v's -> scal[4]
         pbegin();
         if (nZ > 1)
             hipLaunchKernelGGL(k_wz_shrink, dim3((nZ - 1 + NT - 1) / NT, nZ - 1), dim3(NT), 0, st, Wz, ld, nZ, wz3, wz2, w6,
@@ -946,10 +1186,11 @@ struct RsqpLargeEngine::Impl {
 
     // append the Y column `ycol` (already stored at Y[:, nAC]) for constraint r whose products
     // with the old Y are in a1 (wY) and with the new column in scal[eta_slot]
-    void minv_append(int eta_slot) {
-        // new row nAC: -(wY' Minv)/eta ; new column nAC: 0 ; corner 1/eta
+    void minv_append(int eta_slot, bool eta_from_house, int r, int side) {
+        // new row nAC: -(wY' Minv)/eta ; new column nAC: 0 ; corner 1/eta ; working set: constraint r at position nAC
         gemv_t(Minv, ldm, nAC, nAC, a1, a2);  // a2[j] = sum_i wY[i] Minv[i][j]
-        hipLaunchKernelGGL(k_minv_border, g1(nAC + 1), dim3(NT), 0, st, Minv, ldm, nAC, a2, scal, eta_slot);
+        hipLaunchKernelGGL(k_minv_border, g1(nAC + 1), dim3(NT), 0, st, Minv, ldm, nAC, a2, scal, eta_slot, eta_from_house ? 1 : 0,
+                           AC, posAC, Sc, r, side);
     }
 
     int add_constraint(int r, int side, bool skipZ) {
@@ -958,15 +1199,13 @@ struct RsqpLargeEngine::Impl {
             z_reflect_and_shrink();
             // new Y column = last column of the reflected Z; eta = a'y_new = image sign * alpha
             copy(Zc(nZ - 1), Yc(nAC), nV);
-            hipLaunchKernelGGL(k_eta_from_house, dim3(1), dim3(1), 0, st, scal);  // scal[5] = scal[2]*scal[0]
         } else {
             // exchange / flip: the row is orthogonal to all null-space columns but the last
             copy(Zc(nZ - 1), Yc(nAC), nV);
             dot(w1, Zc(nZ - 1), nV, 5);
         }
         nZ--;
-        minv_append(5);
-        hipLaunchKernelGGL(k_set_ws, dim3(1), dim3(1), 0, st, AC, posAC, Sc, nAC, r, side);
+        minv_append(5, !skipZ, r, side);
         hAC[nAC] = r; hSc[r] = side;
         nAC++;
         return RET_OK;
@@ -980,15 +1219,12 @@ struct RsqpLargeEngine::Impl {
             if (nb > 0)
                 hipLaunchKernelGGL(k_row_times_bases, dim3(nb), dim3(256), 0, st, M.Arp, M.Aci, M.Arv, r, Z, nZ, wz1, Y, nAC, a1, ld);
         } else {
-            gemv_t(Z, ld, nV, nZ, w1, wz1);
-            gemv_t(Y, ld, nV, nAC, w1, a1);
+            gemv_t_pair(gt_task(Z, ld, nV, nZ, w1, wz1), gt_task(Y, ld, nV, nAC, w1, a1));
         }
         hipLaunchKernelGGL(k_norms_publish, dim3(1), dim3(NT), 0, st, w1, nV, wz1, nZ, scal, 6, 7, d_ctl);
     }
     void bound_products(int v) {
-        if (nZ > 0) hipLaunchKernelGGL(k_get_row, g1(nZ), dim3(NT), 0, st, Z, ld, v, nZ, wz1);
-        if (nAC > 0) hipLaunchKernelGGL(k_get_row, g1(nAC), dim3(NT), 0, st, Y, ld, v, nAC, a1);
-        hipLaunchKernelGGL(k_norms_publish, dim3(1), dim3(NT), 0, st, (const double *)nullptr, 0, wz1, nZ, scal, 6, 7, d_ctl);
+        hipLaunchKernelGGL(k_bound_products, dim3(1), dim3(NT), 0, st, Z, Y, ld, v, nZ, nAC, wz1, a1, scal, 6, 7, d_ctl);
     }
 
     // second stage shared by add_bound and (mirrored) remove_bound: reflection on [Y, extra]
@@ -998,8 +1234,7 @@ struct RsqpLargeEngine::Impl {
         double *zs = Zc(nZ - 1);
         nZ--;
         // q~ = [qY ; q*]; |q~| = 1. vt = q~ with last += sgn(q*); beta~ = 1/(1+|q*|)
-        hipLaunchKernelGGL(k_copy1, dim3(1), dim3(1), 0, st, a1, nAC, zs, v);   // a1[nAC] = q*
-        hipLaunchKernelGGL(k_house_unit, dim3(1), dim3(1), 0, st, a1, nAC, scal);  // a1[nAC] += sgn; scal[8]=beta~, scal[9]=gamma, scal[10]=vlast
+        hipLaunchKernelGGL(k_house_unit, dim3(1), dim3(1), 0, st, a1, nAC, scal, zs, v);  // a1[nAC] = q* + sgn; scal[8]=beta~, scal[9]=gamma, scal[10]=vlast
         // t = Y vY + zs * vlast
         gemv_n(Y, ld, nV, nAC, a1, 1.0, 0.0, nullptr, w5);
         hipLaunchKernelGGL(k_axpy_s, g1(nV), dim3(NT), 0, st, nV, scal, 10, zs, w5);
@@ -1008,9 +1243,7 @@ struct RsqpLargeEngine::Impl {
         gemv_t(Minv, ldm, nAC, nAC, a1, a2);
         ger(Minv, ldm, nAC, nAC, a1, a2, 9, 1.0);
         // clean row v
-        if (nAC > 0) hipLaunchKernelGGL(k_set_row, g1(nAC), dim3(NT), 0, st, Y, ld, v, nAC, (const double *)nullptr, 0.0);
-        if (nZ > 0) hipLaunchKernelGGL(k_set_row, g1(nZ), dim3(NT), 0, st, Z, ld, v, nZ, (const double *)nullptr, 0.0);
-        hipLaunchKernelGGL(k_seti, dim3(1), dim3(1), 0, st, Sb, v, side);
+        hipLaunchKernelGGL(k_clean_bound, g1(std::max(std::max(nAC, nZ), 1)), dim3(NT), 0, st, Y, Z, ld, v, nAC, nZ, Sb, side);
         hSb[v] = side;
         nFR--;
         return RET_OK;
@@ -1020,11 +1253,10 @@ struct RsqpLargeEngine::Impl {
     int wz_grow(int *pd) {
         double *z = Zc(nZ);
         H_times(z, w2);
-        dot(z, w2, nV, 11);                       // kappa
         gemv_t(Z, ld, nV, nZ, w2, wz1);           // k = Z'Hz
         gemv_n(Wz, ld, nZ, nZ, wz1, 1.0, 0.0, nullptr, wz2);  // u = Wz k
-        if (nZ > 0) dot(wz1, wz2, nZ, 12); else hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, scal, 12, 0.0);
-        hipLaunchKernelGGL(k_rho2, dim3(1), dim3(1), 0, st, scal, d_ctl);   // scal[13] = rho2, scal[14] = threshold
+        // kappa = z'Hz, ku = k'u, scal[13] = rho2, scal[14] = threshold
+        hipLaunchKernelGGL(k_rho2, dim3(1), dim3(NT), 0, st, scal, d_ctl, z, w2, nV, wz1, wz2, nZ);
         LCHK(hipStreamSynchronize(st));
         *pd = h_ctl[4] > h_ctl[5];
         if (*pd) {
@@ -1049,13 +1281,9 @@ struct RsqpLargeEngine::Impl {
         // delete row (nAC-1) [implicit] and column k: move the last column into k
         if (k != nAC - 1) {
             copy(Minv + (long long)(nAC - 1) * ldm, Minv + k * ldm, nAC);
-            const int rl = hAC[nAC - 1];
-            hAC[k] = rl;
-            hipLaunchKernelGGL(k_seti, dim3(1), dim3(1), 0, st, AC, k, rl);
-            hipLaunchKernelGGL(k_seti, dim3(1), dim3(1), 0, st, posAC, rl, k);
+            hAC[k] = hAC[nAC - 1];
         }
-        hipLaunchKernelGGL(k_seti, dim3(1), dim3(1), 0, st, posAC, r, -1);
-        hipLaunchKernelGGL(k_seti, dim3(1), dim3(1), 0, st, Sc, r, 0);
+        hipLaunchKernelGGL(k_ws_remove_c, dim3(1), dim3(1), 0, st, AC, posAC, Sc, k, nAC - 1, r, y, nV + r);   // also y[nV + r] = 0
         hSc[r] = 0;
         nAC--;
     }
@@ -1066,7 +1294,7 @@ struct RsqpLargeEngine::Impl {
 
     // TQ part of freeing variable v: null space gains the column Z[:, nZ]
     void remove_bound_tq(int v) {
-        hipLaunchKernelGGL(k_seti, dim3(1), dim3(1), 0, st, Sb, v, 0);
+        hipLaunchKernelGGL(k_free_bound_ws, dim3(1), dim3(1), 0, st, Sb, v, y);   // Sb[v] = 0, y[v] = 0
         hSb[v] = 0;
         nFR++;
         double *znew = Zc(nZ);
@@ -1103,8 +1331,7 @@ struct RsqpLargeEngine::Impl {
         int pd = 0;
         if (is_bound) {
             const int old = hSb[idx];
-            remove_bound_tq(idx);
-            hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, y, idx, 0.0);
+            remove_bound_tq(idx);   // (zeroes y[idx] as well)
             if (wz_grow(&pd) != RET_OK) return RET_SETUP_FAILED;
             if (pd) return RET_OK;
             // flip: put the variable back on the opposite side (or the same if that one is infinite)
@@ -1123,8 +1350,7 @@ struct RsqpLargeEngine::Impl {
             return RET_OK;
         } else {
             const int old = hSc[idx], k = position_of(idx);
-            remove_constraint_tq(k);
-            hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, y, nV + idx, 0.0);
+            remove_constraint_tq(k);   // (zeroes y[nV + idx] as well)
             if (wz_grow(&pd) != RET_OK) return RET_SETUP_FAILED;
             if (pd) return RET_OK;
             LCHK(hipMemcpyAsync(h_pinned, lbAN + idx, 8, hipMemcpyDeviceToHost, st));
@@ -1186,11 +1412,9 @@ struct RsqpLargeEngine::Impl {
             if (rc != RET_OK) return rc;
             int pd = 0;
             if (pkind == 1) {
-                remove_constraint_tq(position_of(pidx));
-                hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, y, nV + pidx, 0.0);
+                remove_constraint_tq(position_of(pidx));   // (zeroes y[nV + pidx] as well)
             } else {
-                remove_bound_tq(pidx);
-                hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, y, pidx, 0.0);
+                remove_bound_tq(pidx);   // (zeroes y[pidx] as well)
             }
             if (wz_grow(&pd) != RET_OK) return RET_SETUP_FAILED;
             full = pd != 0;
@@ -1212,27 +1436,28 @@ struct RsqpLargeEngine::Impl {
         hipLaunchKernelGGL(k_dx_fixed_zero_dy, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, lb, ub, lbN, ubN, dx, dy);
         A_times(dx, c1);                                                   // A dx_FX
         H_times(dx, w2);
-        if (nAC > 0)
-            hipLaunchKernelGGL(k_rhs_active, g1(nAC), dim3(NT), 0, st, nAC, AC, Sc, lbA, ubA, lbAN, ubAN, c1, a1);  // bA
-        hipLaunchKernelGGL(k_add_dg, g1(nV), dim3(NT), 0, st, nV, w2, gN, g, w1);   // tmpg
+        hipLaunchKernelGGL(k_sd_prep, g1(std::max(nAC, nV)), dim3(NT), 0, st, nAC, AC, Sc, lbA, ubA, lbAN, ubAN, c1, a1, nV, w2, gN, g,
+                           w1);                                            // bA -> a1, tmpg -> w1
         // range space: wY = Minv bA ; xY = Y wY
         gemv_n(Minv, ldm, nAC, nAC, a1, 1.0, 0.0, nullptr, a2);
         gemv_n(Y, ld, nV, nAC, a2, 1.0, 0.0, nullptr, w3);                 // xY
         // null space: wZ = -Wz Z'(tmpg + H xY) ; dx_FR = xY + Z wZ
-        H_times(w3, w2);
-        hipLaunchKernelGGL(k_axpby, g1(nV), dim3(NT), 0, st, nV, 1.0, w2, 1.0, w1, w2);
+        H_times(w3, w2, w1);                                               // w2 = H xY + tmpg
         gemv_t(Z, ld, nV, nZ, w2, wz1);
         gemv_n(Wz, ld, nZ, nZ, wz1, -1.0, 0.0, nullptr, wz2);
-        gemv_n(Z, ld, nV, nZ, wz2, 1.0, 1.0, w3, w4);                      // xY + Z wZ
-        hipLaunchKernelGGL(k_merge_free, g1(nV), dim3(NT), 0, st, nV, Sb, w4, dx);
+        gemv_n(Z, ld, nV, nZ, wz2, 1.0, 1.0, w3, w4, Sb, dx);              // xY + Z wZ, merged into dx on the free variables
         // multipliers: dyAC = Minv' Y'(H dx + dg)
         H_times(dx, Hdx);
-        hipLaunchKernelGGL(k_add_dg, g1(nV), dim3(NT), 0, st, nV, Hdx, gN, g, w2);   // res
-        gemv_t(Y, ld, nV, nAC, w2, a1);
-        gemv_t(Minv, ldm, nAC, nAC, a1, a2);                               // a2[j] = sum_i Minv[i][j] rhsY[i]
-        if (nAC > 0) hipLaunchKernelGGL(k_scatter_active, g1(nAC), dim3(NT), 0, st, a2, AC, nAC, dy + nV);
+        {
+            GtTask t = gt_task(Y, ld, nV, nAC, Hdx, a1);                   // a1 = Y'(H dx + (gN - g))
+            t.xa = gN; t.xb = g;
+            gemv_t_task(t);
+            GtTask u = gt_task(Minv, ldm, nAC, nAC, a1, dy + nV);          // dy[nV + AC[j]] = sum_i Minv[i][j] a1[i]
+            u.omap = AC;
+            gemv_t_task(u);
+        }
         AT_times(dy + nV, ATdy);
-        hipLaunchKernelGGL(k_dy_fixed, g1(nV), dim3(NT), 0, st, nV, Sb, w2, ATdy, dy);
+        hipLaunchKernelGGL(k_dy_fixed2, g1(nV), dim3(NT), 0, st, nV, Sb, Hdx, gN, g, ATdy, dy);
         A_times(dx, dAx);
         chk("step_direction");
     }
@@ -1282,15 +1507,11 @@ struct RsqpLargeEngine::Impl {
                 else { kind = 4; idx = bid - 3 * nC - 2 * nV; side = 1; }
             } else tau = 1.0;
             const int done = kind == 0;
-            hipLaunchKernelGGL(k_step_all_v, g1(nV), dim3(NT), 0, st, nV, tau, done, Sb, x, g, lb, ub, gN, lbN, ubN, dx, ATdy,
-                               ATy, Hdx, Hx);
-            hipLaunchKernelGGL(k_axpy, g1(nV + nC), dim3(NT), 0, st, nV + nC, tau, dy, y);
-            if (nC > 0)
-                hipLaunchKernelGGL(k_step_all_c, g1(nC), dim3(NT), 0, st, nC, tau, done, lbA, ubA, lbAN, ubAN, dAx, Ax);
+            const int fix = (!done && iter < maxit && (kind == 3 || kind == 4)) ? 1 : 0;   // blocking quantity exactly on its side
+            hipLaunchKernelGGL(k_step_all, g1(nV + nC), dim3(NT), 0, st, nV, nC, tau, done, Sb, x, g, lb, ub, gN, lbN, ubN, dx, ATdy,
+                               ATy, Hdx, Hx, lbA, ubA, lbAN, ubAN, dAx, Ax, dy, y, fix, kind, idx, side);
             if (done) { A_times(x, Ax); status = QPS_SOLVED; break; }
             if (iter >= maxit) { rcode = RET_MAX_NWSR; break; }
-            if (kind == 3) hipLaunchKernelGGL(k_copy1, dim3(1), dim3(1), 0, st, side == -1 ? lbA : ubA, idx, Ax, idx);
-            else if (kind == 4) hipLaunchKernelGGL(k_copy1, dim3(1), dim3(1), 0, st, side == -1 ? lb : ub, idx, x, idx);
             rcode = change_active_set(kind, idx, side);
             if (rcode == RET_INFEASIBLE) { infeasible = 1; break; }
             if (rcode == RET_UNBOUNDED) { unbounded = 1; break; }
@@ -1571,8 +1792,10 @@ int RsqpLargeEngine::solve(int mode, const double *d_g, const double *d_lb, cons
             }
             for (int i = 0; i < nC; i++) {
                 int s = 0;
-                if (have_x0) s = hAx[i] <= hlA[i] + RSQP_BOUND_TOLERANCE ? -1 : (hAx[i] >= huA[i] - RSQP_BOUND_TOLERANCE ? 1 : 0);
-                else if (have_y0) s = hy[nV + i] > RSQP_EPS ? -1 : (hy[nV + i] < -RSQP_EPS ? 1 : 0);
+                // no guessed constraints in this call shape: sides from the signs of y0 (reinit_from_y0, the default)
+                // or, as qpOASES does when x0 is given too, only from where A x0 sits
+                if (have_y0 && (!have_x0 || P.reinit_from_y0)) s = hy[nV + i] > RSQP_EPS ? -1 : (hy[nV + i] < -RSQP_EPS ? 1 : 0);
+                else if (have_x0) s = hAx[i] <= hlA[i] + RSQP_BOUND_TOLERANCE ? -1 : (hAx[i] >= huA[i] - RSQP_BOUND_TOLERANCE ? 1 : 0);
                 if (s == -1 && hlA[i] <= -RSQP_INFTY) s = 0;
                 if (s == 1 && huA[i] >= RSQP_INFTY) s = 0;
                 gc[i] = s;
@@ -1611,6 +1834,7 @@ const char *RsqpLargeEngine::profile_name(int k) {
     return k >= 0 && k < PROFILE_CLASSES ? nm[k] : "";
 }
 void RsqpLargeEngine::profile_enable(bool on) { p_->profile = on; }
+void RsqpLargeEngine::set_reinit_from_y0(bool on) { p_->reinit_from_y0 = on; }
 void RsqpLargeEngine::profile_get(double *out) const {
     for (int k = 0; k < PROFILE_CLASSES; k++) {
         out[4 * k] = (double)p_->prof[k].calls; out[4 * k + 1] = p_->prof[k].ms; out[4 * k + 2] = p_->prof[k].bytes; out[4 * k + 3] = 0.0;

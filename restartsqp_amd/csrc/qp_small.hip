@@ -534,7 +534,7 @@ struct Engine {
 
     // warm-start inputs are staged by the caller: x0 in wv4, y0 in dy, guessed bound status in
     // wq and guessed constraint status in wc1 (as doubles); the flags say which are present
-    __device__ __forceinline__ int setup_aux(bool x0, bool y0, bool guess_b, bool guess_c) {
+    __device__ __forceinline__ int setup_aux(bool x0, bool y0, bool guess_b, bool guess_c, bool cy0 = false) {
         status = QPS_PREPARINGAUXILIARYQP;
         infeasible = unbounded = 0;
         PFOR(v, nV) {
@@ -573,8 +573,8 @@ struct Engine {
         for (int i = 0; i < nC; i++) {
             int s = 0;
             if (guess_c) s = (int)wc1[i];
+            else if (y0 && (!x0 || cy0)) s = y[nV + i] > RSQP_EPS ? -1 : (y[nV + i] < -RSQP_EPS ? 1 : 0);
             else if (x0) s = Ax[i] <= lbAN[i] + RSQP_BOUND_TOLERANCE ? -1 : (Ax[i] >= ubAN[i] - RSQP_BOUND_TOLERANCE ? 1 : 0);
-            else if (y0) s = y[nV + i] > RSQP_EPS ? -1 : (y[nV + i] < -RSQP_EPS ? 1 : 0);
             if (s == -1 && lbAN[i] <= -RSQP_INFTY) s = 0;
             if (s == 1 && ubAN[i] >= RSQP_INFTY) s = 0;
             if (s != 0 && constraint_is_LI(i)) add_constraint(i, s, false, false);
@@ -1091,7 +1091,9 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
         if (P.y0) for (int i = lane; i < d.nV + d.nC; i += L) E.dy[i] = P.y0[d.offV + d.offC + i];
         if (P.guess_b) for (int v = lane; v < d.nV; v += L) E.wq[v] = (double)P.guess_b[d.offV + v];
         SYNC();
-        rcode = E.setup_aux(P.x0 != nullptr, P.y0 != nullptr, P.guess_b != nullptr, false);
+        // no guessed constraints in this call shape (qpOASESInterface.cpp:204-206): their sides come from the signs of
+        // y0 (P.reinit_from_y0, the default) -- or, as qpOASES does, only from where A x0 sits
+        rcode = E.setup_aux(P.x0 != nullptr, P.y0 != nullptr, P.guess_b != nullptr, false, P.reinit_from_y0 != 0);
         if (rcode != RET_OK) rcode = E.setup_aux(false, false, false, false);
     } else {
         E.infeasible = E.unbounded = 0;
@@ -1153,7 +1155,9 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     // uniform hs071-scale batches (8 x 2 through the QPhandler formulation; parameter scans of one NLP iterate) run
     // the build with the shape as a compile-time constant and the target vectors in registers (see RegVec)
     static const int noshape = env_int("RSQP_SMALL_NOSHAPE", 0);
-    const bool shape82 = eng == 0 && p.uniV == 8 && p.uniC == 2 && !noshape && mat_bytes_max >= 0;
+    static const int forcedL0 = env_int("RSQP_SMALL_LANES", -1);
+    const bool shape82 = eng == 0 && p.uniV == 8 && p.uniC == 2 && !noshape && mat_bytes_max >= 0 &&
+                         (forcedL0 < 0 || forcedL0 == 8);        // only the 8-lane build has the shape instantiation
     // LDS image of the chosen formulation (the persistent copy in HBM is sized for the larger one)
     const long long imgd = eng == 1 ? EngineX<64, true>::image_doubles(nVmax, nCmax)
                                     : (shape82 ? Engine<8, true, true>::image_doubles(nVmax, nCmax) : Engine<64, true>::image_doubles(nVmax, nCmax));
@@ -1270,6 +1274,8 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
         // occupancy of both builds is capped at 2 waves per SIMD by the LDS a wave of 8 problems needs
         if (shape82) SQ_LAUNCH_SHAPE(8, 2, 8, 2);
         else SQ_LAUNCH(8, true, 2);
+    } else if (shape82) {
+        return hipErrorInvalidValue;    // the image was sized for the 8-lane shape build: never launch another one on it
     } else if (L == 16) {
         SQ_WAVES(16)
     } else if (L == 32) {

@@ -785,7 +785,7 @@ struct EngineX {
 
     // warm-start inputs staged by the caller: x0 in wv4 (= w4), y0 in dy, guessed bound status in wq
     // (= wz1) and guessed constraint status in wc1 (= c1), as doubles
-    __device__ __forceinline__ int setup_aux(bool x0, bool y0, bool guess_b, bool guess_c) {
+    __device__ __forceinline__ int setup_aux(bool x0, bool y0, bool guess_b, bool guess_c, bool cy0 = false) {
         status = QPS_PREPARINGAUXILIARYQP;
         infeasible = unbounded = 0;
         PFOR(v, nV) {
@@ -822,8 +822,8 @@ struct EngineX {
         for (int i = 0; i < nC; i++) {
             int s = 0;
             if (guess_c) s = (int)c2[i];
+            else if (y0 && (!x0 || cy0)) s = y[nV + i] > RSQP_EPS ? -1 : (y[nV + i] < -RSQP_EPS ? 1 : 0);
             else if (x0) s = Ax[i] <= lbAN[i] + RSQP_BOUND_TOLERANCE ? -1 : (Ax[i] >= ubAN[i] - RSQP_BOUND_TOLERANCE ? 1 : 0);
-            else if (y0) s = y[nV + i] > RSQP_EPS ? -1 : (y[nV + i] < -RSQP_EPS ? 1 : 0);
             if (s == -1 && lbAN[i] <= -RSQP_INFTY) s = 0;
             if (s == 1 && ubAN[i] >= RSQP_INFTY) s = 0;
             if (s != 0) {

@@ -207,6 +207,7 @@ struct rsqp_solver {
     bool fits_small = true;
     RsqpLargeEngine *large = nullptr;
     bool large_ready = false, profile_large = false;
+    bool reinit_from_y0 = true;   // rsqp_set_reinit_guess
     DevBuf<double> denseA, denseH;   // dense copies for the HBM-resident engine (dense matrices only)
     ~rsqp_solver() {
         delete large;
@@ -292,6 +293,7 @@ QPPools pools_of(rsqp_solver *s) {
     p.obj = s->d_obj.p; p.state = s->d_state.p;
     p.uniV = s->nV; p.uniC = s->nC;
     p.keep_state = 1;
+    p.reinit_from_y0 = s->reinit_from_y0 ? 1 : 0;
     return p;
 }
 
@@ -410,6 +412,12 @@ extern "C" int rsqp_engine_profile_names(const char **names, int n) {
 }
 extern "C" int rsqp_get_nV(const rsqp_solver *s) { return s ? s->nV : -1; }
 extern "C" int rsqp_get_nC(const rsqp_solver *s) { return s ? s->nC : -1; }
+
+extern "C" int rsqp_set_reinit_guess(rsqp_solver *s, int from_y0) {
+    if (!s) return fail(RSQP_ERR_ARG, "null solver");
+    s->reinit_from_y0 = from_y0 != 0;
+    return RSQP_OK;
+}
 
 extern "C" int rsqp_set_options(rsqp_solver *s, int qp_maxiter, int lp_maxiter) {
     if (!s || qp_maxiter < 0 || lp_maxiter < 0) return fail(RSQP_ERR_ARG, "rsqp_set_options");
@@ -611,6 +619,7 @@ int solve_large(rsqp_solver *s, int mode, int *nWSR, const double *x0, const dou
         m.denseH = s->denseH.p;
     }
     s->large->set_matrices(m);
+    s->large->set_reinit_from_y0(s->reinit_from_y0);
     int rc = s->large->solve(mode, s->d_vec[RSQP_VEC_G].p, s->d_vec[RSQP_VEC_LB].p, s->d_vec[RSQP_VEC_UB].p,
                              s->d_vec[RSQP_VEC_LBA].p, s->d_vec[RSQP_VEC_UBA].p, nWSR, x0, y0, guess_b);
     if (s->large->last_error() != hipSuccess)

@@ -42,6 +42,7 @@ public:
     static constexpr int PROFILE_CLASSES = 8;
     static const char *profile_name(int k);
     void profile_enable(bool on);
+    void set_reinit_from_y0(bool on);   // warm start without guessed constraints: sides from sign(y0) (default) or from A x0
     void profile_get(double *out4n) const;
     struct Impl;
 private:

@@ -194,18 +194,18 @@ def sparse_qp(n=10000, m=20000, nnz=200000, seed=20260102, box=1.0):
 
 
 def sparse_sequence(q, nsteps=50, seed=20260102):
-    """Warm-started sequence of SURVEY.md 8(d): odd k perturb g and bounds by 1 % (FIXED matrices
-    -> HOT_VECTORS), even k additionally rescale the Jacobian values by (1 + 0.01 N(0,1))
-    (VARIED -> HOT_MATRICES). Yields (QPData, matrices_changed)."""
+    """Warm-started sequence of SURVEY.md 8(d): QP_k = the base QP with g and the bounds perturbed by 1 %
+    (odd k: FIXED matrices -> hot start on vectors); even k additionally rescale the base Jacobian values by
+    (1 + 0.01 N(0,1)) (VARIED). Every member is a perturbation of the BASE problem: accumulating the
+    perturbations is a random walk of 20 000 constraint intervals, which makes the QP infeasible after ~35
+    steps (observed: status 22, confirmed by a cold start). Yields (QPData, matrices_changed)."""
     rng = np.random.default_rng(seed + 1)
-    cur = q
     for k in range(1, nsteps + 1):
-        nxt = perturb(rng, cur)
+        nxt = perturb(rng, q)
         changed = k % 2 == 0
         if changed:
-            nxt.A_val = cur.A_val * (1.0 + 0.01 * rng.normal(size=cur.A_val.shape))
-        cur = nxt
-        yield cur, changed
+            nxt.A_val = q.A_val * (1.0 + 0.01 * rng.normal(size=q.A_val.shape))
+        yield nxt, changed
 
 
 # ------------------------------------------------------------------------------------

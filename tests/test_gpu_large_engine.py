@@ -124,6 +124,7 @@ def test_hot_start_modes(capi, oracle):
         for w, v in zip(range(5), (q3.g, q3.lb, q3.ub, q3.lbA, q3.ubA)):
             s.set_vector(w, v)
         n = s.solve(capi.MODE_WARM_REINIT, 5000, x0, y0, gb)
+        qp.set_guess_constraints_from_y0(True)      # the engine's default rule for the constraints
         rc, n_or = qp.init(q3.g, q3.lb, q3.ub, q3.lbA, q3.ubA, 5000, x0=x0, y0=y0, guess_b=gb)
         same_as_oracle(s, n, qp, n_or)
 
@@ -235,6 +236,7 @@ def test_blocked_setup_matches_oracle(capi, oracle, kind):
     for w, v in zip(range(5), (q3.g, q3.lb, q3.ub, q3.lbA, q3.ubA)):
         s.set_vector(w, v)
     n = s.solve(capi.MODE_WARM_REINIT, 100000, x0, y0, gb)
+    qp.set_guess_constraints_from_y0(True)      # the engine's default rule for the constraints
     rc, n_or = qp.init(q3.g, q3.lb, q3.ub, q3.lbA, q3.ubA, 100000, x0=x0, y0=y0, guess_b=gb)
     same_as_oracle(s, n, qp, n_or)
 
@@ -254,6 +256,7 @@ def test_blocked_setup_falls_back_on_dependent_guess(capi, oracle):
     qp, rc, n_or = oracle_cold(oracle, q, 100000)
     same_as_oracle(s, n, qp, n_or)
     x0, y0, gb = s.x, s.y, s.working_set_raw()[0]
+    s.set_reinit_guess(False)                    # the reference's rule: constraint sides from A x0
     n = s.solve(capi.MODE_WARM_REINIT, 100000, x0, y0, gb)    # constraints guessed from A x0: both copies look active
     rc, n_or = qp.init(q.g, q.lb, q.ub, q.lbA, q.ubA, 100000, x0=x0, y0=y0, guess_b=gb)
     same_as_oracle(s, n, qp, n_or)

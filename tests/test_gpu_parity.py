@@ -241,12 +241,16 @@ def test_assembly_from_triplets(capi, oracle):
         assert np.array_equal(s.get_H_csc()[2], oracle.sphb_set_matval_sym(hr + 1, hc + 1, True, ooo, nv, ov.copy()))
 
 
-def test_dispatch_state_machine(capi, oracle):
+@pytest.mark.parametrize("from_y0", [True, False])
+def test_dispatch_state_machine(capi, oracle, from_y0):
     """optimizeQP's FIXED / VARIED dispatch (qpOASESInterface.cpp:137-224, 817-833) driven by
     the QPhandler call sequence of Algorithm::setupQP: cold init, hot start on vectors, status
     flip -> init(..., x_qp, y_qp, &bounds), hot start with matrices; the oracle is driven by a
     restatement of the same decisions. hs071 with c2 relaxed to an inequality (see the next
-    test for why the reference's own equality handling cannot be replayed)."""
+    test for why the reference's own equality handling cannot be replayed).
+    from_y0: the status flip re-initialises without guessed constraints; the engine's default takes their sides
+    from sign(y_qp), rsqp_set_reinit_guess(0) follows the reference (constraints from A x_qp only). Each rule
+    against the oracle run with the same rule; both must reach the same point and working set."""
     from restartsqp_amd.handler import QPhandler
     from restartsqp_amd.sqptypes import Stats
 
@@ -257,6 +261,7 @@ def test_dispatch_state_machine(capi, oracle):
 
     nlp = nlp_at(None)
     h = QPhandler(nlp["info"])
+    h.solverInterface_._s.set_reinit_guess(from_y0)
     stats = Stats()
     h.set_A(nlp["J"]); h.set_H(nlp["H"])
     h.set_bounds(1.0, nlp["x_l"], nlp["x_u"], nlp["x"], nlp["c_l"], nlp["c_u"], nlp["c"])
@@ -264,6 +269,7 @@ def test_dispatch_state_machine(capi, oracle):
     h.solveQP(stats)
     q = problems.handler_qp(nlp)
     qp, rc, n = oracle_cold(oracle, q)
+    qp.set_guess_constraints_from_y0(from_y0)
     assert stats.qp_iter == n and h.get_status() == 20
     assert np.abs(h.get_optimal_solution() - qp.x).max() < 1e-12
     # iteration 2: rejected step, trust region shrinks (update_delta): FIXED -> hotstart(vectors)
@@ -327,6 +333,50 @@ def test_stale_ubA_quirk_reports_infeasible(capi, oracle):
     assert q.lbA[1] > q.ubA[1]
     qp, rc, n = oracle_cold(oracle, q)
     assert rc == 2 and n == 0 and qp.exitflag() == 22
+
+
+@pytest.mark.parametrize("engine", [1, 2])
+def test_handle_error_iteration_limit_then_cold_reinit(capi, oracle, engine):
+    """handle_error, QP branch (reference src/qpOASESInterface.cpp:718-757): a hot start that exhausts qp_maxiter
+    leaves the solver unsolved and NOT infeasible -> plain re-init (init from scratch, :737-749) with a fresh
+    budget, which succeeds here: cold start of the first QP 31 changes; the second QP (same matrices, unrelated
+    vectors) needs 65 changes as a hot start but 43 from scratch; budget 50. optimizeQP reports 50 + 43 to
+    Stats::qp_iter and ends solved. (The other rescue -- infeasible -> re-init from the slack point x_0 -- cannot
+    SUCCEED on consistent data: every QP along the homotopy between two feasible QPs is feasible, so "infeasible"
+    means inconsistent bounds, which x_0 does not cure; its failing case is
+    test_stale_ubA_quirk_reports_infeasible.)"""
+    rng = np.random.default_rng(7024)
+    nV, nC = int(rng.integers(8, 20)), int(rng.integers(6, 20))
+    qa = problems.random_qp(rng, nV, nC)
+    xh = rng.normal(size=nV) * 3
+    A = qa.dense_A()
+    lb = xh - np.abs(rng.normal(size=nV)); ub = xh + np.abs(rng.normal(size=nV))
+    lbA = A @ xh - np.abs(rng.normal(size=nC)); ubA = A @ xh + np.abs(rng.normal(size=nC))
+    g = 10 * rng.normal(size=nV)
+    qb = QPData(nV, nC, qa.H_jc, qa.H_ir, qa.H_val, qa.A_jc, qa.A_ir, qa.A_val, g, lb, ub, lbA, ubA)
+    qp, rc, na = oracle_cold(oracle, qa)
+    rc, nh = qp.hotstart(qb.g, qb.lb, qb.ub, qb.lbA, qb.ubA, 1000)
+    qc, rc2, ncold = oracle_cold(oracle, qb)
+    assert (nV, nC, na, nh, ncold) == (18, 14, 31, 65, 43)          # the instance this test was built on
+    s = capi.Solver(nV, nC)
+    s.set_engine(engine)
+    s.set_options(qp_maxiter=50)
+    s.set_A_csc(qa.A_jc, qa.A_ir, qa.A_val); s.set_H_csc(qa.H_jc, qa.H_ir, qa.H_val)
+    for w, v in zip(range(5), (qa.g, qa.lb, qa.ub, qa.lbA, qa.ubA)):
+        s.set_vector(w, v)
+    assert s.optimize_qp() == na and s.status == 20
+    for w, v in zip(range(5), (qb.g, qb.lb, qb.ub, qb.lbA, qb.ubA)):
+        s.set_vector(w, v)
+    assert s.optimize_qp() == 50 + ncold        # the exhausted hot start + the re-init
+    assert s.status == 20 and s.is_solved()
+    wb, wc = s.working_set_raw()
+    assert np.array_equal(wb, qc.ws_bounds) and np.array_equal(wc, qc.ws_constraints)
+    assert np.abs(s.x - qc.x).max() <= 1e-9 * max(1.0, np.abs(qc.x).max())
+    # budget too small for the re-init as well: still unsolved, status "performing homotopy" (28), the adapter throws
+    s.set_options(qp_maxiter=20)
+    for w, v in zip(range(5), (qa.g, qa.lb, qa.ub, qa.lbA, qa.ubA)):
+        s.set_vector(w, v)
+    assert s.optimize_qp() == 40 and not s.is_solved() and s.status == 28
 
 
 def test_spmv_batched_parity_and_properties(capi, oracle):

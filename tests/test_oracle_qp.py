@@ -210,3 +210,30 @@ def test_unsolved_qp_headers(oracle):
             assert np.all(qp.x >= clamp(q.lb) - 1e-9) and np.all(qp.x <= clamp(q.ub) + 1e-9)
     assert got == {"hs034": (23, 2), "hs035_unbounded": (20, 7), "hs039": (20, 4), "hs046": (20, 9), "hs047": (28, 1000),
                    "hs062": (20, 4), "hs066": (23, 2), "hs067_unbounded": (20, 25), "hs070": (20, 5)}
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_warm_init_constraint_guess_rules_agree(oracle, seed):
+    """init(.., x0, y0, guessedBounds) without guessed constraints -- the FIXED <-> VARIED flip of
+    qpOASESInterface.cpp:199-207. The reference's rule (constraints only where A x0 sits on a bound) and the
+    HIP engine's default (sides from sign(y0)) are different STARTING working sets for the same strictly convex
+    QP: same solution, same final working set; the y0 rule needs far fewer working-set changes."""
+    rng = np.random.default_rng(300 + seed)
+    q = problems.random_qp(rng, 30, 40)
+    qp, rc, n = oracle_cold(oracle, q)
+    assert rc == 0
+    x0, y0, gb = qp.x.copy(), qp.y.copy(), qp.ws_bounds.copy()
+    q2 = problems.perturb(rng, q, 0.02)
+    q2.A_val = q.A_val * (1.0 + 0.01 * rng.normal(size=q.A_val.shape))
+    out = []
+    for from_y0 in (False, True):
+        w = oracle.OracleQP(q.nV, q.nC)
+        w.set_A_csc(q2.A_jc, q2.A_ir, q2.A_val); w.set_H_csc(q2.H_jc, q2.H_ir, q2.H_val)
+        w.set_guess_constraints_from_y0(from_y0)
+        rc, nw = w.init(q2.g, q2.lb, q2.ub, q2.lbA, q2.ubA, 1000, x0=x0, y0=y0, guess_b=gb)
+        assert rc == 0 and w.exitflag() == 20
+        out.append((w.x.copy(), w.ws_bounds.copy(), w.ws_constraints.copy(), nw))
+    (xa, ba, ca, na), (xb, bb, cb, nb) = out
+    assert np.abs(xa - xb).max() <= 1e-9 * max(1.0, np.abs(xa).max())
+    assert np.array_equal(ba, bb) and np.array_equal(ca, cb)
+    assert nb <= na
