@@ -239,6 +239,8 @@ int rsqp_batch_test_optimality(rsqp_batch *b, rsqp_optimality_status *out /* nq 
  * rec_dev: caller-owned device buffer of nq * stride doubles; enqueued on the batch's stream. */
 int rsqp_batch_record_stride(const rsqp_batch *b);
 int rsqp_batch_pack_records_dev(rsqp_batch *b, double *rec_dev);
+/* the same records packed on the device and copied to a host buffer (gathers that run over host memory) */
+int rsqp_batch_pack_records_host(rsqp_batch *b, double *rec_host);
 
 /* ------------------------------------------------------------------------------------ */
 /* batched sparse products, device resident -- the SpMV the roofline target names        */

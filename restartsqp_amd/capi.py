@@ -89,6 +89,7 @@ SYMBOLS = {
     "rsqp_batch_test_optimality": (C.c_int, [C.c_void_p, C.c_void_p, ip]),
     "rsqp_batch_record_stride": (C.c_int, [C.c_void_p]),
     "rsqp_batch_pack_records_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rsqp_batch_pack_records_host": (C.c_int, [C.c_void_p, dp]),
     "rsqp_time_value_refresh": (C.c_int, [C.c_void_p, C.c_int, fp, fp]),
     "rsqp_spmv_plan_create": (C.c_int, [C.c_int, C.c_int, ip, ip, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "rsqp_spmv_plan_destroy": (None, [C.c_void_p]),
@@ -446,6 +447,12 @@ class Batch:
         """fixed-stride result records (parallel.pack_records layout) into device memory at `dev_ptr`
         (nq * record_stride doubles, e.g. a torch tensor's data_ptr()); asynchronous on the batch's stream"""
         check(lib().rsqp_batch_pack_records_dev(self._h, C.c_void_p(dev_ptr)))
+
+    def pack_records(self):
+        """the same records, packed on the device and copied to the host: array [nq, record_stride]"""
+        out = np.zeros(self.nq * self.record_stride)
+        check(lib().rsqp_batch_pack_records_host(self._h, _dp(out)))
+        return out.reshape(self.nq, self.record_stride)
 
     def test_optimality(self):
         st = (OptimalityStatus * self.nq)()

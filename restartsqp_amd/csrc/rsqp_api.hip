@@ -970,6 +970,7 @@ struct rsqp_batch {
     DevBuf<int> ws_b, ws_c, status, ret, nwsr, nflips;
     DevBuf<double> Ax, ATy, Hx, kkt;
     DevBuf<int> Wb, Wc, kV, kC;
+    DevBuf<double> recbuf;   // rsqp_batch_pack_records_host
     DevBuf<long long> koV, koC;
     float last_ms = 0.f;
     bool keep_state = true;
@@ -1255,6 +1256,18 @@ extern "C" int rsqp_batch_pack_records_dev(rsqp_batch *b, double *rec_dev) {
                        b->nCmax, b->d_desc.p, b->x.p, b->y.p, b->ws_b.p, b->ws_c.p, b->status.p, b->nwsr.p, b->obj.p,
                        b->kkt.p /* null until the certificate has run */, rec_dev);
     HIPCHK(hipGetLastError());
+    return RSQP_OK;
+}
+
+extern "C" int rsqp_batch_pack_records_host(rsqp_batch *b, double *rec_host) {
+    if (!b || !rec_host) return fail(RSQP_ERR_ARG, "rsqp_batch_pack_records_host");
+    HIPCHK(hipSetDevice(b->device));
+    const size_t tot = (size_t)b->nq * rsqp_batch_record_stride(b);
+    if (b->recbuf.n < tot) HIPCHK(b->recbuf.alloc(tot, false));
+    int rc = rsqp_batch_pack_records_dev(b, b->recbuf.p);
+    if (rc != RSQP_OK) return rc;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(b->recbuf.download(rec_host, tot));
     return RSQP_OK;
 }
 

@@ -589,3 +589,27 @@ def test_fuzz_mixed_shapes_against_oracle():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "checks", "fuzz_small_vs_oracle.py"), "7", "120"],
                        capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0 and "FUZZ OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_device_side_result_records_match_host_packing(capi):
+    """rsqp_batch_pack_records_dev (what a rank hands to the RCCL all-gather of a sharded batch) writes the
+    same fixed-stride records as parallel.pack_records builds on the host from rsqp_batch_get_results: Exitflag, nWSR,
+    objective, KKT error, x, y (bounds | constraints), working sets -- on a mixed-shape batch incl. an infeasible member."""
+    from restartsqp_amd import parallel
+    probs = problems.hs_batch(40)
+    bad = problems.random_qp(np.random.default_rng(2), 5, 3)
+    bad.lbA[:] = 5.0; bad.ubA[:] = 4.0              # inconsistent: status 22
+    probs.append(bad)
+    b = capi.Batch(probs)
+    b.solve(capi.MODE_COLD, 1000)
+    ok, kkt = b.test_optimality()
+    res = b.results()
+    nVmax, nCmax = max(p.nV for p in probs), max(p.nC for p in probs)
+    stride = b.record_stride
+    assert stride == parallel.RECORD_HEAD + 3 * nVmax + 2 * nCmax
+    got = b.pack_records()          # the device kernel of rsqp_batch_pack_records_dev, then a copy to the host
+    want = parallel.pack_records(res, kkt, nVmax, nCmax)
+    assert want.shape == got.shape and np.array_equal(got, want)
+    assert got[-1, 0] == 22 and got[0, 0] == 20
+    back = parallel.unpack_record(got[3], probs[3].nV, probs[3].nC, nVmax, nCmax)
+    assert np.array_equal(back["x"], res[3]["x"]) and np.array_equal(back["ws_c"], res[3]["ws_c"])
