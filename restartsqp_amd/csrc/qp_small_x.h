@@ -27,32 +27,35 @@
 // hardware divide; the lane -> (output, slice) maps below are evaluated on every product): (a + 0.5) / b is at
 // least 0.5 / 256 away from an integer, far beyond the error of a float reciprocal
 __device__ __forceinline__ int fdiv_small(int a, int b) { return (int)(((float)a + 0.5f) * __frcp_rn((float)b)); }
-// strided dot: sum_{j = j0, j0 + st, ... < n} a[j * sa] * b[j], four independent partial sums
-__device__ __forceinline__ double xdots(const ldouble *a, int sa, const ldouble *b, int j0, int st, int n) {
+// dot over a contiguous slice: sum_{j in [j0, j1)} a[j * sa] * b[j], four independent partial sums. UNIT: sa == 1 at
+// compile time -- both operands are then contiguous, the eight loads of a trip sit at immediate offsets of one address
+// and pair up into ds_read2_b64 (4 LDS instructions + 2 FMA per two terms instead of 4 loads + address arithmetic)
+template <bool UNIT>
+__device__ __forceinline__ double xdots(const ldouble *a, int sa, const ldouble *b, int j0, int j1) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    const int da = st * sa;
-    const ldouble *pa = a + j0 * sa, *pb = b + j0;
-    int left = j0 < n ? (st == 1 ? n - j0 : fdiv_small(n - j0 + st - 1, st)) : 0;        // terms of this slice
-    for (; left >= 8; left -= 8) {                         // 16 LDS reads in flight
+    const int da = UNIT ? 1 : sa;
+    const ldouble *pa = a + j0 * da, *pb = b + j0;
+    int left = j1 - j0;
+    for (; left >= 8; left -= 8) {
         double m[8], x[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { m[u] = pa[u * da]; x[u] = pb[u * st]; }
+        for (int u = 0; u < 8; u++) { m[u] = pa[u * da]; x[u] = pb[u]; }
         s0 += m[0] * x[0]; s1 += m[1] * x[1]; s2 += m[2] * x[2]; s3 += m[3] * x[3];
         s0 += m[4] * x[4]; s1 += m[5] * x[5]; s2 += m[6] * x[6]; s3 += m[7] * x[7];
-        pa += 8 * da; pb += 8 * st;
+        pa += 8 * da; pb += 8;
     }
     if (left >= 4) {
         double m[4], x[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { m[u] = pa[u * da]; x[u] = pb[u * st]; }
+        for (int u = 0; u < 4; u++) { m[u] = pa[u * da]; x[u] = pb[u]; }
         s0 += m[0] * x[0]; s1 += m[1] * x[1]; s2 += m[2] * x[2]; s3 += m[3] * x[3];
-        pa += 4 * da; pb += 4 * st; left -= 4;
+        pa += 4 * da; pb += 4; left -= 4;
     }
-    for (; left > 0; left--) { s0 += pa[0] * pb[0]; pa += da; pb += st; }
+    for (; left > 0; left--) { s0 += pa[0] * pb[0]; pa += da; pb += 1; }
     return (s0 + s1) + (s2 + s3);
 }
 // The outputs of a product are dealt to the waves [w0, w0 + nw) in runs of opw = ceil(nout / nw); inside a wave
-// P = 64 / opw lanes share an output, each summing an interleaved slice of the inner dimension; the slices meet in
+// P = 64 / opw lanes share an output, each summing a contiguous slice of the inner dimension; the slices meet in
 // `part` behind a wave-scope fence (LDS operations of one wave execute in order) and are added in slice order
 // by the first lane of the output. Waves outside [w0, w0 + nw) skip the call, so independent products given
 // disjoint wave ranges run side by side; the caller closes the group with ONE workgroup barrier.
@@ -70,7 +73,7 @@ __device__ RSQP_XINLINE void xgemv_w(const ldouble *M, int l, int nrows, int nco
         for (int o = li; o < opw; o += 64) {
             const int og = w * opw + o;
             if (og < nout) {
-                const double t = TR ? xdots(M + og * l, 1, xv, 0, 1, ninner) : xdots(M + og, l, xv, 0, 1, ninner);
+                const double t = TR ? xdots<true>(M + og * l, 1, xv, 0, ninner) : xdots<false>(M + og, l, xv, 0, ninner);
                 out[og] = TR ? t : (base ? beta * base[og] : 0.0) + alpha * t;
             }
         }
@@ -80,7 +83,8 @@ __device__ RSQP_XINLINE void xgemv_w(const ldouble *M, int l, int nrows, int nco
     if (P > 8) P = 8;
     const int p = fdiv_small(li, opw), o = li - p * opw, og = w * opw + o;
     const bool on = p < P && og < nout;
-    if (on) pw[li] = TR ? xdots(M + og * l, 1, xv, p, P, ninner) : xdots(M + og, l, xv, p, P, ninner);
+    const int ch = P == 1 ? ninner : fdiv_small(ninner + P - 1, P), j0 = p * ch, j1 = j0 + ch < ninner ? j0 + ch : ninner;
+    if (on) pw[li] = j0 < j1 ? (TR ? xdots<true>(M + og * l, 1, xv, j0, j1) : xdots<false>(M + og, l, xv, j0, j1)) : 0.0;
     WSYNC();
     if (on && p == 0) {
         double t = pw[o];
