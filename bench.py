@@ -117,12 +117,16 @@ def spmv_roofline(capi, problems, nbatch, repeats):
         out[name] = {"ms_per_launch": st["median"], "ms_stats": st, "bytes_per_launch": bytes_one * nbatch, "achieved": gbs,
                      "kernel_variant": plan.variant(tr)[0], "idx16": plan.variant(tr)[1]}
     best = out["ATy_csc"]
-    # bytes the kernel actually streams: the plan keeps 16-bit copies of the index arrays when
-    # both dimensions are < 65536 (10 B instead of 12 B per entry)
-    streamed = (10 * nnz + 4 * (n + 1) + 8 * n + 8 * m) * nbatch
-    traffic, tfile = pmc_traffic("csx_ldsvec_spmv_pipe2<4, 3", 2.0) if nbatch == 256 else (None, None)
-    res = {"kernel": "csx_ldsvec_spmv_pipe2<4,3,ushort> (A'y on CSC = SpHbMat::transposed_times; input vector resident in LDS; "
-                     "parity: tests/test_gpu_parity.py::test_roofline_spmv_kernels_match_the_oracle)",
+    # bytes the kernel actually streams: the plan keeps 16-bit copies of the index arrays when both dimensions are
+    # < 65536 (10 B instead of 12 B per entry); the entry-parallel kernel reads one start bit per entry instead of the pointers
+    streamed = (10 * nnz + (nnz // 8 if best["kernel_variant"] == 40 else 4 * (n + 1)) + 8 * n + 8 * m) * nbatch
+    names = {40: ("csx_ldsvec_segscan<true>", "csx_ldsvec_segscan"), 35: ("csx_ldsvec_spmv_pipe2<4,3,ushort>", "csx_ldsvec_spmv_pipe2<4, 3"),
+             38: ("csx_ldsvec_spmv_pipe2<2,4,ushort>", "csx_ldsvec_spmv_pipe2<2, 4")}
+    kname, ksub = names.get(best["kernel_variant"], ("variant %d" % best["kernel_variant"], "csx_"))
+    traffic, tfile = pmc_traffic(ksub, 2.0) if nbatch == 256 else (None, None)
+    res = {"kernel": kname + " (A'y on CSC = SpHbMat::transposed_times; input vector resident in LDS; "
+                     "parity: tests/test_gpu_parity.py::test_roofline_spmv_kernels_match_the_oracle, "
+                     "test_entry_parallel_spmv_edge_patterns)",
            "bound": "hbm", "achieved": best["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": best["achieved"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tfile,
            "matrices_per_launch": nbatch, "kernel_variant": best["kernel_variant"],

@@ -135,6 +135,40 @@ std::vector<int4> build_blocks(int nmajor, const int *ptr, int chunk) {
     return blk;
 }
 
+// entry-parallel SpMV variant (sparse.hip csx_ldsvec_segscan): chunks of whole majors with at most 512 entries, one
+// "starts a major" bit per entry (16 words per chunk), the non-empty majors in order, the empty ones
+struct SegHost {
+    std::vector<int4> chunks;
+    std::vector<int> nz, empties;
+    std::vector<unsigned> bits;
+    bool ok = true;
+};
+SegHost build_seg(int nmajor, const int *ptr) {
+    constexpr int CH = 512;
+    SegHost h;
+    for (int c = 0; c < nmajor; c++) {
+        const int len = ptr[c + 1] - ptr[c];
+        if (len == 0) h.empties.push_back(c);
+        else { h.nz.push_back(c); if (len > CH) h.ok = false; }
+    }
+    if (!h.ok) return h;
+    size_t i = 0;
+    while (i < h.nz.size()) {
+        const int e0 = ptr[h.nz[i]];
+        size_t j = i;
+        unsigned w[16] = {0};
+        while (j < h.nz.size() && ptr[h.nz[j] + 1] - e0 <= CH) {
+            const int b = ptr[h.nz[j]] - e0;
+            w[b >> 5] |= 1u << (b & 31);
+            j++;
+        }
+        h.chunks.push_back(make_int4(e0, (int)i, ptr[h.nz[j - 1] + 1] - e0, 0));
+        h.bits.insert(h.bits.end(), w, w + 16);
+        i = j;
+    }
+    return h;
+}
+
 int exitflag_of(int status_word, int ret) {
     // qpOASESInterface::get_status (src/qpOASESInterface.cpp:332-357)
     if (status_word >= 200) return RSQP_QPERROR_UNBOUNDED;
@@ -1310,6 +1344,12 @@ struct rsqp_spmv_plan {
     DevBuf<int4> blk_c, blk_r;
     DevBuf<int> slice_c, slice_r;   // one slice = all majors (1 workgroup per member)
     DevBuf<unsigned short> ir16, ci16;  // 16-bit index copies (vector length < 65536)
+    // entry-parallel variant 40: per orientation (t: CSC majors = columns, n: CSR majors = rows)
+    DevBuf<int4> seg_chunks[2];
+    DevBuf<int> seg_nz[2], seg_empt[2];
+    DevBuf<unsigned> seg_bits[2];       // one copy per member, like the index arrays
+    int seg_nchunks[2] = {0, 0}, seg_nempty[2] = {0, 0};
+    bool seg_ok[2] = {false, false};
     bool use16 = false;
     int variant_t = 0, variant_n = 0;  // 0: stream kernel; >0: LDS-resident-vector kernel
     int nslices = 1;
@@ -1373,19 +1413,43 @@ extern "C" int rsqp_spmv_plan_create(int nrow, int ncol, const int *jc, const in
         HIPCHK(hipMemcpy(p->rp.p + m * (nrow + 1), r.rp.data(), sizeof(int) * (nrow + 1), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(p->ci.p + m * nnz, r.ci.data(), sizeof(int) * nnz, hipMemcpyHostToDevice));
     }
-    HIPCHK(p->val.alloc(B * nnz + 2)); HIPCHK(p->rval.alloc(B * nnz + 2));
+    HIPCHK(p->val.alloc(B * nnz + 528)); HIPCHK(p->rval.alloc(B * nnz + 528));   // variant 40 reads (and masks) up to 520 entries past a chunk
     {
         const char *e16 = getenv("RSQP_SPMV_IDX16");
         p->use16 = nrow < 65536 && ncol < 65536 && !(e16 && atoi(e16) == 0);
         if (p->use16) {
             std::vector<unsigned short> a16(ir, ir + nnz), c16(r.ci.begin(), r.ci.end());
-            HIPCHK(p->ir16.alloc(B * nnz + 4, true)); HIPCHK(p->ci16.alloc(B * nnz + 4, true));
+            HIPCHK(p->ir16.alloc(B * nnz + 528, true)); HIPCHK(p->ci16.alloc(B * nnz + 528, true));
             for (size_t m = 0; m < B; m++) {
                 HIPCHK(hipMemcpy(p->ir16.p + m * nnz, a16.data(), 2 * nnz, hipMemcpyHostToDevice));
                 HIPCHK(hipMemcpy(p->ci16.p + m * nnz, c16.data(), 2 * nnz, hipMemcpyHostToDevice));
             }
         }
     }
+    // entry-parallel kernel (variant 40): needs the 16-bit indices and majors of at most 512 entries; preferred over the
+    // sub-wave-per-major kernels wherever those would be chosen (measured 0.099 vs 0.135 ms on the 10k x 20k shape)
+    if (p->use16) {
+        const char *ev = getenv("RSQP_SPMV_VARIANT");
+        const int forced = ev ? atoi(ev) : -1;
+        for (int o = 0; o < 2; o++) {
+            SegHost h = build_seg(o == 0 ? ncol : nrow, o == 0 ? jc : r.rp.data());
+            if (!h.ok || h.chunks.empty()) continue;
+            HIPCHK(p->seg_chunks[o].from(h.chunks)); HIPCHK(p->seg_nz[o].from(h.nz));
+            HIPCHK(p->seg_empt[o].alloc(std::max<size_t>(h.empties.size(), 1))); HIPCHK(p->seg_empt[o].upload(h.empties.data(), h.empties.size()));
+            HIPCHK(p->seg_bits[o].alloc(B * h.bits.size(), false));
+            for (size_t m = 0; m < B; m++)
+                HIPCHK(hipMemcpy(p->seg_bits[o].p + m * h.bits.size(), h.bits.data(), 4 * h.bits.size(), hipMemcpyHostToDevice));
+            p->seg_nchunks[o] = (int)h.chunks.size(); p->seg_nempty[o] = (int)h.empties.size();
+            p->seg_ok[o] = true;
+            // measured on the 10k x 20k shape (tools/spmv_bound_check.py): majors of ~20 entries 0.127 ms vs 0.135 ms for the
+            // sub-wave kernel <4,3>; majors of ~10 entries 0.139 vs 0.135 ms for <2,4> -- the scan's fixed cost per lane
+            // (the kernel is bound by its VALU instruction count, ~0.9 per entry) needs long majors to pay off
+            int &var = o == 0 ? p->variant_t : p->variant_n;
+            if (forced < 0 ? var == 35 : forced == 40) var = 40;
+        }
+    }
+    if (p->variant_t == 40 && !p->seg_ok[0]) p->variant_t = 0;
+    if (p->variant_n == 40 && !p->seg_ok[1]) p->variant_n = 0;
     HIPCHK(p->vin_r.alloc(B * nrow)); HIPCHK(p->vin_c.alloc(B * ncol));
     HIPCHK(p->vout_r.alloc(B * nrow)); HIPCHK(p->vout_c.alloc(B * ncol));
     guard.p = nullptr;
@@ -1419,7 +1483,13 @@ extern "C" int rsqp_spmv_plan_run(rsqp_spmv_plan *p, int transposed, int repeats
     HIPCHK(hipEventRecord(p->ev0, p->stream));
     for (int r = 0; r < repeats; r++) {
         hipError_t e;
-        if (transposed && p->variant_t > 0)
+        if (transposed && p->variant_t == 40)
+            e = rsqp_launch_spmv_segscan(p->nrow, p->seg_chunks[0].p, p->seg_nchunks[0], p->seg_nz[0].p, p->seg_empt[0].p, p->seg_nempty[0],
+                                         p->seg_bits[0].p, p->ir16.p, p->val.p, p->vin_r.p, p->vout_c.p, p->nbatch, p->nnz, p->nrow, p->ncol, p->stream);
+        else if (!transposed && p->variant_n == 40)
+            e = rsqp_launch_spmv_segscan(p->ncol, p->seg_chunks[1].p, p->seg_nchunks[1], p->seg_nz[1].p, p->seg_empt[1].p, p->seg_nempty[1],
+                                         p->seg_bits[1].p, p->ci16.p, p->rval.p, p->vin_c.p, p->vout_r.p, p->nbatch, p->nnz, p->ncol, p->nrow, p->stream);
+        else if (transposed && p->variant_t > 0)
             e = rsqp_launch_spmv_ldsvec(p->variant_t, p->nrow, p->nslices, p->slice_c.p, p->jc.p, p->ir.p, p->use16 ? p->ir16.p : nullptr, p->val.p, p->vin_r.p,
                                         p->vout_c.p, p->nbatch, p->ncol + 1, p->nnz, p->nrow, p->ncol, p->stream);
         else if (!transposed && p->variant_n > 0)

@@ -34,6 +34,12 @@ hipError_t rsqp_launch_spmv_ldsvec(int variant, int nminor, int nslices, const i
                                    const int *idx, const unsigned short *idx16, const double *val, const double *in,
                                    double *out, int nbatch, long long ptr_stride, long long nnz_stride, long long in_stride,
                                    long long out_stride, hipStream_t stream);
+// entry-parallel variant (40): chunks of whole majors with <= 512 entries, one start bit per entry (16 words per chunk
+// and member), list of the non-empty majors, list of the empty ones
+hipError_t rsqp_launch_spmv_segscan(int nminor, const int4 *chunks, int nchunks, const int *nzlist, const int *empties,
+                                    int nempty, const unsigned *sbits, const unsigned short *idx16, const double *val,
+                                    const double *in, double *out, int nbatch, long long nnz_stride, long long in_stride,
+                                    long long out_stride, hipStream_t stream);
 hipError_t rsqp_launch_scatter(int n, const int *order, const int *tmap, const double *tv, double *val,
                                hipStream_t stream);
 hipError_t rsqp_launch_gather(int n, const int *perm, const double *src, double *dst, hipStream_t stream);

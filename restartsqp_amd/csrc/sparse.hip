@@ -296,6 +296,209 @@ csx_ldsvec_spmv_pipe2(int nminor, int nslices, const int *__restrict__ slice, co
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Entry-parallel batched product with the input vector resident in LDS (variant 40). The sub-wave-per-major kernels
+// above read every major as its own little segment: a wave instruction touches 16 pieces of 64 bytes and the value
+// stream runs at 4.4 TB/s, while the pure stream of this shape runs at 6.2 TB/s (tools/spmv_bound_check.py 50).
+// Here the plan cuts the entry stream into CHUNKS of whole majors with at most 512 entries; a wave owns a chunk
+// (no sum ever crosses a wave), a lane owns 8 CONSECUTIVE entries of it:
+//   * loads: 16 bytes of indices per lane = 1 KB contiguous per wave; 4 x 16 bytes of values per lane (the four
+//     instructions of a wave sweep the same 4 KB, sector by sector);
+//   * "this entry starts a major" is one bit per entry (a byte per lane, 64 bytes per chunk); the pointer array is
+//     never read -- the ordinal of a major is a prefix count of those bits;
+//   * a lane sums its 8 products sequentially and stores the majors that lie wholly inside it; the piece running in
+//     from the previous lanes and the piece running out meet in ONE segmented scan over the 64 lanes (DPP row shifts
+//     and row broadcasts: no LDS traffic), after which the lanes holding the end of a major store its sum.
+// Fixed-shape tree per major => run-to-run deterministic; not the entry order of the reference loop (tolerance test).
+// ---------------------------------------------------------------------------------
+struct SegPlanView {
+    const int4 *chunks;       // per chunk: {first entry, ordinal of its first major in nzlist, entries, 0}
+    const int *nzlist;        // the non-empty majors, in order
+    const int *empties;       // the empty majors (their output is zero)
+    int nchunks, nempty;
+};
+
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64(double x) {      // lanes without a source (or in a masked row) receive 0.0
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_i32(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, ROWMASK, 0xf, false); }
+// one round of the inclusive segmented scan: (pv, pf) is the aggregate of the lanes before, where there is one
+// DIRECT: the pattern has no empty major, so the ordinal of a major IS its index (no look-up in the store path)
+template <bool DIRECT>
+__global__ void __launch_bounds__(LV_NT)
+csx_ldsvec_segscan(int nminor, SegPlanView sp, const unsigned char *__restrict__ sbits, const unsigned short *__restrict__ idx,
+                   const double *__restrict__ val, const double *__restrict__ in, double *__restrict__ out,
+                   long long nnz_stride, long long in_stride, long long out_stride) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];
+    const int m = blockIdx.x;
+    idx += m * nnz_stride; val += m * nnz_stride; in += m * in_stride; out += m * out_stride;
+    sbits += (long long)m * sp.nchunks * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NWV = LV_NT / 64;
+    auto put = [&](int o, double t) { out[DIRECT ? o : sp.nzlist[o]] = t; };
+    struct Ld { double2 v[4]; ushort4 ja, jb; unsigned char b; };
+    // lane l holds the entries [8 l, 8 l + 8) of the chunk; what lies past the chunk (the next chunk's entries, or
+    // the padding behind the last member) is loaded and masked
+    auto issue = [&](const int4 &c, int kk, Ld &d) {
+        const long long e = (long long)c.x + 8 * lane;
+#pragma unroll
+        for (int q = 0; q < 4; q++) __builtin_memcpy(&d.v[q], val + e + 2 * q, 16);
+        __builtin_memcpy(&d.ja, idx + e, 8);
+        __builtin_memcpy(&d.jb, idx + e + 4, 8);
+        d.b = kk < sp.nchunks ? sbits[kk * 64 + lane] : (unsigned char)0;
+    };
+    int k = wave;
+    int4 ch = k < sp.nchunks ? sp.chunks[k] : make_int4(0, 0, 0, 0);
+    Ld cur, nxt;
+    issue(ch, k, cur);                       // the first chunk's loads go out before the vector is staged
+    for (int i = 2 * tid; i + 1 < nminor; i += 2 * LV_NT)
+        *reinterpret_cast<double2 *>(xs + i) = *reinterpret_cast<const double2 *>(in + i);
+    if (tid == 0 && (nminor & 1)) xs[nminor - 1] = in[nminor - 1];
+    for (int i = tid; i < sp.nempty; i += LV_NT) out[sp.empties[i]] = 0.0;
+    __syncthreads();
+    for (; k < sp.nchunks; k += NWV) {
+        const int kn = k + NWV;
+        const int4 chn = kn < sp.nchunks ? sp.chunks[kn] : make_int4(0, 0, 0, 0);
+        issue(chn, kn, nxt);                 // next chunk in flight while this one is reduced
+        const int n = ch.z, want = 8 * lane;
+        const unsigned bits = cur.b;         // bit i: entry want + i starts a major (0 beyond the chunk)
+        const int nflag = __popc(bits);
+        // starts in the lanes before this one -> ordinal of the first major that starts in this lane
+        int sc = nflag;
+        sc += dpp_i32<0x111, 0xf>(sc); sc += dpp_i32<0x112, 0xf>(sc); sc += dpp_i32<0x114, 0xf>(sc); sc += dpp_i32<0x118, 0xf>(sc);
+        sc += dpp_i32<0x142, 0xa>(sc); sc += dpp_i32<0x143, 0xc>(sc);
+        const int ord0 = ch.y + sc - nflag;
+        const unsigned short jj[8] = {cur.ja.x, cur.ja.y, cur.ja.z, cur.ja.w, cur.jb.x, cur.jb.y, cur.jb.z, cur.jb.w};
+        // sequential pass over the lane's entries: head = the part before the first start, majors that lie wholly
+        // inside the lane are stored at once, acc = the part after the last start
+        double xv[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) xv[i] = xs[jj[i]];       // eight independent gathers (always inside the vector)
+        double acc = 0.0, head = 0.0;
+        int seen = 0, nstart = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const double a = (i & 1) ? cur.v[i >> 1].y : cur.v[i >> 1].x;
+            const double pi = want + i < n ? a * xv[i] : 0.0;
+            const int f = (bits >> i) & 1;
+            if (f & seen) put(ord0 + nstart - 1, acc);      // a major that lies wholly inside the lane (predicated store)
+            head = (f & (seen ^ 1)) ? acc : head;
+            acc = f ? 0.0 : acc;
+            seen |= f;
+            nstart += f;
+            acc += pi;
+        }
+        // segmented inclusive scan over the lanes of (piece running out of the lane, any start in the lane)
+        double sv = acc;
+        int sf = seen;
+#define SEG_ROUND(CTRL, ROWMASK)                                         \
+        do {                                                             \
+            const double pv_ = dpp_f64<CTRL, ROWMASK>(sv);               \
+            const int pf_ = dpp_i32<CTRL, ROWMASK>(sf);                  \
+            if (!sf) sv += pv_;                                          \
+            sf |= pf_;                                                   \
+        } while (0)
+        SEG_ROUND(0x111, 0xf); SEG_ROUND(0x112, 0xf); SEG_ROUND(0x114, 0xf); SEG_ROUND(0x118, 0xf);   // row_shr 1, 2, 4, 8
+        SEG_ROUND(0x142, 0xa);      // row_bcast15 into rows 1 and 3
+        SEG_ROUND(0x143, 0xc);      // row_bcast31 into rows 2 and 3
+#undef SEG_ROUND
+        double ex = __shfl_up(sv, 1);        // the sum running into this lane
+        if (lane == 0) ex = 0.0;
+        int nextstart = __shfl_down((int)(bits & 1u), 1);
+        if (lane == 63) nextstart = 1;
+        const int lastlane = (n - 1) >> 3;
+        const bool ends_here = lane == lastlane || (lane < lastlane && nextstart);
+        if (lane <= lastlane) {
+            if (seen) {
+                if (!(bits & 1u)) put(ord0 - 1, ex + head);            // runs in from before, ends inside this lane
+                if (ends_here) put(ord0 + nflag - 1, acc);
+            } else if (ends_here) {
+                put(ord0 - 1, ex + acc);
+            }
+        }
+        ch = chn;
+        cur = nxt;
+    }
+}
+
+#ifdef RSQP_SPMV_EXPERIMENT
+// TIMING EXPERIMENT ONLY (never selected by the plan): upper bound of an entry-parallel design -- every wave streams
+// contiguous 128-entry steps fully coalesced (16-byte value + 4-byte index loads), gathers from the LDS vector and
+// just accumulates; the result is meaningless (no segmented reduction)
+template <int U>
+__global__ void __launch_bounds__(LV_NT)
+csx_ldsvec_streambound(int nminor, int nnz, const unsigned short *__restrict__ idx, const double *__restrict__ val,
+                       const double *__restrict__ in, double *__restrict__ out, long long nnz_stride, long long in_stride,
+                       long long out_stride) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];
+    const int m = blockIdx.x;
+    idx += m * nnz_stride; val += m * nnz_stride; in += m * in_stride; out += m * out_stride;
+    const int tid = threadIdx.x;
+    for (int i = 2 * tid; i + 1 < nminor; i += 2 * LV_NT)
+        *reinterpret_cast<double2 *>(xs + i) = *reinterpret_cast<const double2 *>(in + i);
+    __syncthreads();
+    double s = 0.0;
+    const int step = 2 * LV_NT * U;
+    for (int base = 0; base < nnz; base += step) {
+        double2 v[U];
+        ushort2 j[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int e = base + u * 2 * LV_NT + 2 * tid;
+            e = e + 1 < nnz ? e : nnz - 2;
+            __builtin_memcpy(&v[u], val + e, 16);
+            __builtin_memcpy(&j[u], idx + e, 4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) s += v[u].x * xs[j[u].x] + v[u].y * xs[j[u].y];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((tid & 63) == 0) out[tid >> 6] = s;
+}
+// the load pattern of csx_ldsvec_segscan alone: 8 consecutive entries per lane (4 x 16 B of values at a 64-B lane
+// stride, 16 B of indices), chunks of 512 entries per wave, next chunk in flight; no reduction logic
+__global__ void __launch_bounds__(LV_NT)
+csx_ldsvec_lanegroup_bound(int nminor, int nnz, const unsigned short *__restrict__ idx, const double *__restrict__ val,
+                           const double *__restrict__ in, double *__restrict__ out, long long nnz_stride, long long in_stride,
+                           long long out_stride) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];
+    const int m = blockIdx.x;
+    idx += m * nnz_stride; val += m * nnz_stride; in += m * in_stride; out += m * out_stride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = 2 * tid; i + 1 < nminor; i += 2 * LV_NT)
+        *reinterpret_cast<double2 *>(xs + i) = *reinterpret_cast<const double2 *>(in + i);
+    __syncthreads();
+    double s = 0.0;
+    const int nch = nnz / 512;
+    double2 v[4], vn[4];
+    ushort4 ja, jb, jan, jbn;
+    auto issue = [&](int k, double2 *vv, ushort4 &a, ushort4 &b) {
+        const long long e = (long long)(k < nch ? k : 0) * 512 + 8 * lane + 1;    // + 1: misaligned like a real chunk start
+#pragma unroll
+        for (int q = 0; q < 4; q++) __builtin_memcpy(&vv[q], val + e + 2 * q, 16);
+        __builtin_memcpy(&a, idx + e, 8);
+        __builtin_memcpy(&b, idx + e + 4, 8);
+    };
+    issue(wave, v, ja, jb);
+    for (int k = wave; k < nch; k += LV_NT / 64) {
+        issue(k + LV_NT / 64, vn, jan, jbn);
+        s += v[0].x * xs[ja.x] + v[0].y * xs[ja.y] + v[1].x * xs[ja.z] + v[1].y * xs[ja.w] +
+             v[2].x * xs[jb.x] + v[2].y * xs[jb.y] + v[3].x * xs[jb.z] + v[3].y * xs[jb.w];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = vn[q];
+        ja = jan; jb = jbn;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[wave] = s;
+}
+#endif
+
 __global__ void scatter_values(int n, const int *__restrict__ order, const int *__restrict__ tmap,
                                const double *__restrict__ tv, double *__restrict__ val) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -529,9 +732,51 @@ hipError_t rsqp_launch_spmv_ldsvec(int variant, int nminor, int nslices, const i
     case 37: L2_LAUNCH(8, 2); break;
     case 38: L2_LAUNCH(2, 4); break;
 #undef L2_LAUNCH
+#ifdef RSQP_SPMV_EXPERIMENT
+    case 52: {
+        static std::atomic<unsigned long long> s5{0};
+        if (!idx16) return hipErrorInvalidValue;
+        rsqp_allow_full_lds(reinterpret_cast<const void *>(&csx_ldsvec_lanegroup_bound), s5, 160 * 1024);
+        hipLaunchKernelGGL(csx_ldsvec_lanegroup_bound, dim3(nbatch), dim3(LV_NT), lds, stream, nminor, (int)nnz_stride, idx16, val, in, out, nnz_stride, in_stride, out_stride);
+        break;
+    }
+    case 50: case 51: {
+        static std::atomic<unsigned long long> s4{0}, s8{0};
+        if (!idx16) return hipErrorInvalidValue;
+        if (variant == 50) {
+            rsqp_allow_full_lds(reinterpret_cast<const void *>(&csx_ldsvec_streambound<4>), s4, 160 * 1024);
+            hipLaunchKernelGGL((csx_ldsvec_streambound<4>), dim3(nbatch), dim3(LV_NT), lds, stream, nminor, (int)nnz_stride, idx16, val, in, out, nnz_stride, in_stride, out_stride);
+        } else {
+            rsqp_allow_full_lds(reinterpret_cast<const void *>(&csx_ldsvec_streambound<8>), s8, 160 * 1024);
+            hipLaunchKernelGGL((csx_ldsvec_streambound<8>), dim3(nbatch), dim3(LV_NT), lds, stream, nminor, (int)nnz_stride, idx16, val, in, out, nnz_stride, in_stride, out_stride);
+        }
+        break;
+    }
+#endif
     default: return hipErrorInvalidValue;
     }
 #undef LV_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t rsqp_launch_spmv_segscan(int nminor, const int4 *chunks, int nchunks, const int *nzlist, const int *empties,
+                                    int nempty, const unsigned *sbits, const unsigned short *idx16, const double *val,
+                                    const double *in, double *out, int nbatch, long long nnz_stride, long long in_stride,
+                                    long long out_stride, hipStream_t stream) {
+    const size_t lds = (size_t)nminor * 8 + 16;
+    if (lds > 160 * 1024 || !idx16 || nchunks <= 0) return hipErrorInvalidValue;
+    static std::atomic<unsigned long long> set0_{0}, set1_{0};
+    SegPlanView sp;
+    sp.chunks = chunks; sp.nzlist = nzlist; sp.empties = empties; sp.nchunks = nchunks; sp.nempty = nempty;
+    if (nempty == 0) {
+        rsqp_allow_full_lds(reinterpret_cast<const void *>(&csx_ldsvec_segscan<true>), set1_, 160 * 1024);
+        hipLaunchKernelGGL(csx_ldsvec_segscan<true>, dim3(nbatch), dim3(LV_NT), lds, stream, nminor, sp,
+                           reinterpret_cast<const unsigned char *>(sbits), idx16, val, in, out, nnz_stride, in_stride, out_stride);
+    } else {
+        rsqp_allow_full_lds(reinterpret_cast<const void *>(&csx_ldsvec_segscan<false>), set0_, 160 * 1024);
+        hipLaunchKernelGGL(csx_ldsvec_segscan<false>, dim3(nbatch), dim3(LV_NT), lds, stream, nminor, sp,
+                           reinterpret_cast<const unsigned char *>(sbits), idx16, val, in, out, nnz_stride, in_stride, out_stride);
+    }
     return hipGetLastError();
 }
 

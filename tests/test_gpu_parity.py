@@ -425,7 +425,7 @@ def test_spmv_batched_parity_and_properties(capi, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", ["plain_10k_x_20k", "handler_J_I_mI", "plain_int_index"])
+@pytest.mark.parametrize("shape", ["plain_10k_x_20k", "handler_J_I_mI", "plain_int_index", "plain_subwave_kernels"])
 def test_roofline_spmv_kernels_match_the_oracle(capi, oracle, shape, monkeypatch):
     """The kernels behind `roofline_spmv` in bench.py (profiles/*kernel_stats*:
     csx_ldsvec_spmv_pipe2<4,3,unsigned short> for A'y and <2,4,unsigned short> for Ax) at the benchmarked
@@ -449,9 +449,13 @@ def test_roofline_spmv_kernels_match_the_oracle(capi, oracle, shape, monkeypatch
         n, m, nnz = 10000, 20000, 200000
         jc, ir, rng = problems.sparse_pattern(n, m, nnz)
         ncol, ident = n, None
-        expect_t, expect_n = 35, 38         # 20 entries per column -> <4,3>; 10 per row -> <2,4>
+        expect_t, expect_n = 40, 38         # 20 entries per column -> entry-parallel csx_ldsvec_segscan; 10 per row -> <2,4>
+    if shape == "plain_subwave_kernels":
+        monkeypatch.setenv("RSQP_SPMV_VARIANT", "35")   # csx_ldsvec_spmv_pipe2<4,3,unsigned short> for both products
+        expect_t, expect_n = 35, 35
     if shape == "plain_int_index":
         monkeypatch.setenv("RSQP_SPMV_IDX16", "0")     # the <.., int> instantiation (dimensions >= 65 536 take it by themselves)
+        expect_t = 35                                   # the entry-parallel kernel exists for 16-bit indices only
     nb = 64
     vals = rng.normal(size=(nb, nnz))
     if ident is not None:
@@ -613,3 +617,42 @@ def test_device_side_result_records_match_host_packing(capi):
     assert got[-1, 0] == 22 and got[0, 0] == 20
     back = parallel.unpack_record(got[3], probs[3].nV, probs[3].nC, nVmax, nCmax)
     assert np.array_equal(back["x"], res[3]["x"]) and np.array_equal(back["ws_c"], res[3]["ws_c"])
+
+
+def test_entry_parallel_spmv_edge_patterns(capi, oracle, monkeypatch):
+    """csx_ldsvec_segscan (SpMV variant 40) on the patterns that stress its segmented scan: empty majors, majors of a
+    single entry (eight starts in one lane), majors as long as a whole chunk (512 entries) and just below, starts on
+    every position of a lane, a last chunk of one entry -- against the oracle's SpHbMat::times / transposed_times
+    (reference src/SpHbMat.cpp:659-737). A major longer than a chunk makes the plan fall back to the sub-wave kernels."""
+    monkeypatch.setenv("RSQP_SPMV_VARIANT", "40")
+    rng = np.random.default_rng(77)
+    eps = 2.3e-16
+
+    def check(nrow, ncol, col_lengths, nb=64, expect40=True):
+        jc = np.concatenate([[0], np.cumsum(col_lengths)]).astype(np.int32)
+        ir = np.concatenate([np.sort(rng.choice(nrow, size=int(k), replace=False)) for k in col_lengths] + [np.zeros(0, int)]).astype(np.int32)
+        nnz = int(jc[-1])
+        vals = rng.normal(size=(nb, nnz)); x = rng.normal(size=(nb, ncol)); y = rng.normal(size=(nb, nrow))
+        p = capi.SpmvPlan(nrow, ncol, jc, ir, nb)
+        vt, _ = p.variant(True)
+        assert (vt == 40) == expect40, (vt, expect40)
+        p.upload(vals, x, transposed=False); p.upload(None, y, transposed=True)
+        p.run(False); p.run(True)
+        Ax, ATy = p.download(False), p.download(True)
+        per_col = max(int(max(col_lengths)), 1); per_row = max(int(np.bincount(ir, minlength=nrow).max()), 1)
+        for k in (0, 13, nb - 1):
+            ax = oracle.sphb_times(nrow, ncol, jc, ir, vals[k], x[k])
+            aty = oracle.sphb_transposed_times(nrow, ncol, jc, ir, vals[k], y[k])
+            ax_abs = oracle.sphb_times(nrow, ncol, jc, ir, np.abs(vals[k]), np.abs(x[k]))
+            aty_abs = oracle.sphb_transposed_times(nrow, ncol, jc, ir, np.abs(vals[k]), np.abs(y[k]))
+            assert np.all(np.abs(ATy[k] - aty) <= 4 * per_col * eps * aty_abs + 1e-300), ("A'y", k)
+            assert np.all(np.abs(Ax[k] - ax) <= 4 * per_row * eps * ax_abs + 1e-300), ("Ax", k)
+        p.close()
+
+    check(900, 700, rng.integers(0, 40, size=700))                       # mixed lengths incl. empty columns
+    check(800, 800, np.ones(800, int))                                   # every major a single entry
+    check(2000, 40, np.array([512, 511, 1, 0, 513 - 1, 7, 8, 9] * 5))    # whole-chunk majors, neighbours of every size
+    check(600, 1025, np.concatenate([np.full(1024, 4), [1]]))            # 4 096 entries = 8 full chunks, then a chunk of one entry
+    lens = np.zeros(300, int); lens[::3] = 23                            # two empty columns between the filled ones
+    check(500, 300, lens)
+    check(3000, 10, np.array([600] + [5] * 9), expect40=False)           # a major longer than a chunk: not this kernel
