@@ -120,7 +120,7 @@ def spmv_roofline(capi, problems, nbatch, repeats):
     # bytes the kernel actually streams: the plan keeps 16-bit copies of the index arrays when both dimensions are
     # < 65536 (10 B instead of 12 B per entry); the entry-parallel kernel reads one start bit per entry instead of the pointers
     streamed = (10 * nnz + (nnz // 8 if best["kernel_variant"] == 40 else 4 * (n + 1)) + 8 * n + 8 * m) * nbatch
-    names = {40: ("csx_ldsvec_segscan<true>", "csx_ldsvec_segscan"), 35: ("csx_ldsvec_spmv_pipe2<4,3,ushort>", "csx_ldsvec_spmv_pipe2<4, 3"),
+    names = {40: ("csx_ldsvec_segscan", "csx_ldsvec_segscan"), 35: ("csx_ldsvec_spmv_pipe2<4,3,ushort>", "csx_ldsvec_spmv_pipe2<4, 3"),
              38: ("csx_ldsvec_spmv_pipe2<2,4,ushort>", "csx_ldsvec_spmv_pipe2<2, 4")}
     kname, ksub = names.get(best["kernel_variant"], ("variant %d" % best["kernel_variant"], "csx_"))
     traffic, tfile = pmc_traffic(ksub, 2.0) if nbatch == 256 else (None, None)

@@ -135,7 +135,7 @@ std::vector<int4> build_blocks(int nmajor, const int *ptr, int chunk) {
     return blk;
 }
 
-// entry-parallel SpMV variant (sparse.hip csx_ldsvec_segscan): chunks of whole majors with at most 512 entries, one
+// entry-parallel SpMV variant (sparse.hip csx_ldsvec_segscan): chunks of whole majors with at most 512 entries and 128 majors, one
 // "starts a major" bit per entry (16 words per chunk), the non-empty majors in order, the empty ones
 struct SegHost {
     std::vector<int4> chunks;
@@ -157,12 +157,15 @@ SegHost build_seg(int nmajor, const int *ptr) {
         const int e0 = ptr[h.nz[i]];
         size_t j = i;
         unsigned w[16] = {0};
-        while (j < h.nz.size() && ptr[h.nz[j] + 1] - e0 <= CH) {
+        while (j < h.nz.size() && ptr[h.nz[j] + 1] - e0 <= CH && j - i < 128) {     // <= 128 majors: the kernel's LDS window
             const int b = ptr[h.nz[j]] - e0;
             w[b >> 5] |= 1u << (b & 31);
             j++;
         }
-        h.chunks.push_back(make_int4(e0, (int)i, ptr[h.nz[j - 1] + 1] - e0, 0));
+        const int nent = ptr[h.nz[j - 1] + 1] - e0;
+        if (nent < CH) w[nent >> 5] |= 1u << (nent & 31);      // one bit behind the last entry: what a lane loads past the chunk
+                                                               // becomes a dummy major that the kernel never stores
+        h.chunks.push_back(make_int4(e0, (int)i, nent, (int)(j - i)));
         h.bits.insert(h.bits.end(), w, w + 16);
         i = j;
     }
@@ -1427,7 +1430,7 @@ extern "C" int rsqp_spmv_plan_create(int nrow, int ncol, const int *jc, const in
         }
     }
     // entry-parallel kernel (variant 40): needs the 16-bit indices and majors of at most 512 entries; preferred over the
-    // sub-wave-per-major kernels wherever those would be chosen (measured 0.099 vs 0.135 ms on the 10k x 20k shape)
+    // sub-wave-per-major kernels wherever those would be chosen (see the measurements below)
     if (p->use16) {
         const char *ev = getenv("RSQP_SPMV_VARIANT");
         const int forced = ev ? atoi(ev) : -1;
@@ -1441,11 +1444,12 @@ extern "C" int rsqp_spmv_plan_create(int nrow, int ncol, const int *jc, const in
                 HIPCHK(hipMemcpy(p->seg_bits[o].p + m * h.bits.size(), h.bits.data(), 4 * h.bits.size(), hipMemcpyHostToDevice));
             p->seg_nchunks[o] = (int)h.chunks.size(); p->seg_nempty[o] = (int)h.empties.size();
             p->seg_ok[o] = true;
-            // measured on the 10k x 20k shape (tools/spmv_bound_check.py): majors of ~20 entries 0.127 ms vs 0.135 ms for the
-            // sub-wave kernel <4,3>; majors of ~10 entries 0.139 vs 0.135 ms for <2,4> -- the scan's fixed cost per lane
-            // (the kernel is bound by its VALU instruction count, ~0.9 per entry) needs long majors to pay off
+            // measured on the 10k x 20k shape (tools/spmv_bound_check.py): majors of ~20 entries 0.120 ms vs 0.133 ms for the
+            // sub-wave kernel <4,3>; majors of ~10 entries 0.128 vs 0.136 ms for <2,4>. Majors shorter than ~8 entries
+            // (the [J I -I] columns) would leave the 128-major chunks mostly empty: those stay with <2,4>
             int &var = o == 0 ? p->variant_t : p->variant_n;
-            if (forced < 0 ? var == 35 : forced == 40) var = 40;
+            const double avg = (double)p->nnz / std::max<size_t>(h.nz.size(), 1);
+            if (forced < 0 ? (var == 35 || (var == 38 && avg >= 8.0)) : forced == 40) var = 40;
         }
     }
     if (p->variant_t == 40 && !p->seg_ok[0]) p->variant_t = 0;

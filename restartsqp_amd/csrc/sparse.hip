@@ -312,7 +312,7 @@ csx_ldsvec_spmv_pipe2(int nminor, int nslices, const int *__restrict__ slice, co
 // Fixed-shape tree per major => run-to-run deterministic; not the entry order of the reference loop (tolerance test).
 // ---------------------------------------------------------------------------------
 struct SegPlanView {
-    const int4 *chunks;       // per chunk: {first entry, ordinal of its first major in nzlist, entries, 0}
+    const int4 *chunks;       // per chunk: {first entry, ordinal of its first major in nzlist, entries, majors}
     const int *nzlist;        // the non-empty majors, in order
     const int *empties;       // the empty majors (their output is zero)
     int nchunks, nempty;
@@ -329,7 +329,9 @@ template <int CTRL, int ROWMASK>
 __device__ __forceinline__ int dpp_i32(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, ROWMASK, 0xf, false); }
 // one round of the inclusive segmented scan: (pv, pf) is the aggregate of the lanes before, where there is one
 // DIRECT: the pattern has no empty major, so the ordinal of a major IS its index (no look-up in the store path)
-template <bool DIRECT>
+// STAGE: the sums of a chunk (at most 128 majors, consecutive ordinals) are collected in a 1 KB LDS window of the wave and
+// leave as ONE run of consecutive 8-byte stores instead of one scattered store per lane and store site
+template <bool DIRECT, bool STAGE>
 __global__ void __launch_bounds__(LV_NT)
 csx_ldsvec_segscan(int nminor, SegPlanView sp, const unsigned char *__restrict__ sbits, const unsigned short *__restrict__ idx,
                    const double *__restrict__ val, const double *__restrict__ in, double *__restrict__ out,
@@ -341,10 +343,10 @@ csx_ldsvec_segscan(int nminor, SegPlanView sp, const unsigned char *__restrict__
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NWV = LV_NT / 64;
-    auto put = [&](int o, double t) { out[DIRECT ? o : sp.nzlist[o]] = t; };
+    double *const stg = xs + ((nminor + 1) & ~1) + wave * 128;
     struct Ld { double2 v[4]; ushort4 ja, jb; unsigned char b; };
     // lane l holds the entries [8 l, 8 l + 8) of the chunk; what lies past the chunk (the next chunk's entries, or
-    // the padding behind the last member) is loaded and masked
+    // the padding behind the last member) is loaded too and ends up in a dummy major (see the start bits below)
     auto issue = [&](const int4 &c, int kk, Ld &d) {
         const long long e = (long long)c.x + 8 * lane;
 #pragma unroll
@@ -353,21 +355,16 @@ csx_ldsvec_segscan(int nminor, SegPlanView sp, const unsigned char *__restrict__
         __builtin_memcpy(&d.jb, idx + e + 4, 8);
         d.b = kk < sp.nchunks ? sbits[kk * 64 + lane] : (unsigned char)0;
     };
-    int k = wave;
-    int4 ch = k < sp.nchunks ? sp.chunks[k] : make_int4(0, 0, 0, 0);
-    Ld cur, nxt;
-    issue(ch, k, cur);                       // the first chunk's loads go out before the vector is staged
-    for (int i = 2 * tid; i + 1 < nminor; i += 2 * LV_NT)
-        *reinterpret_cast<double2 *>(xs + i) = *reinterpret_cast<const double2 *>(in + i);
-    if (tid == 0 && (nminor & 1)) xs[nminor - 1] = in[nminor - 1];
-    for (int i = tid; i < sp.nempty; i += LV_NT) out[sp.empties[i]] = 0.0;
-    __syncthreads();
-    for (; k < sp.nchunks; k += NWV) {
-        const int kn = k + NWV;
-        const int4 chn = kn < sp.nchunks ? sp.chunks[kn] : make_int4(0, 0, 0, 0);
-        issue(chn, kn, nxt);                 // next chunk in flight while this one is reduced
-        const int n = ch.z, want = 8 * lane;
-        const unsigned bits = cur.b;         // bit i: entry want + i starts a major (0 beyond the chunk)
+    // one chunk: the lane's 8 products, the majors inside the lane, the segmented scan over the lanes, the stores
+    auto reduce_chunk = [&](const Ld &cur, const int4 &ch) __attribute__((always_inline)) {
+        auto put = [&](int o, double t) {
+            if (STAGE) stg[o - ch.y] = t;
+            else out[DIRECT ? o : sp.nzlist[o]] = t;
+        };
+        const int n = ch.z;
+        const unsigned bits = cur.b;         // bit i: entry 8 lane + i starts a major; behind the last entry of a chunk that
+                                             // is not full the plan sets ONE more bit, so what a lane loaded past the chunk
+                                             // forms a dummy major that is never stored (no validity masks needed)
         const int nflag = __popc(bits);
         // starts in the lanes before this one -> ordinal of the first major that starts in this lane
         int sc = nflag;
@@ -375,24 +372,43 @@ csx_ldsvec_segscan(int nminor, SegPlanView sp, const unsigned char *__restrict__
         sc += dpp_i32<0x142, 0xa>(sc); sc += dpp_i32<0x143, 0xc>(sc);
         const int ord0 = ch.y + sc - nflag;
         const unsigned short jj[8] = {cur.ja.x, cur.ja.y, cur.ja.z, cur.ja.w, cur.jb.x, cur.jb.y, cur.jb.z, cur.jb.w};
-        // sequential pass over the lane's entries: head = the part before the first start, majors that lie wholly
-        // inside the lane are stored at once, acc = the part after the last start
-        double xv[8];
+        double av[8], xv[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) xv[i] = xs[jj[i]];       // eight independent gathers (always inside the vector)
-        double acc = 0.0, head = 0.0;
-        int seen = 0, nstart = 0;
+        for (int i = 0; i < 8; i++) { av[i] = (i & 1) ? cur.v[i >> 1].y : cur.v[i >> 1].x; xv[i] = xs[jj[i]]; }
+        // all prefix sums S[i] = p_0 + .. + p_i and all suffix sums T[i] = p_i + .. + p_7 of the lane's products, one
+        // FMA each: the part before the first start is S[first - 1], the part from the last start on is T[last]
+        double S[8], T[8];
+        S[0] = av[0] * xv[0];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const double a = (i & 1) ? cur.v[i >> 1].y : cur.v[i >> 1].x;
-            const double pi = want + i < n ? a * xv[i] : 0.0;
-            const int f = (bits >> i) & 1;
-            if (f & seen) put(ord0 + nstart - 1, acc);      // a major that lies wholly inside the lane (predicated store)
-            head = (f & (seen ^ 1)) ? acc : head;
-            acc = f ? 0.0 : acc;
-            seen |= f;
-            nstart += f;
-            acc += pi;
+        for (int i = 1; i < 8; i++) S[i] = fma(av[i], xv[i], S[i - 1]);
+        T[7] = av[7] * xv[7];
+#pragma unroll
+        for (int i = 6; i >= 0; i--) T[i] = fma(av[i], xv[i], T[i + 1]);
+        const int seen = bits != 0;
+        const int j1 = seen ? __ffs(bits) - 1 : 8, jl = seen ? 31 - __clz(bits) : 0;
+        auto pick8 = [](double a0, double a1, double a2, double a3, double a4, double a5, double a6, double a7, int t) {
+            // element t of eight registers as a select tree (registers cannot be indexed)
+            const double b0 = (t & 1) ? a1 : a0, b1 = (t & 1) ? a3 : a2, b2 = (t & 1) ? a5 : a4, b3 = (t & 1) ? a7 : a6;
+            const double c0 = (t & 2) ? b1 : b0, c1 = (t & 2) ? b3 : b2;
+            return (t & 4) ? c1 : c0;
+        };
+        const double head = pick8(S[0], S[1], S[2], S[3], S[4], S[5], S[6], S[7], (j1 + 7) & 7);          // S[j1 - 1] (unused when j1 == 0); no start at all: S[7], the whole lane
+        const double acc = seen ? pick8(T[0], T[1], T[2], T[3], T[4], T[5], T[6], T[7], jl) : head;       // the piece running out of the lane
+        // majors that start AND end inside the lane (short ones; also the last one of a chunk that is not full): summed and
+        // stored here, one per trip of a loop that only lanes with two or more starts enter
+        {
+            unsigned bb = bits;
+            int a = j1, kk = 0;
+            bb &= bb - 1;
+            while (bb) {
+                const int b = __ffs(bb) - 1;
+                double t = 0.0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) t = (i >= a && i < b) ? fma(av[i], xv[i], t) : t;
+                if (8 * lane + a < n) put(ord0 + kk, t);
+                a = b; kk++;
+                bb &= bb - 1;
+            }
         }
         // segmented inclusive scan over the lanes of (piece running out of the lane, any start in the lane)
         double sv = acc;
@@ -413,18 +429,50 @@ csx_ldsvec_segscan(int nminor, SegPlanView sp, const unsigned char *__restrict__
         int nextstart = __shfl_down((int)(bits & 1u), 1);
         if (lane == 63) nextstart = 1;
         const int lastlane = (n - 1) >> 3;
-        const bool ends_here = lane == lastlane || (lane < lastlane && nextstart);
+        // the piece running out of this lane ends a major when the next lane begins with a start; in the last lane of the
+        // chunk only when the chunk fills it (otherwise that piece is the dummy major behind the chunk)
+        const bool ends_here = lane == lastlane ? (n & 7) == 0 : (lane < lastlane && nextstart);
         if (lane <= lastlane) {
             if (seen) {
-                if (!(bits & 1u)) put(ord0 - 1, ex + head);            // runs in from before, ends inside this lane
+                if (j1 > 0) put(ord0 - 1, ex + head);                  // runs in from before, ends inside this lane
                 if (ends_here) put(ord0 + nflag - 1, acc);
             } else if (ends_here) {
                 put(ord0 - 1, ex + acc);
             }
         }
-        ch = chn;
-        cur = nxt;
+        if (STAGE) {
+            __builtin_amdgcn_wave_barrier();         // LDS operations of a wave execute in order; keep the compiler from moving them
+            for (int r = lane; r < ch.w; r += 64) out[DIRECT ? ch.y + r : sp.nzlist[ch.y + r]] = stg[r];
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    int k = wave;
+    auto chunk_at = [&](int kk) { return kk < sp.nchunks ? sp.chunks[kk] : make_int4(0, 0, 0, 0); };
+    // TWO chunks (10 KB per wave, 160 KB per CU) stay in flight while one is reduced: with one, the 16 waves of a CU
+    // cover only ~80 KB of the latency x bandwidth product. Three buffers change roles in a loop unrolled by three --
+    // copying "next" into "current" would wait for the loads just issued and undo the prefetch
+    // (the descriptor of a chunk is fetched one trip before its loads are issued, so no trip waits for a scalar load)
+    int4 c0 = chunk_at(k), c1 = chunk_at(k + NWV), c2, cn = chunk_at(k + 2 * NWV);
+    Ld b0, b1, b2;
+    issue(c0, k, b0);                        // the first two chunks' loads go out before the vector is staged
+    issue(c1, k + NWV, b1);
+    for (int i = 2 * tid; i + 1 < nminor; i += 2 * LV_NT)
+        *reinterpret_cast<double2 *>(xs + i) = *reinterpret_cast<const double2 *>(in + i);
+    if (tid == 0 && (nminor & 1)) xs[nminor - 1] = in[nminor - 1];
+    for (int i = tid; i < sp.nempty; i += LV_NT) out[sp.empties[i]] = 0.0;
+    __syncthreads();
+#define SEG_TRIP(BN, CN, BC, CC)                                                                  \
+        CN = cn; cn = chunk_at(k + 3 * NWV);                                                      \
+        issue(CN, k + 2 * NWV, BN);                                                               \
+        reduce_chunk(BC, CC); k += NWV;
+    while (k < sp.nchunks) {
+        SEG_TRIP(b2, c2, b0, c0)
+        if (k >= sp.nchunks) break;
+        SEG_TRIP(b0, c0, b1, c1)
+        if (k >= sp.nchunks) break;
+        SEG_TRIP(b1, c1, b2, c2)
     }
+#undef SEG_TRIP
 }
 
 #ifdef RSQP_SPMV_EXPERIMENT
@@ -763,20 +811,24 @@ hipError_t rsqp_launch_spmv_segscan(int nminor, const int4 *chunks, int nchunks,
                                     int nempty, const unsigned *sbits, const unsigned short *idx16, const double *val,
                                     const double *in, double *out, int nbatch, long long nnz_stride, long long in_stride,
                                     long long out_stride, hipStream_t stream) {
-    const size_t lds = (size_t)nminor * 8 + 16;
+    size_t lds = (size_t)((nminor + 1) & ~1) * 8;
     if (lds > 160 * 1024 || !idx16 || nchunks <= 0) return hipErrorInvalidValue;
-    static std::atomic<unsigned long long> set0_{0}, set1_{0};
+    const size_t stage = (size_t)(LV_NT / 64) * 128 * 8;          // 1 KB per wave, when the vector leaves room
+    const bool st = lds + stage <= 160 * 1024;
+    if (st) lds += stage;
+    static std::atomic<unsigned long long> set_[4] = {{0}, {0}, {0}, {0}};
     SegPlanView sp;
     sp.chunks = chunks; sp.nzlist = nzlist; sp.empties = empties; sp.nchunks = nchunks; sp.nempty = nempty;
-    if (nempty == 0) {
-        rsqp_allow_full_lds(reinterpret_cast<const void *>(&csx_ldsvec_segscan<true>), set1_, 160 * 1024);
-        hipLaunchKernelGGL(csx_ldsvec_segscan<true>, dim3(nbatch), dim3(LV_NT), lds, stream, nminor, sp,
-                           reinterpret_cast<const unsigned char *>(sbits), idx16, val, in, out, nnz_stride, in_stride, out_stride);
-    } else {
-        rsqp_allow_full_lds(reinterpret_cast<const void *>(&csx_ldsvec_segscan<false>), set0_, 160 * 1024);
-        hipLaunchKernelGGL(csx_ldsvec_segscan<false>, dim3(nbatch), dim3(LV_NT), lds, stream, nminor, sp,
-                           reinterpret_cast<const unsigned char *>(sbits), idx16, val, in, out, nnz_stride, in_stride, out_stride);
-    }
+#define SEG_LAUNCH(D, S)                                                                                              \
+    do {                                                                                                              \
+        rsqp_allow_full_lds(reinterpret_cast<const void *>(&csx_ldsvec_segscan<D, S>), set_[2 * D + S], 160 * 1024);  \
+        hipLaunchKernelGGL((csx_ldsvec_segscan<D, S>), dim3(nbatch), dim3(LV_NT), lds, stream, nminor, sp,            \
+                           reinterpret_cast<const unsigned char *>(sbits), idx16, val, in, out, nnz_stride, in_stride, \
+                           out_stride);                                                                               \
+    } while (0)
+    if (nempty == 0) { if (st) SEG_LAUNCH(true, true); else SEG_LAUNCH(true, false); }
+    else             { if (st) SEG_LAUNCH(false, true); else SEG_LAUNCH(false, false); }
+#undef SEG_LAUNCH
     return hipGetLastError();
 }
 

@@ -427,8 +427,8 @@ def test_spmv_batched_parity_and_properties(capi, oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", ["plain_10k_x_20k", "handler_J_I_mI", "plain_int_index", "plain_subwave_kernels"])
 def test_roofline_spmv_kernels_match_the_oracle(capi, oracle, shape, monkeypatch):
-    """The kernels behind `roofline_spmv` in bench.py (profiles/*kernel_stats*:
-    csx_ldsvec_spmv_pipe2<4,3,unsigned short> for A'y and <2,4,unsigned short> for Ax) at the benchmarked
+    """The kernels behind `roofline_spmv` in bench.py (profiles/*kernel_stats*: csx_ldsvec_segscan for A'y and Ax;
+    the sub-wave kernels csx_ldsvec_spmv_pipe2<4,3,.> / <2,4,.> for short majors and 32-bit indices) at the benchmarked
     shape -- n=10k columns, m=20k rows, 200 000 entries, nbatch >= 64 -- against the oracle's restatement of
     SpHbMat::times / transposed_times (reference src/SpHbMat.cpp:659-737). The chosen kernel variant is
     asserted so that a change of the selection rule cannot silently move the test to another kernel.
@@ -449,13 +449,13 @@ def test_roofline_spmv_kernels_match_the_oracle(capi, oracle, shape, monkeypatch
         n, m, nnz = 10000, 20000, 200000
         jc, ir, rng = problems.sparse_pattern(n, m, nnz)
         ncol, ident = n, None
-        expect_t, expect_n = 40, 38         # 20 entries per column -> entry-parallel csx_ldsvec_segscan; 10 per row -> <2,4>
+        expect_t, expect_n = 40, 40         # 20 entries per column, 10 per row -> entry-parallel csx_ldsvec_segscan
     if shape == "plain_subwave_kernels":
         monkeypatch.setenv("RSQP_SPMV_VARIANT", "35")   # csx_ldsvec_spmv_pipe2<4,3,unsigned short> for both products
         expect_t, expect_n = 35, 35
     if shape == "plain_int_index":
         monkeypatch.setenv("RSQP_SPMV_IDX16", "0")     # the <.., int> instantiation (dimensions >= 65 536 take it by themselves)
-        expect_t = 35                                   # the entry-parallel kernel exists for 16-bit indices only
+        expect_t, expect_n = 35, 38                     # the entry-parallel kernel exists for 16-bit indices only
     nb = 64
     vals = rng.normal(size=(nb, nnz))
     if ident is not None:
