@@ -134,6 +134,10 @@ int rsqp_get_vector(const rsqp_solver *s, int which, double *v);
  * SpHbMat::setMatVal (SpHbMat.cpp:368-380): the scatter through `order` (20 B per entry) and the
  * refresh of the CSR copy -- on the values staged by the last rsqp_set_A_triplet */
 int rsqp_time_value_refresh(rsqp_solver *s, int repeats, float *ms_scatter, float *ms_gather);
+/* tuning aid for the HBM-resident engine (no reference counterpart): device ms per call of one of its streaming
+ * kernel classes -- kind 0: y = M w (column-major), 1: y = M'x, 2: rank-1 update -- on an nrows x ncols block of an
+ * n x n buffer (leading dimension n), exactly as the engine launches them */
+int rsqp_time_large_kernel(int device, int n, int kind, int nrows, int ncols, int repeats, float *ms);
 /* reset_constraints (qpOASESInterface.cpp:897-902) */
 int rsqp_reset_constraints(rsqp_solver *s);
 

@@ -91,6 +91,7 @@ SYMBOLS = {
     "rsqp_batch_pack_records_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rsqp_batch_pack_records_host": (C.c_int, [C.c_void_p, dp]),
     "rsqp_time_value_refresh": (C.c_int, [C.c_void_p, C.c_int, fp, fp]),
+    "rsqp_time_large_kernel": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp]),
     "rsqp_spmv_plan_create": (C.c_int, [C.c_int, C.c_int, ip, ip, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "rsqp_spmv_plan_destroy": (None, [C.c_void_p]),
     "rsqp_spmv_plan_upload": (C.c_int, [C.c_void_p, dp, dp, C.c_int]),

@@ -290,6 +290,35 @@ __global__ void __launch_bounds__(NT) k_ger(double *__restrict__ M, long long ld
     M[c * ld + r] += cs * scal[ci] * t[r] * v[c];
 }
 
+// the same update, a lane owning two consecutive rows (16-byte accesses) of GER_COLS columns: 8 independent
+// read-modify-writes per lane in flight instead of one 8-byte one (leading dimension even, M 16-byte aligned)
+constexpr int GER_COLS = 4;
+__global__ void __launch_bounds__(NT) k_ger_v(double *__restrict__ M, long long ld, int nrows, int ncols,
+                                              const double *__restrict__ t, const double *__restrict__ v,
+                                              const double *__restrict__ scal, int ci, double cs) {
+    const int r = (blockIdx.x * NT + threadIdx.x) * 2, c0 = blockIdx.y * GER_COLS;
+    if (r >= nrows) return;
+    const double coef = cs * scal[ci];
+    if (r + 1 < nrows) {
+        const double2 tv = *reinterpret_cast<const double2 *>(t + r);
+        const double a0 = coef * tv.x, a1 = coef * tv.y;
+        double2 m[GER_COLS];
+#pragma unroll
+        for (int k = 0; k < GER_COLS; k++)
+            if (c0 + k < ncols) m[k] = *reinterpret_cast<const double2 *>(M + (c0 + k) * ld + r);
+#pragma unroll
+        for (int k = 0; k < GER_COLS; k++)
+            if (c0 + k < ncols) {
+                const double vc = v[c0 + k];
+                m[k].x += a0 * vc; m[k].y += a1 * vc;
+                *reinterpret_cast<double2 *>(M + (c0 + k) * ld + r) = m[k];
+            }
+    } else {
+        const double a0 = coef * t[r];
+        for (int k = 0; k < GER_COLS && c0 + k < ncols; k++) M[(c0 + k) * ld + r] += a0 * v[c0 + k];
+    }
+}
+
 // scal[slot] = sum_i a[i]*b[i]
 __global__ void __launch_bounds__(NT) k_dot(const double *__restrict__ a, const double *__restrict__ b, int n,
                                             double *__restrict__ scal, int slot) {
@@ -1012,6 +1041,7 @@ struct RsqpLargeEngine::Impl {
     double *big = nullptr;    // 2 nV^2 scratch, allocated by the first blocked set-up
     int *d_fpos = nullptr, *d_cand = nullptr, *d_freev = nullptr;
     bool blocked_setup = getenv("RSQP_NO_BLOCKED_SETUP") == nullptr;
+    int gemv_wgs = getenv("RSQP_GEMV_WGS") ? atoi(getenv("RSQP_GEMV_WGS")) : 4096;     // workgroups the chunked y = M w aims for
     bool reinit_from_y0 = true;
     static constexpr int BLOCKED_MIN = 32;   // fewer active constraints: the sequential construction is as fast
 
@@ -1100,10 +1130,11 @@ struct RsqpLargeEngine::Impl {
             chk("gemv_n1");
             return;
         }
-        // chunks: enough workgroups to fill the 256 CUs a few times, as few partials as possible
+        // chunks: ~4096 workgroups (at most 32 partials per row). Measured on 10 000 x 10 000 (tools/large_kernel_bench.py):
+        // 768 workgroups 152 us, 2048 145 us, 4096 (capped: 2528) 136 us = 5.9 TB/s -- more loads in flight per CU
         const bool vec = ((l & 1) == 0) && ((reinterpret_cast<unsigned long long>(Mx) & 15) == 0) && nrows >= 128;
         const int rb = vec ? (nrows + 127) / 128 : (nrows + 63) / 64;
-        int nch = std::max(1, std::min(std::min((768 + rb - 1) / rb, 32), (ncols + 15) / 16));
+        int nch = std::max(1, std::min(std::min((gemv_wgs + rb - 1) / rb, 32), (ncols + 15) / 16));
         while ((long long)nch * nrows > part_cap) nch = (nch + 1) / 2;
         const int chunk = (ncols + nch - 1) / nch;
         nch = (ncols + chunk - 1) / chunk;
@@ -1120,8 +1151,14 @@ struct RsqpLargeEngine::Impl {
     }
     void ger(double *Mx, long long l, int nrows, int ncols, const double *t, const double *v, int ci, double cs) {
         pbegin();
-        if (ncols > 0 && nrows > 0)
-            hipLaunchKernelGGL(k_ger, dim3((nrows + NT - 1) / NT, ncols), dim3(NT), 0, st, Mx, l, nrows, ncols, t, v, scal, ci, cs);
+        if (ncols > 0 && nrows > 0) {
+            const bool vec = ((l & 1) == 0) && (((reinterpret_cast<unsigned long long>(Mx) | reinterpret_cast<unsigned long long>(t)) & 15) == 0);
+            if (vec)
+                hipLaunchKernelGGL(k_ger_v, dim3((nrows + 2 * NT - 1) / (2 * NT), (ncols + GER_COLS - 1) / GER_COLS), dim3(NT), 0, st, Mx, l,
+                                   nrows, ncols, t, v, scal, ci, cs);
+            else
+                hipLaunchKernelGGL(k_ger, dim3((nrows + NT - 1) / NT, ncols), dim3(NT), 0, st, Mx, l, nrows, ncols, t, v, scal, ci, cs);
+        }
         pend(2, 16.0 * nrows * (double)ncols);
     }
     void dot(const double *a, const double *b, int n, int slot) {
@@ -1485,6 +1522,7 @@ struct RsqpLargeEngine::Impl {
 
     int homotopy(int maxit, int *nWSR) {
         int iter = 0, rcode = RET_OK;
+        double sum_nFR = 0.0, sum_nAC = 0.0, sum_nZ = 0.0;      // reported by RSQP_PROFILE: the sizes the products run on
         status = QPS_PERFORMINGHOMOTOPY;
         refresh_products();
         hipLaunchKernelGGL(k_rerelax, g1(nV), dim3(NT), 0, st, nV, Sb, x, lbN, ubN, lb, ub);
@@ -1517,8 +1555,12 @@ struct RsqpLargeEngine::Impl {
             if (rcode == RET_UNBOUNDED) { unbounded = 1; break; }
             if (rcode != RET_OK) break;
             iter++;
+            sum_nFR += nFR; sum_nAC += nAC; sum_nZ += nZ;
             drift_correction();
         }
+        if (profile && iter > 0)
+            fprintf(stderr, "[rsqp profile] homotopy: %d changes, mean nFR %.1f nAC %.1f nZ %.1f (nV %d nC %d)\n", iter,
+                    sum_nFR / iter, sum_nAC / iter, sum_nZ / iter, nV, nC);
         *nWSR = iter;
         return rcode;
     }
@@ -1834,6 +1876,31 @@ const char *RsqpLargeEngine::profile_name(int k) {
     return k >= 0 && k < PROFILE_CLASSES ? nm[k] : "";
 }
 void RsqpLargeEngine::profile_enable(bool on) { p_->profile = on; }
+// tuning aid: device time per call of one product / update kernel class on an nrows x ncols matrix (the engine's Z
+// buffer, leading dimension nV; contents are whatever the buffer holds -- the result is not looked at)
+int RsqpLargeEngine::time_kernel(int kind, int nrows, int ncols, int reps, float *ms) {
+    Impl &P = *p_;
+    if (nrows <= 0 || ncols <= 0 || nrows > P.nV || ncols > P.nV || reps <= 0 || kind < 0 || kind > 2) return -1;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1;
+    (void)hipMemsetAsync(P.Z, 0, sizeof(double) * (size_t)P.nV * P.nV, P.st);
+    P.fill(P.w1, P.nV, 1.0); P.fill(P.w2, P.nV, 0.5);
+    for (int pass = 0; pass < 2; pass++) {            // pass 0 warms up
+        (void)hipEventRecord(e0, P.st);
+        for (int r = 0; r < (pass ? reps : 2); r++) {
+            if (kind == 0) P.gemv_n(P.Z, P.ld, nrows, ncols, P.w1, 1.0, 0.0, nullptr, P.w3);
+            else if (kind == 1) P.gemv_t(P.Z, P.ld, nrows, ncols, P.w1, P.w3);
+            else P.ger(P.Z, P.ld, nrows, ncols, P.w1, P.w2, 0, 1e-3);
+        }
+        (void)hipEventRecord(e1, P.st);
+        if (hipEventSynchronize(e1) != hipSuccess) return -1;
+    }
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms = t / reps;
+    return P.err_ == hipSuccess ? 0 : -1;
+}
 void RsqpLargeEngine::set_reinit_from_y0(bool on) { p_->reinit_from_y0 = on; }
 void RsqpLargeEngine::profile_get(double *out) const {
     for (int k = 0; k < PROFILE_CLASSES; k++) {

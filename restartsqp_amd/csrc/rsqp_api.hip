@@ -1334,6 +1334,20 @@ extern "C" int rsqp_time_value_refresh(rsqp_solver *s, int repeats, float *ms_sc
     return RSQP_OK;
 }
 
+extern "C" int rsqp_time_large_kernel(int device, int n, int kind, int nrows, int ncols, int repeats, float *ms) {
+    if (n <= 0 || !ms) return fail(RSQP_ERR_ARG, "rsqp_time_large_kernel");
+    HIPCHK(hipSetDevice(device));
+    RsqpLargeEngine eng;
+    hipStream_t st = nullptr;
+    HIPCHK(hipStreamCreate(&st));
+    hipError_t e = eng.init(n, 0, st);
+    int rc = e == hipSuccess ? eng.time_kernel(kind, nrows, ncols, repeats, ms) : -1;
+    (void)hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st);
+    if (e != hipSuccess) return fail(RSQP_ERR_DEVICE, std::string("rsqp_time_large_kernel: ") + hipGetErrorString(e));
+    return rc == 0 ? RSQP_OK : fail(RSQP_ERR_ARG, "rsqp_time_large_kernel: bad shape or launch failure");
+}
+
 // =====================================================================================
 // batched SpMV plan (device resident)
 // =====================================================================================

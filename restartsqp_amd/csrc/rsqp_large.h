@@ -44,6 +44,8 @@ public:
     void profile_enable(bool on);
     void set_reinit_from_y0(bool on);   // warm start without guessed constraints: sides from sign(y0) (default) or from A x0
     void profile_get(double *out4n) const;
+    // device ms per call of kernel class `kind` (0 gemv_n, 1 gemv_t, 2 ger) on an nrows x ncols matrix (<= nV each)
+    int time_kernel(int kind, int nrows, int ncols, int reps, float *ms);
     struct Impl;
 private:
     Impl *p_;
