@@ -217,13 +217,14 @@ __global__ void __launch_bounds__(NT) k_gemv_n_reduce(const double *__restrict__
 // groups; the 32 partial sums of a row meet in LDS and are added in group order (deterministic). 128 workgroups
 // x 256 threads x 8 loads in flight keep ~4 MB on the wire for a 2048 x 2048 matrix.
 // Optional epilogue (the step direction's "dx on the free variables", k_merge_free): mdst[r] = out[r] where mSb[r] == 0.
-template <bool VEC>
-__global__ void __launch_bounds__(NT) k_gemv_n1(const double *__restrict__ M, long long ld, int nrows, int ncols,
+template <bool VEC, int NTH>
+__global__ void __launch_bounds__(NTH) k_gemv_n1(const double *__restrict__ M, long long ld, int nrows, int ncols,
                                                 const double *__restrict__ w, double alpha, double beta,
                                                 const double *__restrict__ base, double *__restrict__ out,
                                                 const int *__restrict__ mSb, double *__restrict__ mdst) {
     constexpr int RPL = VEC ? 2 : 1;
-    __shared__ double sh[32][8 * RPL + 1];
+    constexpr int NG = NTH / 8;          // column groups
+    __shared__ double sh[NG][8 * RPL + 1];
     const int rl = threadIdx.x & 7, cg = threadIdx.x >> 3;
     const int r = (blockIdx.x * 8 + rl) * RPL;
     double a0 = 0.0, a1 = 0.0;
@@ -231,36 +232,36 @@ __global__ void __launch_bounds__(NT) k_gemv_n1(const double *__restrict__ M, lo
         if (r + 1 < nrows) {
             double2 s0 = {0, 0}, s1 = {0, 0}, s2 = {0, 0}, s3 = {0, 0};
             int c = cg;
-            for (; c + 96 < ncols; c += 128) {
+            for (; c + 3 * NG < ncols; c += 4 * NG) {
                 const double2 m0 = *reinterpret_cast<const double2 *>(M + c * ld + r);
-                const double2 m1 = *reinterpret_cast<const double2 *>(M + (c + 32) * ld + r);
-                const double2 m2 = *reinterpret_cast<const double2 *>(M + (c + 64) * ld + r);
-                const double2 m3 = *reinterpret_cast<const double2 *>(M + (c + 96) * ld + r);
-                const double w0 = w[c], w1 = w[c + 32], w2 = w[c + 64], w3 = w[c + 96];
+                const double2 m1 = *reinterpret_cast<const double2 *>(M + (c + NG) * ld + r);
+                const double2 m2 = *reinterpret_cast<const double2 *>(M + (c + 2 * NG) * ld + r);
+                const double2 m3 = *reinterpret_cast<const double2 *>(M + (c + 3 * NG) * ld + r);
+                const double w0 = w[c], w1 = w[c + NG], w2 = w[c + 2 * NG], w3 = w[c + 3 * NG];
                 s0.x += m0.x * w0; s0.y += m0.y * w0; s1.x += m1.x * w1; s1.y += m1.y * w1;
                 s2.x += m2.x * w2; s2.y += m2.y * w2; s3.x += m3.x * w3; s3.y += m3.y * w3;
             }
-            for (; c < ncols; c += 32) {
+            for (; c < ncols; c += NG) {
                 const double2 m0 = *reinterpret_cast<const double2 *>(M + c * ld + r);
                 s0.x += m0.x * w[c]; s0.y += m0.y * w[c];
             }
             a0 = (s0.x + s1.x) + (s2.x + s3.x);
             a1 = (s0.y + s1.y) + (s2.y + s3.y);
         } else if (r < nrows) {
-            for (int c = cg; c < ncols; c += 32) a0 += M[c * ld + r] * w[c];
+            for (int c = cg; c < ncols; c += NG) a0 += M[c * ld + r] * w[c];
         }
         sh[cg][2 * rl] = a0; sh[cg][2 * rl + 1] = a1;
     } else {
         if (r < nrows) {
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
             int c = cg;
-            for (; c + 96 < ncols; c += 128) {
+            for (; c + 3 * NG < ncols; c += 4 * NG) {
                 s0 += M[c * ld + r] * w[c];
-                s1 += M[(c + 32) * ld + r] * w[c + 32];
-                s2 += M[(c + 64) * ld + r] * w[c + 64];
-                s3 += M[(c + 96) * ld + r] * w[c + 96];
+                s1 += M[(c + NG) * ld + r] * w[c + NG];
+                s2 += M[(c + 2 * NG) * ld + r] * w[c + 2 * NG];
+                s3 += M[(c + 3 * NG) * ld + r] * w[c + 3 * NG];
             }
-            for (; c < ncols; c += 32) s0 += M[c * ld + r] * w[c];
+            for (; c < ncols; c += NG) s0 += M[c * ld + r] * w[c];
             a0 = (s0 + s1) + (s2 + s3);
         }
         sh[cg][rl] = a0;
@@ -271,7 +272,7 @@ __global__ void __launch_bounds__(NT) k_gemv_n1(const double *__restrict__ M, lo
         if (rr < nrows) {
             double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
 #pragma unroll
-            for (int g = 0; g < 32; g += 4) {
+            for (int g = 0; g < NG; g += 4) {
                 t0 += sh[g][threadIdx.x]; t1 += sh[g + 1][threadIdx.x]; t2 += sh[g + 2][threadIdx.x]; t3 += sh[g + 3][threadIdx.x];
             }
             const double v = (base ? beta * base[rr] : 0.0) + alpha * ((t0 + t1) + (t2 + t3));
@@ -1041,6 +1042,7 @@ struct RsqpLargeEngine::Impl {
     double *big = nullptr;    // 2 nV^2 scratch, allocated by the first blocked set-up
     int *d_fpos = nullptr, *d_cand = nullptr, *d_freev = nullptr;
     bool blocked_setup = getenv("RSQP_NO_BLOCKED_SETUP") == nullptr;
+    int n1_threads = getenv("RSQP_GEMV_N1_THREADS") ? atoi(getenv("RSQP_GEMV_N1_THREADS")) : 0;   // tuning: force 256 / 512 threads in k_gemv_n1
     int gemv_wgs = getenv("RSQP_GEMV_WGS") ? atoi(getenv("RSQP_GEMV_WGS")) : 4096;     // workgroups the chunked y = M w aims for
     bool reinit_from_y0 = true;
     static constexpr int BLOCKED_MIN = 32;   // fewer active constraints: the sequential construction is as fast
@@ -1124,8 +1126,12 @@ struct RsqpLargeEngine::Impl {
         pbegin();
         if (nrows <= 8192 || mSb) {   // launch-bound sizes: one kernel, no partials (k_gemv_n1)
             const bool vec1 = ((l & 1) == 0) && ((reinterpret_cast<unsigned long long>(Mx) & 15) == 0);
-            if (vec1) hipLaunchKernelGGL(k_gemv_n1<true>, dim3((nrows + 15) / 16), dim3(NT), 0, st, Mx, l, nrows, ncols, wv, alpha, beta, base, out, mSb, mdst);
-            else hipLaunchKernelGGL(k_gemv_n1<false>, dim3((nrows + 7) / 8), dim3(NT), 0, st, Mx, l, nrows, ncols, wv, alpha, beta, base, out, mSb, mdst);
+            // 16-row workgroups: up to 3072 rows they cover at most 192 of the 256 CUs, so each gets 512 threads (64 column
+            // groups, twice the loads in flight: 2048 x 2048 8.7 -> 6.7 us); taller matrices fill the chip with 256 (4096 x
+            // 4096: 19.9 us vs 21.4 with 512). 1024 threads measured 2x slower. (tools/large_kernel_bench.py)
+            if (vec1 && (n1_threads == 512 || (n1_threads == 0 && nrows <= 3072))) hipLaunchKernelGGL((k_gemv_n1<true, 512>), dim3((nrows + 15) / 16), dim3(512), 0, st, Mx, l, nrows, ncols, wv, alpha, beta, base, out, mSb, mdst);
+            else if (vec1) hipLaunchKernelGGL((k_gemv_n1<true, NT>), dim3((nrows + 15) / 16), dim3(NT), 0, st, Mx, l, nrows, ncols, wv, alpha, beta, base, out, mSb, mdst);
+            else hipLaunchKernelGGL((k_gemv_n1<false, NT>), dim3((nrows + 7) / 8), dim3(NT), 0, st, Mx, l, nrows, ncols, wv, alpha, beta, base, out, mSb, mdst);
             pend(0, 8.0 * nrows * (double)ncols + 8.0 * nrows + 8.0 * ncols);
             chk("gemv_n1");
             return;
