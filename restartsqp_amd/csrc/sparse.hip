@@ -353,7 +353,8 @@ csx_ldsvec_segscan(int nminor, SegPlanView sp, const unsigned char *__restrict__
         for (int q = 0; q < 4; q++) __builtin_memcpy(&d.v[q], val + e + 2 * q, 16);
         __builtin_memcpy(&d.ja, idx + e, 8);
         __builtin_memcpy(&d.jb, idx + e + 4, 8);
-        d.b = kk < sp.nchunks ? sbits[kk * 64 + lane] : (unsigned char)0;
+        d.b = sbits[(kk < sp.nchunks ? kk : sp.nchunks - 1) * 64 + lane];      // unconditional (clamped): a branch around a
+                                                                                // load makes the compiler drain the prefetch
     };
     // one chunk: the lane's 8 products, the majors inside the lane, the segmented scan over the lanes, the stores
     auto reduce_chunk = [&](const Ld &cur, const int4 &ch) __attribute__((always_inline)) {
@@ -440,14 +441,21 @@ csx_ldsvec_segscan(int nminor, SegPlanView sp, const unsigned char *__restrict__
                 put(ord0 - 1, ex + acc);
             }
         }
-        if (STAGE) {
-            __builtin_amdgcn_wave_barrier();         // LDS operations of a wave execute in order; keep the compiler from moving them
-            for (int r = lane; r < ch.w; r += 64) out[DIRECT ? ch.y + r : sp.nzlist[ch.y + r]] = stg[r];
-            __builtin_amdgcn_wave_barrier();
-        }
+        if (STAGE) __builtin_amdgcn_wave_barrier();  // LDS operations of a wave execute in order; keep the compiler from moving them
+    };
+    // STAGE: the sums of the chunk reduced in the PREVIOUS trip leave the LDS window at the top of the next trip, BEFORE
+    // that trip's loads are issued. Loads and stores share one in-order counter (vmcnt) and the compiler waits for a store
+    // before it reuses the store's operand registers: a store issued after the prefetch loads makes that wait drain the
+    // prefetch; issued before them, the wait leaves the newest chunk in flight.
+    auto flush = [&](int base, int count) __attribute__((always_inline)) {
+        if (!STAGE) return;
+        for (int r = lane; r < count; r += 64) out[DIRECT ? base + r : sp.nzlist[base + r]] = stg[r];
+        __builtin_amdgcn_wave_barrier();
     };
     int k = wave;
-    auto chunk_at = [&](int kk) { return kk < sp.nchunks ? sp.chunks[kk] : make_int4(0, 0, 0, 0); };
+    auto chunk_at = [&](int kk) {           // past the end: the last chunk's addresses (valid loads), never reduced
+        return sp.chunks[kk < sp.nchunks ? kk : sp.nchunks - 1];
+    };
     // TWO chunks (10 KB per wave, 160 KB per CU) stay in flight while one is reduced: with one, the 16 waves of a CU
     // cover only ~80 KB of the latency x bandwidth product. Three buffers change roles in a loop unrolled by three --
     // copying "next" into "current" would wait for the loads just issued and undo the prefetch
@@ -461,18 +469,21 @@ csx_ldsvec_segscan(int nminor, SegPlanView sp, const unsigned char *__restrict__
     if (tid == 0 && (nminor & 1)) xs[nminor - 1] = in[nminor - 1];
     for (int i = tid; i < sp.nempty; i += LV_NT) out[sp.empties[i]] = 0.0;
     __syncthreads();
+    int pbase = 0, pcount = 0;
 #define SEG_TRIP(BN, CN, BC, CC)                                                                  \
+        flush(pbase, pcount);                                                                     \
         CN = cn; cn = chunk_at(k + 3 * NWV);                                                      \
         issue(CN, k + 2 * NWV, BN);                                                               \
-        reduce_chunk(BC, CC); k += NWV;
-    while (k < sp.nchunks) {
+        pcount = 0;                                                                               \
+        if (k < sp.nchunks) { reduce_chunk(BC, CC); pbase = CC.y; pcount = CC.w; }                \
+        k += NWV;
+    while (k < sp.nchunks) {        // no exit inside the body: the trips past the end load the last chunk again and skip the reduction
         SEG_TRIP(b2, c2, b0, c0)
-        if (k >= sp.nchunks) break;
         SEG_TRIP(b0, c0, b1, c1)
-        if (k >= sp.nchunks) break;
         SEG_TRIP(b1, c1, b2, c2)
     }
 #undef SEG_TRIP
+    flush(pbase, pcount);
 }
 
 #ifdef RSQP_SPMV_EXPERIMENT
