@@ -522,6 +522,10 @@ csx_ldsvec_streambound(int nminor, int nnz, const unsigned short *__restrict__ i
 }
 // the load pattern of csx_ldsvec_segscan alone: 8 consecutive entries per lane (4 x 16 B of values at a 64-B lane
 // stride, 16 B of indices), chunks of 512 entries per wave, next chunk in flight; no reduction logic
+// WORK: dummy work between the issue of the next chunk's loads and the use of this one's, to see what the stream
+// tolerates: 0 none; 1: 192 dependent f64 FMAs; 2: 24 dependent DPP row shifts + adds (f64); 3: 12 ds_bpermute round
+// trips; 4: 1 + 2 + 3
+template <int WORK>
 __global__ void __launch_bounds__(LV_NT)
 csx_ldsvec_lanegroup_bound(int nminor, int nnz, const unsigned short *__restrict__ idx, const double *__restrict__ val,
                            const double *__restrict__ in, double *__restrict__ out, long long nnz_stride, long long in_stride,
@@ -549,9 +553,73 @@ csx_ldsvec_lanegroup_bound(int nminor, int nnz, const unsigned short *__restrict
         issue(k + LV_NT / 64, vn, jan, jbn);
         s += v[0].x * xs[ja.x] + v[0].y * xs[ja.y] + v[1].x * xs[ja.z] + v[1].y * xs[ja.w] +
              v[2].x * xs[jb.x] + v[2].y * xs[jb.y] + v[3].x * xs[jb.z] + v[3].y * xs[jb.w];
+        if (WORK == 1 || WORK == 4) {
+#pragma unroll
+            for (int q = 0; q < 192; q++) s = fma(s, 1.0000001, 1e-9);
+        }
+        if (WORK == 2 || WORK == 4) {
+#pragma unroll
+            for (int q = 0; q < 24; q++) s += dpp_f64<0x111, 0xf>(s);
+        }
+        if (WORK == 3 || WORK == 4) {
+#pragma unroll
+            for (int q = 0; q < 12; q++) s += __shfl_up(s, 1);
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) v[q] = vn[q];
         ja = jan; jb = jbn;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[wave] = s;
+}
+
+// the same with TWO chunks in flight (three buffers, unrolled by three, no exit inside the loop)
+template <int WORK>
+__global__ void __launch_bounds__(LV_NT)
+csx_ldsvec_lanegroup_bound2(int nminor, int nnz, const unsigned short *__restrict__ idx, const double *__restrict__ val,
+                            const double *__restrict__ in, double *__restrict__ out, long long nnz_stride, long long in_stride,
+                            long long out_stride) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];
+    const int m = blockIdx.x;
+    idx += m * nnz_stride; val += m * nnz_stride; in += m * in_stride; out += m * out_stride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = 2 * tid; i + 1 < nminor; i += 2 * LV_NT)
+        *reinterpret_cast<double2 *>(xs + i) = *reinterpret_cast<const double2 *>(in + i);
+    __syncthreads();
+    double s = 0.0;
+    const int nch = nnz / 512;
+    constexpr int NWV = LV_NT / 64;
+    struct B { double2 v[4]; ushort4 ja, jb; };
+    auto issue = [&](int k, B &b) {
+        const long long e = (long long)(k < nch ? k : 0) * 512 + 8 * lane + 1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) __builtin_memcpy(&b.v[q], val + e + 2 * q, 16);
+        __builtin_memcpy(&b.ja, idx + e, 8);
+        __builtin_memcpy(&b.jb, idx + e + 4, 8);
+    };
+    auto work = [&](const B &b) __attribute__((always_inline)) {
+        s += b.v[0].x * xs[b.ja.x] + b.v[0].y * xs[b.ja.y] + b.v[1].x * xs[b.ja.z] + b.v[1].y * xs[b.ja.w] +
+             b.v[2].x * xs[b.jb.x] + b.v[2].y * xs[b.jb.y] + b.v[3].x * xs[b.jb.z] + b.v[3].y * xs[b.jb.w];
+        if (WORK == 1 || WORK == 4) {
+#pragma unroll
+            for (int q = 0; q < 192; q++) s = fma(s, 1.0000001, 1e-9);
+        }
+        if (WORK == 2 || WORK == 4) {
+#pragma unroll
+            for (int q = 0; q < 24; q++) s += dpp_f64<0x111, 0xf>(s);
+        }
+        if (WORK == 3 || WORK == 4) {
+#pragma unroll
+            for (int q = 0; q < 12; q++) s += __shfl_up(s, 1);
+        }
+    };
+    B b0, b1, b2;
+    int k = wave;
+    issue(k, b0); issue(k + NWV, b1);
+    while (k < nch) {
+        issue(k + 2 * NWV, b2); if (k < nch) work(b0); k += NWV;
+        issue(k + 2 * NWV, b0); if (k < nch) work(b1); k += NWV;
+        issue(k + 2 * NWV, b1); if (k < nch) work(b2); k += NWV;
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) out[wave] = s;
@@ -792,13 +860,28 @@ hipError_t rsqp_launch_spmv_ldsvec(int variant, int nminor, int nslices, const i
     case 38: L2_LAUNCH(2, 4); break;
 #undef L2_LAUNCH
 #ifdef RSQP_SPMV_EXPERIMENT
-    case 52: {
-        static std::atomic<unsigned long long> s5{0};
-        if (!idx16) return hipErrorInvalidValue;
-        rsqp_allow_full_lds(reinterpret_cast<const void *>(&csx_ldsvec_lanegroup_bound), s5, 160 * 1024);
-        hipLaunchKernelGGL(csx_ldsvec_lanegroup_bound, dim3(nbatch), dim3(LV_NT), lds, stream, nminor, (int)nnz_stride, idx16, val, in, out, nnz_stride, in_stride, out_stride);
-        break;
+#define LG_LAUNCH(V, W)                                                                                                \
+    case V: {                                                                                                          \
+        static std::atomic<unsigned long long> s5{0};                                                                  \
+        if (!idx16) return hipErrorInvalidValue;                                                                       \
+        rsqp_allow_full_lds(reinterpret_cast<const void *>(&csx_ldsvec_lanegroup_bound<W>), s5, 160 * 1024);           \
+        hipLaunchKernelGGL(csx_ldsvec_lanegroup_bound<W>, dim3(nbatch), dim3(LV_NT), lds, stream, nminor,              \
+                           (int)nnz_stride, idx16, val, in, out, nnz_stride, in_stride, out_stride);                   \
+        break;                                                                                                         \
     }
+    LG_LAUNCH(52, 0) LG_LAUNCH(53, 1) LG_LAUNCH(54, 2) LG_LAUNCH(55, 3) LG_LAUNCH(56, 4)
+#undef LG_LAUNCH
+#define LG2_LAUNCH(V, W)                                                                                               \
+    case V: {                                                                                                          \
+        static std::atomic<unsigned long long> s6{0};                                                                  \
+        if (!idx16) return hipErrorInvalidValue;                                                                       \
+        rsqp_allow_full_lds(reinterpret_cast<const void *>(&csx_ldsvec_lanegroup_bound2<W>), s6, 160 * 1024);          \
+        hipLaunchKernelGGL(csx_ldsvec_lanegroup_bound2<W>, dim3(nbatch), dim3(LV_NT), lds, stream, nminor,             \
+                           (int)nnz_stride, idx16, val, in, out, nnz_stride, in_stride, out_stride);                   \
+        break;                                                                                                         \
+    }
+    LG2_LAUNCH(62, 0) LG2_LAUNCH(66, 4)
+#undef LG2_LAUNCH
     case 50: case 51: {
         static std::atomic<unsigned long long> s4{0}, s8{0};
         if (!idx16) return hipErrorInvalidValue;
