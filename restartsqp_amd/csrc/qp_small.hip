@@ -20,7 +20,7 @@
 //     bank-conflict free for ds_read_b64; T row-major with the same stride.
 //   * sparse H / A stay in global memory in CSC (+ a CSR copy of A): they are read-only
 //     and L2-resident; lane-per-row / lane-per-column products, no atomics.
-//   * reductions are butterflies over the L lanes of a problem (__shfl_xor, identical result
+//   * reductions are butterflies over the L lanes of a problem (DPP permutations inside a row, identical result
 //     in each of them) so control flow stays uniform per problem; argmin carries the candidate
 //     id for the deterministic tie break. With nV <= L every lane owns at most one entry of a
 //     vector, so the sums are bit-identical for every L (tools/small_pack_check.py).
@@ -58,7 +58,7 @@ typedef LDS char lchar;
 
 // diagnostic build only (-DRSQP_STAMPS, tools/stamp_small_kernel.py): cycles per phase of block 0
 #ifdef RSQP_STAMPS
-__device__ unsigned long long g_stamps[16];
+__device__ unsigned long long g_stamps[48];
 #define STAMP(k)                                                                                    \
     do {                                                                                            \
         long long t_ = clock64();                                                                   \
@@ -66,9 +66,9 @@ __device__ unsigned long long g_stamps[16];
         tlast = t_;                                                                                 \
     } while (0)
 extern "C" void rsqp_debug_stamps(unsigned long long *out, int reset) {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 48);
     if (reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[48] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z));
     }
 }
@@ -93,6 +93,38 @@ struct LdsVec {
     __device__ __forceinline__ ldouble &operator[](int i) const { return p[i]; }
     template <int L> __device__ __forceinline__ double bcast(int i) const { return p[i]; }
 };
+// ---- partner exchange of an all-reduce WITHOUT the LDS crossbar. __shfl_xor compiles to ds_bpermute_b32 (two per
+// double, ~100 cycles each and a slot of the LDS pipe the kernel's data also goes through); inside a row of 16 lanes
+// a DPP permutation does the same in the VALU. Step S pairs every lane with one that holds the sum of the OTHER
+// 2^S-lane block of its 2^(S+1)-lane block: S = 0, 1 quad_perm (xor 1, xor 2), S = 2 row_half_mirror (i <-> 7 - i),
+// S = 3 row_mirror (i <-> 15 - i); S = 4, 5 (xor 16, 32) cross rows and stay on ds_bpermute. Steps must run in
+// ASCENDING order (the mirrors rely on the blocks below being reduced already); every lane of a block ends with the
+// same bits because floating-point addition is commutative.
+template <int S> __device__ __forceinline__ int xchg_i32(int x) {
+    if constexpr (S == 0) return __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false);       // quad_perm [1,0,3,2]
+    else if constexpr (S == 1) return __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+    else if constexpr (S == 2) return __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false); // row_half_mirror
+    else if constexpr (S == 3) return __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false); // row_mirror
+    else return __shfl_xor(x, 1 << S);
+}
+template <int S> __device__ __forceinline__ double xchg_f64(double x) {
+    if constexpr (S >= 4) return __shfl_xor(x, 1 << S);
+    else return __hiloint2double(xchg_i32<S>(__double2hiint(x)), xchg_i32<S>(__double2loint(x)));
+}
+template <int NSTEP, int S = 0> __device__ __forceinline__ double allreduce_sum(double v) {
+    if constexpr (S < NSTEP) { v += xchg_f64<S>(v); return allreduce_sum<NSTEP, S + 1>(v); }
+    else return v;
+}
+template <int NSTEP, int S = 0> __device__ __forceinline__ void allreduce_argmin(double &t, int &id) {   // lexicographic min of (t, id)
+    if constexpr (S < NSTEP) {
+        const double t2 = xchg_f64<S>(t);
+        const int id2 = xchg_i32<S>(id);
+        if (t2 < t || (t2 == t && id2 < id)) { t = t2; id = id2; }
+        allreduce_argmin<NSTEP, S + 1>(t, id);
+    }
+}
+constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n / 2); }
+
 struct RegVec {
     double r;
     __device__ __forceinline__ double &operator[](int) { return r; }                 // index == owning lane by construction
@@ -180,20 +212,9 @@ struct Engine {
     // ------------------------------------------------------------------ reductions
     // butterflies over the L lanes of this problem (xor offsets < L never leave the group);
     // every lane of the group ends with the same value, so control flow stays group-uniform
-    __device__ __forceinline__ double block_sum(double v) {
-#pragma unroll
-        for (int o = L / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        return v;
-    }
+    __device__ __forceinline__ double block_sum(double v) { return allreduce_sum<ilog2c(L)>(v); }
     // lexicographic min of (t, id)
-    __device__ __forceinline__ void block_argmin(double &t, int &id) {
-#pragma unroll
-        for (int o = L / 2; o > 0; o >>= 1) {
-            double t2 = __shfl_xor(t, o);
-            int id2 = __shfl_xor(id, o);
-            if (t2 < t || (t2 == t && id2 < id)) { t = t2; id = id2; }
-        }
-    }
+    __device__ __forceinline__ void block_argmin(double &t, int &id) { allreduce_argmin<ilog2c(L)>(t, id); }
     __device__ __forceinline__ double dot(const ldouble *a, const ldouble *b, int n) {
         double s = 0.0;
         PFOR(i, n) s += a[i] * b[i];

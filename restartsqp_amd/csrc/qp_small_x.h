@@ -80,7 +80,10 @@ __device__ RSQP_XINLINE void xgemv_w(const ldouble *M, int l, int nrows, int nco
         return;
     }
     int P = fdiv_small(64, opw);
-    if (P > 8) P = 8;
+#ifndef RSQP_XPMAX
+#define RSQP_XPMAX 8
+#endif
+    if (P > RSQP_XPMAX) P = RSQP_XPMAX;
     const int p = fdiv_small(li, opw), o = li - p * opw, og = w * opw + o;
     const bool on = p < P && og < nout;
     const int ch = P == 1 ? ninner : fdiv_small(ninner + P - 1, P), j0 = p * ch, j1 = j0 + ch < ninner ? j0 + ch : ninner;
@@ -204,8 +207,7 @@ struct EngineX {
     // butterflies over the lanes of the problem; with several waves (L > 64) the wave results meet
     // in `scal` and are combined in wave order, so every lane ends with the same value
     __device__ __forceinline__ double block_sum(double v) {
-#pragma unroll
-        for (int o = (L > 64 ? 64 : L) / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        v = allreduce_sum<ilog2c(L > 64 ? 64 : L)>(v);
         if constexpr (L > 64) {
             __syncthreads();
             if ((lane & 63) == 0) scal[lane >> 6] = v;
@@ -217,12 +219,7 @@ struct EngineX {
         return v;
     }
     __device__ __forceinline__ void block_argmin(double &t, int &id) {
-#pragma unroll
-        for (int o = (L > 64 ? 64 : L) / 2; o > 0; o >>= 1) {
-            double t2 = __shfl_xor(t, o);
-            int id2 = __shfl_xor(id, o);
-            if (t2 < t || (t2 == t && id2 < id)) { t = t2; id = id2; }
-        }
+        allreduce_argmin<ilog2c(L > 64 ? 64 : L)>(t, id);
         if constexpr (L > 64) {
             __syncthreads();
             if ((lane & 63) == 0) { scal[lane >> 6] = t; scal[8 + (lane >> 6)] = (double)id; }   // ids exceed the 16-bit LDS integers
@@ -241,9 +238,7 @@ struct EngineX {
             // operands -- same arithmetic in each of them, so all lanes agree and no workgroup barrier is needed
             double s = 0.0;
             for (int i = lane & 63; i < n; i += 64) s += a[i] * b[i];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            return s;
+            return allreduce_sum<6>(s);
         }
         double s = 0.0;
         PFOR(i, n) s += a[i] * b[i];
@@ -435,12 +430,15 @@ struct EngineX {
     __device__ __forceinline__ void z_reflect_and_shrink(bool wz_enabled, double &alpha, double &sgi) {
         double beta;
         house(wz1, nZ, wz2, alpha, beta, sgi);
+        STAMP(19);
         if constexpr (FUSED) {
             const int wt = wz_enabled ? NW / 2 : NW;
             gemv_w<false>(Z, ld, nV, nZ, wz2, 1.0, 0.0, nullptr, w5, 0, wt);                        // t = Z v
             if (wz_enabled) gemv_w<false>(Wz, ld, nZ, nZ, wz2, 1.0, 0.0, nullptr, wz3, wt, NW - wt); // s = Wz v
             SYNC();
+            STAMP(20);
             ger(Z, ld, nV, nZ, w5, wz2, -beta);                   // Z -= beta t v'
+            STAMP(21);
             if (!wz_enabled) return;
         } else {
         gemv_n(Z, ld, nV, nZ, wz2, 1.0, 0.0, nullptr, w5);        // t = Z v
@@ -453,6 +451,7 @@ struct EngineX {
         const double vl = wz2[l], sl = wz3[l];
         PFOR(a, nZ) w6[a] = Wz[l * ld + a] - beta * wz3[a] * vl - beta * wz2[a] * sl + beta * beta * theta * wz2[a] * vl;
         SYNC();
+        STAMP(22);
         const double w22 = w6[l];
         {
             // one division per row (the HBM engine divides per element; same value up to rounding)
@@ -472,6 +471,7 @@ struct EngineX {
             }
         }
         SYNC();
+        STAMP(23);
     }
 
     // new row nAC: -(wY' Minv)/eta ; new column nAC: 0 ; corner 1/eta   (wY in a1)
@@ -482,12 +482,14 @@ struct EngineX {
             else Minv[nAC * ldm + nAC] = 1.0 / eta;
         }
         SYNC();
+        STAMP(24);
     }
 
     // products of constraint row r with the bases: w1 = a_FR, wz1 = Z'a, a1 = Y'a (rows of fixed
     // variables are zero in both bases, so the sparse row is used as it is)
     __device__ __forceinline__ void constraint_products(int r, double &na2, double &wz2n) {
         row_of_A(r, w1, false);
+        STAMP(16);
         if constexpr (FUSED) {
             int wz = nAC == 0 ? NW : (nZ == 0 ? 0 : fdiv_small(NW * nZ + ((nZ + nAC) >> 1), nZ + nAC));
             if (nZ > 0 && wz < 1) wz = 1;
@@ -504,8 +506,10 @@ struct EngineX {
             PFOR(c, nAC) a1[c] = sparse_dot(Aci, Arv, Yc(c), k0, k1);
             SYNC();
         }
+        STAMP(17);
         na2 = dot(w1, w1, nV);
         wz2n = dot(wz1, wz1, nZ);
+        STAMP(18);
     }
     __device__ __forceinline__ void bound_products(int v, double &na2, double &wz2n) {
         PFOR(c, nZ) wz1[c] = Z[c * ld + v];
@@ -557,6 +561,7 @@ struct EngineX {
         if (lane == 0) Sb[v] = side;
         nFR--;
         SYNC();
+        STAMP(25);
     }
 
     // grow Wz by the null-space column Z[:, nZ]; false = not positive definite (nZ unchanged)
@@ -582,6 +587,7 @@ struct EngineX {
         }
         nZ++;
         SYNC();
+        STAMP(26);
         return true;
     }
 
@@ -604,6 +610,7 @@ struct EngineX {
         if (lane == 0) { posAC[r] = -1; Sc[r] = 0; }
         nAC--;
         SYNC();
+        STAMP(27);
     }
 
     // variable v becomes free: the null space gains the column Z[:, nZ]
@@ -646,6 +653,7 @@ struct EngineX {
         gemv_t(Minv, ldm, nAC, nAC, a1, a4);                       // q2' = vY' Minv
         const double d = dot(a1, a3, nAC);
         ger(Minv, ldm, nAC, nAC, a3, a4, beta / (1.0 - beta * d));
+        STAMP(28);
     }
 
     // ------------------------------------------------------------------ removal with definiteness guard
@@ -728,6 +736,7 @@ struct EngineX {
         y_new = sgn * bt;
         pkind = bid < nC ? 1 : 2;
         pidx = bid < nC ? bid : bid - nC;
+        STAMP(29);
         return RET_OK;
     }
 

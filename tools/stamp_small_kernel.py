@@ -17,7 +17,7 @@ if wide:
 else:
     probs = problems.hs071_scale_batch(int(sys.argv[1]) if len(sys.argv) > 1 else 16384)
 b = capi.Batch(probs)
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 48)()
 b.solve(capi.MODE_COLD, 1000)
 L.rsqp_debug_stamps(buf, 1)
 reps = 5
@@ -26,8 +26,11 @@ for _ in range(reps):
 L.rsqp_debug_stamps(buf, 0)
 names = {0: "prologue (zero image, stage matrices)", 2: "targets + setup_aux", 3: "step_direction", 4: "ratio_tests",
          5: "step + A x", 10: "  sd: dx_FX loop + barrier", 11: "  sd: A dx | H dx (one fused stage)", 12: "  sd: rhs loops + barrier",
-         13: "  sd: Minv bA, Y wY (2 stages)", 14: "  sd: H xY, +, Z', Wz, Z (5 stages)", 15: "  sd: merge loop + barrier", 6: "change_active_set", 7: "drift_correction", 8: "objective", 9: "results + image write-back"}
-tot = sum(buf[k] for k in names if k < 10)
+         13: "  sd: Minv bA, Y wY (2 stages)", 14: "  sd: H xY, +, Z', Wz, Z (5 stages)", 15: "  sd: merge loop + barrier", 16: "  cas: row of A", 17: "  cas: Z'a | Y'a (one fused stage)", 18: "  cas: two dots", 19: "  cas: house (dot, vector)", 20: "  cas: Z v | Wz v (one fused stage)",
+         21: "  cas: Z -= beta t v'", 22: "  cas: theta, Wz last column", 23: "  cas: Wz update", 24: "  cas: copy column + Minv append", 25: "  cas: add_bound tail (Y, Minv updates)",
+         26: "  cas: wz_grow (remove paths incl.)", 27: "  cas: remove_constraint", 28: "  cas: remove_bound", 29: "  cas: ensure_LI (exchange)",
+         6: "change_active_set (rest)", 7: "drift_correction", 8: "objective", 9: "results + image write-back"}
+tot = sum(buf[k] for k in names)
 nw = b.results()[0]["nWSR"]
 for k, n in names.items():
     print("%-40s %9.0f cycles  %5.1f %%  (%6.0f per working-set change)" % (n, buf[k] / reps, 100.0 * buf[k] / tot, buf[k] / reps / max(nw, 1)))
