@@ -575,15 +575,31 @@ struct EngineX {
         const double rho2 = kappa - ku, thr = RSQP_EPS_PD_REL * (fabs(kappa) + fabs(ku)) + RSQP_EPS_PD_ABS;
         if (!(rho2 > thr)) return false;
         const double ir2 = 1.0 / rho2;
-        PFOR(a, nZ + 1) {
-            if (a < nZ) {
-                const double ua = wz2[a] / rho2;
-                for (int b = 0; b < nZ; b++) Wz[b * ld + a] += ua * wz2[b];
-                Wz[nZ * ld + a] = -ua;
+        {
+            // Wz += (u / rho2) u': a lane per row walked the whole row (nZ of the 256 lanes busy, nZ dependent LDS round
+            // trips each: 16 % of the four-wave kernel's time); now (row, column slice) pairs over all lanes, same
+            // arithmetic per element
+            const int n = nZ;
+            int a = lane, b0 = 0, b1 = n, np = 1;
+            bool on = lane < n;
+            if constexpr (L > 64) { if (n > 0 && n <= L / 2) on = split2d(n, n, a, b0, b1, np); }
+            if (np > 1) {
+                if (on) {
+                    const double ua = wz2[a] / rho2;
+                    for (int b = b0; b < b1; b++) Wz[b * ld + a] += ua * wz2[b];
+                }
             } else {
-                for (int b = 0; b < nZ; b++) Wz[b * ld + nZ] = -(wz2[b] / rho2);
-                Wz[nZ * ld + nZ] = ir2;
+                PFOR(aa, n) {
+                    const double ua = wz2[aa] / rho2;
+                    for (int b = 0; b < n; b++) Wz[b * ld + aa] += ua * wz2[b];
+                }
             }
+            PFOR(aa, n) {                       // new last column and row
+                const double ua = wz2[aa] / rho2;
+                Wz[n * ld + aa] = -ua;
+                Wz[aa * ld + n] = -ua;
+            }
+            if (lane == 0) Wz[n * ld + n] = ir2;
         }
         nZ++;
         SYNC();
