@@ -954,23 +954,40 @@ struct EngineX {
     __device__ __forceinline__ Blocking ratio_tests() {
         double bt = 1.0;
         int bid = 0x7fffffff;
-        PFOR(i, nC) {
-            double Axi = Ax[i], dA = dAx[i];
-            if (Sc[i] != 0) {
-                double yi = y[nV + i], d = dy[nV + i];
-                if (Sc[i] == -1) cand(yi, -d, i, bt, bid); else cand(-yi, d, i, bt, bid);
+        // one candidate (one f64 division) per lane: the items are (constraint, lower or active), (constraint, upper),
+        // (variable, lower or active), (variable, upper) -- a lane per constraint / variable evaluated up to two
+        // candidates one after the other on the first nC lanes. The lexicographic minimum does not depend on the order.
+        const int items = 2 * (nC + nV);
+        for (int it = lane; it < items; it += L) {
+            if (it < 2 * nC) {
+                const bool upper = it >= nC;
+                const int i = upper ? it - nC : it;
+                const int sc = Sc[i];
+                if (sc != 0) {
+                    if (!upper) {
+                        const double yi = y[nV + i], d = dy[nV + i];
+                        if (sc == -1) cand(yi, -d, i, bt, bid); else cand(-yi, d, i, bt, bid);
+                    }
+                } else if (!upper) {
+                    if (lbAN[i] > -RSQP_INFTY) cand(Ax[i] - lbA[i], delta_of(lbAN[i], lbA[i]) - dAx[i], nC + nV + i, bt, bid);
+                } else {
+                    if (ubAN[i] < RSQP_INFTY) cand(ubA[i] - Ax[i], dAx[i] - delta_of(ubAN[i], ubA[i]), 2 * nC + nV + i, bt, bid);
+                }
             } else {
-                if (lbAN[i] > -RSQP_INFTY) cand(Axi - lbA[i], delta_of(lbAN[i], lbA[i]) - dA, nC + nV + i, bt, bid);
-                if (ubAN[i] < RSQP_INFTY) cand(ubA[i] - Axi, dA - delta_of(ubAN[i], ubA[i]), 2 * nC + nV + i, bt, bid);
-            }
-        }
-        PFOR(v, nV) {
-            if (Sb[v] != 0) {
-                double yi = y[v], d = dy[v];
-                if (Sb[v] == -1) cand(yi, -d, nC + v, bt, bid); else cand(-yi, d, nC + v, bt, bid);
-            } else {
-                if (lbN[v] > -RSQP_INFTY) cand(x[v] - lb[v], delta_of(lbN[v], lb[v]) - dx[v], 3 * nC + nV + v, bt, bid);
-                if (ubN[v] < RSQP_INFTY) cand(ub[v] - x[v], dx[v] - delta_of(ubN[v], ub[v]), 3 * nC + 2 * nV + v, bt, bid);
+                const int jt = it - 2 * nC;
+                const bool upper = jt >= nV;
+                const int v = upper ? jt - nV : jt;
+                const int sb = Sb[v];
+                if (sb != 0) {
+                    if (!upper) {
+                        const double yi = y[v], d = dy[v];
+                        if (sb == -1) cand(yi, -d, nC + v, bt, bid); else cand(-yi, d, nC + v, bt, bid);
+                    }
+                } else if (!upper) {
+                    if (lbN[v] > -RSQP_INFTY) cand(x[v] - lb[v], delta_of(lbN[v], lb[v]) - dx[v], 3 * nC + nV + v, bt, bid);
+                } else {
+                    if (ubN[v] < RSQP_INFTY) cand(ub[v] - x[v], dx[v] - delta_of(ubN[v], ub[v]), 3 * nC + 2 * nV + v, bt, bid);
+                }
             }
         }
         if (!(bt < 1.0)) { bt = 1.0; bid = 0x7fffffff; }
@@ -1031,10 +1048,16 @@ struct EngineX {
             PFOR(i, nV + nC) y[i] += tau * dy[i];
             PFOR(i, nC) {
                 if (done) { lbA[i] = lbAN[i]; ubA[i] = ubAN[i]; }
-                else { lbA[i] += tau * delta_of(lbAN[i], lbA[i]); ubA[i] += tau * delta_of(ubAN[i], ubA[i]); }
+                else {
+                    lbA[i] += tau * delta_of(lbAN[i], lbA[i]); ubA[i] += tau * delta_of(ubAN[i], ubA[i]);
+                    // A x follows the step by its increment (a by-product of the step direction): between here and the
+                    // exact product in drift_correction only Ax[blocking] / Ax[flipped] are read, and only into bounds
+                    // that drift_correction overwrites with the exact product once the constraint is active
+                    Ax[i] += tau * dAx[i];
+                }
             }
             SYNC();
-            A_times(x, Ax);
+            if (done) A_times(x, Ax);
             STAMP(5);
             if (done) { status = QPS_SOLVED; break; }
             if (iter >= maxit) { rcode = RET_MAX_NWSR; break; }
