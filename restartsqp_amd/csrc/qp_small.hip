@@ -954,10 +954,16 @@ struct Engine {
             PFOR(i, nV + nC) y[i] += tau * dy[i];
             PFOR(i, nC) {
                 if (done) { lbA[i] = lbAN[i]; ubA[i] = ubAN[i]; }
-                else { lbA[i] += tau * delta_of(lbAN[i], lbA[i]); ubA[i] += tau * delta_of(ubAN[i], ubA[i]); }
+                else {
+                    lbA[i] += tau * delta_of(lbAN[i], lbA[i]); ubA[i] += tau * delta_of(ubAN[i], ubA[i]);
+                    // A x follows the step by its increment (dAx, a by-product of the step direction). Until the exact
+                    // product in drift_correction only Ax[blocking] / Ax[flipped] are read, and only into bounds that
+                    // drift_correction overwrites with the exact product once the constraint is active
+                    Ax[i] += tau * dAx[i];
+                }
             }
             SYNC();
-            A_times(x, Ax);
+            if (done) A_times(x, Ax);
             STAMP(5);
             if (done) { status = QPS_SOLVED; break; }
             if (iter >= maxit) { rcode = RET_MAX_NWSR; break; }
