@@ -111,12 +111,31 @@ template <int S> __device__ __forceinline__ double xchg_f64(double x) {
     if constexpr (S >= 4) return __shfl_xor(x, 1 << S);
     else return __hiloint2double(xchg_i32<S>(__double2hiint(x)), xchg_i32<S>(__double2loint(x)));
 }
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// A whole wave (NSTEP == 6): after the four DPP steps every lane holds the sum of its row of 16; the four row sums are
+// read through scalar registers (v_readlane) and added as (R0 + R1) + (R2 + R3) -- the value the xor-16 / xor-32
+// exchanges produce in every lane (addition is commutative), without their four ds_bpermute round trips.
 template <int NSTEP, int S = 0> __device__ __forceinline__ double allreduce_sum(double v) {
-    if constexpr (S < NSTEP) { v += xchg_f64<S>(v); return allreduce_sum<NSTEP, S + 1>(v); }
+    if constexpr (NSTEP == 6 && S == 4) {
+        const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+        return (r0 + r1) + (r2 + r3);
+    } else if constexpr (S < NSTEP) { v += xchg_f64<S>(v); return allreduce_sum<NSTEP, S + 1>(v); }
     else return v;
 }
 template <int NSTEP, int S = 0> __device__ __forceinline__ void allreduce_argmin(double &t, int &id) {   // lexicographic min of (t, id)
-    if constexpr (S < NSTEP) {
+    if constexpr (NSTEP == 6 && S == 4) {
+        double bt = readlane_f64(t, 0);
+        int bi = __builtin_amdgcn_readlane(id, 0);
+#pragma unroll
+        for (int r = 16; r < 64; r += 16) {
+            const double t2 = readlane_f64(t, r);
+            const int id2 = __builtin_amdgcn_readlane(id, r);
+            if (t2 < bt || (t2 == bt && id2 < bi)) { bt = t2; bi = id2; }
+        }
+        t = bt; id = bi;
+    } else if constexpr (S < NSTEP) {
         const double t2 = xchg_f64<S>(t);
         const int id2 = xchg_i32<S>(id);
         if (t2 < t || (t2 == t && id2 < id)) { t = t2; id = id2; }
