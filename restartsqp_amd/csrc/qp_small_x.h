@@ -127,6 +127,7 @@ struct EngineX {
     ldouble *Ad, *Hd;                             // nC x nV (ld nC), nV x nV (ld nV)
     ldouble *Z, *Wz, *Y, *Minv;
     ldouble *x, *g, *lb, *ub, *gN, *lbN, *ubN, *dx, *w1, *w2, *w3, *w4, *w5, *w6, *wz1, *wz2, *wz3;
+    ldouble *Hx, *ATy;         // (H + hreg I) x and A'y_C of the iterate, carried by their increments (see drift_correction)
     ldouble *Ax, *lbA, *ubA, *lbAN, *ubAN, *dAx, *c1, *c2, *c3;
     ldouble *a1, *a2, *a3, *a4;
     ldouble *y, *dy, *scal;
@@ -135,12 +136,13 @@ struct EngineX {
     lint *Sb, *Sc, *AC, *posAC, *iscal;
     int lane;
     int nFR, nAC, nZ, status, infeasible, unbounded, nflips;
+    int since_refresh, dirty_products;
     long long tlast;
 
     // doubles of this formulation's image (<= rsqp_image_doubles, the size of the persistent copy)
     __host__ __device__ static long long image_doubles(int nV, int nC) {
         const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
-        return 2 * ld * nV + sT * ld + 17LL * nV + 9LL * nC + 2LL * (nV + nC) + 16 + 4 * (sT + 2);
+        return 2 * ld * nV + sT * ld + 19LL * nV + 9LL * nC + 2LL * (nV + nC) + 16 + 4 * (sT + 2);
     }
     __host__ __device__ static long long factor_doubles(int nV, int nC) {   // Z (+Y), Wz: (re)initialised by setup_aux
         return 2LL * rsqp_ld(nV) * nV;
@@ -169,7 +171,7 @@ struct EngineX {
         // ... and the per-solve scratch
         CARVE_V(gN); CARVE_V(lbN); CARVE_V(ubN);
         CARVE_V(dx); CARVE_V(w1); CARVE_V(w2); CARVE_V(w3); CARVE_V(w4); CARVE_V(w5); CARVE_V(w6);
-        CARVE_V(wz1); CARVE_V(wz2); CARVE_V(wz3);
+        CARVE_V(wz1); CARVE_V(wz2); CARVE_V(wz3); CARVE_V(Hx); CARVE_V(ATy);
         CARVE_C(lbAN); CARVE_C(ubAN); CARVE_C(dAx); CARVE_C(c1); CARVE_C(c2); CARVE_C(c3);
 #undef CARVE_V
 #undef CARVE_C
@@ -749,6 +751,7 @@ struct EngineX {
         PFOR(i, nC) if (Sc[i] != 0) y[nV + i] -= bt * sgn * c1[i];
         PFOR(v, nV) if (Sb[v] != 0) y[v] -= bt * sgn * w3[v];
         SYNC();
+        dirty_products = 1;                                        // the duals moved outside a step: A'y is recomputed
         y_new = sgn * bt;
         pkind = bid < nC ? 1 : 2;
         pidx = bid < nC ? bid : bid - nC;
@@ -1006,12 +1009,21 @@ struct EngineX {
     }
 
     // ------------------------------------------------------------------ homotopy (as Engine)
+    // A x, A'y_C and (H + hreg I) x follow the iterate by axpy (their increments are by-products of the step direction)
+    // and are recomputed exactly every REFRESH working-set changes and whenever an exchange moved the duals outside a
+    // step -- the scheme of the HBM-resident engine (qp_large.hip refresh_products / drift_correction). Before, every
+    // change paid the three products (11 % of the four-wave kernel's time).
+    static constexpr int REFRESH = 8;
+    __device__ __forceinline__ void refresh_products() {
+        AAtH_times(x, y + nV, Ax, ATy, Hx);
+        dirty_products = 0; since_refresh = 0;
+    }
     __device__ __forceinline__ void drift_correction() {
         PFOR(v, nV) if (Sb[v] != 0) x[v] = Sb[v] == -1 ? lb[v] : ub[v];
         SYNC();
-        AAtH_times(x, y + nV, Ax, w1, w2);
+        if (dirty_products || ++since_refresh >= REFRESH) refresh_products();
         PFOR(i, nC) { if (Sc[i] == -1) lbA[i] = Ax[i]; else if (Sc[i] == 1) ubA[i] = Ax[i]; }
-        PFOR(v, nV) g[v] = w1[v] + y[v] - w2[v];
+        PFOR(v, nV) g[v] = ATy[v] + y[v] - Hx[v];
         SYNC();
     }
     __device__ __forceinline__ int homotopy(int maxit, int &nWSR) {
@@ -1025,6 +1037,11 @@ struct EngineX {
             if (Sc[i] != -1 && lbA[i] <= -RSQP_INFTY && lbAN[i] > -RSQP_INFTY) lbA[i] = fmin(lbAN[i], Ax[i] - RSQP_BOUND_RELAXATION);
             if (Sc[i] != 1 && ubA[i] >= RSQP_INFTY && ubAN[i] < RSQP_INFTY) ubA[i] = fmax(ubAN[i], Ax[i] + RSQP_BOUND_RELAXATION);
         }
+        SYNC();
+        PFOR(i, nC) c3[i] = Ax[i];                  // (the relaxation above used the Ax of the set-up: keep that copy bit for bit)
+        SYNC();
+        refresh_products();                         // Hx, ATy (and Ax) of the starting point
+        PFOR(i, nC) Ax[i] = c3[i];
         SYNC();
         for (;;) {
             STAMP(7);
@@ -1046,6 +1063,7 @@ struct EngineX {
                 }
             }
             PFOR(i, nV + nC) y[i] += tau * dy[i];
+            if (!done) { PFOR(v, nV) { Hx[v] += tau * w5[v]; ATy[v] += tau * w3[v]; } }   // H dx and A'dy_C of the step direction
             PFOR(i, nC) {
                 if (done) { lbA[i] = lbAN[i]; ubA[i] = ubAN[i]; }
                 else {

@@ -55,7 +55,7 @@ __host__ __device__ inline long long rsqp_image_doubles(int nV, int nC) {
     long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
     //        Q|Z      R|Wz     T|Y      vectors of nV   vectors of nC   y,dy        scalars
     //        (explicit-inverse engine: Y lives inside Z's array, Minv in the T slot) + four vectors of sT + 2
-    return ld * nV + ld * nV + sT * ld + 18LL * nV + 9LL * nC + 2LL * (nV + nC) + 16 + 4 * (sT + 2);
+    return ld * nV + ld * nV + sT * ld + 19LL * nV + 9LL * nC + 2LL * (nV + nC) + 16 + 4 * (sT + 2);
 }
 __host__ __device__ inline long long rsqp_image_ints(int nV, int nC) { return nV + 3LL * nC + 8; }
 __host__ __device__ inline long long rsqp_image_bytes(int nV, int nC) {
