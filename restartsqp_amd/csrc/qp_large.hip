@@ -50,6 +50,14 @@ __device__ inline double block_sum(double v, double *sh) {
 // keeps GT_COLS independent 16-byte loads in flight per step and x is read once for all of them.
 // (ld and the column bases are even for every matrix of this engine, so the double2 loads are
 // 16-byte aligned; an odd tail row is handled separately.)
+// The decision block `ctl` is host-mapped memory. A kernel that publishes into it ends with publish(): a system-scope
+// fence, then the sequence number of this publication in ctl[63]. The host spins on that number (Impl::wait_ctl)
+// instead of sleeping in hipStreamSynchronize: a blocking wait costs ~11 us per round trip on this platform (measured:
+// one more of them per working-set change = +5 % on the dense 2048 x 4096 solve), and a change has two or three.
+__device__ __forceinline__ void publish(double *ctl, double seqv) {
+    __threadfence_system();
+    reinterpret_cast<volatile double *>(ctl)[63] = seqv;
+}
 constexpr int GT_COLS = 4;
 // one transposed product with optional fused element-wise work:
 //   x-prologue  x[r] := x[r] + (xa[r] - xb[r])       (the residual H dx + (gN - g) of the multiplier step)
@@ -546,7 +554,7 @@ k_ratio1(int nV, int nC, const int *__restrict__ Sb, const int *__restrict__ Sc,
     if (threadIdx.x == 0) { pt[blockIdx.x] = bt; pid[blockIdx.x] = bid; }
 }
 __global__ void __launch_bounds__(NT) k_argmin2(int n, const double *__restrict__ pt, const int *__restrict__ pid,
-                                                double *__restrict__ ctl) {
+                                                double *__restrict__ ctl, double seqv, double *__restrict__ dev2) {
     __shared__ double sht[4];
     __shared__ int shi[4];
     double bt = RSQP_INFTY * 10.0;
@@ -554,7 +562,10 @@ __global__ void __launch_bounds__(NT) k_argmin2(int n, const double *__restrict_
     for (int i = threadIdx.x; i < n; i += NT)
         if (pt[i] < bt || (pt[i] == bt && pid[i] < bid)) { bt = pt[i]; bid = pid[i]; }
     argmin_reduce(bt, bid, sht, shi);
-    if (threadIdx.x == 0) { ctl[0] = bt; ctl[1] = (double)bid; }   // ctl: host-mapped decision block
+    if (threadIdx.x == 0) {
+        if (dev2) { dev2[0] = bt; dev2[1] = (double)bid; }       // device copy: the homotopy step is launched before the host has looked
+        ctl[0] = bt; ctl[1] = (double)bid; publish(ctl, seqv);   // ctl: host-mapped decision block
+    }
 }
 
 // homotopy step; done: data := targets
@@ -698,15 +709,30 @@ __global__ void k_dy_fixed2(int nV, const int *__restrict__ Sb, const double *__
 }
 // the whole homotopy step in one launch: variables, constraints, multipliers, and -- fix != 0 -- the blocking
 // bound / constraint put exactly on its new side (fkind 3: constraint fidx, 4: variable fidx)
-__global__ void k_step_all(int nV, int nC, double tau, int done, const int *__restrict__ Sb, double *__restrict__ x,
+// (the winner of the ratio test is decoded HERE from the device copy k_argmin2 left in res[0..1], exactly as the host
+// decodes its own copy: the launch does not wait for the host round trip)
+__global__ void k_step_all(int nV, int nC, const double *__restrict__ res, int allow_fix, const int *__restrict__ Sb, double *__restrict__ x,
                            double *__restrict__ g, double *__restrict__ lb, double *__restrict__ ub,
                            const double *__restrict__ gN, const double *__restrict__ lbN, const double *__restrict__ ubN,
                            const double *__restrict__ dx, const double *__restrict__ ATdy, double *__restrict__ ATy,
                            const double *__restrict__ Hdx, double *__restrict__ Hx, double *__restrict__ lbA,
                            double *__restrict__ ubA, const double *__restrict__ lbAN, const double *__restrict__ ubAN,
                            const double *__restrict__ dAx, double *__restrict__ Ax, const double *__restrict__ dy,
-                           double *__restrict__ y, int fix, int fkind, int fidx, int fside) {
+                           double *__restrict__ y) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double tau = res[0];
+    const int bid = (int)res[1];
+    int fkind = 0, fidx = -1, fside = 0;
+    if (bid != 0x7fffffff) {
+        if (bid < nC) { fkind = 1; fidx = bid; }
+        else if (bid < nC + nV) { fkind = 2; fidx = bid - nC; }
+        else if (bid < 2 * nC + nV) { fkind = 3; fidx = bid - nC - nV; fside = -1; }
+        else if (bid < 3 * nC + nV) { fkind = 3; fidx = bid - 2 * nC - nV; fside = 1; }
+        else if (bid < 3 * nC + 2 * nV) { fkind = 4; fidx = bid - 3 * nC - nV; fside = -1; }
+        else { fkind = 4; fidx = bid - 3 * nC - 2 * nV; fside = 1; }
+    } else tau = 1.0;
+    const int done = fkind == 0;
+    const int fix = !done && allow_fix && (fkind == 3 || fkind == 4);
     if (i < nV) {
         const int v = i;
         if (done) {
@@ -736,13 +762,13 @@ __global__ void k_step_all(int nV, int nC, double tau, int done, const int *__re
 // products of variable v with the bases -- rows v of Z and Y -- and the norms of the independence test, one workgroup
 __global__ void __launch_bounds__(NT) k_bound_products(const double *__restrict__ Z, const double *__restrict__ Y, long long ld,
                                                        int v, int nZ, int nAC, double *__restrict__ wz1, double *__restrict__ a1,
-                                                       double *__restrict__ scal, int s1, int s2, double *__restrict__ ctl) {
+                                                       double *__restrict__ scal, int s1, int s2, double *__restrict__ ctl, double seqv) {
     __shared__ double sh[4];
     double q = 0.0;
     for (int c = threadIdx.x; c < nZ; c += NT) { const double t = Z[c * ld + v]; wz1[c] = t; q += t * t; }
     for (int c = threadIdx.x; c < nAC; c += NT) a1[c] = Y[c * ld + v];
     q = block_sum(q, sh);
-    if (threadIdx.x == 0) { scal[s1] = 1.0; scal[s2] = q; ctl[2] = 1.0; ctl[3] = q; }
+    if (threadIdx.x == 0) { scal[s1] = 1.0; scal[s2] = q; ctl[2] = 1.0; ctl[3] = q; publish(ctl, seqv); }
 }
 // a variable joins the fixed set: rows v of both bases are cleared, the working set updated
 __global__ void k_clean_bound(double *__restrict__ Y, double *__restrict__ Z, long long ld, int v, int nAC, int nZ,
@@ -830,14 +856,14 @@ __global__ void __launch_bounds__(NT) k_row_of_A_fused(const int *__restrict__ r
 // scal[s1] = |a|^2 (n1 entries; 1.0 if a is null), scal[s2] = |b|^2 (n2 entries); both published to ctl
 __global__ void __launch_bounds__(NT) k_norms_publish(const double *__restrict__ a, int n1, const double *__restrict__ b,
                                                       int n2, double *__restrict__ scal, int s1, int s2,
-                                                      double *__restrict__ ctl) {
+                                                      double *__restrict__ ctl, double seqv) {
     __shared__ double sh[4];
     double p = 0.0, q = 0.0;
     if (a) for (int i = threadIdx.x; i < n1; i += NT) p += a[i] * a[i];
     for (int i = threadIdx.x; i < n2; i += NT) q += b[i] * b[i];
     p = a ? block_sum(p, sh) : 1.0;
     q = block_sum(q, sh);
-    if (threadIdx.x == 0) { scal[s1] = p; scal[s2] = q; ctl[2] = p; ctl[3] = q; }
+    if (threadIdx.x == 0) { scal[s1] = p; scal[s2] = q; ctl[2] = p; ctl[3] = q; publish(ctl, seqv); }
 }
 
 // Z[:, k] = e_{free[k]} (columns zero-filled beforehand)
@@ -968,7 +994,7 @@ __global__ void k_newcol_free(int nV, int v, const double *t, const double *scal
 __global__ void k_sm_coef(double *scal) { scal[16] = scal[8] / (1.0 - scal[8] * scal[15]); }
 // kappa = z'(H z), ku = k'u (both dots formed here), rho2 = kappa - ku and its threshold
 __global__ void __launch_bounds__(NT) k_rho2(double *scal, double *ctl, const double *__restrict__ z, const double *__restrict__ Hz,
-                                             int nV, const double *__restrict__ kv, const double *__restrict__ uv, int nZ) {
+                                             int nV, const double *__restrict__ kv, const double *__restrict__ uv, int nZ, double seqv) {
     __shared__ double sh[4];
     double p = 0.0, q = 0.0;
     for (int i = threadIdx.x; i < nV; i += NT) p += z[i] * Hz[i];
@@ -981,6 +1007,7 @@ __global__ void __launch_bounds__(NT) k_rho2(double *scal, double *ctl, const do
     scal[13] = kappa - ku;
     scal[14] = RSQP_EPS_PD_REL * (fabs(kappa) + fabs(ku)) + RSQP_EPS_PD_ABS;
     ctl[4] = scal[13]; ctl[5] = scal[14];
+    publish(ctl, seqv);
 }
 __global__ void k_clip_y(int nV, int nC, const int *Sb, const int *Sc, double *y) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1028,6 +1055,29 @@ struct RsqpLargeEngine::Impl {
     int nFR = 0, nAC = 0, nZ = 0;
     int status = QPS_NOTINITIALISED, infeasible = 0, unbounded = 0, nflips = 0;
     double *h_ctl = nullptr, *d_ctl = nullptr;   // host-mapped decision block written by kernels
+    unsigned long long ctl_seq = 0;              // number of the last publication launched (see publish())
+    int spin_misses = 0;                         // publications that only became visible at the end of the kernel's stream
+    bool spin_wait = getenv("RSQP_LARGE_NO_SPIN") == nullptr;
+    double next_seq() { return (double)(++ctl_seq); }
+    // wait for the last launched publication: spin on its sequence number for up to 5 ms, then (or when spinning is
+    // off) block in hipStreamSynchronize. A platform on which the number never shows up early turns the spinning off.
+    int wait_ctl() {
+        if (spin_wait) {
+            const double want = (double)ctl_seq;
+            volatile double *flag = h_ctl + 63;
+            const double t0 = now_s();
+            for (int it = 0;; it++) {
+                if (*flag == want) return RET_OK;
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+                if ((it & 1023) == 1023 && now_s() - t0 > 5e-3) break;
+            }
+            if (++spin_misses >= 16) spin_wait = false;
+        }
+        LCHK(hipStreamSynchronize(st));
+        return RET_OK;
+    }
     double *h_pinned = nullptr;  // small pinned read-back buffer
     int *h_pinned_i = nullptr;
     int nblk_ratio = 0;
@@ -1042,6 +1092,7 @@ struct RsqpLargeEngine::Impl {
     double *big = nullptr;    // 2 nV^2 scratch, allocated by the first blocked set-up
     int *d_fpos = nullptr, *d_cand = nullptr, *d_freev = nullptr;
     bool blocked_setup = getenv("RSQP_NO_BLOCKED_SETUP") == nullptr;
+    bool extra_sync = getenv("RSQP_LARGE_EXTRA_SYNC") != nullptr;
     int n1_threads = getenv("RSQP_GEMV_N1_THREADS") ? atoi(getenv("RSQP_GEMV_N1_THREADS")) : 0;   // tuning: force 256 / 512 threads in k_gemv_n1
     int gemv_wgs = getenv("RSQP_GEMV_WGS") ? atoi(getenv("RSQP_GEMV_WGS")) : 4096;     // workgroups the chunked y = M w aims for
     bool reinit_from_y0 = true;
@@ -1264,10 +1315,10 @@ struct RsqpLargeEngine::Impl {
         } else {
             gemv_t_pair(gt_task(Z, ld, nV, nZ, w1, wz1), gt_task(Y, ld, nV, nAC, w1, a1));
         }
-        hipLaunchKernelGGL(k_norms_publish, dim3(1), dim3(NT), 0, st, w1, nV, wz1, nZ, scal, 6, 7, d_ctl);
+        hipLaunchKernelGGL(k_norms_publish, dim3(1), dim3(NT), 0, st, w1, nV, wz1, nZ, scal, 6, 7, d_ctl, next_seq());
     }
     void bound_products(int v) {
-        hipLaunchKernelGGL(k_bound_products, dim3(1), dim3(NT), 0, st, Z, Y, ld, v, nZ, nAC, wz1, a1, scal, 6, 7, d_ctl);
+        hipLaunchKernelGGL(k_bound_products, dim3(1), dim3(NT), 0, st, Z, Y, ld, v, nZ, nAC, wz1, a1, scal, 6, 7, d_ctl, next_seq());
     }
 
     // second stage shared by add_bound and (mirrored) remove_bound: reflection on [Y, extra]
@@ -1299,8 +1350,8 @@ struct RsqpLargeEngine::Impl {
         gemv_t(Z, ld, nV, nZ, w2, wz1);           // k = Z'Hz
         gemv_n(Wz, ld, nZ, nZ, wz1, 1.0, 0.0, nullptr, wz2);  // u = Wz k
         // kappa = z'Hz, ku = k'u, scal[13] = rho2, scal[14] = threshold
-        hipLaunchKernelGGL(k_rho2, dim3(1), dim3(NT), 0, st, scal, d_ctl, z, w2, nV, wz1, wz2, nZ);
-        LCHK(hipStreamSynchronize(st));
+        hipLaunchKernelGGL(k_rho2, dim3(1), dim3(NT), 0, st, scal, d_ctl, z, w2, nV, wz1, wz2, nZ, next_seq());
+        if (wait_ctl() != RET_OK) return RET_SETUP_FAILED;
         *pd = h_ctl[4] > h_ctl[5];
         if (*pd) {
             pbegin();
@@ -1420,8 +1471,8 @@ struct RsqpLargeEngine::Impl {
         hipLaunchKernelGGL(k_xiB, g1(nV), dim3(NT), 0, st, nV, Sb, w4, w2, w3);
         const double sgn = side == 1 ? -1.0 : 1.0;
         hipLaunchKernelGGL(k_partner1, dim3(nblk_ratio), dim3(NT), 0, st, nV, nC, Sb, Sc, y, c1, w3, sgn, pt, pid);
-        hipLaunchKernelGGL(k_argmin2, dim3(1), dim3(NT), 0, st, nblk_ratio, pt, pid, d_ctl);
-        LCHK(hipStreamSynchronize(st));
+        hipLaunchKernelGGL(k_argmin2, dim3(1), dim3(NT), 0, st, nblk_ratio, pt, pid, d_ctl, next_seq(), (double *)nullptr);
+        if (wait_ctl() != RET_OK) return RET_SETUP_FAILED;
         const double t = h_ctl[0];
         const int id = (int)h_ctl[1];
         if (id == 0x7fffffff) return RET_INFEASIBLE;
@@ -1434,7 +1485,7 @@ struct RsqpLargeEngine::Impl {
     }
 
     int li_decision(bool *li) {
-        LCHK(hipStreamSynchronize(st));
+        if (wait_ctl() != RET_OK) return RET_SETUP_FAILED;
         const double a2 = h_ctl[2], w2n = h_ctl[3];
         *li = nZ > 0 && a2 > 0.0 && std::sqrt(w2n) > RSQP_EPS_LI * std::sqrt(a2);
         return RET_OK;
@@ -1537,8 +1588,11 @@ struct RsqpLargeEngine::Impl {
             step_direction();
             hipLaunchKernelGGL(k_ratio1, dim3(nblk_ratio), dim3(NT), 0, st, nV, nC, Sb, Sc, x, y, dx, dy, Ax, dAx, lb, ub,
                                lbA, ubA, lbN, ubN, lbAN, ubAN, pt, pid);
-            hipLaunchKernelGGL(k_argmin2, dim3(1), dim3(NT), 0, st, nblk_ratio, pt, pid, d_ctl);
-            LCHK(hipStreamSynchronize(st));
+            hipLaunchKernelGGL(k_argmin2, dim3(1), dim3(NT), 0, st, nblk_ratio, pt, pid, d_ctl, next_seq(), scal + 30);
+            // the homotopy step decodes the winner on the device and runs while the host waits for its own copy
+            hipLaunchKernelGGL(k_step_all, g1(nV + nC), dim3(NT), 0, st, nV, nC, scal + 30, iter < maxit ? 1 : 0, Sb, x, g, lb, ub, gN, lbN,
+                               ubN, dx, ATdy, ATy, Hdx, Hx, lbA, ubA, lbAN, ubAN, dAx, Ax, dy, y);
+            if (wait_ctl() != RET_OK) return RET_SETUP_FAILED;
             double tau = h_ctl[0];
             const int bid = (int)h_ctl[1];
             int kind = 0, idx = -1, side = 0;
@@ -1551,9 +1605,8 @@ struct RsqpLargeEngine::Impl {
                 else { kind = 4; idx = bid - 3 * nC - 2 * nV; side = 1; }
             } else tau = 1.0;
             const int done = kind == 0;
-            const int fix = (!done && iter < maxit && (kind == 3 || kind == 4)) ? 1 : 0;   // blocking quantity exactly on its side
-            hipLaunchKernelGGL(k_step_all, g1(nV + nC), dim3(NT), 0, st, nV, nC, tau, done, Sb, x, g, lb, ub, gN, lbN, ubN, dx, ATdy,
-                               ATy, Hdx, Hx, lbA, ubA, lbAN, ubAN, dAx, Ax, dy, y, fix, kind, idx, side);
+            (void)tau;
+            if (extra_sync) (void)hipStreamSynchronize(st);      // tuning: what one more host round trip per change costs
             if (done) { A_times(x, Ax); status = QPS_SOLVED; break; }
             if (iter >= maxit) { rcode = RET_MAX_NWSR; break; }
             rcode = change_active_set(kind, idx, side);
