@@ -416,6 +416,7 @@ __global__ void __launch_bounds__(NT) k_wz_grow(double *__restrict__ Wz, long lo
     const int a = blockIdx.x * NT + threadIdx.x, b = blockIdx.y;
     if (a > nZ || b > nZ) return;
     const double r2 = scal[sr];
+    if (!(r2 > scal[sr + 1])) return;      // not positive definite (the host takes the same decision from its copy): no growth
     double val;
     if (a < nZ && b < nZ) val = Wz[(long long)b * ld + a] + u[a] * u[b] / r2;
     else if (a == nZ && b == nZ) val = 1.0 / r2;
@@ -1351,14 +1352,13 @@ struct RsqpLargeEngine::Impl {
         gemv_n(Wz, ld, nZ, nZ, wz1, 1.0, 0.0, nullptr, wz2);  // u = Wz k
         // kappa = z'Hz, ku = k'u, scal[13] = rho2, scal[14] = threshold
         hipLaunchKernelGGL(k_rho2, dim3(1), dim3(NT), 0, st, scal, d_ctl, z, w2, nV, wz1, wz2, nZ, next_seq());
+        // the growth is launched before the host has the verdict: the kernel tests rho2 > threshold itself (scal[13], [14])
+        pbegin();
+        hipLaunchKernelGGL(k_wz_grow, dim3((nZ + 1 + NT - 1) / NT, nZ + 1), dim3(NT), 0, st, Wz, ld, nZ, wz2, scal, 13);
+        pend(4, 16.0 * (double)nZ * nZ);
         if (wait_ctl() != RET_OK) return RET_SETUP_FAILED;
         *pd = h_ctl[4] > h_ctl[5];
-        if (*pd) {
-            pbegin();
-            hipLaunchKernelGGL(k_wz_grow, dim3((nZ + 1 + NT - 1) / NT, nZ + 1), dim3(NT), 0, st, Wz, ld, nZ, wz2, scal, 13);
-            pend(4, 16.0 * (double)nZ * nZ);
-            nZ++;
-        }
+        if (*pd) nZ++;
         return RET_OK;
     }
 
