@@ -524,9 +524,11 @@ k_ratio1(int nV, int nC, const int *__restrict__ Sb, const int *__restrict__ Sc,
          const double *__restrict__ Ax, const double *__restrict__ dAx, const double *__restrict__ lb,
          const double *__restrict__ ub, const double *__restrict__ lbA, const double *__restrict__ ubA,
          const double *__restrict__ lbN, const double *__restrict__ ubN, const double *__restrict__ lbAN,
-         const double *__restrict__ ubAN, double *__restrict__ pt, int *__restrict__ pid) {
+         const double *__restrict__ ubAN, double *__restrict__ pt, int *__restrict__ pid,
+         double *__restrict__ ctl, double seqv, double *__restrict__ dev2, int *__restrict__ ticket) {
     __shared__ double sht[4];
     __shared__ int shi[4];
+    __shared__ int s_last;
     double bt = 1.0;
     int bid = 0x7fffffff;
     for (int i = blockIdx.x * NT + threadIdx.x; i < nC + nV; i += gridDim.x * NT) {
@@ -552,7 +554,29 @@ k_ratio1(int nV, int nC, const int *__restrict__ Sb, const int *__restrict__ Sc,
     }
     if (!(bt < 1.0)) { bt = 1.0; bid = 0x7fffffff; }
     argmin_reduce(bt, bid, sht, shi);
-    if (threadIdx.x == 0) { pt[blockIdx.x] = bt; pid[blockIdx.x] = bid; }
+    // The workgroup that draws the last ticket finishes the reduction (what k_argmin2 did in a second launch): partial
+    // results are released at device scope before the ticket is drawn and read back with device-scope loads -- the
+    // workgroups sit on different XCDs, whose L2s are not coherent for plain loads.
+    if (threadIdx.x == 0) {
+        pt[blockIdx.x] = bt; pid[blockIdx.x] = bid;
+        __threadfence();
+        s_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    bt = RSQP_INFTY * 10.0; bid = 0x7fffffff;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += NT) {
+        const double t2 = __hip_atomic_load(pt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int id2 = __hip_atomic_load(pid + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t2 < bt || (t2 == bt && id2 < bid)) { bt = t2; bid = id2; }
+    }
+    argmin_reduce(bt, bid, sht, shi);
+    if (threadIdx.x == 0) {
+        *ticket = 0;                                             // next use (stream order: nobody draws before this kernel ends)
+        if (dev2) { dev2[0] = bt; dev2[1] = (double)bid; }       // device copy: the homotopy step is launched before the host has looked
+        ctl[0] = bt; ctl[1] = (double)bid; publish(ctl, seqv);   // ctl: host-mapped decision block
+    }
 }
 __global__ void __launch_bounds__(NT) k_argmin2(int n, const double *__restrict__ pt, const int *__restrict__ pid,
                                                 double *__restrict__ ctl, double seqv, double *__restrict__ dev2) {
@@ -833,13 +857,17 @@ __global__ void k_drift_all(int nV, int nC, const int *__restrict__ Sb, const in
                             const double *__restrict__ lb, const double *__restrict__ ub, double *__restrict__ x,
                             const double *__restrict__ Ax, double *__restrict__ lbA, double *__restrict__ ubA,
                             const double *__restrict__ ATy, const double *__restrict__ y, const double *__restrict__ Hx,
-                            double *__restrict__ g) {
+                            double *__restrict__ g, const double *__restrict__ lbN, const double *__restrict__ ubN,
+                            double *__restrict__ dx, double *__restrict__ dy) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nV) {
         if (Sb[i] != 0) x[i] = Sb[i] == -1 ? lb[i] : ub[i];
         g[i] = ATy[i] + y[i] - Hx[i];
+        // first kernel of the next step direction (k_dx_fixed_zero_dy) rides along: it reads nothing this one writes
+        dx[i] = Sb[i] == -1 ? delta_of(lbN[i], lb[i]) : (Sb[i] == 1 ? delta_of(ubN[i], ub[i]) : 0.0);
     }
     if (i < nC) { if (Sc[i] == -1) lbA[i] = Ax[i]; else if (Sc[i] == 1) ubA[i] = Ax[i]; }
+    if (i < nV + nC) dy[i] = 0.0;
 }
 // working-set bookkeeping of an added constraint
 __global__ void k_set_ws(int *AC, int *posAC, int *Sc, int nAC, int r, int side) { AC[nAC] = r; posAC[r] = nAC; Sc[r] = side; }
@@ -1093,6 +1121,7 @@ struct RsqpLargeEngine::Impl {
     double *big = nullptr;    // 2 nV^2 scratch, allocated by the first blocked set-up
     int *d_fpos = nullptr, *d_cand = nullptr, *d_freev = nullptr;
     bool blocked_setup = getenv("RSQP_NO_BLOCKED_SETUP") == nullptr;
+    bool dx_ready = false;
     bool extra_sync = getenv("RSQP_LARGE_EXTRA_SYNC") != nullptr;
     int n1_threads = getenv("RSQP_GEMV_N1_THREADS") ? atoi(getenv("RSQP_GEMV_N1_THREADS")) : 0;   // tuning: force 256 / 512 threads in k_gemv_n1
     int gemv_wgs = getenv("RSQP_GEMV_WGS") ? atoi(getenv("RSQP_GEMV_WGS")) : 4096;     // workgroups the chunked y = M w aims for
@@ -1527,7 +1556,8 @@ struct RsqpLargeEngine::Impl {
 
     // ---- step direction -----------------------------------------------------------------
     void step_direction() {
-        hipLaunchKernelGGL(k_dx_fixed_zero_dy, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, lb, ub, lbN, ubN, dx, dy);
+        if (!dx_ready) hipLaunchKernelGGL(k_dx_fixed_zero_dy, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, lb, ub, lbN, ubN, dx, dy);
+        dx_ready = false;           // (set by drift_correction, whose kernel then has done this already)
         A_times(dx, c1);                                                   // A dx_FX
         H_times(dx, w2);
         hipLaunchKernelGGL(k_sd_prep, g1(std::max(nAC, nV)), dim3(NT), 0, st, nAC, AC, Sc, lbA, ubA, lbAN, ubAN, c1, a1, nV, w2, gN, g,
@@ -1572,8 +1602,9 @@ struct RsqpLargeEngine::Impl {
             hipLaunchKernelGGL(k_fix_x, g1(nV), dim3(NT), 0, st, nV, Sb, lb, ub, x);
             refresh_products();
         }
-        hipLaunchKernelGGL(k_drift_all, g1(std::max(nV, nC)), dim3(NT), 0, st, nV, nC, Sb, Sc, lb, ub, x, Ax, lbA, ubA, ATy,
-                           y, Hx, g);
+        hipLaunchKernelGGL(k_drift_all, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, Sc, lb, ub, x, Ax, lbA, ubA, ATy,
+                           y, Hx, g, lbN, ubN, dx, dy);
+        dx_ready = true;
         chk("drift");
     }
 
@@ -1581,14 +1612,14 @@ struct RsqpLargeEngine::Impl {
         int iter = 0, rcode = RET_OK;
         double sum_nFR = 0.0, sum_nAC = 0.0, sum_nZ = 0.0;      // reported by RSQP_PROFILE: the sizes the products run on
         status = QPS_PERFORMINGHOMOTOPY;
+        dx_ready = false;
         refresh_products();
         hipLaunchKernelGGL(k_rerelax, g1(nV), dim3(NT), 0, st, nV, Sb, x, lbN, ubN, lb, ub);
         if (nC > 0) hipLaunchKernelGGL(k_rerelax, g1(nC), dim3(NT), 0, st, nC, Sc, Ax, lbAN, ubAN, lbA, ubA);
         for (;;) {
             step_direction();
             hipLaunchKernelGGL(k_ratio1, dim3(nblk_ratio), dim3(NT), 0, st, nV, nC, Sb, Sc, x, y, dx, dy, Ax, dAx, lb, ub,
-                               lbA, ubA, lbN, ubN, lbAN, ubAN, pt, pid);
-            hipLaunchKernelGGL(k_argmin2, dim3(1), dim3(NT), 0, st, nblk_ratio, pt, pid, d_ctl, next_seq(), scal + 30);
+                               lbA, ubA, lbN, ubN, lbAN, ubAN, pt, pid, d_ctl, next_seq(), scal + 30, res_id);
             // the homotopy step decodes the winner on the device and runs while the host waits for its own copy
             hipLaunchKernelGGL(k_step_all, g1(nV + nC), dim3(NT), 0, st, nV, nC, scal + 30, iter < maxit ? 1 : 0, Sb, x, g, lb, ub, gN, lbN,
                                ubN, dx, ATdy, ATy, Hdx, Hx, lbA, ubA, lbAN, ubAN, dAx, Ax, dy, y);
@@ -1807,6 +1838,7 @@ hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
     P.nblk_ratio = std::min(1024, std::max(1, (nV + nC + NT - 1) / NT));
     DA(pt, P.nblk_ratio); DA(res_t, 2);
     DA(Sb, nV); DA(Sc, nC); DA(AC, nC); DA(posAC, nC); DA(pid, P.nblk_ratio); DA(res_id, 2);
+    if ((e = hipMemsetAsync(P.res_id, 0, 2 * sizeof(int), stream)) != hipSuccess) return e;      // res_id[0]: ticket counter of k_ratio1
     DA(d_fpos, nV); DA(d_cand, nC); DA(d_freev, nV);
 #undef DA
     if ((e = rsqp_dense_work_alloc(&P.dw, nV)) != hipSuccess) return e;
