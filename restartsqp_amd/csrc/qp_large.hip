@@ -225,7 +225,13 @@ __global__ void __launch_bounds__(NT) k_gemv_n_reduce(const double *__restrict__
 // groups; the 32 partial sums of a row meet in LDS and are added in group order (deterministic). 128 workgroups
 // x 256 threads x 8 loads in flight keep ~4 MB on the wire for a 2048 x 2048 matrix.
 // Optional epilogue (the step direction's "dx on the free variables", k_merge_free): mdst[r] = out[r] where mSb[r] == 0.
-template <bool VEC, int NTH>
+// SKIP0: a column whose weight is exactly zero is not read -- for products whose vector lives on a subset (dx on the
+// fixed variables): the pass costs the live columns only (0 * m is dropped, not added)
+template <bool SKIP0> __device__ __forceinline__ double2 ld_live(const double *p, double wc) {
+    if (SKIP0 && wc == 0.0) return make_double2(0.0, 0.0);
+    return *reinterpret_cast<const double2 *>(p);
+}
+template <bool VEC, int NTH, bool SKIP0 = false>
 __global__ void __launch_bounds__(NTH) k_gemv_n1(const double *__restrict__ M, long long ld, int nrows, int ncols,
                                                 const double *__restrict__ w, double alpha, double beta,
                                                 const double *__restrict__ base, double *__restrict__ out,
@@ -241,17 +247,18 @@ __global__ void __launch_bounds__(NTH) k_gemv_n1(const double *__restrict__ M, l
             double2 s0 = {0, 0}, s1 = {0, 0}, s2 = {0, 0}, s3 = {0, 0};
             int c = cg;
             for (; c + 3 * NG < ncols; c += 4 * NG) {
-                const double2 m0 = *reinterpret_cast<const double2 *>(M + c * ld + r);
-                const double2 m1 = *reinterpret_cast<const double2 *>(M + (c + NG) * ld + r);
-                const double2 m2 = *reinterpret_cast<const double2 *>(M + (c + 2 * NG) * ld + r);
-                const double2 m3 = *reinterpret_cast<const double2 *>(M + (c + 3 * NG) * ld + r);
                 const double w0 = w[c], w1 = w[c + NG], w2 = w[c + 2 * NG], w3 = w[c + 3 * NG];
+                const double2 m0 = ld_live<SKIP0>(M + c * ld + r, w0);
+                const double2 m1 = ld_live<SKIP0>(M + (c + NG) * ld + r, w1);
+                const double2 m2 = ld_live<SKIP0>(M + (c + 2 * NG) * ld + r, w2);
+                const double2 m3 = ld_live<SKIP0>(M + (c + 3 * NG) * ld + r, w3);
                 s0.x += m0.x * w0; s0.y += m0.y * w0; s1.x += m1.x * w1; s1.y += m1.y * w1;
                 s2.x += m2.x * w2; s2.y += m2.y * w2; s3.x += m3.x * w3; s3.y += m3.y * w3;
             }
             for (; c < ncols; c += NG) {
-                const double2 m0 = *reinterpret_cast<const double2 *>(M + c * ld + r);
-                s0.x += m0.x * w[c]; s0.y += m0.y * w[c];
+                const double w0 = w[c];
+                const double2 m0 = ld_live<SKIP0>(M + c * ld + r, w0);
+                s0.x += m0.x * w0; s0.y += m0.y * w0;
             }
             a0 = (s0.x + s1.x) + (s2.x + s3.x);
             a1 = (s0.y + s1.y) + (s2.y + s3.y);
@@ -1090,7 +1097,10 @@ struct RsqpLargeEngine::Impl {
     double next_seq() { return (double)(++ctl_seq); }
     // wait for the last launched publication: spin on its sequence number for up to 5 ms, then (or when spinning is
     // off) block in hipStreamSynchronize. A platform on which the number never shows up early turns the spinning off.
+    double wait_seconds = 0.0;                   // host time spent waiting for publications (RSQP_PROFILE report)
+    long long wait_calls = 0;
     int wait_ctl() {
+        struct Acc { Impl *p; double t0; ~Acc() { p->wait_seconds += now_s() - t0; p->wait_calls++; } } acc{this, now_s()};
         if (spin_wait) {
             const double want = (double)ctl_seq;
             volatile double *flag = h_ctl + 63;
@@ -1122,6 +1132,7 @@ struct RsqpLargeEngine::Impl {
     int *d_fpos = nullptr, *d_cand = nullptr, *d_freev = nullptr;
     bool blocked_setup = getenv("RSQP_NO_BLOCKED_SETUP") == nullptr;
     bool dx_ready = false;
+    bool live_skip = getenv("RSQP_LARGE_NO_LIVE_SKIP") == nullptr;
     bool extra_sync = getenv("RSQP_LARGE_EXTRA_SYNC") != nullptr;
     int n1_threads = getenv("RSQP_GEMV_N1_THREADS") ? atoi(getenv("RSQP_GEMV_N1_THREADS")) : 0;   // tuning: force 256 / 512 threads in k_gemv_n1
     int gemv_wgs = getenv("RSQP_GEMV_WGS") ? atoi(getenv("RSQP_GEMV_WGS")) : 4096;     // workgroups the chunked y = M w aims for
@@ -1236,6 +1247,16 @@ struct RsqpLargeEngine::Impl {
         pend(0, 8.0 * nrows * (double)ncols + 8.0 * nrows + 8.0 * ncols);
         chk("gemv_n");
     }
+    // out = M w for a vector w with `live` non-zeros (the kernel skips the other columns); falls back to gemv_n
+    void gemv_n_live(const double *Mx, long long l, int nrows, int ncols, const double *wv, double *out, int live) {
+        const bool vec1 = ((l & 1) == 0) && ((reinterpret_cast<unsigned long long>(Mx) & 15) == 0);
+        if (!vec1 || nrows <= 0 || ncols <= 0 || nrows > 8192) { gemv_n(Mx, l, nrows, ncols, wv, 1.0, 0.0, nullptr, out); return; }
+        pbegin();
+        if (nrows <= 3072) hipLaunchKernelGGL((k_gemv_n1<true, 512, true>), dim3((nrows + 15) / 16), dim3(512), 0, st, Mx, l, nrows, ncols, wv, 1.0, 0.0, (const double *)nullptr, out, (const int *)nullptr, (double *)nullptr);
+        else hipLaunchKernelGGL((k_gemv_n1<true, NT, true>), dim3((nrows + 15) / 16), dim3(NT), 0, st, Mx, l, nrows, ncols, wv, 1.0, 0.0, (const double *)nullptr, out, (const int *)nullptr, (double *)nullptr);
+        pend(0, 8.0 * nrows * (double)live + 8.0 * nrows + 8.0 * ncols);
+        chk("gemv_n_live");
+    }
     void ger(double *Mx, long long l, int nrows, int ncols, const double *t, const double *v, int ci, double cs) {
         pbegin();
         if (ncols > 0 && nrows > 0) {
@@ -1264,6 +1285,16 @@ struct RsqpLargeEngine::Impl {
         if (nC <= 0) fill(out, nV, 0.0);
         else if (M.denseA) gemv_t(M.denseA, nC, nC, nV, in, out);
         else (void)rsqp_launch_spmv(M.blk_c, M.nblk_c, M.Ajc, M.Air, M.Aval, in, out, 1, 0, 0, 0, 0, st);
+    }
+    // A in and (H + hreg I) in of the SAME vector in one launch when both matrices have dense copies (A through its
+    // row-major copy: both are transposed products then); otherwise one after the other
+    void AH_times(const double *in, double *outA, double *outH) {
+        if (nC > 0 && M.denseAT && M.haveH && M.denseH && M.hreg == 0.0) {
+            gemv_t_pair(gt_task(M.denseAT, nV, nV, nC, in, outA), gt_task(M.denseH, nV, nV, nV, in, outH));
+            return;
+        }
+        A_times(in, outA);
+        H_times(in, outH);
     }
     // out = (H + hreg I) in [+ add]
     void H_times(const double *in, double *out, const double *add = nullptr) {
@@ -1558,8 +1589,12 @@ struct RsqpLargeEngine::Impl {
     void step_direction() {
         if (!dx_ready) hipLaunchKernelGGL(k_dx_fixed_zero_dy, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, lb, ub, lbN, ubN, dx, dy);
         dx_ready = false;           // (set by drift_correction, whose kernel then has done this already)
-        A_times(dx, c1);                                                   // A dx_FX
-        H_times(dx, w2);
+        // A dx_FX, H dx_FX: dx is zero on the free variables here (mean over the dense 2048 x 4096 cold start: 196 of
+        // 2048 entries live), so the column-major products read the live columns only
+        if (live_skip && M.denseA && M.haveH && M.denseH && M.hreg == 0.0 && 4 * (nV - nFR) < nV) {
+            gemv_n_live(M.denseA, nC, nC, nV, dx, c1, nV - nFR);
+            gemv_n_live(M.denseH, nV, nV, nV, dx, w2, nV - nFR);           // H symmetric
+        } else AH_times(dx, c1, w2);
         hipLaunchKernelGGL(k_sd_prep, g1(std::max(nAC, nV)), dim3(NT), 0, st, nAC, AC, Sc, lbA, ubA, lbAN, ubAN, c1, a1, nV, w2, gN, g,
                            w1);                                            // bA -> a1, tmpg -> w1
         // range space: wY = Minv bA ; xY = Y wY
@@ -1570,8 +1605,8 @@ struct RsqpLargeEngine::Impl {
         gemv_t(Z, ld, nV, nZ, w2, wz1);
         gemv_n(Wz, ld, nZ, nZ, wz1, -1.0, 0.0, nullptr, wz2);
         gemv_n(Z, ld, nV, nZ, wz2, 1.0, 1.0, w3, w4, Sb, dx);              // xY + Z wZ, merged into dx on the free variables
-        // multipliers: dyAC = Minv' Y'(H dx + dg)
-        H_times(dx, Hdx);
+        // multipliers: dyAC = Minv' Y'(H dx + dg); A dx (for the ratio tests) rides along with H dx
+        AH_times(dx, dAx, Hdx);
         {
             GtTask t = gt_task(Y, ld, nV, nAC, Hdx, a1);                   // a1 = Y'(H dx + (gN - g))
             t.xa = gN; t.xb = g;
@@ -1582,7 +1617,6 @@ struct RsqpLargeEngine::Impl {
         }
         AT_times(dy + nV, ATdy);
         hipLaunchKernelGGL(k_dy_fixed2, g1(nV), dim3(NT), 0, st, nV, Sb, Hdx, gN, g, ATdy, dy);
-        A_times(dx, dAx);
         chk("step_direction");
     }
 
@@ -1648,9 +1682,9 @@ struct RsqpLargeEngine::Impl {
             sum_nFR += nFR; sum_nAC += nAC; sum_nZ += nZ;
             drift_correction();
         }
-        if (profile && iter > 0)
-            fprintf(stderr, "[rsqp profile] homotopy: %d changes, mean nFR %.1f nAC %.1f nZ %.1f (nV %d nC %d)\n", iter,
-                    sum_nFR / iter, sum_nAC / iter, sum_nZ / iter, nV, nC);
+        if ((profile || getenv("RSQP_LARGE_WAITSTAT")) && iter > 0)
+            fprintf(stderr, "[rsqp profile] homotopy: %d changes, mean nFR %.1f nAC %.1f nZ %.1f (nV %d nC %d); host waited %.3f s in %lld round trips\n", iter,
+                    sum_nFR / iter, sum_nAC / iter, sum_nZ / iter, nV, nC, wait_seconds, wait_calls);
         *nWSR = iter;
         return rcode;
     }

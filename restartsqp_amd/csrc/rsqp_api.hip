@@ -245,7 +245,7 @@ struct rsqp_solver {
     RsqpLargeEngine *large = nullptr;
     bool large_ready = false, profile_large = false;
     bool reinit_from_y0 = true;   // rsqp_set_reinit_guess
-    DevBuf<double> denseA, denseH;   // dense copies for the HBM-resident engine (dense matrices only)
+    DevBuf<double> denseA, denseAT, denseH;   // dense copies for the HBM-resident engine (dense matrices only)
     ~rsqp_solver() {
         delete large;
         if (io_host) {   // mapped views first, then the block
@@ -648,6 +648,11 @@ int solve_large(rsqp_solver *s, int mode, int *nWSR, const double *x0, const dou
         if (rsqp_launch_densify(s->nC, s->nV, s->A.jc.p, s->A.ir.p, s->A.val.p, s->denseA.p, s->stream) != hipSuccess)
             return fail(RSQP_ERR_DEVICE, "densify launch failed");
         m.denseA = s->denseA.p;
+        // the row-major copy (the CSR arrays are the CSC arrays of A')
+        if (!s->denseAT.p) HIPCHK(s->denseAT.alloc((size_t)s->nC * s->nV, false));
+        if (rsqp_launch_densify(s->nV, s->nC, s->A.rp.p, s->A.ci.p, s->A.rval.p, s->denseAT.p, s->stream) != hipSuccess)
+            return fail(RSQP_ERR_DEVICE, "densify launch failed");
+        m.denseAT = s->denseAT.p;
     }
     if (s->H.initialised && !s->lp_mode && (double)s->H.nnz > 0.25 * (double)s->nV * s->nV) {
         if (!s->denseH.p) HIPCHK(s->denseH.alloc((size_t)s->nV * s->nV, false));

@@ -14,6 +14,8 @@ struct RsqpLargeMatrices {
     double hreg = 0.0;               // H + hreg*I
     // optional dense column-major copies (null when the matrix is sparse)
     const double *denseA = nullptr;   // nC x nV, ld = nC
+    const double *denseAT = nullptr;  // the same matrix row-major (= A' column-major, nV x nC, ld = nV): A x as a transposed
+                                      // product, which shares a launch with H x (k_gemv_t2)
     const double *denseH = nullptr;   // nV x nV, ld = nV
 };
 
