@@ -384,6 +384,23 @@ __global__ void __launch_bounds__(NT) k_house(const double *__restrict__ w, int 
     }
 }
 
+// the same Householder data for w = wz1 whose squared norm s a publishing kernel has just formed (same loop, same
+// tree: the same bits as k_house would compute) -- what the reflection of Z needs if the independence test passes;
+// written after the publication, i.e. while the host is still on its way (hv == nullptr or n == 0: nothing)
+__device__ __forceinline__ void house_tail(const double *__restrict__ w, int n, double s, double *__restrict__ hv,
+                                           double *__restrict__ scal) {
+    if (!hv || n <= 0) return;
+    __syncthreads();            // w may have been written by this workgroup (k_bound_products)
+    const double alpha = sqrt(s), wl = w[n - 1], sg = wl >= 0.0 ? 1.0 : -1.0;
+    for (int i = threadIdx.x; i < n; i += NT) hv[i] = w[i] + (i == n - 1 ? sg * alpha : 0.0);
+    if (threadIdx.x == 0) {
+        scal[0] = alpha;
+        scal[1] = alpha > 0.0 ? 1.0 / (alpha * (alpha + fabs(wl))) : 0.0;
+        scal[2] = -sg;
+        scal[3] = s;
+    }
+}
+
 // ---- Wz updates ------------------------------------------------------------------
 // two-sided reflection + elimination of the last row/column (null space loses its last
 // column after the reflection P = I - beta v v'):
@@ -532,7 +549,9 @@ k_ratio1(int nV, int nC, const int *__restrict__ Sb, const int *__restrict__ Sc,
          const double *__restrict__ ub, const double *__restrict__ lbA, const double *__restrict__ ubA,
          const double *__restrict__ lbN, const double *__restrict__ ubN, const double *__restrict__ lbAN,
          const double *__restrict__ ubAN, double *__restrict__ pt, int *__restrict__ pid,
-         double *__restrict__ ctl, double seqv, double *__restrict__ dev2, int *__restrict__ ticket) {
+         double *__restrict__ ctl, double seqv, double *__restrict__ dev2, int *__restrict__ ticket,
+         const double *__restrict__ Hdx, const double *__restrict__ gN, const double *__restrict__ g,
+         const double *__restrict__ ATdy, double *__restrict__ dyw) {
     __shared__ double sht[4];
     __shared__ int shi[4];
     __shared__ int s_last;
@@ -551,7 +570,10 @@ k_ratio1(int nV, int nC, const int *__restrict__ Sb, const int *__restrict__ Sc,
         } else {
             const int v = i - nC;
             if (Sb[v] != 0) {
-                const double yi = y[v], d = dy[v];
+                // the multiplier step of a fixed variable is formed here (it was the launch k_dy_fixed2) and stored for the
+                // homotopy step; the free variables keep the zero written with dx_FX
+                const double yi = y[v], d = (Hdx[v] + (gN[v] - g[v])) - ATdy[v];
+                dyw[v] = d;
                 if (Sb[v] == -1) cand(yi, -d, nC + v, bt, bid); else cand(-yi, d, nC + v, bt, bid);
             } else {
                 if (lbN[v] > -RSQP_INFTY) cand(x[v] - lb[v], delta_of(lbN[v], lb[v]) - dx[v], 3 * nC + nV + v, bt, bid);
@@ -794,13 +816,15 @@ __global__ void k_step_all(int nV, int nC, const double *__restrict__ res, int a
 // products of variable v with the bases -- rows v of Z and Y -- and the norms of the independence test, one workgroup
 __global__ void __launch_bounds__(NT) k_bound_products(const double *__restrict__ Z, const double *__restrict__ Y, long long ld,
                                                        int v, int nZ, int nAC, double *__restrict__ wz1, double *__restrict__ a1,
-                                                       double *__restrict__ scal, int s1, int s2, double *__restrict__ ctl, double seqv) {
+                                                       double *__restrict__ scal, int s1, int s2, double *__restrict__ ctl, double seqv,
+                                                       double *__restrict__ hv) {
     __shared__ double sh[4];
     double q = 0.0;
     for (int c = threadIdx.x; c < nZ; c += NT) { const double t = Z[c * ld + v]; wz1[c] = t; q += t * t; }
     for (int c = threadIdx.x; c < nAC; c += NT) a1[c] = Y[c * ld + v];
     q = block_sum(q, sh);
     if (threadIdx.x == 0) { scal[s1] = 1.0; scal[s2] = q; ctl[2] = 1.0; ctl[3] = q; publish(ctl, seqv); }
+    house_tail(wz1, nZ, q, hv, scal);
 }
 // a variable joins the fixed set: rows v of both bases are cleared, the working set updated
 __global__ void k_clean_bound(double *__restrict__ Y, double *__restrict__ Z, long long ld, int v, int nAC, int nZ,
@@ -892,7 +916,7 @@ __global__ void __launch_bounds__(NT) k_row_of_A_fused(const int *__restrict__ r
 // scal[s1] = |a|^2 (n1 entries; 1.0 if a is null), scal[s2] = |b|^2 (n2 entries); both published to ctl
 __global__ void __launch_bounds__(NT) k_norms_publish(const double *__restrict__ a, int n1, const double *__restrict__ b,
                                                       int n2, double *__restrict__ scal, int s1, int s2,
-                                                      double *__restrict__ ctl, double seqv) {
+                                                      double *__restrict__ ctl, double seqv, double *__restrict__ hv) {
     __shared__ double sh[4];
     double p = 0.0, q = 0.0;
     if (a) for (int i = threadIdx.x; i < n1; i += NT) p += a[i] * a[i];
@@ -900,6 +924,7 @@ __global__ void __launch_bounds__(NT) k_norms_publish(const double *__restrict__
     p = a ? block_sum(p, sh) : 1.0;
     q = block_sum(q, sh);
     if (threadIdx.x == 0) { scal[s1] = p; scal[s2] = q; ctl[2] = p; ctl[3] = q; publish(ctl, seqv); }
+    house_tail(b, n2, q, hv, scal);
 }
 
 // Z[:, k] = e_{free[k]} (columns zero-filled beforehand)
@@ -1132,6 +1157,7 @@ struct RsqpLargeEngine::Impl {
     int *d_fpos = nullptr, *d_cand = nullptr, *d_freev = nullptr;
     bool blocked_setup = getenv("RSQP_NO_BLOCKED_SETUP") == nullptr;
     bool dx_ready = false;
+    bool house_done = false;      // wz2 / scal[0..3] hold the Householder data of the current wz1 (constraint_products / bound_products)
     bool live_skip = getenv("RSQP_LARGE_NO_LIVE_SKIP") == nullptr;
     bool extra_sync = getenv("RSQP_LARGE_EXTRA_SYNC") != nullptr;
     int n1_threads = getenv("RSQP_GEMV_N1_THREADS") ? atoi(getenv("RSQP_GEMV_N1_THREADS")) : 0;   // tuning: force 256 / 512 threads in k_gemv_n1
@@ -1326,7 +1352,8 @@ struct RsqpLargeEngine::Impl {
     // reflection of Z that puts the direction Z w (w in wz1, length nZ) into the last column;
     // Wz follows; the last column is then taken out of the null space. scal[0..3] = house.
     void z_reflect_and_shrink() {
-        hipLaunchKernelGGL(k_house, dim3(1), dim3(NT), 0, st, wz1, nZ, wz2, scal, 0);   // v -> wz2
+        if (!house_done) hipLaunchKernelGGL(k_house, dim3(1), dim3(NT), 0, st, wz1, nZ, wz2, scal, 0);   // v -> wz2 (else: done by the products' kernel)
+        house_done = false;
         gemv_n(Z, ld, nV, nZ, wz2, 1.0, 0.0, nullptr, w5);                               // t = Z v
         ger(Z, ld, nV, nZ, w5, wz2, 1, -1.0);                                            // Z -= beta t v'
         if (!wz_enabled) return;
@@ -1356,6 +1383,7 @@ struct RsqpLargeEngine::Impl {
             copy(Zc(nZ - 1), Yc(nAC), nV);
         } else {
             // exchange / flip: the row is orthogonal to all null-space columns but the last
+            house_done = false;
             copy(Zc(nZ - 1), Yc(nAC), nV);
             dot(w1, Zc(nZ - 1), nV, 5);
         }
@@ -1376,16 +1404,19 @@ struct RsqpLargeEngine::Impl {
         } else {
             gemv_t_pair(gt_task(Z, ld, nV, nZ, w1, wz1), gt_task(Y, ld, nV, nAC, w1, a1));
         }
-        hipLaunchKernelGGL(k_norms_publish, dim3(1), dim3(NT), 0, st, w1, nV, wz1, nZ, scal, 6, 7, d_ctl, next_seq());
+        hipLaunchKernelGGL(k_norms_publish, dim3(1), dim3(NT), 0, st, w1, nV, wz1, nZ, scal, 6, 7, d_ctl, next_seq(), wz2);
+        house_done = nZ > 0;
     }
     void bound_products(int v) {
-        hipLaunchKernelGGL(k_bound_products, dim3(1), dim3(NT), 0, st, Z, Y, ld, v, nZ, nAC, wz1, a1, scal, 6, 7, d_ctl, next_seq());
+        hipLaunchKernelGGL(k_bound_products, dim3(1), dim3(NT), 0, st, Z, Y, ld, v, nZ, nAC, wz1, a1, scal, 6, 7, d_ctl, next_seq(), wz2);
+        house_done = nZ > 0;
     }
 
     // second stage shared by add_bound and (mirrored) remove_bound: reflection on [Y, extra]
     // add_bound(v): qY (row v of Y) in a1, q* = zs[v] where zs = Z's last column after stage 1
     int add_bound(int v, int side, bool skipZ) {
         if (!skipZ) z_reflect_and_shrink();          // wz1 = row v of Z (from bound_products)
+        else house_done = false;
         double *zs = Zc(nZ - 1);
         nZ--;
         // q~ = [qY ; q*]; |q~| = 1. vt = q~ with last += sgn(q*); beta~ = 1/(1+|q*|)
@@ -1616,7 +1647,7 @@ struct RsqpLargeEngine::Impl {
             gemv_t_task(u);
         }
         AT_times(dy + nV, ATdy);
-        hipLaunchKernelGGL(k_dy_fixed2, g1(nV), dim3(NT), 0, st, nV, Sb, Hdx, gN, g, ATdy, dy);
+        // (dy of the fixed variables: formed by k_ratio1, which is the next kernel)
         chk("step_direction");
     }
 
@@ -1653,7 +1684,7 @@ struct RsqpLargeEngine::Impl {
         for (;;) {
             step_direction();
             hipLaunchKernelGGL(k_ratio1, dim3(nblk_ratio), dim3(NT), 0, st, nV, nC, Sb, Sc, x, y, dx, dy, Ax, dAx, lb, ub,
-                               lbA, ubA, lbN, ubN, lbAN, ubAN, pt, pid, d_ctl, next_seq(), scal + 30, res_id);
+                               lbA, ubA, lbN, ubN, lbAN, ubAN, pt, pid, d_ctl, next_seq(), scal + 30, res_id, Hdx, gN, g, ATdy, dy);
             // the homotopy step decodes the winner on the device and runs while the host waits for its own copy
             hipLaunchKernelGGL(k_step_all, g1(nV + nC), dim3(NT), 0, st, nV, nC, scal + 30, iter < maxit ? 1 : 0, Sb, x, g, lb, ub, gN, lbN,
                                ubN, dx, ATdy, ATy, Hdx, Hx, lbA, ubA, lbAN, ubAN, dAx, Ax, dy, y);
