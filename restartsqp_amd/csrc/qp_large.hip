@@ -1156,6 +1156,9 @@ struct RsqpLargeEngine::Impl {
     double *big = nullptr;    // 2 nV^2 scratch, allocated by the first blocked set-up
     int *d_fpos = nullptr, *d_cand = nullptr, *d_freev = nullptr;
     bool blocked_setup = getenv("RSQP_NO_BLOCKED_SETUP") == nullptr;
+    // rows up to which y = M w runs as ONE launch (k_gemv_n1); beyond, chunks + a reduction launch. Measured
+    // (tools/large_kernel_bench.py): 4096 x 4096 19.8 vs 27.8 us, 5000 x 5000 44.2 vs 35.6 us, 7670 x 7670 116.9 vs 84.5 us
+    int n1_maxrows = getenv("RSQP_GEMV_N1_MAXROWS") ? atoi(getenv("RSQP_GEMV_N1_MAXROWS")) : 4096;
     bool dx_ready = false;
     bool house_done = false;      // wz2 / scal[0..3] hold the Householder data of the current wz1 (constraint_products / bound_products)
     bool live_skip = getenv("RSQP_LARGE_NO_LIVE_SKIP") == nullptr;
@@ -1242,7 +1245,7 @@ struct RsqpLargeEngine::Impl {
             return;
         }
         pbegin();
-        if (nrows <= 8192 || mSb) {   // launch-bound sizes: one kernel, no partials (k_gemv_n1)
+        if (nrows <= n1_maxrows || mSb) {   // launch-bound sizes: one kernel, no partials (k_gemv_n1)
             const bool vec1 = ((l & 1) == 0) && ((reinterpret_cast<unsigned long long>(Mx) & 15) == 0);
             // 16-row workgroups: up to 3072 rows they cover at most 192 of the 256 CUs, so each gets 512 threads (64 column
             // groups, twice the loads in flight: 2048 x 2048 8.7 -> 6.7 us); taller matrices fill the chip with 256 (4096 x
