@@ -433,6 +433,62 @@ __global__ void __launch_bounds__(NT) k_wz_shrink(double *__restrict__ Wz, long 
     Wz[(long long)b * ld + a] += -beta * s[a] * v[b] - beta * v[a] * s[b] + beta * beta * theta * v[a] * v[b] -
                                  col[a] * col[b] / w22;
 }
+// the two Wz updates with 16-byte accesses: a lane owns two consecutive rows of WZ_COLS columns (the element
+// expressions are those of the scalar kernels, term by term). Leading dimension even, Wz 16-byte aligned.
+constexpr int WZ_COLS = 4;
+__global__ void __launch_bounds__(NT) k_wz_shrink_v(double *__restrict__ Wz, long long ld, int nZ,
+                                                    const double *__restrict__ s, const double *__restrict__ v,
+                                                    const double *__restrict__ col, const double *__restrict__ scal, int sb,
+                                                    int st) {
+    const int a = (blockIdx.x * NT + threadIdx.x) * 2, b0 = blockIdx.y * WZ_COLS;
+    const int l = nZ - 1;
+    if (a >= l) return;
+    const double beta = scal[sb], theta = scal[st], w22 = col[l];
+    const bool two = a + 1 < l;
+    const double sa0 = s[a], va0 = v[a], ca0 = col[a];
+    const double sa1 = two ? s[a + 1] : 0.0, va1 = two ? v[a + 1] : 0.0, ca1 = two ? col[a + 1] : 0.0;
+#pragma unroll
+    for (int k = 0; k < WZ_COLS; k++) {
+        const int b = b0 + k;
+        if (b >= l) break;
+        const double vb = v[b], sbv = s[b], cb = col[b];
+        double *p = Wz + (long long)b * ld + a;
+        if (two) {
+            double2 m = *reinterpret_cast<double2 *>(p);
+            m.x += -beta * sa0 * vb - beta * va0 * sbv + beta * beta * theta * va0 * vb - ca0 * cb / w22;
+            m.y += -beta * sa1 * vb - beta * va1 * sbv + beta * beta * theta * va1 * vb - ca1 * cb / w22;
+            *reinterpret_cast<double2 *>(p) = m;
+        } else {
+            p[0] += -beta * sa0 * vb - beta * va0 * sbv + beta * beta * theta * va0 * vb - ca0 * cb / w22;
+        }
+    }
+}
+__global__ void __launch_bounds__(NT) k_wz_grow_v(double *__restrict__ Wz, long long ld, int nZ,
+                                                  const double *__restrict__ u, const double *__restrict__ scal, int sr) {
+    const int a = (blockIdx.x * NT + threadIdx.x) * 2, b0 = blockIdx.y * WZ_COLS;
+    if (a > nZ) return;
+    const double r2 = scal[sr];
+    if (!(r2 > scal[sr + 1])) return;      // not positive definite (the host takes the same decision from its copy): no growth
+    auto elem = [&](int aa, int b, double old) -> double {
+        if (aa < nZ && b < nZ) return old + u[aa] * u[b] / r2;
+        if (aa == nZ && b == nZ) return 1.0 / r2;
+        return -u[aa < nZ ? aa : b] / r2;
+    };
+#pragma unroll
+    for (int k = 0; k < WZ_COLS; k++) {
+        const int b = b0 + k;
+        if (b > nZ) break;
+        double *p = Wz + (long long)b * ld + a;
+        if (a + 1 <= nZ) {
+            double2 m = *reinterpret_cast<double2 *>(p);     // (row / column nZ hold stale values: read, not used)
+            m.x = elem(a, b, m.x);
+            m.y = elem(a + 1, b, m.y);
+            *reinterpret_cast<double2 *>(p) = m;
+        } else {
+            p[0] = elem(a, b, p[0]);
+        }
+    }
+}
 // bordering (null space gains column nZ): u = Wz k, rho2 = kappa - k'u
 //   Wz' = [[Wz + u u'/rho2, -u/rho2], [-u'/rho2, 1/rho2]]
 __global__ void __launch_bounds__(NT) k_wz_grow(double *__restrict__ Wz, long long ld, int nZ,
@@ -1363,9 +1419,14 @@ struct RsqpLargeEngine::Impl {
         gemv_n(Wz, ld, nZ, nZ, wz2, 1.0, 0.0, nullptr, wz3);                             // s = Wz v
         hipLaunchKernelGGL(k_wz_lastcol, g1(nZ), dim3(NT), 0, st, Wz, ld, nZ, wz3, wz2, scal, 1, 4, w6);   // theta = v's -> scal[4]
         pbegin();
-        if (nZ > 1)
-            hipLaunchKernelGGL(k_wz_shrink, dim3((nZ - 1 + NT - 1) / NT, nZ - 1), dim3(NT), 0, st, Wz, ld, nZ, wz3, wz2, w6,
-                               scal, 1, 4);
+        if (nZ > 1) {
+            if ((ld & 1) == 0)
+                hipLaunchKernelGGL(k_wz_shrink_v, dim3((nZ - 1 + 2 * NT - 1) / (2 * NT), (nZ - 1 + WZ_COLS - 1) / WZ_COLS), dim3(NT), 0, st, Wz,
+                                   ld, nZ, wz3, wz2, w6, scal, 1, 4);
+            else
+                hipLaunchKernelGGL(k_wz_shrink, dim3((nZ - 1 + NT - 1) / NT, nZ - 1), dim3(NT), 0, st, Wz, ld, nZ, wz3, wz2, w6,
+                                   scal, 1, 4);
+        }
         pend(3, 16.0 * (double)nZ * nZ);
     }
 
@@ -1448,7 +1509,11 @@ struct RsqpLargeEngine::Impl {
         hipLaunchKernelGGL(k_rho2, dim3(1), dim3(NT), 0, st, scal, d_ctl, z, w2, nV, wz1, wz2, nZ, next_seq());
         // the growth is launched before the host has the verdict: the kernel tests rho2 > threshold itself (scal[13], [14])
         pbegin();
-        hipLaunchKernelGGL(k_wz_grow, dim3((nZ + 1 + NT - 1) / NT, nZ + 1), dim3(NT), 0, st, Wz, ld, nZ, wz2, scal, 13);
+        if ((ld & 1) == 0)
+            hipLaunchKernelGGL(k_wz_grow_v, dim3((nZ + 1 + 2 * NT - 1) / (2 * NT), (nZ + 1 + WZ_COLS - 1) / WZ_COLS), dim3(NT), 0, st, Wz, ld,
+                               nZ, wz2, scal, 13);
+        else
+            hipLaunchKernelGGL(k_wz_grow, dim3((nZ + 1 + NT - 1) / NT, nZ + 1), dim3(NT), 0, st, Wz, ld, nZ, wz2, scal, 13);
         pend(4, 16.0 * (double)nZ * nZ);
         if (wait_ctl() != RET_OK) return RET_SETUP_FAILED;
         *pd = h_ctl[4] > h_ctl[5];
