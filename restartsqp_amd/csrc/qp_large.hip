@@ -81,6 +81,7 @@ __device__ inline void gemv_t_body(const GtTask &t, int blk, double *sh) {
                      (!t.xa || (((reinterpret_cast<unsigned long long>(t.xa) | reinterpret_cast<unsigned long long>(t.xb)) & 15) == 0));
     if (vec) {
         const int n2 = nrows >> 1;
+#pragma unroll 2
         for (int r = threadIdx.x; r < n2; r += NT) {
             double2 xv = reinterpret_cast<const double2 *>(x)[r];
             if (t.xa) {
