@@ -1162,7 +1162,9 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
         P.obj[q] = obj;
         E.iscal[1] = E.nFR; E.iscal[2] = E.nAC; E.iscal[3] = E.status;
     }
+    if (P.done_flag) __threadfence_system();      // the results above are in host-mapped memory: visible before the flag
     SYNC();
+    if (P.done_flag && q == 0 && lane == 0) *reinterpret_cast<volatile int *>(P.done_flag) = P.done_val;
     if (P.keep_state) {
         for (int k = lane; k < np; k += L) img[k] = simg[k];
         for (int k = lane; k < ni; k += L) iimg[k] = siimg[k];

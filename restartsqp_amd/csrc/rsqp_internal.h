@@ -44,6 +44,8 @@ struct QPPools {
     double *state;
     int uniV, uniC;   // nV / nC of every problem when the batch is uniform in shape, else -1
     int reinit_from_y0;   // warm re-initialisation (mode 3) without guessed constraints: 1 = sides from sign(y0), 0 = from A x0
+    int *done_flag;   // single-QP solves: host-mapped word that receives done_val once the results are out (the host spins
+    int done_val;     //   on it instead of sleeping in hipStreamSynchronize); nullptr for batches
     int keep_state;   // 1: write the hot-start part of the engine image back to HBM at the end of a solve (what the
                       //    SQProblem object keeps between calls); 0: cold-start-only batches skip that write --
                       //    the image is marked "not initialised", a later hot start falls back to a cold start
