@@ -350,6 +350,22 @@ int fetch_results(rsqp_solver *s) {
     return RSQP_OK;
 }
 
+// wait for a single-QP kernel that raises the host-mapped completion word to `val`: spin for up to 2 ms, then block
+int wait_done(rsqp_solver *s, int val) {
+    volatile int *flag = s->h_done;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int it = 0;; it++) {
+        if (*flag == val) return RSQP_OK;
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+        if ((it & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return RSQP_OK;
+}
+bool spin_enabled() { static const bool on = getenv("RSQP_NO_SPIN") == nullptr; return on; }
+
 bool solved(const rsqp_solver *s) { return s->status_word == QPS_SOLVED; }
 bool infeasible(const rsqp_solver *s) { return s->status_word >= 100 && s->status_word < 200; }
 
@@ -704,27 +720,15 @@ extern "C" int rsqp_solve(rsqp_solver *s, int mode, int *nWSR, const double *x0,
         if (y0) { HIPCHK(s->d_y0.upload(y0, s->nV + s->nC)); p.y0 = s->d_y0.p; }
         if (guess_b) { HIPCHK(s->d_guess.upload(guess_b, s->nV)); p.guess_b = s->d_guess.p; }
     }
-    static const bool spin = getenv("RSQP_NO_SPIN") == nullptr;
-    if (s->d_done && spin) { p.done_flag = s->d_done; p.done_val = ++s->done_seq; }
+    if (s->d_done && spin_enabled()) { p.done_flag = s->d_done; p.done_val = ++s->done_seq; }
     hipError_t e = rsqp_launch_small_qp(p, 1, s->nV, s->nC,
                                         rsqp_mat_lds_bytes(s->nV, s->nC, s->A.initialised ? s->A.nnz : 0, s->H.initialised ? s->H.nnz : 0),
                                         mode, *nWSR, s->stream);
     if (e != hipSuccess) return fail(RSQP_ERR_DEVICE, std::string("QP kernel launch: ") + hipGetErrorString(e));
     // the results live in host-mapped memory and the kernel raises a host-mapped flag behind them: spinning on it saves
     // the ~10 us a blocking hipStreamSynchronize takes to wake up (a single hs071-scale solve is ~30 us end to end)
-    bool seen = false;
-    if (p.done_flag) {
-        volatile int *flag = s->h_done;
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int it = 0; !seen; it++) {
-            if (*flag == p.done_val) { seen = true; break; }
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
-            if ((it & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
-        }
-    }
-    if (!seen) HIPCHK(hipStreamSynchronize(s->stream));
+    if (p.done_flag) { if ((rc = wait_done(s, p.done_val)) != RSQP_OK) return rc; }
+    else HIPCHK(hipStreamSynchronize(s->stream));
     rc = fetch_results(s);
     if (rc != RSQP_OK) return rc;
     HIPCHK(s->d_nwsr.download(nWSR, 1));
@@ -950,12 +954,14 @@ int run_certificate(rsqp_solver *s, rsqp_optimality_status *out, int *W_c, int *
     a.ub = s->d_vec[RSQP_VEC_UB].p; a.lbA = s->d_vec[RSQP_VEC_LBA].p; a.ubA = s->d_vec[RSQP_VEC_UBA].p;
     a.Ax = s->d_Ax.p; a.ATy = s->d_ATy.p; a.Hx = s->d_Hx.p;
     a.ws_b = s->d_wsb.p; a.ws_c = s->d_wsc.p; a.W_b = s->d_Wb.p; a.W_c = s->d_Wc.p; a.out = s->d_kkt.p;
+    if (s->d_done && spin_enabled()) { a.done_flag = s->d_done; a.done_val = ++s->done_seq; }
     if (fused) {
         QPPools p = pools_of(s);
         if (rsqp_launch_small_certificate(p, a, 1, s->d_Ax.p, s->d_ATy.p, s->d_Hx.p, s->stream) != hipSuccess)
             return fail(RSQP_ERR_DEVICE, "certificate launch failed");
     } else if (rsqp_launch_kkt(a, 1, s->stream) != hipSuccess) return fail(RSQP_ERR_DEVICE, "kkt launch failed");
-    HIPCHK(hipStreamSynchronize(s->stream));
+    if (a.done_flag) { if ((rc = wait_done(s, a.done_val)) != RSQP_OK) return rc; }
+    else HIPCHK(hipStreamSynchronize(s->stream));
     double o[6];
     HIPCHK(s->d_kkt.download(o, 6));
     if (out) {

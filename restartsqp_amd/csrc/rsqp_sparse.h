@@ -19,6 +19,8 @@ struct RsqpKktArgs {
     const int *ws_b, *ws_c;
     int *W_b, *W_c;
     double *out;  // 6 doubles per problem: primal, dual, compl, stat, KKT_error, invalid
+    int *done_flag;   // single-QP certificate: host-mapped word that receives done_val behind the results (or nullptr)
+    int done_val;
 };
 
 // row/column blocks for csx_stream_spmv: consecutive majors with at most `chunk`

@@ -712,6 +712,7 @@ __device__ __forceinline__ void kkt_body(const RsqpKktArgs &a, double *sh) {
         primal += fmax(0.0, l - ax) + -fmin(0.0, u - ax);            // :524-527
         kkt_terms(W, yv, ax, l, u, dual, compl_, bad);
     }
+    if (a.done_flag) __threadfence_system();      // W_b / W_c (host-mapped for a single QP) visible before the flag below
     primal = block_sum_256(primal, sh);
     dual = block_sum_256(dual, sh);
     compl_ = block_sum_256(compl_, sh);
@@ -722,6 +723,7 @@ __device__ __forceinline__ void kkt_body(const RsqpKktArgs &a, double *sh) {
         o[0] = primal; o[1] = dual; o[2] = compl_; o[3] = stat;
         o[4] = compl_ + stat + dual + primal;   // :664-665
         o[5] = fb;
+        if (a.done_flag && q == 0) { __threadfence_system(); *reinterpret_cast<volatile int *>(a.done_flag) = a.done_val; }
     }
 }
 __global__ void __launch_bounds__(KKT_NT)
