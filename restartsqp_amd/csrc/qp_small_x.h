@@ -1013,7 +1013,10 @@ struct EngineX {
     // and are recomputed exactly every REFRESH working-set changes and whenever an exchange moved the duals outside a
     // step -- the scheme of the HBM-resident engine (qp_large.hip refresh_products / drift_correction). Before, every
     // change paid the three products (11 % of the four-wave kernel's time).
-    static constexpr int REFRESH = 8;
+#ifndef RSQP_X_REFRESH
+#define RSQP_X_REFRESH 8
+#endif
+    static constexpr int REFRESH = RSQP_X_REFRESH;
     __device__ __forceinline__ void refresh_products() {
         AAtH_times(x, y + nV, Ax, ATy, Hx);
         dirty_products = 0; since_refresh = 0;
