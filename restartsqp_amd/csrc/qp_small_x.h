@@ -137,6 +137,7 @@ struct EngineX {
     int lane;
     int nFR, nAC, nZ, status, infeasible, unbounded, nflips;
     int since_refresh, dirty_products;
+    int hdim;                  // the stored entries of H lie in its leading hdim x hdim block (see stage_dense)
     long long tlast;
 
     // doubles of this formulation's image (<= rsqp_image_doubles, the size of the persistent copy)
@@ -197,12 +198,28 @@ struct EngineX {
         Hd = Ad + nC * nV;
         for (int k = lane; k < nC * nV + nV * nV; k += L) Ad[k] = 0.0;
         SYNC();
+        int hm = 0;
         PFOR(c, nV) {
             for (int k = gAjc[c]; k < gAjc[c + 1]; k++) Ad[gAir[k] + c * nC] = gAval[k];
             if (haveH)
-                for (int k = gHjc[c]; k < gHjc[c + 1]; k++) Hd[gHir[k] + c * nV] = gHval[k];
+                for (int k = gHjc[c]; k < gHjc[c + 1]; k++) {
+                    const int r = gHir[k];
+                    Hd[r + c * nV] = gHval[k];
+                    hm = max(hm, max(r, c) + 1);
+                }
         }
         SYNC();
+        // The QPhandler formulation [x u v] gives H entries to the original variables only (the slacks have a linear
+        // penalty): for a 69 x 28 member of the hs0xx batch 13 x 13 of the 69 x 69 dense copy. The Hessian products run
+        // on that leading block; the rest of their output is zero. (Skipped terms are exact zeros: same sums.)
+        double t = -(double)hm;
+        int id = 0;
+        block_argmin(t, id);
+        hdim = (int)(-t);
+    }
+    // out = H v on the leading hdim x hdim block, zero beyond; the caller closes with the barrier
+    __device__ __forceinline__ void h_tail_zero(ldouble *out) {
+        for (int c = hdim + lane; c < nV; c += L) out[c] = 0.0;
     }
 
     // ------------------------------------------------------------------ reductions
@@ -359,7 +376,8 @@ struct EngineX {
     }
     __device__ __forceinline__ void H_times(const ldouble *v, ldouble *out) {
         if constexpr (DENSE_MATS) {
-            gemv_t(Hd, nV, nV, nV, v, out);        // H is symmetric: column sums = row sums
+            h_tail_zero(out);
+            gemv_t(Hd, nV, hdim, hdim, v, out);    // H is symmetric: column sums = row sums
             if (hreg != 0.0) { PFOR(c, nV) out[c] += hreg * v[c]; SYNC(); }
             return;
         }
@@ -374,9 +392,12 @@ struct EngineX {
     // outA = A v, outH = (H + hreg I) v
     __device__ __forceinline__ void AH_times(const ldouble *v, ldouble *outA, ldouble *outH) {
         if constexpr (FUSED) {
-            const int wa = nC > 0 ? 1 : 0;
+            // waves in proportion to the work: A has nC x nV entries, the Hessian block hdim x hdim
+            int wa = nC > 0 ? 1 : 0;
+            if (nC > 0 && 3 * hdim * hdim < nC * nV) wa = NW - 1;
             gemv_w<false>(Ad, nC, nC, nV, v, 1.0, 0.0, nullptr, outA, 0, wa);
-            gemv_w<true>(Hd, nV, nV, nV, v, 1.0, 0.0, nullptr, outH, wa, NW - wa);
+            gemv_w<true>(Hd, nV, hdim, hdim, v, 1.0, 0.0, nullptr, outH, wa, NW - wa);
+            h_tail_zero(outH);
             SYNC();
             if (hreg != 0.0) { PFOR(c, nV) outH[c] += hreg * v[c]; SYNC(); }
         } else {
@@ -388,9 +409,11 @@ struct EngineX {
     __device__ __forceinline__ void AAtH_times(const ldouble *xv, const ldouble *yc, ldouble *outA, ldouble *aty, ldouble *hx) {
         if constexpr (FUSED) {
             const int wa = nC > 0 ? 1 : 0;
+            const int wh = (nC > 0 && 3 * hdim * hdim < nC * nV) ? 1 : NW - wa - 1;   // waves of the Hessian block
             gemv_w<false>(Ad, nC, nC, nV, xv, 1.0, 0.0, nullptr, outA, 0, wa);
-            gemv_w<true>(Ad, nC, nC, nV, yc, 1.0, 0.0, nullptr, aty, wa, 1);       // inner dimension nC: short sums
-            gemv_w<true>(Hd, nV, nV, nV, xv, 1.0, 0.0, nullptr, hx, wa + 1, NW - wa - 1);
+            gemv_w<true>(Ad, nC, nC, nV, yc, 1.0, 0.0, nullptr, aty, wa, NW - wa - wh);   // inner dimension nC: short sums
+            gemv_w<true>(Hd, nV, hdim, hdim, xv, 1.0, 0.0, nullptr, hx, NW - wh, wh);
+            h_tail_zero(hx);
             SYNC();
             if (hreg != 0.0) { PFOR(c, nV) hx[c] += hreg * xv[c]; SYNC(); }
         } else {
