@@ -60,9 +60,14 @@ __device__ __forceinline__ double xdots(const ldouble *a, int sa, const ldouble 
 // by the first lane of the output. Waves outside [w0, w0 + nw) skip the call, so independent products given
 // disjoint wave ranges run side by side; the caller closes the group with ONE workgroup barrier.
 // TR: out[c] = sum_r M[c*l + r] xv[r] (nout = ncols, inner = nrows); else out[r] = beta base[r] + alpha sum_c M[c*l + r] xv[c]
-template <bool TR>
+// EPI: element-wise work that rides on the product -- called as epi(index, value) by the lane that stores out[index]
+// (what used to be a separate loop + barrier after the product: a barrier-separated stage costs ~1 k cycles here
+// whatever it computes)
+struct XNoEpi { __device__ __forceinline__ void operator()(int, double) const {} };
+template <bool TR, class EPI = XNoEpi>
 __device__ RSQP_XINLINE void xgemv_w(const ldouble *M, int l, int nrows, int ncols, const ldouble *xv, double alpha,
-                                     double beta, const ldouble *base, ldouble *out, int w0, int nw, ldouble *part, int lane) {
+                                     double beta, const ldouble *base, ldouble *out, int w0, int nw, ldouble *part, int lane,
+                                     EPI epi = EPI()) {
     const int w = (lane >> 6) - w0, li = lane & 63;
     if (w < 0 || w >= nw) return;
     const int nout = TR ? ncols : nrows, ninner = TR ? nrows : ncols;
@@ -74,7 +79,9 @@ __device__ RSQP_XINLINE void xgemv_w(const ldouble *M, int l, int nrows, int nco
             const int og = w * opw + o;
             if (og < nout) {
                 const double t = TR ? xdots<true>(M + og * l, 1, xv, 0, ninner) : xdots<false>(M + og, l, xv, 0, ninner);
-                out[og] = TR ? t : (base ? beta * base[og] : 0.0) + alpha * t;
+                const double val = TR ? t : (base ? beta * base[og] : 0.0) + alpha * t;
+                out[og] = val;
+                epi(og, val);
             }
         }
         return;
@@ -92,7 +99,9 @@ __device__ RSQP_XINLINE void xgemv_w(const ldouble *M, int l, int nrows, int nco
     if (on && p == 0) {
         double t = pw[o];
         for (int k = 1; k < P; k++) t += pw[k * opw + o];
-        out[og] = TR ? t : (base ? beta * base[og] : 0.0) + alpha * t;
+        const double val = TR ? t : (base ? beta * base[og] : 0.0) + alpha * t;
+        out[og] = val;
+        epi(og, val);
     }
 }
 // M[c*l + r] += coef * t[r] * v[c], the nrows x ncols elements dealt over nl lanes (rows fastest)
@@ -137,6 +146,7 @@ struct EngineX {
     int lane;
     int nFR, nAC, nZ, status, infeasible, unbounded, nflips;
     int since_refresh, dirty_products;
+    int dx_ready;              // dx_FX and dy = 0 of the next step direction were written by drift_correction (FUSED builds)
     int hdim;                  // the stored entries of H lie in its leading hdim x hdim block (see stage_dense)
     long long tlast;
 
@@ -218,8 +228,9 @@ struct EngineX {
         hdim = (int)(-t);
     }
     // out = H v on the leading hdim x hdim block, zero beyond; the caller closes with the barrier
-    __device__ __forceinline__ void h_tail_zero(ldouble *out) {
-        for (int c = hdim + lane; c < nV; c += L) out[c] = 0.0;
+    template <class EPI = XNoEpi>
+    __device__ __forceinline__ void h_tail_zero(ldouble *out, EPI epi = EPI()) {
+        for (int c = hdim + lane; c < nV; c += L) { out[c] = 0.0; epi(c, 0.0); }
     }
 
     // ------------------------------------------------------------------ reductions
@@ -294,10 +305,10 @@ struct EngineX {
     }
     // ---- several waves per problem (L > 64): one workgroup barrier per product or group of independent products (xgemv_w)
     static constexpr int NW = L > 64 ? L / 64 : 1;
-    template <bool TR>
+    template <bool TR, class EPI = XNoEpi>
     __device__ __forceinline__ void gemv_w(const ldouble *M, int l, int nrows, int ncols, const ldouble *xv, double alpha,
-                                           double beta, const ldouble *base, ldouble *out, int w0, int nw) {
-        xgemv_w<TR>(M, l, nrows, ncols, xv, alpha, beta, base, out, w0, nw, part, lane);
+                                           double beta, const ldouble *base, ldouble *out, int w0, int nw, EPI epi = EPI()) {
+        xgemv_w<TR, EPI>(M, l, nrows, ncols, xv, alpha, beta, base, out, w0, nw, part, lane, epi);
     }
 
     // out[c] = sum_r M[c*l + r] * xv[r]      (lane per column; eight rows per trip: their 16 LDS reads
@@ -390,14 +401,17 @@ struct EngineX {
     // independent products of one stage, side by side on disjoint waves (several waves per problem, dense copies)
     static constexpr bool FUSED = L > 64 && MAT_LDS;
     // outA = A v, outH = (H + hreg I) v
-    __device__ __forceinline__ void AH_times(const ldouble *v, ldouble *outA, ldouble *outH) {
+    __device__ __forceinline__ void AH_times(const ldouble *v, ldouble *outA, ldouble *outH) { AH_times(v, outA, outH, XNoEpi(), XNoEpi()); }
+    // epiA / epiH ride on the two products (FUSED builds; the callers of the other builds keep their separate loops)
+    template <class EA, class EH>
+    __device__ __forceinline__ void AH_times(const ldouble *v, ldouble *outA, ldouble *outH, EA epiA, EH epiH) {
         if constexpr (FUSED) {
             // waves in proportion to the work: A has nC x nV entries, the Hessian block hdim x hdim
             int wa = nC > 0 ? 1 : 0;
             if (nC > 0 && 3 * hdim * hdim < nC * nV) wa = NW - 1;
-            gemv_w<false>(Ad, nC, nC, nV, v, 1.0, 0.0, nullptr, outA, 0, wa);
-            gemv_w<true>(Hd, nV, hdim, hdim, v, 1.0, 0.0, nullptr, outH, wa, NW - wa);
-            h_tail_zero(outH);
+            gemv_w<false>(Ad, nC, nC, nV, v, 1.0, 0.0, nullptr, outA, 0, wa, epiA);
+            gemv_w<true>(Hd, nV, hdim, hdim, v, 1.0, 0.0, nullptr, outH, wa, NW - wa, epiH);
+            h_tail_zero(outH, epiH);
             SYNC();
             if (hreg != 0.0) { PFOR(c, nV) outH[c] += hreg * v[c]; SYNC(); }
         } else {
@@ -923,7 +937,64 @@ struct EngineX {
     __device__ __forceinline__ static double delta_of(double target, double cur) {
         return (fabs(target) >= RSQP_INFTY && fabs(cur) >= RSQP_INFTY) ? 0.0 : target - cur;
     }
+    // The step direction of the several-waves build: every element-wise loop that followed a product (right-hand side of
+    // the active constraints, tmpg, the sum H xY + tmpg, the merge of dx on the free variables, H dx + dg, the scatter
+    // of the active multipliers, the multipliers of the fixed variables) rides on the product that feeds it, and dx_FX /
+    // dy = 0 ride on the drift correction of the previous change: 17 barrier-separated stages become 10. Same arithmetic
+    // per element as the plain version below.
+    __device__ __forceinline__ void step_direction_fused() {
+        if (!dx_ready) {
+            PFOR(v, nV) dx[v] = Sb[v] == -1 ? delta_of(lbN[v], lb[v]) : (Sb[v] == 1 ? delta_of(ubN[v], ub[v]) : 0.0);
+            PFOR(i, nV + nC) dy[i] = 0.0;
+            SYNC();
+        }
+        dx_ready = 0;
+        STAMP(10);
+        auto epi_bA = [&](int r, double val) {                    // bA of an active constraint, at its working-set position
+            const int pj = posAC[r];
+            if (pj >= 0) a1[pj] = (Sc[r] == -1 ? delta_of(lbAN[r], lbA[r]) : delta_of(ubAN[r], ubA[r])) - val;
+        };
+        auto epi_tmpg = [&](int v, double val) { w1[v] = val + (gN[v] - g[v]); };
+        if (nZ > 0) AH_times(dx, c1, w2, epi_bA, epi_tmpg);        // A dx_FX -> bA, H dx_FX -> tmpg
+        else { gemv_w<false>(Ad, nC, nC, nV, dx, 1.0, 0.0, nullptr, c1, 0, NW, epi_bA); SYNC(); }
+        STAMP(11);
+        STAMP(12);
+        // range space: wY = Minv bA ; xY = Y wY
+        gemv_n(Minv, ldm, nAC, nAC, a1, 1.0, 0.0, nullptr, a2);
+        gemv_n(Y, ldy, nV, nAC, a2, 1.0, 0.0, nullptr, w3);
+        STAMP(13);
+        // null space: wZ = -Wz Z'(tmpg + H xY) ; dx_FR = xY + Z wZ
+        auto epi_merge = [&](int v, double val) { if (Sb[v] == 0) dx[v] = val; };
+        if (nZ > 0) {
+            auto epi_sum = [&](int v, double val) { w2[v] = 1.0 * val + 1.0 * w1[v]; };
+            gemv_w<true>(Hd, nV, hdim, hdim, w3, 1.0, 0.0, nullptr, w2, 0, NW, epi_sum);
+            h_tail_zero(w2, epi_sum);
+            SYNC();
+            gemv_t(Z, ld, nV, nZ, w2, wz1);
+            gemv_n(Wz, ld, nZ, nZ, wz1, -1.0, 0.0, nullptr, wz2);
+            gemv_w<false>(Z, ld, nV, nZ, wz2, 1.0, 1.0, w3, w4, 0, NW, epi_merge);
+            SYNC();
+        } else {
+            PFOR(v, nV) { const double t = w3[v]; w4[v] = t; if (Sb[v] == 0) dx[v] = t; }
+            SYNC();
+        }
+        STAMP(14);
+        STAMP(15);
+        // multipliers: dyAC = Minv' Y'(H dx + dg)
+        auto epi_dg = [&](int v, double val) { w2[v] = val + (gN[v] - g[v]); };
+        AH_times(dx, dAx, w5, XNoEpi(), epi_dg);                    // A dx (for the ratio tests) rides along with H dx
+        gemv_t(Y, ldy, nV, nAC, w2, a1);
+        auto epi_dyc = [&](int j, double val) { dy[nV + AC[j]] = val; };
+        gemv_w<true>(Minv, ldm, nAC, nAC, a1, 1.0, 0.0, nullptr, a2, 0, NW, epi_dyc);
+        SYNC();
+        auto epi_dyb = [&](int v, double val) { dy[v] = Sb[v] != 0 ? w2[v] - val : 0.0; };
+        gemv_w<true>(Ad, nC, nC, nV, dy + nV, 1.0, 0.0, nullptr, w3, 0, NW, epi_dyb);
+        SYNC();
+    }
+
     __device__ __forceinline__ void step_direction() {
+        if constexpr (FUSED) { if (hreg == 0.0) { step_direction_fused(); return; } }   // (regularised LPs keep the plain version)
+        dx_ready = 0;
         double anynz = 0.0;
         PFOR(v, nV) {
             const double d = Sb[v] == -1 ? delta_of(lbN[v], lb[v]) : (Sb[v] == 1 ? delta_of(ubN[v], ub[v]) : 0.0);
@@ -1067,6 +1138,11 @@ struct EngineX {
         if (dirty_products || ++since_refresh >= REFRESH) refresh_products();
         PFOR(i, nC) { if (Sc[i] == -1) lbA[i] = Ax[i]; else if (Sc[i] == 1) ubA[i] = Ax[i]; }
         PFOR(v, nV) g[v] = ATy[v] + y[v] - Hx[v];
+        if constexpr (FUSED) {      // first loop of the next step direction: it reads nothing this function writes but Sb / lb / ub
+            PFOR(v, nV) dx[v] = Sb[v] == -1 ? delta_of(lbN[v], lb[v]) : (Sb[v] == 1 ? delta_of(ubN[v], ub[v]) : 0.0);
+            PFOR(i, nV + nC) dy[i] = 0.0;
+            dx_ready = 1;
+        }
         SYNC();
     }
     __device__ __forceinline__ int homotopy(int maxit, int &nWSR) {
@@ -1083,6 +1159,7 @@ struct EngineX {
         SYNC();
         PFOR(i, nC) c3[i] = Ax[i];                  // (the relaxation above used the Ax of the set-up: keep that copy bit for bit)
         SYNC();
+        dx_ready = 0;
         refresh_products();                         // Hx, ATy (and Ax) of the starting point
         PFOR(i, nC) Ax[i] = c3[i];
         SYNC();
