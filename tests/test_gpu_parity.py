@@ -584,6 +584,22 @@ def test_both_formulations_pass_the_parity_suite(engine):
 
 
 @pytest.mark.gpu
+def test_blocking_waits_give_the_same_answers():
+    """Single-QP solves, the certificate and the HBM-resident engine wait for their results by spinning on a host-mapped
+    sequence word the kernels raise (INTEGRATION.md "Host waits"); RSQP_NO_SPIN / RSQP_LARGE_NO_SPIN select the blocking
+    hipStreamSynchronize fallback instead. The single-QP tests of this file and the mid-size tests of the HBM engine must
+    pass on that path as well (the switches are read once per process, hence the subprocess)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RSQP_NO_SPIN="1", RSQP_LARGE_NO_SPIN="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"),
+                        os.path.join(root, "tests", "test_gpu_large_engine.py"), "-q", "-x", "-k",
+                        "hs071_single_qp or dispatch_state_machine or optimize_lp or random_convex_against_oracle or hot_start_modes"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
 def test_fuzz_mixed_shapes_against_oracle():
     """Randomised shapes (nV = 1, nC = 0, nC > nV included) in four size classes, so that every packing
     of the LDS engines (8 / 16 / 32 lanes per problem, one and four waves) and both formulations see
