@@ -300,15 +300,20 @@ csx_ldsvec_spmv_pipe2(int nminor, int nslices, const int *__restrict__ slice, co
 // Entry-parallel batched product with the input vector resident in LDS (variant 40). The sub-wave-per-major kernels
 // above read every major as its own little segment: a wave instruction touches 16 pieces of 64 bytes and the value
 // stream runs at 4.4 TB/s, while the pure stream of this shape runs at 6.2 TB/s (tools/spmv_bound_check.py 50).
-// Here the plan cuts the entry stream into CHUNKS of whole majors with at most 512 entries; a wave owns a chunk
-// (no sum ever crosses a wave), a lane owns 8 CONSECUTIVE entries of it:
+// Here the plan cuts the entry stream into CHUNKS of whole majors with at most 512 entries and 128 majors; a wave owns
+// a chunk (no sum ever crosses a wave), a lane owns 8 CONSECUTIVE entries of it:
 //   * loads: 16 bytes of indices per lane = 1 KB contiguous per wave; 4 x 16 bytes of values per lane (the four
 //     instructions of a wave sweep the same 4 KB, sector by sector);
 //   * "this entry starts a major" is one bit per entry (a byte per lane, 64 bytes per chunk); the pointer array is
 //     never read -- the ordinal of a major is a prefix count of those bits;
-//   * a lane sums its 8 products sequentially and stores the majors that lie wholly inside it; the piece running in
-//     from the previous lanes and the piece running out meet in ONE segmented scan over the 64 lanes (DPP row shifts
-//     and row broadcasts: no LDS traffic), after which the lanes holding the end of a major store its sum.
+//   * a lane forms all prefix and suffix sums of its 8 products (two FMA chains), from which the piece before its first
+//     start and the piece from its last start on are picked; majors wholly inside a lane are summed in a loop only lanes
+//     with two starts enter; the piece running in from the previous lanes and the piece running out meet in ONE
+//     segmented scan over the 64 lanes (DPP row shifts and row broadcasts: no LDS traffic), after which the lanes
+//     holding the end of a major emit its sum (straight to memory, or through a 1 KB LDS window of the wave that leaves
+//     as one run of consecutive stores at the top of the next trip -- STAGE);
+//   * behind the last entry of a chunk that is not full the plan sets one more start bit: what a lane loaded past the
+//     chunk forms a dummy major that is never emitted (no validity masks in the inner code).
 // Fixed-shape tree per major => run-to-run deterministic; not the entry order of the reference loop (tolerance test).
 // ---------------------------------------------------------------------------------
 struct SegPlanView {
