@@ -18,8 +18,10 @@
 // never moves a matrix: the reflection is aimed at the LAST column, which is then dropped;
 // deleting constraint k of Minv moves one column. The step directions are independent of the
 // choice of basis, so iterates and decisions equal those of the Givens formulation up to
-// rounding. Control flow runs on the host: it reads back a few scalars per working-set change
-// (ratio-test winner, independence / definiteness tests).
+// rounding. Control flow runs on the host: it needs a few scalars per working-set change
+// (ratio-test winner, independence / definiteness tests); the kernels publish them into a
+// host-mapped block behind a sequence number the host spins on (publish() / Impl::wait_ctl),
+// and whatever does not depend on the verdict is launched before the host looks.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
