@@ -194,6 +194,7 @@ hipError_t rsqp_dgemm(bool transA, bool transB, int m, int n, int k, double alph
 namespace {
 
 constexpr int NB = 64;
+constexpr int OB = 256;    // outer block of the QR: the trailing matrix is updated once per OB columns (aggregated reflector)
 
 template <int NTHR>
 __device__ __forceinline__ double block_sum(double v, double *red) {
@@ -337,6 +338,12 @@ __global__ void k_build_V(const double *__restrict__ B, long long ldb, int m, in
     V[(i - k0) + (long long)c * ldv] = i < k0 + c ? 0.0 : (i == k0 + c ? 1.0 : B[i + (long long)(k0 + c) * ldb]);
 }
 
+__global__ void k_copy_block(int rows, int cols, const double *__restrict__ src, long long lds, double *__restrict__ dst,
+                             long long ldd) {
+    const int c = blockIdx.y, r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows && c < cols) dst[r + (long long)c * ldd] = src[r + (long long)c * lds];
+}
+
 __global__ void k_set_identity(int m, double *__restrict__ Q, long long ldq) {
     const int j = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) Q[i + (long long)j * ldq] = i == j ? 1.0 : 0.0;
@@ -438,14 +445,16 @@ hipError_t rsqp_dense_work_alloc(RsqpDenseWork *w, long long mmax) {
     if (mmax < 1) mmax = 1;
     const long long np = (mmax + NB - 1) / NB;
     hipError_t e;
-    if ((e = hipMalloc((void **)&w->V, sizeof(double) * mmax * NB)) != hipSuccess) return e;
+    if ((e = hipMalloc((void **)&w->V, sizeof(double) * mmax * OB)) != hipSuccess) return e;
     if ((e = hipMalloc((void **)&w->T, sizeof(double) * np * NB * NB)) != hipSuccess) return e;
-    if ((e = hipMalloc((void **)&w->W, sizeof(double) * mmax * NB)) != hipSuccess) return e;
-    if ((e = hipMalloc((void **)&w->W2, sizeof(double) * mmax * NB)) != hipSuccess) return e;
+    if ((e = hipMalloc((void **)&w->W, sizeof(double) * mmax * OB)) != hipSuccess) return e;
+    if ((e = hipMalloc((void **)&w->W2, sizeof(double) * mmax * OB)) != hipSuccess) return e;
+    if ((e = hipMalloc((void **)&w->T2, sizeof(double) * (2LL * OB * OB + (long long)OB * NB))) != hipSuccess) return e;   // T2, S2, tmp
+    if ((e = hipMalloc((void **)&w->Tout, sizeof(double) * ((mmax + OB - 1) / OB) * OB * OB)) != hipSuccess) return e;
     if ((e = hipMalloc((void **)&w->tau, sizeof(double) * 2 * mmax)) != hipSuccess) return e;   // tau, rdiag
     if ((e = hipMalloc((void **)&w->norm2, sizeof(double) * mmax)) != hipSuccess) return e;
     if ((e = hipMalloc((void **)&w->dblk, sizeof(double) * 66 * NB * NB)) != hipSuccess) return e;   // S, Uinv + split-K slabs
-    w->ws_cap = 4LL * NB * mmax;
+    w->ws_cap = 4LL * OB * mmax;
     if ((e = hipMalloc((void **)&w->ws, sizeof(double) * w->ws_cap)) != hipSuccess) return e;
     if ((e = hipMalloc((void **)&w->flag, sizeof(int) * 4)) != hipSuccess) return e;
     if ((e = hipMemset(w->flag, 0, sizeof(int) * 4)) != hipSuccess) return e;
@@ -454,7 +463,7 @@ hipError_t rsqp_dense_work_alloc(RsqpDenseWork *w, long long mmax) {
 }
 
 void rsqp_dense_work_free(RsqpDenseWork *w) {
-    double *d[] = {w->V, w->T, w->W, w->W2, w->tau, w->norm2, w->dblk, w->ws};
+    double *d[] = {w->V, w->T, w->W, w->W2, w->T2, w->Tout, w->tau, w->norm2, w->dblk, w->ws};
     for (double *p : d) if (p) (void)hipFree(p);
     if (w->flag) (void)hipFree(w->flag);
     *w = RsqpDenseWork();
@@ -466,22 +475,60 @@ hipError_t rsqp_dgeqrf(int m, int n, double *B, long long ldb, double eps_li, Rs
     if (n <= 0) return hipSuccess;
     if (m < n || m > w->mmax) return hipErrorInvalidValue;
     double *rdiag = w->tau + w->mmax, *S = w->dblk, *ws = w->dblk + NB * NB;
+    double *T2 = nullptr, *S2 = w->T2 + (long long)OB * OB, *tmp = S2 + (long long)OB * OB;
+    const long long ldv = w->mmax;
     hipLaunchKernelGGL(k_colnorm2, dim3(n), dim3(256), 0, st, m, B, ldb, w->norm2);
-    for (int k0 = 0, p = 0; k0 < n; k0 += NB, p++) {
-        const int jb = std::min(NB, n - k0), mt = m - k0, nt = n - k0 - jb;
-        for (int j = k0; j < k0 + jb; j++)
-            hipLaunchKernelGGL(k_qr_col, dim3(k0 + jb - j), dim3(QC), 0, st, B, ldb, m, j, k0, w->V, w->mmax, w->tau, rdiag,
-                               w->norm2, eps_li, w->flag);
-        // S = V'V (jb x jb, long inner dimension: split K), T factor, reflectors back into B
-        DCHK(dgemm_ws(true, false, jb, jb, mt, 1.0, w->V, w->mmax, w->V, w->mmax, 0.0, S, jb, ws, 64LL * NB * NB, st));
-        hipLaunchKernelGGL(k_qr_T, dim3(1), dim3(256), 0, st, jb, S, w->tau + k0, w->T + (long long)p * NB * NB);
-        hipLaunchKernelGGL(k_panel_writeback, dim3((mt + 255) / 256, jb), dim3(256), 0, st, B, ldb, m, k0, jb, w->V, w->mmax, rdiag);
-        if (nt > 0) {
-            double *Ct = B + k0 + (long long)(k0 + jb) * ldb;
-            DCHK(dgemm_ws(true, false, jb, nt, mt, 1.0, w->V, w->mmax, Ct, ldb, 0.0, w->W, NB, w->ws, w->ws_cap, st));   // W = V'C
-            DCHK(rsqp_dgemm(true, false, jb, nt, jb, 1.0, w->T + (long long)p * NB * NB, NB, w->W, NB, 0.0, w->W2, NB, st));   // T'W
-            DCHK(rsqp_dgemm(false, false, mt, nt, jb, -1.0, w->V, w->mmax, w->W2, NB, 1.0, Ct, ldb, st));   // C -= V (T'W)
+    // Two levels. Panels of NB = 64 columns are factorised one column per launch (k_qr_col) and applied, as
+    // I - V_p T_p V_p', to the rest of their OUTER block of OB = 256 columns only. The reflectors of an outer block sit
+    // side by side in w->V (rows counted from the block's first row); their aggregate I - V T V' (T from the panels'
+    // T_p: T_ab = -T_a (V_a'V_b) T_b) updates the trailing matrix ONCE per outer block with inner dimension 256 -- the
+    // trailing matrix is streamed 3 x n/256 times instead of 3 x n/64, and those products are no longer HBM-bound.
+    for (int K0 = 0, p = 0; K0 < n; K0 += OB) {
+        const int ob = std::min(OB, n - K0), mto = m - K0;
+        hipLaunchKernelGGL(k_zero_block, dim3((ob + 255) / 256, ob), dim3(256), 0, st, ob, ob, w->V, ldv);   // rows above a panel's first
+        for (int k0 = K0; k0 < K0 + ob; k0 += NB, p++) {
+            const int jb = std::min(NB, K0 + ob - k0), mt = m - k0, nin = K0 + ob - k0 - jb;
+            double *Vp = w->V + (k0 - K0) + (long long)(k0 - K0) * ldv;     // panel p inside the outer block's V
+            for (int j = k0; j < k0 + jb; j++)
+                hipLaunchKernelGGL(k_qr_col, dim3(k0 + jb - j), dim3(QC), 0, st, B, ldb, m, j, k0, Vp, ldv, w->tau, rdiag,
+                                   w->norm2, eps_li, w->flag);
+            // S = V'V (jb x jb, long inner dimension: split K), T factor, reflectors back into B
+            DCHK(dgemm_ws(true, false, jb, jb, mt, 1.0, Vp, ldv, Vp, ldv, 0.0, S, jb, ws, 64LL * NB * NB, st));
+            hipLaunchKernelGGL(k_qr_T, dim3(1), dim3(256), 0, st, jb, S, w->tau + k0, w->T + (long long)p * NB * NB);
+            hipLaunchKernelGGL(k_panel_writeback, dim3((mt + 255) / 256, jb), dim3(256), 0, st, B, ldb, m, k0, jb, Vp, ldv, rdiag);
+            if (nin > 0) {      // the rest of the outer block
+                double *Ct = B + k0 + (long long)(k0 + jb) * ldb;
+                DCHK(dgemm_ws(true, false, jb, nin, mt, 1.0, Vp, ldv, Ct, ldb, 0.0, w->W, NB, w->ws, w->ws_cap, st));   // W = V'C
+                DCHK(rsqp_dgemm(true, false, jb, nin, jb, 1.0, w->T + (long long)p * NB * NB, NB, w->W, NB, 0.0, w->W2, NB, st));   // T'W
+                DCHK(rsqp_dgemm(false, false, mt, nin, jb, -1.0, Vp, ldv, w->W2, NB, 1.0, Ct, ldb, st));   // C -= V (T'W)
+            }
         }
+        const int nt = n - K0 - ob;
+        // aggregated T of the outer block (kept in w->Tout for rsqp_dorgqr)
+        const int p0 = p - (ob + NB - 1) / NB;          // first panel of this outer block
+        T2 = w->Tout + (long long)(K0 / OB) * OB * OB;
+        const double *Tagg = T2;
+        const long long ldt = OB;
+        {
+            if (ob > NB) DCHK(dgemm_ws(true, false, ob, ob, mto, 1.0, w->V, ldv, w->V, ldv, 0.0, S2, ob, w->ws, w->ws_cap, st));   // S2 = V'V
+            hipLaunchKernelGGL(k_zero_block, dim3((ob + 255) / 256, ob), dim3(256), 0, st, ob, ob, T2, (long long)OB);
+            int acc = 0;
+            for (int q = 0, off = 0; off < ob; q++, off += NB) {
+                const int jq = std::min(NB, ob - off);
+                const double *Tp = w->T + (long long)(p0 + q) * NB * NB;
+                if (acc > 0) {   // T2[0:acc, off:off+jq] = -T2[0:acc,0:acc] (V_acc'V_q) T_q
+                    DCHK(rsqp_dgemm(false, false, acc, jq, acc, 1.0, T2, OB, S2 + (long long)off * ob, ob, 0.0, tmp, OB, st));
+                    DCHK(rsqp_dgemm(false, false, acc, jq, jq, -1.0, tmp, OB, Tp, NB, 0.0, T2 + (long long)off * OB, OB, st));
+                }
+                hipLaunchKernelGGL(k_copy_block, dim3(1, jq), dim3(64), 0, st, jq, jq, Tp, (long long)NB, T2 + off + (long long)off * OB, (long long)OB);
+                acc += jq;
+            }
+        }
+        if (nt <= 0) continue;
+        double *Ct = B + K0 + (long long)(K0 + ob) * ldb;
+        DCHK(dgemm_ws(true, false, ob, nt, mto, 1.0, w->V, ldv, Ct, ldb, 0.0, w->W, OB, w->ws, w->ws_cap, st));   // W = V'C
+        DCHK(rsqp_dgemm(true, false, ob, nt, ob, 1.0, Tagg, ldt, w->W, OB, 0.0, w->W2, OB, st));                  // T'W
+        DCHK(rsqp_dgemm(false, false, mto, nt, ob, -1.0, w->V, ldv, w->W2, OB, 1.0, Ct, ldb, st));               // C -= V (T'W)
     }
     return hipGetLastError();
 }
@@ -491,14 +538,17 @@ hipError_t rsqp_dorgqr(int m, int n, const double *B, long long ldb, double *Q, 
     if (m <= 0) return hipSuccess;
     if (m > w->mmax) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_set_identity, dim3((m + 255) / 256, m), dim3(256), 0, st, m, Q, ldq);
-    const int np = (n + NB - 1) / NB;
-    for (int p = np - 1; p >= 0; p--) {
-        const int k0 = p * NB, jb = std::min(NB, n - k0), mt = m - k0;
-        hipLaunchKernelGGL(k_build_V, dim3((mt + 255) / 256, jb), dim3(256), 0, st, B, ldb, m, k0, jb, w->V, w->mmax);
-        double *Qs = Q + k0 + (long long)k0 * ldq;
-        DCHK(dgemm_ws(true, false, jb, mt, mt, 1.0, w->V, w->mmax, Qs, ldq, 0.0, w->W, NB, w->ws, w->ws_cap, st));   // W = V'Q
-        DCHK(rsqp_dgemm(false, false, jb, mt, jb, 1.0, w->T + (long long)p * NB * NB, NB, w->W, NB, 0.0, w->W2, NB, st));   // T W
-        DCHK(rsqp_dgemm(false, false, mt, mt, jb, -1.0, w->V, w->mmax, w->W2, NB, 1.0, Qs, ldq, st));       // Q -= V (T W)
+    // backwards over the OUTER blocks of rsqp_dgeqrf with their aggregated factors (inner dimension 256 instead of 64:
+    // Q is streamed 3 x n/256 times)
+    const int nout = (n + OB - 1) / OB;
+    for (int o = nout - 1; o >= 0; o--) {
+        const int K0 = o * OB, ob = std::min(OB, n - K0), mto = m - K0;
+        hipLaunchKernelGGL(k_build_V, dim3((mto + 255) / 256, ob), dim3(256), 0, st, B, ldb, m, K0, ob, w->V, w->mmax);
+        double *Qs = Q + K0 + (long long)K0 * ldq;
+        const double *To = w->Tout + (long long)o * OB * OB;
+        DCHK(dgemm_ws(true, false, ob, mto, mto, 1.0, w->V, w->mmax, Qs, ldq, 0.0, w->W, OB, w->ws, w->ws_cap, st));   // W = V'Q
+        DCHK(rsqp_dgemm(false, false, ob, mto, ob, 1.0, To, OB, w->W, OB, 0.0, w->W2, OB, st));                       // T W
+        DCHK(rsqp_dgemm(false, false, mto, mto, ob, -1.0, w->V, w->mmax, w->W2, OB, 1.0, Qs, ldq, st));               // Q -= V (T W)
     }
     return hipGetLastError();
 }

@@ -14,10 +14,12 @@ hipError_t rsqp_dgemm(bool transA, bool transB, int m, int n, int k, double alph
 
 // Workspace of the blocked factorisations for problems with up to `mmax` rows.
 struct RsqpDenseWork {
-    double *V = nullptr;     // mmax x NB   explicit panel reflectors (unit lower trapezoidal)
+    double *V = nullptr;     // mmax x OB   explicit reflectors of an outer block (four panels side by side, unit lower trapezoidal)
+    double *T2 = nullptr;    // scratch of the aggregation: V'V of an outer block and a product block
+    double *Tout = nullptr;  // OB x OB     aggregated triangular factor of every outer block (rsqp_dgeqrf -> rsqp_dorgqr)
     double *T = nullptr;     // NB x NB     triangular factors of every panel, nb_panels * NB*NB
-    double *W = nullptr;     // NB x mmax   V' C
-    double *W2 = nullptr;    // NB x mmax   T' W / T W
+    double *W = nullptr;     // OB x mmax   V' C
+    double *W2 = nullptr;    // OB x mmax   T' W / T W
     double *tau = nullptr;   // mmax
     double *norm2 = nullptr; // mmax        squared norms of the original columns
     double *dblk = nullptr;  // NB x NB     diagonal block scratch
