@@ -87,6 +87,16 @@ void rsqp_destroy(rsqp_solver *s);
 int rsqp_set_engine_profiling(rsqp_solver *s, int on);
 int rsqp_get_engine_profile(const rsqp_solver *s, double *out4n, int n);
 int rsqp_engine_profile_names(const char **names, int n);
+/* measurement only: the last blocked (matrix-core) set-up of a non-empty working set on the HBM-resident engine --
+ * what SQProblem::hotstart(H, g, A, ..) / init(.., x0, y0, guessedBounds) re-factorise (call sites
+ * qpOASESInterface.cpp:184,197,204-206). out8 = {nFR, nAC, nZ, ms of QR + explicit Q + R^-1, ms of Z'HZ + Cholesky +
+ * inverse (HIP events on the engine's stream), algorithmic flops of the first part, of the second, 0}.
+ * Returns 1, or 0 when no blocked set-up has run on this handle. */
+int rsqp_get_setup_profile(const rsqp_solver *s, double *out8);
+/* seconds of the one-off structure analysis behind the first set_A / set_H (SpHbMat::setStructure, SpHbMat.cpp:196-355:
+ * sort, CSC + CSR copy + SpMV plan, upload), timed apart from the per-solve cost; which: 0 = A, 1 = H;
+ * < 0 when the matrix has not been set. */
+double rsqp_get_structure_seconds(const rsqp_solver *s, int which);
 int rsqp_get_nV(const rsqp_solver *s);
 int rsqp_get_nC(const rsqp_solver *s);
 /* engine selection: 0 = automatic (the LDS-resident kernel when the problem image fits the
@@ -97,9 +107,10 @@ int rsqp_get_engine(const rsqp_solver *s);
 /* The FIXED <-> VARIED flip of optimizeQP re-initialises with init(.., x_qp, y_qp, &bounds) and NO guessed
  * constraints (qpOASESInterface.cpp:199-207); qpOASES then restarts from the constraints A x_qp happens to
  * sit on -- with perturbed data: none -- and re-adds the active set one change at a time (7 292 changes on the
- * sparse 10k x 20k sequence). from_y0 != 0 (default): the constraint sides are taken from the signs of y_qp,
- * i.e. the working set of the previous solve; same KKT point on a convex QP, ~20x fewer changes.
- * from_y0 == 0: the reference's path (what the CPU oracle restates by default). */
+ * sparse 10k x 20k sequence). from_y0 == 0 (DEFAULT): exactly that path (what the CPU oracle restates).
+ * from_y0 != 0 (opt-in shortcut, NOT the reference's behaviour): the constraint sides are taken from the signs
+ * of y_qp, i.e. the working set of the previous solve; same KKT point on a strictly convex QP, ~20x fewer
+ * changes, but nWSR and -- where the solution is not unique -- the point may differ from the reference's. */
 int rsqp_set_reinit_guess(rsqp_solver *s, int from_y0);
 /* Options fields the adapter reads: qp_maxiter, lp_maxiter (Options.cpp:45,54) */
 int rsqp_set_options(rsqp_solver *s, int qp_maxiter, int lp_maxiter);

@@ -63,6 +63,8 @@ def lib():
         L.orc_qp_hotstart_matrices.argtypes = [C.c_void_p] + [c_dbl_p] * 5 + [c_int_p]
         L.orc_qp_init_repeat.argtypes = [C.c_void_p] + [c_dbl_p] * 5 + [C.c_int, C.c_int]
         L.orc_qp_init_repeat.restype = C.c_int
+        L.orc_qp_solveqp_repeat.argtypes = [C.c_void_p, C.POINTER(c_dbl_p), C.POINTER(c_dbl_p), C.c_int, C.c_int]
+        L.orc_qp_solveqp_repeat.restype = C.c_int
         L.orc_qp_set_regularisation.argtypes = [C.c_void_p, C.c_double]
         L.orc_qp_set_guess_constraints_from_y0.argtypes = [C.c_void_p, C.c_int]
         L.orc_qp_get_primal.argtypes = [C.c_void_p, c_dbl_p]
@@ -288,6 +290,12 @@ class OracleQP:
         """`reps` cold solves in a C loop (timing only)"""
         return lib().orc_qp_init_repeat(self._h, *self._vecs(g, lb, ub, lbA, ubA), nWSR, reps)
 
+    def solveqp_repeat(self, vecs_a, vecs_b, nWSR, iters):
+        """`iters` x (hot start on the vector sets a / b in turn + get_working_set + test_optimality), loop in C (timing only)"""
+        keep = [[_d(v) for v in vecs_a], [_d(v) for v in vecs_b]]
+        arrs = [(c_dbl_p * 5)(*[_dp(v) for v in k]) for k in keep]
+        return lib().orc_qp_solveqp_repeat(self._h, arrs[0], arrs[1], nWSR, iters)
+
     def hotstart(self, g, lb, ub, lbA, ubA, nWSR):
         n = C.c_int(nWSR)
         rc = lib().orc_qp_hotstart(self._h, *self._vecs(g, lb, ub, lbA, ubA), C.byref(n))
@@ -340,3 +348,61 @@ class OracleQP:
 
     def exitflag(self):
         return lib().orc_exitflag(self._h)
+
+
+class OracleInterface:
+    """CPU restatement of qpOASESInterface::optimizeQP's warm-start dispatch over the oracle solver
+    (reference src/qpOASESInterface.cpp:137-224 with get_Matrix_change_status :817-833 and reset_flags
+    :488-496): cold init, hotstart(vectors) while the matrices stay FIXED, hotstart(H, g, A, ...) while they
+    stay VARIED, init(.., x_qp, y_qp, &bounds) with no guessed constraints on a FIXED <-> VARIED flip.
+    Test infrastructure (golden vectors, parity tests, bench.py's cpu_baseline legs)."""
+
+    def __init__(self, nV, nC, qp_maxiter=1000, from_y0=False):
+        self.qp = OracleQP(nV, nC)
+        self.qp.set_guess_constraints_from_y0(from_y0)
+        self.qp_maxiter = qp_maxiter
+        self.first_solved = False
+        self.upd_A = self.upd_H = False
+        self.old = self.new = 0          # 0 UNDEFINED, 1 FIXED, 2 VARIED
+        self.modes = []                  # what each call did: "cold" / "hot_vectors" / "hot_matrices" / "reinit"
+
+    def set_A_csc(self, jc, ir, val):
+        if self.first_solved:
+            self.upd_A = True            # :427-429
+        self.qp.set_A_csc(jc, ir, val)
+
+    def set_H_csc(self, jc, ir, val):
+        if self.first_solved:
+            self.upd_H = True            # :407-409
+        self.qp.set_H_csc(jc, ir, val)
+
+    def optimize_qp(self, g, lb, ub, lbA, ubA):
+        """returns nWSR of the call (what the reference adds to stats->qp_iter, :215-216)"""
+        qp, n = self.qp, self.qp_maxiter
+        if not self.first_solved:
+            rc, used = qp.init(g, lb, ub, lbA, ubA, n)
+            self.modes.append("cold")
+            if qp.is_solved():
+                self.first_solved = True
+        else:
+            cur = 2 if (self.upd_A or self.upd_H) else 1
+            if self.old == 0:
+                self.old = cur
+            else:
+                if self.new != 0:
+                    self.old = self.new
+                self.new = cur
+            if self.new == 0 or self.new == self.old:
+                st = self.old if self.new == 0 else self.new
+                if st == 1:
+                    rc, used = qp.hotstart(g, lb, ub, lbA, ubA, n)
+                    self.modes.append("hot_vectors")
+                else:
+                    rc, used = qp.hotstart_matrices(g, lb, ub, lbA, ubA, n)
+                    self.modes.append("hot_matrices")
+            else:
+                rc, used = qp.init(g, lb, ub, lbA, ubA, n, x0=qp.x, y0=qp.y, guess_b=qp.ws_bounds)
+                self.modes.append("reinit")
+                self.new = self.old = 0
+        self.upd_A = self.upd_H = False
+        return used

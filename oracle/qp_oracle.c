@@ -996,3 +996,24 @@ int orc_qp_init_repeat(orc_qp *qp, const double *g, const double *lb, const doub
     }
     return n;
 }
+
+/* QPhandler::solveQP on the CPU, `iters` times inside C (bench.py's hs071_single_qp leg: the interpreter and
+ * ctypes stay out of the timed loop): hot start on the vector set A or B in turn (update_delta, FIXED matrices),
+ * then the working-set mapping and the KKT certificate of the reference (kkt_oracle.c). vec[k] = {g, lb, ub, lbA,
+ * ubA} of set k, already clamped to +-1e20 by the caller. Returns the number of certified solves. */
+int orc_qp_solveqp_repeat(orc_qp *qp, const double *const *vecA, const double *const *vecB, int nWSR_max, int iters) {
+    int nV = qp->nV, nC = qp->nC, good = 0;
+    int *Wb = (int *)xcalloc((size_t)nV, sizeof(int)), *Wc = (int *)xcalloc((size_t)nC, sizeof(int));
+    for (int it = 0; it < iters; it++) {
+        const double *const *v = (it & 1) ? vecB : vecA;
+        int n = nWSR_max;
+        orc_qp_hotstart(qp, v[0], v[1], v[2], v[3], v[4], &n);
+        orc_optimality_status st;
+        if (orc_kkt_get_working_set(nV, nC, qp->Ajc, qp->Air, qp->Aval, qp->x, v[1], v[2], v[3], v[4], qp->Sb, qp->Sc, Wb, Wc) == 0 &&
+            orc_kkt_test_optimality(nV, nC, qp->Ajc, qp->Air, qp->Aval, qp->haveH ? qp->Hjc : 0, qp->haveH ? qp->Hir : 0,
+                                    qp->haveH ? qp->Hval : 0, v[0], v[1], v[2], v[3], v[4], qp->x, qp->y, Wb, Wc, &st) == 1)
+            good++;
+    }
+    free(Wb); free(Wc);
+    return good;
+}

@@ -155,6 +155,8 @@ int orc_qp_hotstart_matrices(orc_qp *qp, const double *g, const double *lb, cons
 
 /* H := H + reg*I for every later solve (qpOASES regularises an all-zero Hessian, i.e. the LP of
  * optimizeLP, src/qpOASESInterface.cpp:227-284); the objective excludes the reg term */
+/* bench.py only: `iters` x (hot start on vector set A / B in turn + working-set mapping + KKT certificate) in C */
+int orc_qp_solveqp_repeat(orc_qp *qp, const double *const *vecA, const double *const *vecB, int nWSR_max, int iters);
 void orc_qp_set_regularisation(orc_qp *qp, double reg);
 /* init(.., x0, y0, guessedBounds) without guessed constraints (the FIXED <-> VARIED flip of
  * src/qpOASESInterface.cpp:199-207). 0 (default) = the reference's path: qpOASES derives no constraint

@@ -47,6 +47,8 @@ SYMBOLS = {
     "rsqp_set_engine_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "rsqp_get_engine_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "rsqp_engine_profile_names": (C.c_int, [C.c_void_p, C.c_int]),
+    "rsqp_get_setup_profile": (C.c_int, [C.c_void_p, dp]),
+    "rsqp_get_structure_seconds": (C.c_double, [C.c_void_p, C.c_int]),
     "rsqp_set_engine": (C.c_int, [C.c_void_p, C.c_int]),
     "rsqp_get_engine": (C.c_int, [C.c_void_p]),
     "rsqp_set_A_triplet": (C.c_int, [C.c_void_p, C.c_int, ip, ip, dp, C.c_int, ip, ip, ip, dp]),
@@ -226,6 +228,17 @@ class Solver:
                                           "frac": byts / (ms * 1e-3) / 1e9 / 8000.0 if ms > 0 else None}
         return out
 
+    def setup_profile(self):
+        """the last blocked (matrix-core) set-up on the HBM-resident engine (rsqp_get_setup_profile), or None"""
+        buf = np.zeros(8)
+        if lib().rsqp_get_setup_profile(self._h, buf.ctypes.data_as(dp)) != 1:
+            return None
+        return {"nFR": int(buf[0]), "nAC": int(buf[1]), "nZ": int(buf[2]), "ms_qr_q_rinv": buf[3], "ms_zhz_chol_inv": buf[4],
+                "flops_qr_q_rinv": buf[5], "flops_zhz_chol_inv": buf[6]}
+
+    def structure_seconds(self, which=0):
+        return lib().rsqp_get_structure_seconds(self._h, which)
+
     def time_value_refresh(self, repeats=50):
         a, b = C.c_float(0), C.c_float(0)
         check(lib().rsqp_time_value_refresh(self._h, repeats, C.byref(a), C.byref(b)))
@@ -240,7 +253,8 @@ class Solver:
         return lib().rsqp_get_engine(self._h)
 
     def set_reinit_guess(self, from_y0=True):
-        """warm re-initialisation without guessed constraints: sides from sign(y0) (default) or, as qpOASES, from A x0"""
+        """warm re-initialisation without guessed constraints: as qpOASES, from A x0 (library default) or -- opt-in,
+        from_y0=True -- sides from sign(y0)"""
         check(lib().rsqp_set_reinit_guess(self._h, int(bool(from_y0))))
 
     def set_options(self, qp_maxiter=1000, lp_maxiter=100):

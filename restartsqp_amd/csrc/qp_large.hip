@@ -1159,6 +1159,7 @@ static hipError_t dalloc(T **p, size_t n) {
 struct RsqpLargeEngine::Impl {
     int nV = 0, nC = 0, nAmax = 0;
     long long ld = 0, ldm = 0;
+    static long long pad16(long long n) { return (n + 15) & ~15LL; }
     hipStream_t st = nullptr;
     hipError_t err_ = hipSuccess;
     RsqpLargeMatrices M;
@@ -1224,7 +1225,11 @@ struct RsqpLargeEngine::Impl {
     bool extra_sync = getenv("RSQP_LARGE_EXTRA_SYNC") != nullptr;
     int n1_threads = getenv("RSQP_GEMV_N1_THREADS") ? atoi(getenv("RSQP_GEMV_N1_THREADS")) : 0;   // tuning: force 256 / 512 threads in k_gemv_n1
     int gemv_wgs = getenv("RSQP_GEMV_WGS") ? atoi(getenv("RSQP_GEMV_WGS")) : 4096;     // workgroups the chunked y = M w aims for
-    bool reinit_from_y0 = true;
+    bool reinit_from_y0 = false;
+    // the last blocked set-up (rsqp_get_setup_profile): HIP-event time and algorithmic flops of its two parts
+    struct SetupStat { int valid = 0, m = 0, n = 0, nZ = 0; float ms_tq = 0.f, ms_wz = 0.f; double flops_tq = 0.0, flops_wz = 0.0; };
+    SetupStat setup_stat;
+    hipEvent_t se0 = nullptr, se1 = nullptr, se2 = nullptr;
     static constexpr int BLOCKED_MIN = 32;   // fewer active constraints: the sequential construction is as fast
 
     ~Impl() {
@@ -1795,7 +1800,7 @@ struct RsqpLargeEngine::Impl {
     static constexpr int RET_FALLBACK = -77;
     int ensure_big() {
         if (big) return RET_OK;
-        LCHK(hipMalloc(reinterpret_cast<void **>(&big), sizeof(double) * 2 * (size_t)nV * nV));
+        LCHK(hipMalloc(reinterpret_cast<void **>(&big), sizeof(double) * 2 * (size_t)ld * ld));
         return RET_OK;
     }
     // Y, Z, Minv for the candidate constraints `cand` (all taken: a linearly dependent one makes
@@ -1810,13 +1815,16 @@ struct RsqpLargeEngine::Impl {
         LCHK(hipMemcpyAsync(d_fpos, fpos.data(), sizeof(int) * nV, hipMemcpyHostToDevice, st));
         LCHK(hipMemcpyAsync(d_cand, cand.data(), sizeof(int) * n, hipMemcpyHostToDevice, st));
         LCHK(hipMemcpyAsync(d_freev, freev.data(), sizeof(int) * m, hipMemcpyHostToDevice, st));
-        double *B = Y;            // m x n, ld m (Y is rewritten at the end)
+        // leading dimensions of the factorisation's operands padded to 16 doubles like the engine state (m = nFR is
+        // whatever the working set leaves: 9983 on the sparse 10k x 20k sequence)
+        const long long lb_ = pad16(m), lx = pad16(n);
+        double *B = Y;            // m x n, ld lb_ <= ld (Y is rewritten at the end)
         double *X = big;          // n x n  R^-1
-        double *Q = big + (size_t)nV * nV;   // m x m
-        LCHK(hipMemsetAsync(B, 0, sizeof(double) * (size_t)m * n, st));
+        double *Q = big + (size_t)ld * ld;   // m x m
+        LCHK(hipMemsetAsync(B, 0, sizeof(double) * (size_t)lb_ * n, st));
         LCHK(hipMemsetAsync(dw.flag, 0, sizeof(int) * 4, st));
-        hipLaunchKernelGGL(k_build_B, dim3(n), dim3(NT), 0, st, M.Arp, M.Aci, M.Arv, d_cand, d_fpos, B, (long long)m);
-        LCHK(rsqp_dgeqrf(m, n, B, m, RSQP_EPS_LI, &dw, st));
+        hipLaunchKernelGGL(k_build_B, dim3(n), dim3(NT), 0, st, M.Arp, M.Aci, M.Arv, d_cand, d_fpos, B, lb_);
+        LCHK(rsqp_dgeqrf(m, n, B, lb_, RSQP_EPS_LI, &dw, st));
         LCHK(hipMemcpyAsync(h_pinned_i, dw.flag, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
         LCHK(hipStreamSynchronize(st));
         if (h_pinned_i[0] != 0) {   // dependent rows in the guess: start over, one constraint at a time
@@ -1826,12 +1834,12 @@ struct RsqpLargeEngine::Impl {
             }
             return RET_FALLBACK;
         }
-        LCHK(rsqp_dtrtri_upper(n, B, m, X, n, &dw, st));
-        hipLaunchKernelGGL(k_transpose, dim3((n + 31) / 32, (n + 31) / 32), dim3(32, 8), 0, st, n, X, (long long)n, Minv, ldm);
-        LCHK(rsqp_dorgqr(m, n, B, m, Q, m, &dw, st));
+        LCHK(rsqp_dtrtri_upper(n, B, lb_, X, lx, &dw, st));
+        hipLaunchKernelGGL(k_transpose, dim3((n + 31) / 32, (n + 31) / 32), dim3(32, 8), 0, st, n, X, lx, Minv, ldm);
+        LCHK(rsqp_dorgqr(m, n, B, lb_, Q, lb_, &dw, st));
         LCHK(hipMemsetAsync(Y, 0, sizeof(double) * (size_t)ld * n, st));
         if (m > n) LCHK(hipMemsetAsync(Z, 0, sizeof(double) * (size_t)ld * (m - n), st));
-        hipLaunchKernelGGL(k_scatter_Q, dim3((m + NT - 1) / NT, m), dim3(NT), 0, st, m, n, Q, (long long)m, d_freev, Y, Z, ld);
+        hipLaunchKernelGGL(k_scatter_Q, dim3((m + NT - 1) / NT, m), dim3(NT), 0, st, m, n, Q, lb_, d_freev, Y, Z, ld);
         // working-set bookkeeping
         std::vector<int> hpos(nC, -1);
         for (int k = 0; k < n; k++) { hAC[k] = cand[k]; hpos[cand[k]] = k; hSc[cand[k]] = gc[cand[k]]; }
@@ -1848,7 +1856,8 @@ struct RsqpLargeEngine::Impl {
     // test as the bordering (wz_grow)
     int setup_wz_blocked() {
         if (ensure_big() != RET_OK) return RET_SETUP_FAILED;
-        double *HZ = big, *G = big + (size_t)nV * nV;
+        double *HZ = big, *G = big + (size_t)ld * ld;
+        const long long lg = pad16(nZ);
         // H Z, column by column of Z in one batched launch
         if (!M.haveH) LCHK(hipMemsetAsync(HZ, 0, sizeof(double) * (size_t)ld * nZ, st));
         else if (M.denseH) LCHK(rsqp_dgemm(false, false, nV, nZ, nV, 1.0, M.denseH, nV, Z, ld, 0.0, HZ, ld, st));
@@ -1857,15 +1866,15 @@ struct RsqpLargeEngine::Impl {
             const long long tot = (long long)ld * nZ;
             hipLaunchKernelGGL(k_add_scaled, dim3((unsigned)((tot + NT - 1) / NT)), dim3(NT), 0, st, tot, M.hreg, Z, HZ);
         }
-        LCHK(rsqp_dgemm(true, false, nZ, nZ, nV, 1.0, Z, ld, HZ, ld, 0.0, G, nZ, st));
+        LCHK(rsqp_dgemm(true, false, nZ, nZ, nV, 1.0, Z, ld, HZ, ld, 0.0, G, lg, st));
         LCHK(hipMemsetAsync(dw.flag, 0, sizeof(int) * 4, st));
-        LCHK(rsqp_dpotrf_upper(nZ, G, nZ, RSQP_EPS_PD_REL, RSQP_EPS_PD_ABS, &dw, st));
+        LCHK(rsqp_dpotrf_upper(nZ, G, lg, RSQP_EPS_PD_REL, RSQP_EPS_PD_ABS, &dw, st));
         LCHK(hipMemcpyAsync(h_pinned_i, dw.flag, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
         LCHK(hipStreamSynchronize(st));
         if (h_pinned_i[1] != 0) return RET_SETUP_FAILED;   // not positive definite on the null space
         double *Ui = HZ;   // nZ x nZ
-        LCHK(rsqp_dtrtri_upper(nZ, G, nZ, Ui, nZ, &dw, st));
-        LCHK(rsqp_dgemm(false, true, nZ, nZ, nZ, 1.0, Ui, nZ, Ui, nZ, 0.0, Wz, ld, st));
+        LCHK(rsqp_dtrtri_upper(nZ, G, lg, Ui, lg, &dw, st));
+        LCHK(rsqp_dgemm(false, true, nZ, nZ, nZ, 1.0, Ui, lg, Ui, lg, 0.0, Wz, ld, st));
         chk("setup_wz_blocked");
         return RET_OK;
     }
@@ -1900,7 +1909,20 @@ struct RsqpLargeEngine::Impl {
         for (int r = 0; r < nC; r++) if (gc[r] != 0) cand.push_back(r);
         bool tq_done = false;
         if (blocked_setup && (int)cand.size() >= BLOCKED_MIN && (int)cand.size() <= nFR) {
+            setup_stat = SetupStat();
+            if (!se0) { (void)hipEventCreate(&se0); (void)hipEventCreate(&se1); (void)hipEventCreate(&se2); }
+            (void)hipEventRecord(se0, st);
             const int rcb = setup_tq_blocked(gc, freev, cand);
+            (void)hipEventRecord(se1, st);
+            if (rcb == RET_OK) {
+                const double m = nFR, n = nAC;
+                (void)hipEventSynchronize(se1);
+                float ms = 0.f; (void)hipEventElapsedTime(&ms, se0, se1);
+                setup_stat.valid = 1; setup_stat.m = nFR; setup_stat.n = nAC; setup_stat.ms_tq = ms;
+                // Householder QR of m x n: 2 n^2 (m - n/3); explicit Q (m x m) from n reflectors: 4 (m^2 n - m n^2 + n^3/3);
+                // inverse of the n x n triangle: n^3 / 3
+                setup_stat.flops_tq = 2.0 * n * n * (m - n / 3.0) + 4.0 * (m * m * n - m * n * n + n * n * n / 3.0) + n * n * n / 3.0;
+            }
             if (rcb == RET_OK) tq_done = true;
             else if (rcb != RET_FALLBACK) return rcb;
         }
@@ -1919,7 +1941,20 @@ struct RsqpLargeEngine::Impl {
         // 3. Wz = (Z'HZ)^-1: blocked Cholesky + inverse, or bordering over the null-space columns
         bool wz_done = false;
         if (blocked_setup && nZ >= BLOCKED_MIN) {
+            if (!se0) { (void)hipEventCreate(&se0); (void)hipEventCreate(&se1); (void)hipEventCreate(&se2); }
+            (void)hipEventRecord(se1, st);
             const int rcw = setup_wz_blocked();
+            (void)hipEventRecord(se2, st);
+            if (rcw == RET_OK && setup_stat.valid) {
+                const double z = nZ, v = nV;
+                (void)hipEventSynchronize(se2);
+                float ms = 0.f; (void)hipEventElapsedTime(&ms, se1, se2);
+                setup_stat.nZ = nZ; setup_stat.ms_wz = ms;
+                // Z'(HZ) (symmetric: v z^2 multiply-adds = 2 v z^2 / 2 ... counted as the half a SYRK needs: v z^2 flops x 1),
+                // Cholesky z^3/3, triangular inverse z^3/3, U^-1 U^-T z^3/3 (symmetric product)
+                setup_stat.flops_wz = v * z * z + z * z * z;
+                if (M.denseH) setup_stat.flops_wz += 2.0 * v * v * z;
+            }
             if (rcw == RET_OK) wz_done = true;
             else return rcw;
         }
@@ -1951,17 +1986,20 @@ RsqpLargeEngine::RsqpLargeEngine() : p_(new Impl()) {}
 RsqpLargeEngine::~RsqpLargeEngine() { delete p_; }
 
 long long RsqpLargeEngine::bytes_needed(int nV, int nC) {
-    const long long nA = std::min(nV, nC);
-    // Z, Wz, Y, Minv, vectors + the scratch of the blocked set-up (2 nV^2, allocated on first use) and its panels
-    return 8LL * (4LL * nV * nV + (long long)nV * nA + nA * nA + 40LL * (nV + nC) + 9LL * 64 * nV);
+    const long long nA = Impl::pad16(std::min(nV, nC)), l = Impl::pad16(nV);
+    // Z, Wz, Y, Minv, vectors + the scratch of the blocked set-up (2 ld^2, allocated on first use) and its panels
+    return 8LL * (4LL * l * l + l * nA + nA * nA + 40LL * (nV + nC) + 9LL * 64 * nV);
 }
 
 hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
     Impl &P = *p_;
-    P.nV = nV; P.nC = nC; P.nAmax = std::min(nV, nC); P.ld = nV; P.ldm = std::max(P.nAmax, 1); P.st = stream;
+    P.nV = nV; P.nC = nC; P.nAmax = std::min(nV, nC); P.st = stream;
+    // leading dimensions padded to 16 doubles (128 B): every column of Z / Y / Wz / Minv starts on a cache-line boundary,
+    // so the 16-byte loads of the column-major products are aligned whatever nV is
+    P.ld = Impl::pad16(nV); P.ldm = Impl::pad16(std::max(P.nAmax, 1));
     hipError_t e;
 #define DA(ptr, n) if ((e = dalloc(&P.ptr, (size_t)(n))) != hipSuccess) return e
-    DA(Z, (size_t)nV * nV); DA(Wz, (size_t)nV * nV); DA(Y, (size_t)nV * std::max(P.nAmax, 1)); DA(Minv, (size_t)P.ldm * P.ldm);
+    DA(Z, (size_t)P.ld * nV); DA(Wz, (size_t)P.ld * nV); DA(Y, (size_t)P.ld * std::max(P.nAmax, 1)); DA(Minv, (size_t)P.ldm * P.ldm);
     DA(x, nV); DA(g, nV); DA(lb, nV); DA(ub, nV); DA(gN, nV); DA(lbN, nV); DA(ubN, nV); DA(dx, nV);
     DA(w1, nV); DA(w2, nV); DA(w3, nV); DA(w4, nV); DA(w5, nV); DA(w6, nV); DA(wz1, nV); DA(wz2, nV); DA(wz3, nV);
     DA(Ax, nC); DA(lbA, nC); DA(ubA, nC); DA(lbAN, nC); DA(ubAN, nC); DA(dAx, nC); DA(c1, nC); DA(c2, nC); DA(c3, nC);
@@ -2061,8 +2099,8 @@ int RsqpLargeEngine::solve(int mode, const double *d_g, const double *d_lb, cons
             }
             for (int i = 0; i < nC; i++) {
                 int s = 0;
-                // no guessed constraints in this call shape: sides from the signs of y0 (reinit_from_y0, the default)
-                // or, as qpOASES does when x0 is given too, only from where A x0 sits
+                // no guessed constraints in this call shape: sides from the signs of y0 (reinit_from_y0, opt-in)
+                // or -- the default, as qpOASES does when x0 is given too -- only from where A x0 sits
                 if (have_y0 && (!have_x0 || P.reinit_from_y0)) s = hy[nV + i] > RSQP_EPS ? -1 : (hy[nV + i] < -RSQP_EPS ? 1 : 0);
                 else if (have_x0) s = hAx[i] <= hlA[i] + RSQP_BOUND_TOLERANCE ? -1 : (hAx[i] >= huA[i] - RSQP_BOUND_TOLERANCE ? 1 : 0);
                 if (s == -1 && hlA[i] <= -RSQP_INFTY) s = 0;
@@ -2103,6 +2141,12 @@ const char *RsqpLargeEngine::profile_name(int k) {
     return k >= 0 && k < PROFILE_CLASSES ? nm[k] : "";
 }
 void RsqpLargeEngine::profile_enable(bool on) { p_->profile = on; }
+int RsqpLargeEngine::setup_profile(double *out8) const {
+    const Impl::SetupStat &t = p_->setup_stat;
+    if (!t.valid) return 0;
+    out8[0] = t.m; out8[1] = t.n; out8[2] = t.nZ; out8[3] = t.ms_tq; out8[4] = t.ms_wz; out8[5] = t.flops_tq; out8[6] = t.flops_wz; out8[7] = 0.0;
+    return 1;
+}
 // tuning aid: device time per call of one product / update kernel class on an nrows x ncols matrix (the engine's Z
 // buffer, leading dimension nV; contents are whatever the buffer holds -- the result is not looked at)
 int RsqpLargeEngine::time_kernel(int kind, int nrows, int ncols, int reps, float *ms) {
@@ -2110,7 +2154,7 @@ int RsqpLargeEngine::time_kernel(int kind, int nrows, int ncols, int reps, float
     if (nrows <= 0 || ncols <= 0 || nrows > P.nV || ncols > P.nV || reps <= 0 || kind < 0 || kind > 2) return -1;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1;
-    (void)hipMemsetAsync(P.Z, 0, sizeof(double) * (size_t)P.nV * P.nV, P.st);
+    (void)hipMemsetAsync(P.Z, 0, sizeof(double) * (size_t)P.ld * P.nV, P.st);
     P.fill(P.w1, P.nV, 1.0); P.fill(P.w2, P.nV, 0.5);
     for (int pass = 0; pass < 2; pass++) {            // pass 0 warms up
         (void)hipEventRecord(e0, P.st);

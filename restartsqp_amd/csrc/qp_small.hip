@@ -1138,7 +1138,7 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
         if (P.guess_b) for (int v = lane; v < d.nV; v += L) E.wq[v] = (double)P.guess_b[d.offV + v];
         SYNC();
         // no guessed constraints in this call shape (qpOASESInterface.cpp:204-206): their sides come from the signs of
-        // y0 (P.reinit_from_y0, the default) -- or, as qpOASES does, only from where A x0 sits
+        // A x0 as qpOASES does (the default) -- or, opt-in (P.reinit_from_y0), from the signs of y0
         rcode = E.setup_aux(P.x0 != nullptr, P.y0 != nullptr, P.guess_b != nullptr, false, P.reinit_from_y0 != 0);
         if (rcode != RET_OK) rcode = E.setup_aux(false, false, false, false);
     } else {

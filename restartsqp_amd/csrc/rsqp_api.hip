@@ -198,6 +198,7 @@ struct DevMatrix {
     int nrow = 0, ncol = 0, nnz = 0;
     bool initialised = false, symmetric = false, from_triplet = false;
     int n_ident_entries = 0, n_triplet = 0;
+    double structure_seconds = 0.0;   // one-off structure analysis (setStructure: sort + CSC / CSR / SpMV plan + upload), rsqp_get_structure_seconds
     std::vector<int> h_jc, h_ir, h_order;  // host mirror of the pattern
     DevBuf<int> jc, ir, order, tmap;                 // CSC
     DevBuf<int4> blk_c, blk_r;
@@ -247,7 +248,7 @@ struct rsqp_solver {
     bool fits_small = true;
     RsqpLargeEngine *large = nullptr;
     bool large_ready = false, profile_large = false;
-    bool reinit_from_y0 = true;   // rsqp_set_reinit_guess
+    bool reinit_from_y0 = false;  // rsqp_set_reinit_guess: default = the reference rule (qpOASESInterface.cpp:199-207); 1 = opt-in shortcut
     DevBuf<double> denseA, denseAT, denseH;   // dense copies for the HBM-resident engine (dense matrices only)
     ~rsqp_solver() {
         delete large;
@@ -468,6 +469,15 @@ extern "C" int rsqp_engine_profile_names(const char **names, int n) {
     for (int k = 0; names && k < n && k < RsqpLargeEngine::PROFILE_CLASSES; k++) names[k] = RsqpLargeEngine::profile_name(k);
     return RsqpLargeEngine::PROFILE_CLASSES;
 }
+extern "C" int rsqp_get_setup_profile(const rsqp_solver *s, double *out8) {
+    if (!s || !out8 || !s->large) return 0;
+    return s->large->setup_profile(out8);
+}
+extern "C" double rsqp_get_structure_seconds(const rsqp_solver *s, int which) {
+    if (!s) return -1.0;
+    const DevMatrix &M = which == 0 ? s->A : s->H;
+    return M.initialised ? M.structure_seconds : -1.0;
+}
 extern "C" int rsqp_get_nV(const rsqp_solver *s) { return s ? s->nV : -1; }
 extern "C" int rsqp_get_nC(const rsqp_solver *s) { return s ? s->nC : -1; }
 
@@ -501,11 +511,14 @@ extern "C" int rsqp_set_A_triplet(rsqp_solver *s, int nnz, const int *irow, cons
         for (size_t k = 0; k < r.size(); k++)
             if (r[k] < 1 || r[k] > s->nC || c[k] < 1 || c[k] > s->nV)
                 return fail(RSQP_ERR_ARG, "rsqp_set_A_triplet: index out of range (indices are 1-based)");
+        const auto t0 = std::chrono::steady_clock::now();
         Compressed cs;
         csc_from_entries(s->nC, s->nV, r, c, v, cs);
         M.from_triplet = true; M.n_triplet = nnz; M.n_ident_entries = nid;
         int rc = upload_matrix(M, cs, true);
         if (rc != RSQP_OK) return rc;
+        (void)hipDeviceSynchronize();
+        M.structure_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         s->desc_ready = false;
         return RSQP_OK;
     }
@@ -534,12 +547,15 @@ extern "C" int rsqp_set_H_triplet(rsqp_solver *s, int nnz, const int *irow, cons
                 r.push_back(jcol[i]); c.push_back(irow[i]); v.push_back(val[i]); tmap.push_back(i);
             }
         }
+        const auto t0 = std::chrono::steady_clock::now();
         Compressed cs;
         csc_from_entries(s->nV, s->nV, r, c, v, cs);
         cs.tmap = tmap;
         M.from_triplet = true; M.n_triplet = nnz; M.symmetric = is_symmetric != 0;
         int rc = upload_matrix(M, cs, false);
         if (rc != RSQP_OK) return rc;
+        (void)hipDeviceSynchronize();
+        M.structure_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         s->desc_ready = false;
         return RSQP_OK;
     }
@@ -577,8 +593,13 @@ int set_csc(rsqp_solver *s, DevMatrix &M, int nrow, int ncol, const int *jc, con
     // a new pattern on an initialised matrix: everything derived from the old one (CSR copy, SpMV
     // blocks, host mirror) is rebuilt; the dirty flag set above makes optimizeQP re-factorise
     M.from_triplet = false;
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = upload_matrix(M, cs, want_csr);
     s->desc_ready = false;
+    if (rc == RSQP_OK) {
+        (void)hipDeviceSynchronize();
+        M.structure_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
     return rc;
 }
 int get_csc(const DevMatrix &M, int *jc, int *ir, double *val, int *order) {

@@ -44,8 +44,11 @@ public:
     static constexpr int PROFILE_CLASSES = 8;
     static const char *profile_name(int k);
     void profile_enable(bool on);
-    void set_reinit_from_y0(bool on);   // warm start without guessed constraints: sides from sign(y0) (default) or from A x0
+    void set_reinit_from_y0(bool on);   // warm start without guessed constraints: from A x0 (default, the reference) or sides from sign(y0) (opt-in)
     void profile_get(double *out4n) const;
+    // the last blocked (matrix-core) set-up of a non-empty working set: {nFR, nAC, nZ, ms QR + Q + R^-1, ms Z'HZ + Cholesky +
+    // inverse, algorithmic flops of the first part, of the second, 0}; returns 0 when no blocked set-up has run
+    int setup_profile(double *out8) const;
     // device ms per call of kernel class `kind` (0 gemv_n, 1 gemv_t, 2 ger) on an nrows x ncols matrix (<= nV each)
     int time_kernel(int kind, int nrows, int ncols, int reps, float *ms);
     struct Impl;

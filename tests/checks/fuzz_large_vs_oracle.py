@@ -46,8 +46,9 @@ for k in range(count):
     q3 = problems.perturb(rng, q2, 0.03)
     for w, v in zip(range(5), (q3.g, q3.lb, q3.ub, q3.lbA, q3.ubA)):
         s.set_vector(w, v)
+    rule = bool(k & 1)                       # even problems: the reference's rule (default), odd: sides from sign(y0)
+    s.set_reinit_guess(rule); qp.set_guess_constraints_from_y0(rule)
     n = s.solve(capi.MODE_WARM_REINIT, 100000, x0, y0, gb)
-    qp.set_guess_constraints_from_y0(True)
     rc, n_or = qp.init(q3.g, q3.lb, q3.ub, q3.lbA, q3.ubA, 100000, x0=x0, y0=y0, guess_b=gb)
     bad += not same(s, n, qp, n_or, "warm", q)
     s.close()

@@ -101,7 +101,7 @@ def test_nonconvex_dumps(capi, oracle):
 
 def test_hot_start_modes(capi, oracle):
     rng = np.random.default_rng(47)
-    for _ in range(4):
+    for trial in range(4):
         q = problems.random_qp(rng, int(rng.integers(8, 40)), int(rng.integers(3, 35)))
         s = load(capi, q)
         n = s.solve(capi.MODE_COLD, 5000)
@@ -123,8 +123,9 @@ def test_hot_start_modes(capi, oracle):
         q3 = problems.perturb(rng, q2, 0.05)
         for w, v in zip(range(5), (q3.g, q3.lb, q3.ub, q3.lbA, q3.ubA)):
             s.set_vector(w, v)
+        rule = bool(trial & 1)                      # the reference's rule (default) and the opt-in sign(y0) rule in turn
+        s.set_reinit_guess(rule); qp.set_guess_constraints_from_y0(rule)
         n = s.solve(capi.MODE_WARM_REINIT, 5000, x0, y0, gb)
-        qp.set_guess_constraints_from_y0(True)      # the engine's default rule for the constraints
         rc, n_or = qp.init(q3.g, q3.lb, q3.ub, q3.lbA, q3.ubA, 5000, x0=x0, y0=y0, guess_b=gb)
         same_as_oracle(s, n, qp, n_or)
 
@@ -169,10 +170,13 @@ def test_baseline_sparse_10k_sequence(capi):
     """BASELINE config 4 as specified: n = 10 000, m = 20 000, 200 000 Jacobian non-zeros; cold start, then the
     warm-started sequence of 50 QPs (odd steps: new vectors, even steps: new Jacobian values as well) driven through
     rsqp_optimize_qp, i.e. through the FIXED / VARIED dispatch of qpOASESInterface.cpp:137-224 (a FIXED <-> VARIED
-    flip re-initialises from (x, y, bounds), :199-207); every answer carries the reference's KKT certificate."""
+    flip re-initialises from (x, y, bounds), :199-207); every answer carries the reference's KKT certificate.
+    All 50 steps under the OPT-IN shortcut rsqp_set_reinit_guess(1) (constraint sides of the re-init from sign(y_qp));
+    the reference's own rule -- the default -- at full size: test_baseline_sparse_10k_reference_rule."""
     q = problems.sparse_qp()
     s = load(capi, q, engine=0)
     s.set_options(qp_maxiter=200000)
+    s.set_reinit_guess(True)
     n = s.optimize_qp()
     ok, st, _, _ = s.test_optimality()
     assert s.status == 20 and ok and st.KKT_error < 1e-8 and n > 1000
@@ -187,6 +191,58 @@ def test_baseline_sparse_10k_sequence(capi):
         assert s.status == 20 and ok and nk < n // 10, (steps, nk, st.KKT_error)
         steps += 1
     assert steps == 50
+
+
+def test_baseline_sparse_10k_reference_rule(capi):
+    """The same configuration under the REFERENCE's re-initialisation rule (the library default): a FIXED <-> VARIED
+    flip calls init(.., x_qp, y_qp, &bounds) with no guessed constraints (qpOASESInterface.cpp:199-207), so the working
+    set of the constraints is rebuilt one change at a time. Cold start + 4 steps (2 of them VARIED = flips) at full size,
+    every answer to the reference's KKT certificate; the flips must take about as many changes as there are active
+    constraints (that is what the rule costs), the FIXED steps in between are plain hot starts."""
+    q = problems.sparse_qp()
+    s = load(capi, q, engine=0)
+    s.set_options(qp_maxiter=200000)
+    n = s.optimize_qp()
+    assert s.status == 20 and n > 1000
+    for k, (qk, changed) in enumerate(problems.sparse_sequence(q, nsteps=4)):
+        for w, v in zip(range(5), (qk.g, qk.lb, qk.ub, qk.lbA, qk.ubA)):
+            s.set_vector(w, v)
+        if changed:
+            s.set_A_csc(qk.A_jc, qk.A_ir, qk.A_val)
+        nk = s.optimize_qp()
+        ok, st, _, _ = s.test_optimality()
+        nact = int((s.working_set_raw()[1] != 0).sum())
+        assert s.status == 20 and ok and st.KKT_error < 1e-8, (k, nk, st.KKT_error)
+        if changed:
+            assert nk >= nact > 1000, (k, nk, nact)        # every active constraint was added again
+        else:
+            assert nk < n // 10, (k, nk)
+
+
+def test_sparse_sequence_reference_rule_matches_oracle_at_2500(capi):
+    """n = 2 500, m = 5 000 through rsqp_optimize_qp under the reference's rule against the committed oracle answers
+    (tests/golden/oracle_sparse_sequence_2500_reference_rule.json, made by tests/golden/make_sequence_golden.py: the
+    oracle driven by the restated dispatch oracle.OracleInterface): cold start, FIXED, VARIED (flip), FIXED, VARIED
+    (flip) -- nWSR and working sets bit-exact at every step, x / y to 1e-9."""
+    gold = json.load(open(os.path.join(GOLDEN, "oracle_sparse_sequence_2500_reference_rule.json")))
+    q = problems.sparse_qp(2500, 5000, 50000)
+    s = load(capi, q, engine=0)
+    s.set_options(qp_maxiter=400000)
+    seq = [(q, False)] + list(problems.sparse_sequence(q, nsteps=len(gold["steps"]) - 1))
+    for k, ((qk, changed), g) in enumerate(zip(seq, gold["steps"])):
+        if k > 0:
+            for w, v in zip(range(5), (qk.g, qk.lb, qk.ub, qk.lbA, qk.ubA)):
+                s.set_vector(w, v)
+            if changed:
+                s.set_A_csc(qk.A_jc, qk.A_ir, qk.A_val)
+        nk = s.optimize_qp()
+        wb, wc = s.working_set_raw()
+        assert g["exitflag"] == s.status == 20 and nk == g["nWSR"], (k, g["mode"], nk, g["nWSR"])
+        assert np.array_equal(wb, g["ws_b"]) and np.array_equal(wc, g["ws_c"]), (k, g["mode"])
+        gx, gy = np.array(g["x"]), np.array(g["y"])
+        assert np.abs(s.x - gx).max() <= 1e-9 * max(1.0, np.abs(gx).max())
+        assert np.abs(s.y - gy).max() <= 1e-9 * max(1.0, np.abs(gy).max())
+    assert [g["mode"] for g in gold["steps"]] == ["cold", "hot_vectors", "reinit", "hot_vectors", "reinit"]
 
 
 def test_sparse_sequence_matches_oracle_at_2500(capi, oracle):
@@ -235,8 +291,9 @@ def test_blocked_setup_matches_oracle(capi, oracle, kind):
     q3 = problems.perturb(rng, q2, 0.02)
     for w, v in zip(range(5), (q3.g, q3.lb, q3.ub, q3.lbA, q3.ubA)):
         s.set_vector(w, v)
+    s.set_reinit_guess(True)                    # the opt-in rule (sides from sign(y0)): the one that starts from a large working set
     n = s.solve(capi.MODE_WARM_REINIT, 100000, x0, y0, gb)
-    qp.set_guess_constraints_from_y0(True)      # the engine's default rule for the constraints
+    qp.set_guess_constraints_from_y0(True)
     rc, n_or = qp.init(q3.g, q3.lb, q3.ub, q3.lbA, q3.ubA, 100000, x0=x0, y0=y0, guess_b=gb)
     same_as_oracle(s, n, qp, n_or)
 
