@@ -378,6 +378,7 @@ def hs_batch_config(capi, problems, parallel, reps=50, cpu_seconds=4.0):
     for tag, idx in (("512_qps", order), ("64_qps_shard_of_8_gpus", shard0)):
         probs = [all_probs[k] for k in idx]
         b = capi.Batch(probs)
+        b.set_keep_state(False)      # cold-start-only batch: the explicit-KKT-inverse kernel + the null-space kernel on what it bails on
         b.solve(capi.MODE_COLD, 1000)
         ms = []
         for _ in range(reps):
@@ -388,7 +389,8 @@ def hs_batch_config(capi, problems, parallel, reps=50, cpu_seconds=4.0):
         res = b.results()
         out[tag] = {"ms_per_batch": st["median"], "ms_stats": st, "qp_solves_per_s": len(probs) / (st["median"] * 1e-3),
                     "all_certified": bool(all(o == 1 for o in ok)), "mean_nWSR": float(np.mean([r["nWSR"] for r in res])),
-                    "order": "largest first (parallel.balanced_order)"}
+                    "order": "largest first (parallel.balanced_order)", "keep_state": False,
+                    "engine": "small_qpk_kernel<3,1,9,4> (explicit KKT inverse, register-resident) + small_qp_kernel<EngineX<256>> on the members it bails on"}
         b.close()
     cpu = cpu_batch_baseline(all_probs, cpu_seconds)
     out["cpu_baseline"] = cpu
@@ -405,6 +407,7 @@ def hs_batch_scaling(capi, problems, parallel, torch, dist, rank, world, local_r
     barrier + device sync on both sides, max over ranks; no collective on the data path."""
     def run(probs):
         b = capi.Batch(probs, device=local_rank)
+        b.set_keep_state(False)
         b.solve(capi.MODE_COLD, 1000)
 
         def sync():

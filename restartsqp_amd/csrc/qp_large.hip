@@ -1159,7 +1159,9 @@ static hipError_t dalloc(T **p, size_t n) {
 struct RsqpLargeEngine::Impl {
     int nV = 0, nC = 0, nAmax = 0;
     long long ld = 0, ldm = 0;
-    static long long pad16(long long n) { return (n + 15) & ~15LL; }
+    // (sizes below 256 keep their own leading dimension: alignment buys nothing there, and the even-ld kernel variants sum in
+    //  another order -- on the reference's non-convex dump hs107 that changed which side a flip takes and the run cycled)
+    static long long pad16(long long n) { static const bool off = getenv("RSQP_LARGE_NO_PAD") != nullptr; return (off || n < 256) ? n : ((n + 15) & ~15LL); }
     hipStream_t st = nullptr;
     hipError_t err_ = hipSuccess;
     RsqpLargeMatrices M;

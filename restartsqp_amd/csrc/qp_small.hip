@@ -1045,6 +1045,7 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
     const int grp = L >= 64 ? 0 : (int)threadIdx.x / L;  // L >= 64: everything below stays workgroup-uniform
     const int q = L >= 64 ? (int)blockIdx.x : blockIdx.x * (64 / L) + grp;
     if (q >= nq) return;  // no workgroup barrier anywhere below: idle groups may leave
+    if (P.only_bailed && P.ret[q] != RET_BAIL) return;   // second pass behind the explicit-KKT-inverse kernel (qp_small_k.h)
     lchar *smem = (lchar *)smem_generic + grp * stride;
     QPDesc d = P.desc[q];
     if constexpr (SHAPE > 0) { d.nV = NVC; d.nC = NCC; }
@@ -1174,6 +1175,8 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
     STAMP(9);
 }
 
+#include "qp_small_k.h"
+
 }  // namespace
 
 static const long long kMaxLds = 160 * 1024;
@@ -1189,8 +1192,10 @@ static int env_int(const char *name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, long long mat_bytes_max, int mode,
+hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCmax, long long mat_bytes_max, int mode,
                                 int maxWSR, hipStream_t stream) {
+    QPPools p = p_in;
+    p.only_bailed = 0;
     if (nq <= 0) return hipSuccess;
     if (align16(rsqp_image_bytes(nVmax, nCmax)) > kMaxLds) return hipErrorInvalidValue;
     // formulation: 0 = Givens / TQ (Engine), 1 = explicit inverses (EngineX, qp_small_x.h), which keeps
@@ -1262,6 +1267,17 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
     // Packed builds with W=6 (80 VGPRs, ~180 spilled) returned wrong results and are not built.
     int waves = L == 64 ? (nVmax <= 16 ? 6 : 4) : 2;
     if (forcedW >= 2 && forcedW <= (L == 64 ? 6 : 4)) waves = forcedW;
+    // ---- cold-start-only batches of mid-size problems: the explicit-KKT-inverse kernel first (qp_small_k.h: ~10 phases per
+    // working-set change instead of ~50); members it cannot carry (non-convex, LP, undecidable tests) come back with
+    // ret == RET_BAIL and are solved by the null-space kernel launched right behind it, which skips everybody else
+    static const int noK = env_int("RSQP_SMALL_NO_KKT", 0);
+    typedef EngineK<3, 1, 9, 4> EK;      // 32 x 8 lane grid: up to 72 variables x 32 constraints (the 69 x 28 class of the hs0xx batch)
+    if (!noK && forcedE < 0 && eng == 1 && wide && mode == 0 && !p.keep_state && !p.done_flag && nVmax <= EK::MAXV && nCmax <= EK::MAXC) {
+        static std::atomic<unsigned long long> setk_{0};
+        rsqp_allow_full_lds(reinterpret_cast<const void *>(&small_qpk_kernel<3, 1, 9, 4>), setk_, (int)kMaxLds);
+        hipLaunchKernelGGL((small_qpk_kernel<3, 1, 9, 4>), dim3(nq), dim3(256), (size_t)EK::lds_bytes(nVmax, nCmax), stream, p, nq, maxWSR);
+        p.only_bailed = 1;
+    }
 #define SQ_LAUNCH_U(ENG, LL, ML, W, U)                                                                        \
     do {                                                                                                      \
         static std::atomic<unsigned long long> set_{0};                                                       \

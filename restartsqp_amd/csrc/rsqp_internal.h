@@ -17,7 +17,8 @@
 // solver status codes kept in the per-problem result record (qpOASES QProblemStatus order)
 enum { QPS_NOTINITIALISED = 0, QPS_PREPARINGAUXILIARYQP = 1, QPS_AUXILIARYQPSOLVED = 2,
        QPS_PERFORMINGHOMOTOPY = 3, QPS_HOMOTOPYQPSOLVED = 4, QPS_SOLVED = 5 };
-enum { RET_OK = 0, RET_MAX_NWSR = 1, RET_INFEASIBLE = 2, RET_UNBOUNDED = 3, RET_SETUP_FAILED = 4 };
+enum { RET_OK = 0, RET_MAX_NWSR = 1, RET_INFEASIBLE = 2, RET_UNBOUNDED = 3, RET_SETUP_FAILED = 4,
+       RET_BAIL = 9 };   // internal: the explicit-KKT-inverse kernel hands the problem to the null-space kernel (never reported)
 
 // one problem of a batch: sizes and offsets into the pooled device arrays
 struct QPDesc {
@@ -46,6 +47,7 @@ struct QPPools {
     int reinit_from_y0;   // warm re-initialisation (mode 3) without guessed constraints: 1 = sides from sign(y0), 0 = from A x0
     int *done_flag;   // single-QP solves: host-mapped word that receives done_val once the results are out (the host spins
     int done_val;     //   on it instead of sleeping in hipStreamSynchronize); nullptr for batches
+    int only_bailed;  // 1: the null-space kernel runs only the members the explicit-KKT-inverse kernel left with ret == RET_BAIL
     int keep_state;   // 1: write the hot-start part of the engine image back to HBM at the end of a solve (what the
                       //    SQProblem object keeps between calls); 0: cold-start-only batches skip that write --
                       //    the image is marked "not initialised", a later hot start falls back to a cold start

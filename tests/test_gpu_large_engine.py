@@ -197,8 +197,8 @@ def test_baseline_sparse_10k_reference_rule(capi):
     """The same configuration under the REFERENCE's re-initialisation rule (the library default): a FIXED <-> VARIED
     flip calls init(.., x_qp, y_qp, &bounds) with no guessed constraints (qpOASESInterface.cpp:199-207), so the working
     set of the constraints is rebuilt one change at a time. Cold start + 4 steps (2 of them VARIED = flips) at full size,
-    every answer to the reference's KKT certificate; the flips must take about as many changes as there are active
-    constraints (that is what the rule costs), the FIXED steps in between are plain hot starts."""
+    every answer to the reference's KKT certificate; the flips must take thousands of changes -- most of the active
+    constraints are added again one by one (that is what the rule costs) --, the FIXED steps in between are plain hot starts."""
     q = problems.sparse_qp()
     s = load(capi, q, engine=0)
     s.set_options(qp_maxiter=200000)
@@ -214,7 +214,7 @@ def test_baseline_sparse_10k_reference_rule(capi):
         nact = int((s.working_set_raw()[1] != 0).sum())
         assert s.status == 20 and ok and st.KKT_error < 1e-8, (k, nk, st.KKT_error)
         if changed:
-            assert nk >= nact > 1000, (k, nk, nact)        # every active constraint was added again
+            assert nact > 1000 and nk > nact // 2, (k, nk, nact)   # (most of) the active constraints were added again
         else:
             assert nk < n // 10, (k, nk)
 

@@ -156,14 +156,16 @@ struct K {
         return b;
     }
 
-    // independence of the incoming row from the working set: 1 independent, 0 dependent, -1 cannot tell (bail)
-    int li_test(double aPa, double na2) {
+    // independence of the incoming row a from the working set, from the residual r = a_FR - A_AC,FR' xi_C of its
+    // representation by the active rows (xi_C = D'a = the constraint part of M [a; 0]): K M = I gives r = H P a, and
+    // Z'r = Z'a, so |Z'a| <= |r| <= cond(Z'HZ) |Z'a| -- a first-order quantity (the oracle tests |Z'a| > 1e-9 |a|), where
+    // a'Pa is of second order and drowns in rounding below ~1e-7. 1 independent, 0 dependent, -1 cannot tell (bail)
+    int li_test(double rn2, double na2) {
         if (nFR - nAC <= 0) return 0;
         if (!(na2 > 0.0)) return 0;
-        const double ratio_ = aPa * hscale / na2;
-        if (ratio_ > 1e-12) return 1;
-        if (ratio_ < 1e-22) return 0;
-        if (getenv("PROTOK_DEBUG")) fprintf(stderr, "grey LI ratio %.3e aPa %.3e na2 %.3e nZ %d nS %d\n", ratio_, aPa, na2, nFR - nAC, nS);
+        const double rel = std::sqrt(rn2 / na2);
+        if (rel > 1e-7) return 1;
+        if (rel < 1e-9) return 0;
         return -1;
     }
 
@@ -175,16 +177,18 @@ struct K {
         double na2 = 0, aPa = 0;
         if (b.kind == 3) { for (int v = 0; v < nV; v++) afull[v] = A[b.idx + (size_t)v * nC]; for (int p = 0; p < nS; p++) { k[p] = skind[p] == 0 ? afull[sid[p]] : 0.0; na2 += k[p] * k[p]; } }
         else { afull[b.idx] = 1.0; k[posV[b.idx]] = 1.0; na2 = 1.0; }
-        for (int p = 0; p < nS; p++) { double t = 0; for (int q = 0; q < nS; q++) t += M[p + (size_t)q * ld] * k[q]; u[p] = t; aPa += 0; }
-        for (int p = 0; p < nS; p++) aPa += k[p] * u[p];
-        const int li = li_test(aPa, na2);
+        for (int p = 0; p < nS; p++) { double t = 0; for (int q = 0; q < nS; q++) t += M[p + (size_t)q * ld] * k[q]; u[p] = t; }
+        (void)aPa;
+        std::vector<double> xiC(nC, 0.0), xiB(nV, 0.0), t(nV);
+        for (int p = 0; p < nS; p++) if (skind[p] == 1) xiC[sid[p]] = u[p];
+        AT_times(xiC.data(), t.data());
+        double rn2 = 0;
+        for (int v = 0; v < nV; v++) if (Sb[v] == 0) { const double r = afull[v] - t[v]; rn2 += r * r; }
+        const int li = li_test(rn2, na2);
         if (li < 0) { bail_reason = 3; return RET_BAIL; }
         double ynew = 0.0;
         if (li == 0) {
             // exchange: c = sum xiC_j a_j (active constraints) + sum xiB_v e_v (fixed variables)
-            std::vector<double> xiC(nC, 0.0), xiB(nV, 0.0), t(nV);
-            for (int p = 0; p < nS; p++) if (skind[p] == 1) xiC[sid[p]] = u[p];
-            AT_times(xiC.data(), t.data());
             for (int v = 0; v < nV; v++) xiB[v] = Sb[v] != 0 ? afull[v] - t[v] : 0.0;
             const double sgn = b.side == 1 ? -1.0 : 1.0;
             double tmin = INFTY; int pk = 0, pi = -1;
