@@ -440,6 +440,36 @@ def hs_batch_scaling(capi, problems, parallel, torch, dist, rank, world, local_r
             "n_gpus": world, "steps": reps}
 
 
+def trajectory_batch(capi, problems, nq=16384, reps=20):
+    """The headline kernel on a REPRESENTATIVE mix: the QPs of a whole hs071 SQP run (tests/golden/sqp_traces.json: the
+    iterates, multipliers, radii and penalties of the trajectory that tests/sqp_driver.py walks to the optimum), each with
+    seeded 1 % perturbations, cold start -- not only the first QP of the run, whose two working-set changes make it the
+    easiest one."""
+    path = os.path.join(ROOT, "tests", "golden", "sqp_traces.json")
+    if not os.path.exists(path):
+        return None
+    tr = json.load(open(path))["hs071"]["qps"]
+    base = [problems.handler_qp(problems.hs071_nlp(np.array(g["x"]), np.array(g["lam"])), delta=g["delta"], rho=g["rho"]) for g in tr]
+    rng = np.random.default_rng(20260104)
+    probs = [problems.perturb(rng, base[k % len(base)]) for k in range(nq)]
+    b = capi.Batch(probs)
+    b.set_keep_state(False)
+    b.solve(capi.MODE_COLD, 1000)
+    ms = []
+    for _ in range(reps):
+        b.solve(capi.MODE_COLD, 1000, sync=True)
+        ms.append(b.last_solve_ms())
+    res = b.results()
+    ok, _ = b.test_optimality()
+    st = quartiles(ms)
+    out = {"qps": nq, "distinct_trajectory_qps": len(base), "ms_per_batch": st["median"], "qp_solves_per_s": nq / (st["median"] * 1e-3),
+           "mean_nWSR": float(np.mean([r["nWSR"] for r in res])), "max_nWSR": int(max(r["nWSR"] for r in res)),
+           "solved_and_certified": int(sum(1 for r, o in zip(res, ok) if r["status"] == 20 and o == 1)),
+           "note": "cold starts of the %d QPs of the hs071 trajectory (x_k, lambda_k, delta_k of every SQP iteration) +- 1 %%" % len(base)}
+    b.close()
+    return out
+
+
 def hs071_single_qp_latency(problems, iters=3000):
     """Wall-clock per SQP iteration of hs071 at the boundary, ONE QP at a time: the C++ host
     adapter (restartsqp_amd/csrc/host) replays QPhandler::update_delta + solveQP (hot start +
@@ -747,6 +777,7 @@ def main():
             line["roofline_spmv"] = spmv_roofline(capi, problems, args.spmv_batch, 40)
             line["roofline_value_refresh"] = value_refresh_roofline(capi, problems)
             line["hs071_single_qp"] = hs071_single_qp_latency(problems)
+            line["hs071_trajectory_batch"] = trajectory_batch(capi, problems)
             line["hs0xx_batch_512"] = hs_batch_config(capi, problems, parallel)
             if not args.no_large:
                 line["large_engine"] = large_configs(capi, problems)

@@ -36,11 +36,16 @@ class QPhandler:
         for i in range(2 * m):
             s.set_ub(n + i, INF)
 
-    def update_bounds(self, delta, x_l, x_u, x_k, c_l, c_u, c_k):  # :342-368 (ubA is NOT refreshed)
+    def update_bounds(self, delta, x_l, x_u, x_k, c_l, c_u, c_k, refresh_ubA=False):  # :342-368 (ubA is NOT refreshed)
+        """refresh_ubA=True is NOT the reference's behaviour: its qpOASES branch leaves ubA stale (QPhandler.cpp:358-360),
+        which turns its own run infeasible after the first accepted step when a constraint is an equality; the whole-
+        trajectory replay (tests/test_sqp_trajectory.py) needs the correct value and says so."""
         s = self.solverInterface_
         n, m = self.nlp_info_.nVar, self.nlp_info_.nCon
         for i in range(m):
             s.set_lbA(i, c_l[i] - c_k[i])
+            if refresh_ubA:
+                s.set_ubA(i, c_u[i] - c_k[i])
         for i in range(n):
             s.set_lb(i, max(x_l[i] - x_k[i], -delta))
             s.set_ub(i, min(x_u[i] - x_k[i], delta))

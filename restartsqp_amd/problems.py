@@ -45,7 +45,27 @@ def hs071_nlp(x=None, lam=None):
                 info=NLPInfo(nCon=2, nVar=4, nnz_jac_g=8, nnz_h_lag=10))
 
 
-def handler_qp(nlp, delta=1.0, rho=1.0):
+def hs065_nlp(x=None, lam=None):
+    """Closed-form hs065 as the reference's AMPL file states it (``test/CUTE_examples/hs065.nl``): 3 free variables,
+    x0 = (-5, 5, 0); objective (x1-x2)^2 + (x1+x2-10)^2/9 + (x3-5)^2; FOUR constraints -- c0 = x1^2+x2^2+x3^2 <= 48 and
+    the three boxes -4.5 <= x1, x2 <= 4.5, -5 <= x3 <= 5 modelled as range constraints c1..c3 = x1..x3 (the `r` block),
+    6 Jacobian entries, Hessian of the Lagrangian f - lam'c (lower triangle, 4 entries: the 3 diagonal ones + (2,1))."""
+    x = np.array([-5.0, 5.0, 0.0]) if x is None else np.asarray(x, float)
+    lam = np.zeros(4) if lam is None else np.asarray(lam, float)
+    x1, x2, x3 = x
+    f = (x1 - x2) ** 2 + (x1 + x2 - 10.0) ** 2 / 9.0 + (x3 - 5.0) ** 2
+    grad = np.array([2 * (x1 - x2) + 2 * (x1 + x2 - 10.0) / 9.0, -2 * (x1 - x2) + 2 * (x1 + x2 - 10.0) / 9.0, 2 * (x3 - 5.0)])
+    c = np.array([x1 * x1 + x2 * x2 + x3 * x3, x1, x2, x3])
+    J = SpTripletMat(4, 3, [1, 1, 1, 2, 3, 4], [1, 2, 3, 1, 2, 3], [2 * x1, 2 * x2, 2 * x3, 1.0, 1.0, 1.0], False)
+    l0 = lam[0]
+    H = SpTripletMat(3, 3, [1, 2, 2, 3], [1, 1, 2, 3],
+                     [2.0 + 2.0 / 9.0 - 2.0 * l0, -2.0 + 2.0 / 9.0, 2.0 + 2.0 / 9.0 - 2.0 * l0, 2.0 - 2.0 * l0], True)
+    return dict(x=x, f=f, grad=grad, c=c, J=J, H=H, x_l=np.full(3, -np.inf), x_u=np.full(3, np.inf),
+                c_l=np.array([-np.inf, -4.5, -4.5, -5.0]), c_u=np.array([48.0, 4.5, 4.5, 5.0]),
+                info=NLPInfo(nCon=4, nVar=3, nnz_jac_g=6, nnz_h_lag=4))
+
+
+def handler_qp(nlp, delta=1.0, rho=1.0, name="hs071_first_qp"):
     """The QP that QPhandler builds from an NLP iterate (src/QPhandler.cpp:39-51,185-201,272-297):
     variables (p, u, v), A = [J I -I], H = blkdiag(H_k, 0), g = (grad f, rho e)."""
     n, m = nlp["info"].nVar, nlp["info"].nCon
@@ -65,7 +85,7 @@ def handler_qp(nlp, delta=1.0, rho=1.0):
     ub[:n] = np.minimum(nlp["x_u"] - nlp["x"], delta)
     g = np.concatenate([nlp["grad"], rho * np.ones(2 * m)])
     lbA = nlp["c_l"] - nlp["c"]; ubA = nlp["c_u"] - nlp["c"]
-    return QPData(nV, m, *dense_to_csc(H), *dense_to_csc(A), g, lb, ub, lbA, ubA, name="hs071_first_qp")
+    return QPData(nV, m, *dense_to_csc(H), *dense_to_csc(A), g, lb, ub, lbA, ubA, name=name)
 
 
 def hs071_first_qp():

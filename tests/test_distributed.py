@@ -99,3 +99,53 @@ def test_two_rank_gloo_gather():
     for p in procs:
         p.join(60)
     assert got == [(0, True, 21), (1, True, 21)]
+
+
+def _hip_worker(rank, world, port, q):
+    """two ranks, BOTH on device 0 (a one-GPU box), collectives over gloo on host tensors: the solver is the HIP engine
+    (capi.Batch through the C ABI), the sharding / packing / gather logic is the product's parallel.solve_sharded"""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from restartsqp_amd import capi
+    probs = problems.hs_batch(96)
+
+    def solve_fn(block):
+        b = capi.Batch(block, device=0)
+        b.set_keep_state(False)
+        b.solve(capi.MODE_COLD, 1000)
+        res = b.results()
+        ok, kkt = b.test_optimality()
+        b.close()
+        return res, list(kkt)
+
+    out = parallel.solve_sharded(probs, solve_fn, dist, balance=True)
+    q.put((rank, [(r["status"], r["nWSR"], r["ws_b"].tolist(), r["ws_c"].tolist(), r["x"].tolist()) for r in out]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_hip_engine_over_gloo(capi, oracle):
+    """The N > 1 path with the HIP engine as the per-rank solver (a one-GPU box: both ranks share device 0, gloo carries the
+    records): every rank ends with every member's answer, identical on both ranks and to the oracle. The ranks are child
+    processes started BEFORE anything here touches the GPU in them (spawn), never an exec from a GPU process."""
+    import torch.multiprocessing as mp
+    from conftest import oracle_cold
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hip_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert sorted(got) == [0, 1] and got[0] == got[1] and len(got[0]) == 96
+    for p, (status, nwsr, wb, wc, x) in zip(problems.hs_batch(96), got[0]):
+        qp, rc, n = oracle_cold(oracle, p)
+        assert status == qp.exitflag() and nwsr == n and wb == qp.ws_bounds.tolist() and wc == qp.ws_constraints.tolist()
+        assert np.abs(np.array(x) - qp.x).max() <= 1e-9 * max(1.0, np.abs(qp.x).max())

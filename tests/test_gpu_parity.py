@@ -554,6 +554,37 @@ def test_degenerate_inputs_both_engines(capi, oracle):
         assert np.abs(s.x - qp.x).max() <= 1e-9 * max(1.0, np.abs(qp.x).max())
 
 
+@pytest.mark.parametrize("keep_state", [True, False])
+def test_degenerate_sweep_mismatch_rate_is_bounded(capi, oracle, keep_state):
+    """The bit-exact claim is for NON-degenerate QPs (unique optimal working set). On degenerate inputs -- duplicate / zero
+    rows, constraints parallel to bounds, integer data, singular H: exact ties in the ratio tests -- a tie is broken by the
+    last bits of differently ordered sums, and a few answers end in another (equally optimal) working set than the
+    oracle's. This sweep (the former tools/random_parity_sweep.py --degenerate) pins the observed rate: at most 1 % of
+    1 500 seeded degenerate inputs may differ, and every one of them must still be a certified KKT point whenever the
+    oracle's answer is. keep_state False = the explicit-KKT-inverse kernel + null-space fallback, True = null-space only."""
+    rng = np.random.default_rng(20260105)
+    probs = [problems.degenerate_qp(rng, k % 5) for k in range(1500)]
+    b = capi.Batch(probs)
+    b.set_keep_state(keep_state)
+    b.solve(capi.MODE_COLD, 2000)
+    res = b.results()
+    ok, kkt = b.test_optimality()
+    differ = 0
+    for q, r, o in zip(probs, res, ok):
+        qp, rc, n = oracle_cold(oracle, q, 2000)
+        same = (r["status"] == qp.exitflag() and r["nWSR"] == n and np.array_equal(r["ws_b"], qp.ws_bounds)
+                and np.array_equal(r["ws_c"], qp.ws_constraints))
+        if same and qp.is_solved():
+            sc = max(1.0, float(np.abs(qp.x).max()), float(np.abs(qp.y).max()))
+            same = np.abs(r["x"] - qp.x).max() <= 1e-9 * sc and np.abs(r["y"] - qp.y).max() <= 1e-9 * sc
+        if not same:
+            differ += 1
+            if qp.is_solved() and r["status"] == 20:      # another vertex of a degenerate face: same objective, certified
+                assert o == 1 and abs(r["obj"] - qp.objective) <= 1e-7 * max(1.0, abs(qp.objective)), (q.name, r["obj"], qp.objective)
+    assert differ <= 15, differ
+    b.close()
+
+
 @pytest.mark.gpu
 def test_packed_waves_match_one_problem_per_wave():
     """64/L problems share a wave in the LDS engine (L = 16 / 32 lanes per problem). Every packing

@@ -1,0 +1,97 @@
+"""Whole SQP trajectories at the QP boundary: hs071 and hs065 walked from their starting points to
+their known optima by the minimal driver tests/sqp_driver.py.
+
+CPU: the oracle behind the restated dispatch reproduces the committed trace (tests/golden/sqp_traces.json) and reaches the
+published optima. GPU: the same trajectory replayed through the QPhandler mirror -> HipQPInterface -> C ABI with the call
+sequence of Algorithm::setupQP (reference src/Algorithm.cpp:645-697) -- every QP of the run compared with the trace."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from restartsqp_amd import problems
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import sqp_driver as D  # noqa: E402
+
+NLPS = {"hs071": problems.hs071_nlp, "hs065": problems.hs065_nlp}
+# optima of the Hock-Schittkowski collection (the reference lists both problems in test/CUTE_examples)
+OPTIMA = {"hs071": ([1.0, 4.74299963, 3.82114998, 1.37940829], 17.0140173), "hs065": ([3.650461821, 3.65046168, 4.6204170507], 0.9535288567)}
+
+
+def trace():
+    return json.load(open(os.path.join(GOLDEN, "sqp_traces.json")))
+
+
+@pytest.mark.parametrize("name", ["hs071", "hs065"])
+def test_oracle_walks_the_trajectory(oracle, name):
+    be = D.OracleBackend(oracle)
+    x, f, it, tr = D.run_sqp(NLPS[name], be, name)
+    xs, fs = OPTIMA[name]
+    assert np.abs(x - np.array(xs)).max() < 1e-5 and abs(f - fs) < 1e-6
+    gold = trace()[name]["qps"]
+    assert len(tr) == len(gold) and [g["mode"] for g in gold] == be.oi.modes
+    for t, g in zip(tr, gold):
+        assert t["nWSR"] == g["nWSR"] and t["status"] == g["status"] == 20
+        assert np.abs(np.array(t["x_qp"]) - np.array(g["x_qp"])).max() <= 1e-12 * max(1.0, np.abs(g["x_qp"]).max())
+    # the trajectory is more than its first QP: several warm-start modes occur, later QPs carry non-zero multipliers
+    assert len(gold) >= 6 and any(np.abs(g["lam"]).max() > 1e-3 for g in gold)
+    if name == "hs065":
+        assert {"cold", "hot_matrices", "hot_vectors", "reinit"} <= set(g["mode"] for g in gold)
+
+
+class HandlerBackend:
+    """QPhandler mirror over HipQPInterface, driven by the dirty flags exactly as Algorithm::setupQP does"""
+
+    def __init__(self, nlp_fn):
+        from restartsqp_amd.handler import QPhandler
+        from restartsqp_amd.sqptypes import Stats
+        self.nlp_fn, self.h, self.stats, self.QPhandler, self.Stats = nlp_fn, None, None, QPhandler, Stats
+
+    def solve_at(self, g):
+        """g: one entry of the trace (iterate, delta, rho, flags)"""
+        nlp = self.nlp_fn(np.array(g["x"]), np.array(g["lam"]))
+        fl = g["flags"]
+        if self.h is None:
+            self.h = self.QPhandler(nlp["info"])
+            self.stats = self.Stats()
+            h = self.h
+            h.set_A(nlp["J"]); h.set_H(nlp["H"])
+            h.set_bounds(g["delta"], nlp["x_l"], nlp["x_u"], nlp["x"], nlp["c_l"], nlp["c_u"], nlp["c"])
+            h.set_g(nlp["grad"], g["rho"])
+        else:
+            h = self.h
+            if fl["A"]:
+                h.update_A(nlp["J"])
+            if fl["H"]:
+                h.update_H(nlp["H"])
+            if fl["bounds"]:
+                h.update_bounds(g["delta"], nlp["x_l"], nlp["x_u"], nlp["x"], nlp["c_l"], nlp["c_u"], nlp["c"], refresh_ubA=True)
+            elif fl["delta"]:
+                h.update_delta(g["delta"], nlp["x_l"], nlp["x_u"], nlp["x"])
+            if fl["penalty"]:
+                h.update_penalty(g["rho"])
+            if fl["g"]:
+                h.update_grad(nlp["grad"])
+        before = self.stats.qp_iter
+        h.solveQP(self.stats)                   # optimizeQP + the mandatory KKT certificate (raises QP_NOT_OPTIMAL)
+        x = h.get_optimal_solution()
+        y = np.concatenate([h.get_multipliers_bounds(), h.get_multipliers_constr()])
+        return x, y, self.stats.qp_iter - before, h.get_status()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["hs071", "hs065"])
+def test_gpu_replays_the_trajectory(capi, name):
+    be = HandlerBackend(NLPS[name])
+    for g in trace()[name]["qps"]:
+        x, y, n, status = be.solve_at(g)
+        assert status == g["status"] == 20 and n == g["nWSR"], (name, g["it"], g["mode"], n, g["nWSR"])
+        gx, gy = np.array(g["x_qp"]), np.array(g["y_qp"])
+        assert np.abs(x - gx).max() <= 1e-9 * max(1.0, np.abs(gx).max()), (name, g["it"], g["mode"])
+        assert np.abs(y - gy).max() <= 1e-9 * max(1.0, np.abs(gy).max()), (name, g["it"], g["mode"])
+        wb, wc = be.h.solverInterface_._s.working_set_raw()
+        assert np.array_equal(wb, g["ws_b"]) and np.array_equal(wc, g["ws_c"]), (name, g["it"], g["mode"])
