@@ -45,6 +45,21 @@ def hs071_nlp(x=None, lam=None):
                 info=NLPInfo(nCon=2, nVar=4, nnz_jac_g=8, nnz_h_lag=10))
 
 
+def hs035_nlp(x=None, lam=None):
+    """Closed-form hs035 as the reference's AMPL file states it (``test/CUTE_examples/hs035.nl``): 3 variables with lower
+    bounds 0, x0 = (0.5, 0.5, 0.5); objective 9 - 8x1 - 6x2 - 4x3 + 2x1^2 + 2x2^2 + x3^2 + 2x1x2 + 2x1x3; one linear
+    constraint x1 + x2 + 2x3 <= 3. A convex QP itself: the SQP run is the trust region growing until the QP step fits."""
+    x = np.array([0.5, 0.5, 0.5]) if x is None else np.asarray(x, float)
+    x1, x2, x3 = x
+    f = 9.0 - 8 * x1 - 6 * x2 - 4 * x3 + 2 * x1 * x1 + 2 * x2 * x2 + x3 * x3 + 2 * x1 * x2 + 2 * x1 * x3
+    grad = np.array([-8 + 4 * x1 + 2 * x2 + 2 * x3, -6 + 4 * x2 + 2 * x1, -4 + 2 * x3 + 2 * x1])
+    c = np.array([x1 + x2 + 2 * x3])
+    J = SpTripletMat(1, 3, [1, 1, 1], [1, 2, 3], [1.0, 1.0, 2.0], False)
+    H = SpTripletMat(3, 3, [1, 2, 2, 3, 3], [1, 1, 2, 1, 3], [4.0, 2.0, 4.0, 2.0, 2.0], True)
+    return dict(x=x, f=f, grad=grad, c=c, J=J, H=H, x_l=np.zeros(3), x_u=np.full(3, np.inf),
+                c_l=np.array([-np.inf]), c_u=np.array([3.0]), info=NLPInfo(nCon=1, nVar=3, nnz_jac_g=3, nnz_h_lag=5))
+
+
 def hs065_nlp(x=None, lam=None):
     """Closed-form hs065 as the reference's AMPL file states it (``test/CUTE_examples/hs065.nl``): 3 free variables,
     x0 = (-5, 5, 0); objective (x1-x2)^2 + (x1+x2-10)^2/9 + (x3-5)^2; FOUR constraints -- c0 = x1^2+x2^2+x3^2 <= 48 and

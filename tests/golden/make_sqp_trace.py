@@ -1,5 +1,5 @@
-"""Regenerates tests/golden/sqp_traces.json: whole SQP trajectories of hs071 and hs065 (analytic evaluators
-restartsqp_amd.problems.hs071_nlp / hs065_nlp, the minimal driver tests/sqp_driver.py) with the ORACLE behind the restated
+"""Regenerates tests/golden/sqp_traces.json: whole SQP trajectories of hs071, hs035 and hs065 (analytic evaluators
+restartsqp_amd.problems.hs071_nlp / hs035_nlp / hs065_nlp, the minimal driver tests/sqp_driver.py) with the ORACLE behind the restated
 optimizeQP dispatch as the QP solver. Per QP solve: the iterate (x_k, lambda_k), delta, rho, the dirty flags handed to the
 boundary, and the oracle's answer (dispatch mode, nWSR, status, x, y, working sets). Inputs for the GPU replay test and
 for bench.py's trajectory batch -- not outputs of the reference (qpOASES is not available: "parity unpinned")."""
@@ -24,7 +24,7 @@ class Recording(D.OracleBackend):
 
 def main():
     out = {}
-    for name, fn in (("hs071", problems.hs071_nlp), ("hs065", problems.hs065_nlp)):
+    for name, fn in (("hs071", problems.hs071_nlp), ("hs035", problems.hs035_nlp), ("hs065", problems.hs065_nlp)):
         be = Recording(O)
         be.log = []
         x, f, it, trace = D.run_sqp(fn, be, name)
