@@ -1271,11 +1271,15 @@ hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCma
     // working-set change instead of ~50); members it cannot carry (non-convex, LP, undecidable tests) come back with
     // ret == RET_BAIL and are solved by the null-space kernel launched right behind it, which skips everybody else
     static const int noK = env_int("RSQP_SMALL_NO_KKT", 0);
-    typedef EngineK<3, 1, 9, 4> EK;      // 32 x 8 lane grid: up to 72 variables x 32 constraints (the 69 x 28 class of the hs0xx batch)
+    // 32 row blocks x 8 column blocks of lanes: up to 72 variables x 32 constraints -- the 69 x 28 class of the hs0xx batch.
+    // (The 512-lane build EngineK<3, 1, 5, 2, 16> -- half the registers per lane, no AGPRs, two waves per SIMD -- measured
+    //  1.01 ms against 0.91 ms on the 512-QP batch: its 4-step reductions and 8-wave barriers cost more than the overlap gains.)
+    typedef EngineK<3, 1, 9, 4, 8> EK;
     if (!noK && forcedE < 0 && eng == 1 && wide && mode == 0 && !p.keep_state && !p.done_flag && nVmax <= EK::MAXV && nCmax <= EK::MAXC) {
         static std::atomic<unsigned long long> setk_{0};
-        rsqp_allow_full_lds(reinterpret_cast<const void *>(&small_qpk_kernel<3, 1, 9, 4>), setk_, (int)kMaxLds);
-        hipLaunchKernelGGL((small_qpk_kernel<3, 1, 9, 4>), dim3(nq), dim3(256), (size_t)EK::lds_bytes(nVmax, nCmax), stream, p, nq, maxWSR);
+        rsqp_allow_full_lds(reinterpret_cast<const void *>(&small_qpk_kernel<3, 1, 9, 4, 8>), setk_, (int)kMaxLds);
+        const size_t kl = (size_t)EK::lds_bytes(nVmax, nCmax);
+        hipLaunchKernelGGL((small_qpk_kernel<3, 1, 9, 4, 8>), dim3(nq), dim3(256), kl, stream, p, nq, maxWSR);
         p.only_bailed = 1;
     }
 #define SQ_LAUNCH_U(ENG, LL, ML, W, U)                                                                        \

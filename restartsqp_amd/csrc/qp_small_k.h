@@ -63,9 +63,12 @@ template <int S> __device__ __forceinline__ int kmin_i32(int v) {
     } else { v = min(v, xchg_i32<S>(v)); return kmin_i32<S + 1>(v); }
 }
 
-template <int RV, int RC, int CV, int CC>
+// GJ_ = lanes per row block: 8 (256 lanes, one wave per SIMD) or 16 (512 lanes, two waves per SIMD: half the matrix block per
+// lane, and a wave's waits overlap with the other wave's issue)
+template <int RV, int RC, int CV, int CC, int GJ_ = 8>
 struct EngineK {
-    static constexpr int NT = 256, GI = 32, GJ = 8;
+    static constexpr int GI = 32, GJ = GJ_, NT = GI * GJ, LGJ = GJ == 8 ? 3 : 4, NW = NT / 64;
+    static_assert(GJ == 8 || GJ == 16, "row blocks of 8 or 16 lanes (inside a DPP row)");
     static constexpr int NVP = GI * RV > GJ * CV ? GI * RV : GJ * CV, NCP = GI * RC > GJ * CC ? GI * RC : GJ * CC;
     static constexpr int MAXV = GI * RV < GJ * CV ? GI * RV : GJ * CV, MAXC = GI * RC < GJ * CC ? GI * RC : GJ * CC;   // largest nV / nC
     static_assert(RV + RC <= GJ, "row owners of a row block must fit its 8 lanes");
@@ -95,7 +98,7 @@ struct EngineK {
 
     __device__ __forceinline__ void carve(lchar *base, int nV_, int nC_) {
         nV = nV_; nC = nC_;
-        tid = (int)threadIdx.x; bi = tid >> 3; bj = tid & 7; wave = tid >> 6;
+        tid = (int)threadIdx.x; bi = tid >> LGJ; bj = tid & (GJ - 1); wave = tid >> 6;
         ldouble *p = (ldouble *)base;
 #define KV_(name) name = p; p += NVP
 #define KC_(name) name = p; p += NCP
@@ -131,7 +134,7 @@ struct EngineK {
     }
     template <int R> __device__ __forceinline__ static void rowsum(double (&acc)[R]) {     // over the 8 lanes of a row block
 #pragma unroll
-        for (int a = 0; a < R; a++) acc[a] = allreduce_sum<3>(acc[a]);
+        for (int a = 0; a < R; a++) acc[a] = allreduce_sum<LGJ>(acc[a]);
     }
     template <int R> __device__ __forceinline__ static void zero(double (&acc)[R]) {
 #pragma unroll
@@ -192,7 +195,7 @@ struct EngineK {
         KSYNC();
         t = red[parity]; id = ired[parity];
 #pragma unroll
-        for (int w = 1; w < 4; w++) {
+        for (int w = 1; w < NW; w++) {
             const double t2 = red[parity + w]; const int id2 = ired[parity + w];
             if (t2 < t || (t2 == t && id2 < id)) { t = t2; id = id2; }
         }
@@ -684,13 +687,13 @@ struct EngineK {
     }
 };
 
-template <int RV, int RC, int CV, int CC>
-__global__ void __launch_bounds__(256, 1) small_qpk_kernel(QPPools P, int nq, int maxWSR) {
+template <int RV, int RC, int CV, int CC, int GJ_>
+__global__ void __launch_bounds__(32 * GJ_, 1) small_qpk_kernel(QPPools P, int nq, int maxWSR) {
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     const int q = (int)blockIdx.x;
     if (q >= nq) return;
     const QPDesc d = P.desc[q];
-    typedef EngineK<RV, RC, CV, CC> ENG;
+    typedef EngineK<RV, RC, CV, CC, GJ_> ENG;
     ENG E;
     E.carve((lchar *)smem_generic, d.nV, d.nC);
     E.nFR = E.nAC = 0; E.status = QPS_NOTINITIALISED; E.infeasible = 0; E.bail_reason = 0;
@@ -719,8 +722,8 @@ __global__ void __launch_bounds__(256, 1) small_qpk_kernel(QPPools P, int nq, in
         if (tid == 0) { P.ret[q] = RET_BAIL; P.nflips[q] = E.bail_reason; }    // the null-space kernel takes this member over
         return;
     }
-    for (int v = tid; v < d.nV; v += 256) { P.x[d.offV + v] = E.x[v]; P.ws_b[d.offV + v] = E.Sb[v]; P.y[d.offV + d.offC + v] = E.yB[v]; }
-    for (int i = tid; i < d.nC; i += 256) { P.y[d.offV + d.offC + d.nV + i] = E.yC[i]; P.ws_c[d.offC + i] = E.Sc[i]; }
+    for (int v = tid; v < d.nV; v += ENG::NT) { P.x[d.offV + v] = E.x[v]; P.ws_b[d.offV + v] = E.Sb[v]; P.y[d.offV + d.offC + v] = E.yB[v]; }
+    for (int i = tid; i < d.nC; i += ENG::NT) { P.y[d.offV + d.offC + d.nV + i] = E.yC[i]; P.ws_c[d.offC + i] = E.Sc[i]; }
     if (tid == 0) {
         const int st = E.status;
         P.status[q] = E.infeasible ? 100 + st : st;
