@@ -500,14 +500,19 @@ hipError_t rsqp_dgeqrf(int m, int n, double *B, long long ldb, double eps_li, Rs
         for (int k0 = K0; k0 < K0 + ob; k0 += NB, p++) {
             const int jb = std::min(NB, K0 + ob - k0), mt = m - k0, nin = K0 + ob - k0 - jb;
             double *Vp = w->V + (k0 - K0) + (long long)(k0 - K0) * ldv;     // panel p inside the outer block's V
+            // (tried in round 3, RSQP_QR_WIDE_PANEL=1: apply a column's reflector to every remaining column of the OUTER block in
+            //  the same launch -- up to 256 workgroups instead of 64 -- and drop the three small-output products below, which run
+            //  at a few per cent of anything (64 x 192 results from an inner dimension of 10 000): 149 ms instead of 138 ms for
+            //  10 000 x 7 670, the column launches turn bandwidth-bound at ~15 us)
+            static const bool wide = getenv("RSQP_QR_WIDE_PANEL") != nullptr;
             for (int j = k0; j < k0 + jb; j++)
-                hipLaunchKernelGGL(k_qr_col, dim3(k0 + jb - j), dim3(QC), 0, st, B, ldb, m, j, k0, Vp, ldv, w->tau, rdiag,
+                hipLaunchKernelGGL(k_qr_col, dim3((wide ? K0 + ob : k0 + jb) - j), dim3(QC), 0, st, B, ldb, m, j, k0, Vp, ldv, w->tau, rdiag,
                                    w->norm2, eps_li, w->flag);
             // S = V'V (jb x jb, long inner dimension: split K), T factor, reflectors back into B
             DCHK(dgemm_ws(true, false, jb, jb, mt, 1.0, Vp, ldv, Vp, ldv, 0.0, S, jb, ws, 64LL * NB * NB, st));
             hipLaunchKernelGGL(k_qr_T_merge, dim3(1), dim3(256), 0, st, jb, S, w->tau + k0, w->T + (long long)p * NB * NB);
             hipLaunchKernelGGL(k_panel_writeback, dim3((mt + 255) / 256, jb), dim3(256), 0, st, B, ldb, m, k0, jb, Vp, ldv, rdiag);
-            if (nin > 0) {      // the rest of the outer block
+            if (nin > 0 && !wide) {      // the rest of the outer block
                 double *Ct = B + k0 + (long long)(k0 + jb) * ldb;
                 DCHK(dgemm_ws(true, false, jb, nin, mt, 1.0, Vp, ldv, Ct, ldb, 0.0, w->W, NB, w->ws, w->ws_cap, st));   // W = V'C
                 DCHK(rsqp_dgemm(true, false, jb, nin, jb, 1.0, w->T + (long long)p * NB * NB, NB, w->W, NB, 0.0, w->W2, NB, st));   // T'W

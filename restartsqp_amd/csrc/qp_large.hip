@@ -1190,10 +1190,13 @@ struct RsqpLargeEngine::Impl {
         struct Acc { Impl *p; double t0; ~Acc() { p->wait_seconds += now_s() - t0; p->wait_calls++; } } acc{this, now_s()};
         if (spin_wait) {
             const double want = (double)ctl_seq;
-            volatile double *flag = h_ctl + 63;
+            double *flag = h_ctl + 63;
             const double t0 = now_s();
             for (int it = 0;; it++) {
-                if (*flag == want) return RET_OK;
+                // acquire load of the sequence word: the decision block behind it is read after it
+                unsigned long long bits = __atomic_load_n(reinterpret_cast<unsigned long long *>(flag), __ATOMIC_ACQUIRE);
+                double seen; std::memcpy(&seen, &bits, sizeof(seen));
+                if (seen == want) { spin_misses = 0; return RET_OK; }     // consecutive misses only (a long blocked set-up is not a reason to stop spinning)
 #if defined(__x86_64__)
                 __builtin_ia32_pause();
 #endif

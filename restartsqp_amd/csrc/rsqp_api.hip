@@ -353,10 +353,16 @@ int fetch_results(rsqp_solver *s) {
 
 // wait for a single-QP kernel that raises the host-mapped completion word to `val`: spin for up to 2 ms, then block
 int wait_done(rsqp_solver *s, int val) {
-    volatile int *flag = s->h_done;
+    int *flag = s->h_done;
     const auto t0 = std::chrono::steady_clock::now();
     for (int it = 0;; it++) {
-        if (*flag == val) return RSQP_OK;
+        // acquire: the results the kernel wrote to host-mapped memory BEFORE it raised the word are read after this load
+        // (a plain volatile read orders nothing on non-x86 hosts and lets the compiler hoist the result reads)
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == val) {
+            // a kernel that faulted after raising the word would otherwise go unnoticed until a later call
+            if (hipStreamQuery(s->stream) == hipErrorLaunchFailure) return fail(RSQP_ERR_DEVICE, "QP kernel faulted");
+            return RSQP_OK;
+        }
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif

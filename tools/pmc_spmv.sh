@@ -3,6 +3,7 @@
 # Usage: tools/pmc_spmv.sh [out.json] [variants...]   (default gpurun_out/pmc_spmv.json, variant 40)
 out=${1:-gpurun_out/pmc_spmv.json}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+python3 __graft_entry__.py > /dev/null || exit 1     # build BEFORE the first rocprofv3 line (no compiler under a profiled process)
 i=0
 while read -r c; do
   i=$((i+1))
