@@ -1274,14 +1274,26 @@ hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCma
     // 32 row blocks x 8 column blocks of lanes: up to 72 variables x 32 constraints -- the 69 x 28 class of the hs0xx batch.
     // (The 512-lane build EngineK<3, 1, 5, 2, 16> -- half the registers per lane, no AGPRs, two waves per SIMD -- measured
     //  1.01 ms against 0.91 ms on the 512-QP batch: its 4-step reductions and 8-wave barriers cost more than the overlap gains.)
-    typedef EngineK<3, 1, 9, 4, 8> EK;
-    if (!noK && forcedE < 0 && eng == 1 && wide && mode == 0 && !p.keep_state && !p.done_flag && nVmax <= EK::MAXV && nCmax <= EK::MAXC) {
-        static std::atomic<unsigned long long> setk_{0};
-        rsqp_allow_full_lds(reinterpret_cast<const void *>(&small_qpk_kernel<3, 1, 9, 4, 8>), setk_, (int)kMaxLds);
-        const size_t kl = (size_t)EK::lds_bytes(nVmax, nCmax);
-        hipLaunchKernelGGL((small_qpk_kernel<3, 1, 9, 4, 8>), dim3(nq), dim3(256), kl, stream, p, nq, maxWSR);
-        p.only_bailed = 1;
+    typedef EngineK<3, 1, 9, 4, 8> EK;      // up to 72 variables x 32 constraints
+    typedef EngineK<2, 2, 8, 8, 8> EK2;     // up to 64 variables x 64 constraints
+    // (only where the null-space kernel would give a problem four waves as well: batches of SMALL problems are throughput-bound
+    //  and better served by 16 / 32 lanes per problem, several problems per wave)
+    if (!noK && forcedE < 0 && eng == 1 && (nVmax > 32 || nCmax > 32) && mode == 0 && !p.keep_state && !p.done_flag) {
+        static std::atomic<unsigned long long> setk_{0}, setk2_{0};
+        if (nVmax <= EK::MAXV && nCmax <= EK::MAXC) {
+            rsqp_allow_full_lds(reinterpret_cast<const void *>(&small_qpk_kernel<3, 1, 9, 4, 8>), setk_, (int)kMaxLds);
+            const size_t kl = (size_t)EK::lds_bytes(nVmax, nCmax);
+            hipLaunchKernelGGL((small_qpk_kernel<3, 1, 9, 4, 8>), dim3(nq), dim3(256), kl, stream, p, nq, maxWSR);
+            p.only_bailed = 1;
+        } else if (nVmax <= EK2::MAXV && nCmax <= EK2::MAXC) {
+            rsqp_allow_full_lds(reinterpret_cast<const void *>(&small_qpk_kernel<2, 2, 8, 8, 8>), setk2_, (int)kMaxLds);
+            const size_t kl = (size_t)EK2::lds_bytes(nVmax, nCmax);
+            hipLaunchKernelGGL((small_qpk_kernel<2, 2, 8, 8, 8>), dim3(nq), dim3(256), kl, stream, p, nq, maxWSR);
+            p.only_bailed = 1;
+        }
     }
+    static const int konly = env_int("RSQP_SMALL_KKT_ONLY", 0);     // diagnostics: no second pass (bailed members keep ret = 9, nflips = reason)
+    if (konly && p.only_bailed) return hipGetLastError();
 #define SQ_LAUNCH_U(ENG, LL, ML, W, U)                                                                        \
     do {                                                                                                      \
         static std::atomic<unsigned long long> set_{0};                                                       \

@@ -545,16 +545,16 @@ struct EngineK {
             if (t < bt || (t == bt && id < bid)) { bt = t; bid = id; }
         }
     }
-    // one candidate per lane, classes aligned to the waves: wave 0 = the constraints (lanes 0..31 lower side / multiplier of
-    // an active one, 32..63 upper side), waves 1..3 = the variables (96 lower / active, 96 upper) -- the arrays a lane
-    // reads are wave-uniform, the side picks an offset into adjacent arrays (no per-lane pointer selects)
-    static_assert(2 * NCP <= 64 && 2 * NVP <= 192, "ratio-test lane map");
+    // one candidate per lane, classes aligned to the waves: the first 2 NCP lanes = the constraints (lower side / multiplier of
+    // an active one, then upper side), the next 2 NVP = the variables -- the arrays a lane reads are wave-uniform, the
+    // side picks an offset into adjacent arrays (no per-lane pointer selects)
+    static_assert(2 * (NCP + NVP) <= NT && (2 * NCP) % 64 == 0, "ratio-test lane map: one lane per candidate, the constraints fill whole waves");
     __device__ __forceinline__ Blocking ratio_tests() {
         double bt = 1.0;
         int bid = 0x7fffffff;
-        if (wave == 0) {
-            const int i = tid & (NCP - 1);
+        if (tid < 2 * NCP) {
             const bool upper = tid >= NCP;
+            const int i = upper ? tid - NCP : tid;
             if (i < nC) {
                 const int s = Sc[i], o = i + (upper ? NCP : 0);
                 const double cur = Ax[i], d = dAx[i], yi = yC[i], dyi = dyC[i], bnd = lbA[o], bndN = lbAN[o];
@@ -567,7 +567,7 @@ struct EngineK {
                 if (ok) cand(num, den, id, bt, bid);
             }
         } else {
-            const int t2 = tid - 64;
+            const int t2 = tid - 2 * NCP;
             const bool upper = t2 >= NVP;
             const int v = upper ? t2 - NVP : t2;
             if (v < nV) {

@@ -49,7 +49,9 @@ def test_cold_only_batches_match_oracle(capi, oracle):
     rng = np.random.default_rng(7)
     rnd = [problems.random_qp(rng, int(rng.integers(9, 70)), int(rng.integers(1, 29)), density=float(rng.choice([0.2, 0.5, 1.0])))
            for _ in range(300)]
-    for probs in ([allp[k] for k in parallel.balanced_order(allp)], rnd):
+    rnd2 = [problems.random_qp(rng, int(rng.integers(33, 64)), int(rng.integers(20, 64)), density=float(rng.choice([0.2, 0.5, 1.0])))
+            for _ in range(60)]                  # the 64 x 64 instantiation of the kernel
+    for probs in ([allp[k] for k in parallel.balanced_order(allp)], rnd, rnd2):
         b = capi.Batch(probs)
         b.set_keep_state(False)
         b.solve(capi.MODE_COLD, 1000)

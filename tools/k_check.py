@@ -58,6 +58,9 @@ if __name__ == "__main__":
             probs = [problems.random_qp(rng, int(rng.integers(9, 70)), int(rng.integers(1, 29)), density=float(rng.choice([0.2, 0.5, 1.0])))
                      for _ in range(nr)]
             bad += run("random convex", probs, reps=3)
+            probs = [problems.random_qp(rng, int(rng.integers(33, 64)), int(rng.integers(20, 64)), density=float(rng.choice([0.2, 0.5, 1.0])))
+                     for _ in range(nr // 2)]
+            bad += run("random convex 33-63 x 20-63 (64 x 64 build)", probs, reps=3)
         sys.exit(1 if bad else 0)
     nr = sys.argv[1] if len(sys.argv) > 1 else "300"
     rc = 0
