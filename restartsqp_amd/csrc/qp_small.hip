@@ -181,6 +181,7 @@ struct Engine {
     long long tlast;
 
     // ------------------------------------------------------------------ carve
+    static constexpr bool K_IMAGE = false;      // (only batches of the explicit-inverse engine are shared with qp_small_k.h)
     // doubles of this formulation's image (<= rsqp_image_doubles, the size of the persistent copy)
     __host__ __device__ static long long image_doubles(int nV, int nC) {
         const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
@@ -1144,6 +1145,14 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
         if (rcode != RET_OK) rcode = E.setup_aux(false, false, false, false);
     } else {
         E.infeasible = E.unbounded = 0;
+        if constexpr (ENG::K_IMAGE) {
+            // the state is one the explicit-KKT-inverse kernel wrote (and then bailed out of this hot start): its factors
+            // are not this engine's -- rebuild them for the stored working set, keep the homotopy data
+            if (E.iscal[4] == 1) {
+                rcode = E.rebuild_factors();
+                if (rcode != RET_OK) rcode = E.setup_aux(false, false, false, false);
+            }
+        }
     }
     STAMP(2);
     if (rcode == RET_OK) rcode = E.homotopy(maxWSR, nWSR);
@@ -1162,6 +1171,7 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
         P.nflips[q] = E.nflips;
         P.obj[q] = obj;
         E.iscal[1] = E.nFR; E.iscal[2] = E.nAC; E.iscal[3] = E.status;
+        if constexpr (ENG::K_IMAGE) E.iscal[4] = 0;      // this engine's factors
     }
     if (P.done_flag) __threadfence_system();      // the results above are in host-mapped memory: visible before the flag
     SYNC();
@@ -1196,6 +1206,8 @@ hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCma
                                 int maxWSR, hipStream_t stream) {
     QPPools p = p_in;
     p.only_bailed = 0;
+    static const int kdbg = env_int("RSQP_K_DEBUG_BAIL", -1);
+    p.k_debug_bail = kdbg;
     if (nq <= 0) return hipSuccess;
     if (align16(rsqp_image_bytes(nVmax, nCmax)) > kMaxLds) return hipErrorInvalidValue;
     // formulation: 0 = Givens / TQ (Engine), 1 = explicit inverses (EngineX, qp_small_x.h), which keeps
@@ -1278,17 +1290,17 @@ hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCma
     typedef EngineK<2, 2, 8, 8, 8> EK2;     // up to 64 variables x 64 constraints
     // (only where the null-space kernel would give a problem four waves as well: batches of SMALL problems are throughput-bound
     //  and better served by 16 / 32 lanes per problem, several problems per wave)
-    if (!noK && forcedE < 0 && eng == 1 && (nVmax > 32 || nCmax > 32) && mode == 0 && !p.keep_state && !p.done_flag) {
+    if (!noK && forcedE < 0 && eng == 1 && (nVmax > 32 || nCmax > 32) && (mode == 0 || mode == 1) && !p.done_flag) {
         static std::atomic<unsigned long long> setk_{0}, setk2_{0};
         if (nVmax <= EK::MAXV && nCmax <= EK::MAXC) {
             rsqp_allow_full_lds(reinterpret_cast<const void *>(&small_qpk_kernel<3, 1, 9, 4, 8>), setk_, (int)kMaxLds);
             const size_t kl = (size_t)EK::lds_bytes(nVmax, nCmax);
-            hipLaunchKernelGGL((small_qpk_kernel<3, 1, 9, 4, 8>), dim3(nq), dim3(256), kl, stream, p, nq, maxWSR);
+            hipLaunchKernelGGL((small_qpk_kernel<3, 1, 9, 4, 8>), dim3(nq), dim3(256), kl, stream, p, nq, mode, maxWSR);
             p.only_bailed = 1;
         } else if (nVmax <= EK2::MAXV && nCmax <= EK2::MAXC) {
             rsqp_allow_full_lds(reinterpret_cast<const void *>(&small_qpk_kernel<2, 2, 8, 8, 8>), setk2_, (int)kMaxLds);
             const size_t kl = (size_t)EK2::lds_bytes(nVmax, nCmax);
-            hipLaunchKernelGGL((small_qpk_kernel<2, 2, 8, 8, 8>), dim3(nq), dim3(256), kl, stream, p, nq, maxWSR);
+            hipLaunchKernelGGL((small_qpk_kernel<2, 2, 8, 8, 8>), dim3(nq), dim3(256), kl, stream, p, nq, mode, maxWSR);
             p.only_bailed = 1;
         }
     }

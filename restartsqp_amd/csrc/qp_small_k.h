@@ -90,6 +90,7 @@ struct EngineK {
     double Mvv[RV][CV], Mvc[RV][CC], Mcv[RC][CV], Mcc[RC][CC];
     int nV, nC, tid, bi, bj, wave;
     int nFR, nAC, status, infeasible, bail_reason, parity;
+    int debug_bail;             // >= 0: a hot start bails out before its debug_bail-th change (tests of the hand-over); else -1
     int since_refresh;          // working-set changes since the carried products were last formed exactly; >= REFRESH: do it now
     static constexpr int REFRESH = 8;
     double hscale;
@@ -258,7 +259,26 @@ struct EngineK {
         for (int v = tid & 63; v < nV; v += 64) hm = fmax(hm, fabs(Hd[v + v * nV]));
 #pragma unroll
         for (int s = 1; s < 64; s <<= 1) hm = fmax(hm, __shfl_xor(hm, s));
-        hscale = hm;
+        // H has to be symmetric (products run over rows, borderings read columns); some of the reference's own inputs
+        // (test/unsolved_QPs/*.hpp) are not -- those go to the null-space kernel. Every lane checks its own block.
+        int asym = 0;
+#pragma unroll
+        for (int a = 0; a < RV; a++)
+#pragma unroll
+            for (int b = 0; b < CV; b++) {
+                const int r = bi * RV + a, c = bj * CV + b;
+                if (r < nV && c < nV && Hb[a][b] != Hd[c + r * nV]) asym = 1;
+            }
+        // (the workgroup-wide OR through this kernel's own LDS slots: __syncthreads_or brings static LDS, and with it the
+        //  160 KB dynamic-LDS attribute of the kernel is refused)
+        const int wany = __any(asym) ? 1 : 0;
+        if ((tid & 63) == 0) ired[wave] = wany;
+        KSYNC();
+        int any = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) any |= ired[w];
+        KSYNC();
+        hscale = any ? 0.0 : hm;      // (hscale = 0 makes the kernel bail)
     }
     __device__ __forceinline__ bool bounds_inconsistent() const {
         double bad = 0.0;
@@ -292,7 +312,9 @@ struct EngineK {
     // A x, H x, A'y_C of the iterate (x already exactly on its active bounds, see the end of enter_leave): active constraint
     // limits := A x, gradient of the current QP from stationarity; A dx_FX, H dx_FX (dx holds the move of the active bounds) ->
     // right-hand side r of the KKT system of the step
-    __device__ __forceinline__ void drift_and_rhs() {
+    // keep_data (first phase of a hot start): g, A x and the limits of the active constraints stay what the previous solve left
+    // (its targets, exactly), as in a hot start of the other engines; only the carried products and the right-hand side are formed
+    __device__ __forceinline__ void drift_and_rhs(bool keep_data) {
         double xv[CV], dv[CV], yc[CC], ax[RC], ad[RC], gyr[RV], hd[RV];
         ldcols<CV>(x, xv); ldcols<CV>(dx, dv); ldcols<CC>(yC, yc);
         zero<RC>(ax); zero<RC>(ad); zero<RV>(gyr); zero<RV>(hd);
@@ -302,19 +324,20 @@ struct EngineK {
         rowsum<RC>(ax); rowsum<RC>(ad); rowsum<RV>(gyr); rowsum<RV>(hd);
         if (ownsV()) {
             const int v = rowV();
-            const double gyv = pick<RV>(gyr, wV), phv = pick<RV>(hd, wV), gv = gyv + yB[v];
-            gy[v] = gyv; pH[v] = phv;
+            const double gyv = pick<RV>(gyr, wV), phv = pick<RV>(hd, wV), gv = keep_data ? g[v] : gyv + yB[v];
+            gy[v] = keep_data ? gv - yB[v] : gyv; pH[v] = phv;
             g[v] = gv;
             rV[v] = Sb[v] == 0 ? -((gN[v] - gv) + phv) : 0.0;
         } else if (ownsC()) {
             const int i = rowC(), s = Sc[i];
-            const double a = pick<RC>(ax, wC), pa = pick<RC>(ad, wC);
+            const double a = keep_data ? Ax[i] : pick<RC>(ax, wC), pa = pick<RC>(ad, wC);
             Ax[i] = a; pA[i] = pa;
             // (lbA | ubA and lbAN | ubAN are adjacent arrays: the side picks an OFFSET -- a select between the two pointers
             //  becomes a table of LDS addresses in scratch memory and a ~500-cycle load from it)
             const int side_off = i + (s == 1 ? NCP : 0);
-            if (s != 0) lbA[side_off] = a;
-            rC[i] = s != 0 ? (lbAN[side_off] - a) - pa : 0.0;
+            const double lim = keep_data ? lbA[side_off] : a;
+            if (s != 0) lbA[side_off] = lim;
+            rC[i] = s != 0 ? (lbAN[side_off] - lim) - pa : 0.0;
         }
         since_refresh = 0;
     }
@@ -599,13 +622,13 @@ struct EngineK {
         return b;
     }
 
-    __device__ __forceinline__ int homotopy(int maxit, int &nWSR) {
+    __device__ __forceinline__ int homotopy(int maxit, int &nWSR, bool hot) {
         int iter = 0, rcode = RET_OK;
         status = QPS_PERFORMINGHOMOTOPY;
         since_refresh = REFRESH;
         for (;;) {
             if (since_refresh >= REFRESH) {
-                drift_and_rhs();
+                drift_and_rhs(hot && iter == 0);
                 KSYNC();
             }
             STAMP(30);
@@ -660,12 +683,25 @@ struct EngineK {
                     ubA[i] = (b.kind == 3 && b.side == 1 && i == b.idx) ? an : u;
                 }
             }
-            if (done) { KSYNC(); status = QPS_SOLVED; break; }
-            if (iter >= maxit) { KSYNC(); rcode = RET_MAX_NWSR; break; }
+            if (done || iter >= maxit) {
+                // A x of the final iterate, exactly (the carried copy is one step behind at a full step): the next hot start
+                // reads it in its ratio tests
+                KSYNC();
+                double xv[CV], aa[RC];
+                ldcols<CV>(x, xv);
+                zero<RC>(aa);
+                mv<RC, CV>(Ab, xv, aa);
+                rowsum<RC>(aa);
+                if (ownsC()) Ax[rowC()] = pick<RC>(aa, wC);
+                KSYNC();
+                if (done) status = QPS_SOLVED; else rcode = RET_MAX_NWSR;
+                break;
+            }
             const int op = b.kind == 1 ? OP_LEAVE_C : (b.kind == 2 ? OP_LEAVE_B : (b.kind == 3 ? OP_ENTER_C : OP_ENTER_B));
             build_k(op, b.idx);
             KSYNC();
             STAMP(34);
+            if (hot && iter == debug_bail) { bail_reason = 13; rcode = RET_BAIL; break; }      // (test hook, see P.k_debug_bail)
             rcode = enter_leave(op, b.idx, b.side);
             if (rcode == RET_INFEASIBLE) { infeasible = 1; break; }
             if (rcode != RET_OK) break;
@@ -674,6 +710,98 @@ struct EngineK {
         nWSR = iter;
         return rcode;
     }
+    // ------------------------------------------------------------------ persistent state (hot starts)
+    // The state lives in the layout of the explicit-inverse engine (qp_small_x.h carve: factors | x g lb ub | A x lbA ubA | y,
+    // then Sb Sc AC posAC iscal as ints), so that engine's hot-start modes work on it unchanged (new matrices / warm re-init
+    // rebuild their factors anyway; a plain hot start rebuilds them when iscal[4] says the factors are not its own) -- and
+    // M = K^-1 goes BEHIND that image, one slot per variable and constraint ((nV + nC)^2 doubles, rsqp_state_bytes).
+    __device__ __forceinline__ void store_state(double *img) const {
+        const long long ldx = rsqp_ld(nV), sT = nV < nC ? nV : nC, voff = 2 * ldx * nV + sT * ldx;
+        double *pv = img + voff;
+        if (tid < nV) { const int v = tid; pv[v] = x[v]; pv[nV + v] = g[v]; pv[2 * nV + v] = lb[v]; pv[3 * nV + v] = ub[v]; pv[4 * nV + 3 * nC + v] = yB[v]; }
+        if (tid >= NT / 2 && tid - NT / 2 < nC) {
+            const int i = tid - NT / 2;
+            pv[4 * nV + i] = Ax[i]; pv[4 * nV + nC + i] = lbA[i]; pv[4 * nV + 2 * nC + i] = ubA[i]; pv[5 * nV + 3 * nC + i] = yC[i];
+        }
+        int *pi = reinterpret_cast<int *>(img + voff + 5LL * nV + 4LL * nC);      // = persist_doubles of that engine
+        if (tid < nV) pi[tid] = Sb[tid];
+        if (tid >= NT / 2 && tid - NT / 2 < nC) pi[nV + tid - NT / 2] = Sc[tid - NT / 2];
+        if (tid == 0) { int *isc = pi + nV + 3 * nC; isc[1] = nFR; isc[2] = nAC; isc[3] = status; isc[4] = 1; }
+        double *pm = img + rsqp_image_bytes(nV, nC) / 8;
+        const int N = nV + nC;
+#pragma unroll
+        for (int a = 0; a < RV; a++) {
+            const int r = bi * RV + a;
+            if (r < nV) {
+#pragma unroll
+                for (int b = 0; b < CV; b++) { const int c = bj * CV + b; if (c < nV) pm[r + (long long)c * N] = Mvv[a][b]; }
+#pragma unroll
+                for (int c_ = 0; c_ < CC; c_++) { const int c = bj * CC + c_; if (c < nC) pm[r + (long long)(nV + c) * N] = Mvc[a][c_]; }
+            }
+        }
+#pragma unroll
+        for (int c_ = 0; c_ < RC; c_++) {
+            const int r = bi * RC + c_;
+            if (r < nC) {
+#pragma unroll
+                for (int b = 0; b < CV; b++) { const int c = bj * CV + b; if (c < nV) pm[nV + r + (long long)c * N] = Mcv[c_][b]; }
+#pragma unroll
+                for (int d_ = 0; d_ < CC; d_++) { const int c = bj * CC + d_; if (c < nC) pm[nV + r + (long long)(nV + c) * N] = Mcc[c_][d_]; }
+            }
+        }
+    }
+    // hot start: false = the stored state is not one this kernel wrote (the caller bails: the null-space kernel takes the member)
+    __device__ __forceinline__ bool load_state(const double *img) {
+        const long long ldx = rsqp_ld(nV), sT = nV < nC ? nV : nC, voff = 2 * ldx * nV + sT * ldx;
+        const double *pv = img + voff;
+        const int *pi = reinterpret_cast<const int *>(img + voff + 5LL * nV + 4LL * nC);
+        const int *isc = pi + nV + 3 * nC;
+        if (isc[4] != 1 || isc[3] == QPS_NOTINITIALISED) return false;
+        nFR = isc[1]; nAC = isc[2]; status = isc[3];
+        if (tid < nV) { const int v = tid; x[v] = pv[v]; g[v] = pv[nV + v]; lb[v] = pv[2 * nV + v]; ub[v] = pv[3 * nV + v]; yB[v] = pv[4 * nV + 3 * nC + v]; Sb[v] = pi[v]; }
+        if (tid >= NT / 2 && tid - NT / 2 < nC) {
+            const int i = tid - NT / 2;
+            Ax[i] = pv[4 * nV + i]; lbA[i] = pv[4 * nV + nC + i]; ubA[i] = pv[4 * nV + 2 * nC + i]; yC[i] = pv[5 * nV + 3 * nC + i]; Sc[i] = pi[nV + i];
+        }
+        const double *pm = img + rsqp_image_bytes(nV, nC) / 8;
+        const int N = nV + nC;
+#pragma unroll
+        for (int a = 0; a < RV; a++) {
+            const int r = bi * RV + a;
+#pragma unroll
+            for (int b = 0; b < CV; b++) { const int c = bj * CV + b; Mvv[a][b] = (r < nV && c < nV) ? pm[r + (long long)c * N] : 0.0; }
+#pragma unroll
+            for (int c_ = 0; c_ < CC; c_++) { const int c = bj * CC + c_; Mvc[a][c_] = (r < nV && c < nC) ? pm[r + (long long)(nV + c) * N] : 0.0; }
+        }
+#pragma unroll
+        for (int c_ = 0; c_ < RC; c_++) {
+            const int r = bi * RC + c_;
+#pragma unroll
+            for (int b = 0; b < CV; b++) { const int c = bj * CV + b; Mcv[c_][b] = (r < nC && c < nV) ? pm[nV + r + (long long)c * N] : 0.0; }
+#pragma unroll
+            for (int d_ = 0; d_ < CC; d_++) { const int c = bj * CC + d_; Mcc[c_][d_] = (r < nC && c < nC) ? pm[nV + r + (long long)(nV + c) * N] : 0.0; }
+        }
+        KSYNC();
+        // (as the homotopy of the other engines begins) an inactive side that was infinite and now has a finite target only has
+        // to stay clear of the iterate; then dx on the fixed variables = the move of their bounds
+        if (tid < NVP) {
+            const int v = tid;
+            const int s = Sb[v];
+            if (v < nV) {
+                if (s != -1 && lb[v] <= -RSQP_INFTY && lbN[v] > -RSQP_INFTY) lb[v] = fmin(lbN[v], x[v] - RSQP_BOUND_RELAXATION);
+                if (s != 1 && ub[v] >= RSQP_INFTY && ubN[v] < RSQP_INFTY) ub[v] = fmax(ubN[v], x[v] + RSQP_BOUND_RELAXATION);
+            }
+            dx[v] = s == -1 ? lbN[v] - lb[v] : (s == 1 ? ubN[v] - ub[v] : 0.0);
+        }
+        if (tid >= NT / 2 && tid - NT / 2 < nC) {
+            const int i = tid - NT / 2, s = Sc[i];
+            if (s != -1 && lbA[i] <= -RSQP_INFTY && lbAN[i] > -RSQP_INFTY) lbA[i] = fmin(lbAN[i], Ax[i] - RSQP_BOUND_RELAXATION);
+            if (s != 1 && ubA[i] >= RSQP_INFTY && ubAN[i] < RSQP_INFTY) ubA[i] = fmax(ubAN[i], Ax[i] + RSQP_BOUND_RELAXATION);
+        }
+        KSYNC();
+        return true;
+    }
+
     // 0.5 x'Hx + gN'x (H x by one product, into tV)
     __device__ __forceinline__ double objective() {
         double xv[CV], ah[RV];
@@ -688,7 +816,7 @@ struct EngineK {
 };
 
 template <int RV, int RC, int CV, int CC, int GJ_>
-__global__ void __launch_bounds__(32 * GJ_, 1) small_qpk_kernel(QPPools P, int nq, int maxWSR) {
+__global__ void __launch_bounds__(32 * GJ_, 1) small_qpk_kernel(QPPools P, int nq, int mode, int maxWSR) {
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     const int q = (int)blockIdx.x;
     if (q >= nq) return;
@@ -696,7 +824,7 @@ __global__ void __launch_bounds__(32 * GJ_, 1) small_qpk_kernel(QPPools P, int n
     typedef EngineK<RV, RC, CV, CC, GJ_> ENG;
     ENG E;
     E.carve((lchar *)smem_generic, d.nV, d.nC);
-    E.nFR = E.nAC = 0; E.status = QPS_NOTINITIALISED; E.infeasible = 0; E.bail_reason = 0;
+    E.nFR = E.nAC = 0; E.status = QPS_NOTINITIALISED; E.infeasible = 0; E.bail_reason = 0; E.debug_bail = P.k_debug_bail;
 #ifdef RSQP_STAMPS
     E.tlast = clock64();
 #endif
@@ -709,11 +837,16 @@ __global__ void __launch_bounds__(32 * GJ_, 1) small_qpk_kernel(QPPools P, int n
         E.stage(P.Ajc + d.offAjc, P.Air + d.offAnz, P.Aval + d.offAnz, P.Hjc + d.offHjc, P.Hir + d.offHnz, P.Hval + d.offHnz,
                 P.g + d.offV, P.lb + d.offV, P.ub + d.offV, P.lbA + d.offC, P.ubA + d.offC);
         if (!(E.hscale > 0.0)) { rcode = RET_BAIL; E.bail_reason = 10; }
-        else if (E.bounds_inconsistent()) { E.infeasible = 1; rcode = RET_INFEASIBLE; }
-        else {
+        else if (mode != 0 && !E.load_state(P.state + d.offState)) { rcode = RET_BAIL; E.bail_reason = 12; }   // not this kernel's state
+        else if (E.bounds_inconsistent()) {
+            // (a hot start keeps the stored iterate: what the null-space kernels return in that case)
+            E.infeasible = 1; rcode = RET_INFEASIBLE;
+        } else if (mode != 0) {
+            rcode = E.homotopy(maxWSR, nWSR, true);
+        } else {
             E.status = QPS_PREPARINGAUXILIARYQP;
             rcode = E.setup_cold();
-            if (rcode == RET_OK) { E.status = QPS_AUXILIARYQPSOLVED; rcode = E.homotopy(maxWSR, nWSR); }
+            if (rcode == RET_OK) { E.status = QPS_AUXILIARYQPSOLVED; rcode = E.homotopy(maxWSR, nWSR, false); }
         }
         if (rcode != RET_BAIL) obj = E.objective();
     }
@@ -731,9 +864,12 @@ __global__ void __launch_bounds__(32 * GJ_, 1) small_qpk_kernel(QPPools P, int n
         P.nwsr[q] = nWSR;
         P.nflips[q] = 0;
         P.obj[q] = obj;
-        // this engine keeps no hot-start image: mark the persistent image of the null-space engine "not initialised"
-        // (its layout: persist_doubles doubles, then the integer image Sb | Sc | AC | posAC | iscal, status in iscal[3])
-        const long long xnp = EngineX<256, true>::persist_doubles(d.nV, d.nC);
-        reinterpret_cast<int *>(P.state + d.offState + xnp)[d.nV + 3 * d.nC + 3] = QPS_NOTINITIALISED;
+        if (!P.keep_state) {
+            // no hot-start state wanted: mark the persistent image "not initialised" (layout of the explicit-inverse engine:
+            // persist_doubles doubles, then the integer image Sb | Sc | AC | posAC | iscal, status in iscal[3])
+            const long long xnp = EngineX<256, true>::persist_doubles(d.nV, d.nC);
+            reinterpret_cast<int *>(P.state + d.offState + xnp)[d.nV + 3 * d.nC + 3] = QPS_NOTINITIALISED;
+        }
     }
+    if (P.keep_state) E.store_state(P.state + d.offState);
 }

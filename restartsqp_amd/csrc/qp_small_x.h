@@ -933,6 +933,43 @@ struct EngineX {
         return RET_OK;
     }
 
+    // A hot start on a state the explicit-KKT-inverse kernel left behind (qp_small_k.h wrote iterate, multipliers, homotopy
+    // data and working set in this engine's layout, its own factor M = K^-1 elsewhere) that that kernel could not finish:
+    // build Z, Y, Minv, Wz for the stored working set and leave everything else -- x, y, g, lb, ub, lbA, ubA, A x -- as it is,
+    // so that the homotopy continues exactly where a hot start of this engine would (the bases differ, the step directions
+    // do not depend on them). Mirrors the factor part of setup_aux.
+    static constexpr bool K_IMAGE = true;
+    __device__ __forceinline__ int rebuild_factors() {
+        for (int k = lane; k < ld * nV; k += L) { Z[k] = 0.0; Wz[k] = 0.0; }
+        for (int k = lane; k < sizeT * ldm; k += L) Minv[k] = 0.0;
+        PFOR(i, nC) { c2[i] = (double)Sc[i]; Sc[i] = 0; posAC[i] = -1; }
+        SYNC();
+        if (lane == 0) {
+            int n = 0;
+            for (int v = 0; v < nV; v++)
+                if (Sb[v] == 0) Z[(n++) * ld + v] = 1.0;
+            iscal[0] = n;
+        }
+        SYNC();
+        nFR = nZ = iscal[0];
+        nAC = 0;
+        for (int i = 0; i < nC; i++) {
+            const int s = (int)c2[i];
+            if (s != 0) {
+                double na2, wz2n;
+                constraint_products(i, na2, wz2n);
+                if (!is_LI(na2, wz2n)) return RET_SETUP_FAILED;
+                add_constraint(i, s, false, false);
+            }
+        }
+        const int nZf = nZ;
+        nZ = 0;
+        for (int k = 0; k < nZf; k++)
+            if (!wz_grow()) return RET_SETUP_FAILED;
+        status = QPS_AUXILIARYQPSOLVED;
+        return RET_OK;
+    }
+
     // ------------------------------------------------------------------ step direction
     __device__ __forceinline__ static double delta_of(double target, double cur) {
         return (fabs(target) >= RSQP_INFTY && fabs(cur) >= RSQP_INFTY) ? 0.0 : target - cur;

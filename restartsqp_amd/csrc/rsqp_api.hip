@@ -439,7 +439,7 @@ extern "C" int rsqp_create(int nV, int nC, int device, rsqp_solver **out) {
         HIPCHK(s->d_status.alloc(1)); HIPCHK(s->d_ret.alloc(1)); HIPCHK(s->d_nwsr.alloc(1)); HIPCHK(s->d_nflips.alloc(1));
         HIPCHK(s->d_kkt.alloc(6)); HIPCHK(s->d_Wb.alloc(nV)); HIPCHK(s->d_Wc.alloc(nC));
     }
-    HIPCHK(s->d_state.alloc(s->fits_small ? (size_t)rsqp_image_bytes(nV, nC) / 8 : 1));
+    HIPCHK(s->d_state.alloc(s->fits_small ? (size_t)rsqp_state_bytes(nV, nC) / 8 : 1));
     HIPCHK(s->d_x0.alloc(nV)); HIPCHK(s->d_y0.alloc(nV + nC)); HIPCHK(s->d_guess.alloc(nV));
     HIPCHK(s->d_dummy_i.alloc(std::max(nV, nC) + 2)); HIPCHK(s->d_dummy_d.alloc(4));
     HIPCHK(s->d_Ax.alloc(nC)); HIPCHK(s->d_ATy.alloc(nV)); HIPCHK(s->d_Hx.alloc(nV));
@@ -1141,7 +1141,7 @@ extern "C" int rsqp_batch_create(int nq, const int *nV, const int *nC, const int
                 if (Hir[offHnz + k] < 0 || Hir[offHnz + k] >= d.nV) return fail(RSQP_ERR_ARG, "rsqp_batch_create: H row index");
             offHjc += d.nV + 1; offHnz += hnnz;
         }
-        offState += rsqp_image_bytes(d.nV, d.nC) / 8;
+        offState += rsqp_state_bytes(d.nV, d.nC) / 8;
     }
     if (!rsqp_small_qp_fits(b->nVmax, b->nCmax))
         return fail(RSQP_ERR_TOO_LARGE, "rsqp_batch_create: a problem exceeds the LDS-resident engine");

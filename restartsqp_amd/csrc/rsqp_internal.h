@@ -47,6 +47,7 @@ struct QPPools {
     int reinit_from_y0;   // warm re-initialisation (mode 3) without guessed constraints: 1 = sides from sign(y0), 0 = from A x0
     int *done_flag;   // single-QP solves: host-mapped word that receives done_val once the results are out (the host spins
     int done_val;     //   on it instead of sleeping in hipStreamSynchronize); nullptr for batches
+    int k_debug_bail; // test hook (RSQP_K_DEBUG_BAIL=n): the explicit-KKT-inverse kernel bails out of a HOT start before its n-th change; -1 off
     int only_bailed;  // 1: the null-space kernel runs only the members the explicit-KKT-inverse kernel left with ret == RET_BAIL
     int keep_state;   // 1: write the hot-start part of the engine image back to HBM at the end of a solve (what the
                       //    SQProblem object keeps between calls); 0: cold-start-only batches skip that write --
@@ -65,6 +66,12 @@ __host__ __device__ inline long long rsqp_image_ints(int nV, int nC) { return nV
 __host__ __device__ inline long long rsqp_image_bytes(int nV, int nC) {
     long long b = rsqp_image_doubles(nV, nC) * 8 + rsqp_image_ints(nV, nC) * 4;
     return (b + 15) & ~15LL;
+}
+
+// persistent state of one problem in HBM: the image of the null-space engines, followed by the extension of the
+// explicit-KKT-inverse kernel (qp_small_k.h): M = K^-1 with one slot per variable and constraint, (nV + nC)^2 doubles
+__host__ __device__ inline long long rsqp_state_bytes(int nV, int nC) {
+    return rsqp_image_bytes(nV, nC) + 8LL * (long long)(nV + nC) * (nV + nC);
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: set it once per

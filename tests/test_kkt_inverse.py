@@ -92,3 +92,20 @@ def test_bailed_members_take_the_null_space_path(capi, oracle):
         if r["status"] == 20:
             assert np.abs(r["x"] - r0["x"]).max() <= 1e-9 * max(1.0, np.abs(r0["x"]).max()), q.name
     b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bail_after", [None, "0", "1", "3"])
+def test_hot_starts_and_hand_over(bail_after):
+    """Default batches (hot-start state kept): members of 20..60 variables run the explicit-KKT-inverse kernel cold AND hot;
+    non-convex members sit in the same batch with null-space states. With the test hook RSQP_K_DEBUG_BAIL=n every hot start
+    of the kernel bails out before its n-th change and the null-space kernel continues from the stored state (factors rebuilt
+    for the stored working set, homotopy data kept): same nWSR, working sets and point as the oracle's hot start either way
+    (tests/checks/k_hot_check.py; a child process: the hook is read once per process)."""
+    import subprocess
+    env = dict(os.environ)
+    if bail_after is not None:
+        env["RSQP_K_DEBUG_BAIL"] = bail_after
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "k_hot_check.py")], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0 and "K HOT OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
