@@ -256,6 +256,18 @@ int rsqp_batch_record_stride(const rsqp_batch *b);
 int rsqp_batch_pack_records_dev(rsqp_batch *b, double *rec_dev);
 /* the same records packed on the device and copied to a host buffer (gathers that run over host memory) */
 int rsqp_batch_pack_records_host(rsqp_batch *b, double *rec_host);
+/* Sharding of a batch of independent QPs over the ranks of a multi-GPU job, for C++ hosts that drive one
+ * process per GPU themselves: every rank calls these with the same arguments, builds an rsqp_batch from ITS members on
+ * its device, solves, packs the fixed-stride records (rsqp_batch_pack_records_dev) and all-gathers them with its own RCCL
+ * communicator (ncclAllGather of count * stride doubles; ranks with one member less pad). Host-only, no device needed.
+ *   rsqp_shard_range:     contiguous block [*lo, *hi) of rank `rank` of `world`; sizes differ by at most one (512 QPs on 8
+ *                         GPUs: 64 each).
+ *   rsqp_balanced_shard:  heterogeneous sizes -- members sorted by nV * max(nC, 1), largest first, and dealt snake-wise
+ *                         (0..W-1, W-1..0, ..), so that every rank gets its share of the expensive members; idx receives the
+ *                         member indices of rank `rank` (largest first), *count their number (<= ceil(nq / world)).
+ * Both are the partitions restartsqp_amd/parallel.py uses (shard_range, balanced_shards). */
+int rsqp_shard_range(int nq, int rank, int world, int *lo, int *hi);
+int rsqp_balanced_shard(int nq, const int *nV, const int *nC, int rank, int world, int *idx, int *count);
 
 /* ------------------------------------------------------------------------------------ */
 /* batched sparse products, device resident -- the SpMV the roofline target names        */

@@ -92,6 +92,8 @@ SYMBOLS = {
     "rsqp_batch_record_stride": (C.c_int, [C.c_void_p]),
     "rsqp_batch_pack_records_dev": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rsqp_batch_pack_records_host": (C.c_int, [C.c_void_p, dp]),
+    "rsqp_shard_range": (C.c_int, [C.c_int, C.c_int, C.c_int, ip, ip]),
+    "rsqp_balanced_shard": (C.c_int, [C.c_int, ip, ip, C.c_int, C.c_int, ip, ip]),
     "rsqp_time_value_refresh": (C.c_int, [C.c_void_p, C.c_int, fp, fp]),
     "rsqp_time_large_kernel": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp]),
     "rsqp_spmv_plan_create": (C.c_int, [C.c_int, C.c_int, ip, ip, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

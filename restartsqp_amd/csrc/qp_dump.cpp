@@ -173,3 +173,32 @@ extern "C" int rsqp_read_qore_dump(const char *path, double *lb, double *ub, dou
     }
     return t.at_end() ? RSQP_OK : RSQP_ERR_ARG;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// sharding of a batch over the ranks of a multi-GPU job (host-only; the same partitions as restartsqp_amd/parallel.py)
+// ---------------------------------------------------------------------------------------------------------------
+#include <algorithm>
+#include <numeric>
+#include <vector>
+extern "C" int rsqp_shard_range(int nq, int rank, int world, int *lo, int *hi) {
+    if (nq < 0 || world <= 0 || rank < 0 || rank >= world || !lo || !hi) return RSQP_ERR_ARG;
+    const int base = nq / world, rem = nq % world;
+    *lo = rank * base + std::min(rank, rem);
+    *hi = *lo + base + (rank < rem ? 1 : 0);
+    return RSQP_OK;
+}
+extern "C" int rsqp_balanced_shard(int nq, const int *nV, const int *nC, int rank, int world, int *idx, int *count) {
+    if (nq < 0 || world <= 0 || rank < 0 || rank >= world || !nV || !nC || !idx || !count) return RSQP_ERR_ARG;
+    std::vector<int> order(nq);
+    std::iota(order.begin(), order.end(), 0);
+    auto cost = [&](int k) { return (long long)nV[k] * std::max(nC[k], 1); };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost(a) > cost(b); });   // largest first, ties by index
+    int n = 0;
+    for (int j = 0; j < nq; j++) {
+        const int rnd = j / world, pos = j % world;
+        if ((rnd % 2 == 0 ? pos : world - 1 - pos) == rank) idx[n++] = order[j];
+    }
+    *count = n;
+    return RSQP_OK;
+}

@@ -114,3 +114,24 @@ def test_mirrors_declare_every_pure_virtual_of_the_reference_interface():
     from restartsqp_amd.interface import HipQPInterface
     for p in want:
         assert callable(getattr(HipQPInterface, p["name"], None)), p["name"]
+
+
+def test_c_abi_sharding_matches_the_python_partitions():
+    """rsqp_shard_range / rsqp_balanced_shard (host-only entries of the C ABI, for C++ hosts that run one process per GPU)
+    give the partitions of restartsqp_amd/parallel.py: 512 hs0xx QPs on 1 / 2 / 3 / 8 ranks."""
+    import ctypes as C
+    from restartsqp_amd import capi, parallel, problems
+    L = capi.lib()
+    ps = problems.hs_batch(512)
+    nV = np.array([p.nV for p in ps], np.int32); nC = np.array([p.nC for p in ps], np.int32)
+    ip = C.POINTER(C.c_int)
+    for world in (1, 2, 3, 8):
+        shards = parallel.balanced_shards(ps, world)
+        for rank in range(world):
+            lo, hi = C.c_int(), C.c_int()
+            assert L.rsqp_shard_range(512, rank, world, C.byref(lo), C.byref(hi)) == 0
+            assert (lo.value, hi.value) == parallel.shard_range(512, rank, world)
+            idx = np.zeros(512, np.int32); cnt = C.c_int()
+            assert L.rsqp_balanced_shard(512, nV.ctypes.data_as(ip), nC.ctypes.data_as(ip), rank, world, idx.ctypes.data_as(ip), C.byref(cnt)) == 0
+            assert idx[:cnt.value].tolist() == shards[rank].tolist()
+    assert L.rsqp_shard_range(10, 3, 3, C.byref(lo), C.byref(hi)) != 0
