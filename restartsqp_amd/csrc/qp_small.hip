@@ -1291,18 +1291,19 @@ hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCma
     // (only where the null-space kernel would give a problem four waves as well: batches of SMALL problems are throughput-bound
     //  and better served by 16 / 32 lanes per problem, several problems per wave)
     if (!noK && forcedE < 0 && eng == 1 && (nVmax > 32 || nCmax > 32) && (mode == 0 || mode == 1) && !p.done_flag) {
-        static std::atomic<unsigned long long> setk_{0}, setk2_{0};
-        if (nVmax <= EK::MAXV && nCmax <= EK::MAXC) {
-            rsqp_allow_full_lds(reinterpret_cast<const void *>(&small_qpk_kernel<3, 1, 9, 4, 8>), setk_, (int)kMaxLds);
-            const size_t kl = (size_t)EK::lds_bytes(nVmax, nCmax);
-            hipLaunchKernelGGL((small_qpk_kernel<3, 1, 9, 4, 8>), dim3(nq), dim3(256), kl, stream, p, nq, mode, maxWSR);
-            p.only_bailed = 1;
-        } else if (nVmax <= EK2::MAXV && nCmax <= EK2::MAXC) {
-            rsqp_allow_full_lds(reinterpret_cast<const void *>(&small_qpk_kernel<2, 2, 8, 8, 8>), setk2_, (int)kMaxLds);
-            const size_t kl = (size_t)EK2::lds_bytes(nVmax, nCmax);
-            hipLaunchKernelGGL((small_qpk_kernel<2, 2, 8, 8, 8>), dim3(nq), dim3(256), kl, stream, p, nq, mode, maxWSR);
-            p.only_bailed = 1;
-        }
+        const bool stateful = mode != 0 || p.keep_state;
+#define KK_LAUNCH(RV_, RC_, CV_, CC_, ST_)                                                                                       \
+        do {                                                                                                                     \
+            static std::atomic<unsigned long long> set_{0};                                                                      \
+            rsqp_allow_full_lds(reinterpret_cast<const void *>(&small_qpk_kernel<RV_, RC_, CV_, CC_, 8, ST_>), set_, (int)kMaxLds); \
+            const size_t kl = (size_t)EngineK<RV_, RC_, CV_, CC_, 8>::lds_bytes(nVmax, nCmax);                                     \
+            hipLaunchKernelGGL((small_qpk_kernel<RV_, RC_, CV_, CC_, 8, ST_>), dim3(nq), dim3(256), kl, stream, p, nq, mode, maxWSR); \
+            p.only_bailed = 1;                                                                                                   \
+        } while (0)
+        (void)stateful;     // (a build without the state I/O exists as a template parameter; it measured the same once the homotopy had ONE call site)
+        if (nVmax <= EK::MAXV && nCmax <= EK::MAXC) KK_LAUNCH(3, 1, 9, 4, true);
+        else if (nVmax <= EK2::MAXV && nCmax <= EK2::MAXC) KK_LAUNCH(2, 2, 8, 8, true);
+#undef KK_LAUNCH
     }
     static const int konly = env_int("RSQP_SMALL_KKT_ONLY", 0);     // diagnostics: no second pass (bailed members keep ret = 9, nflips = reason)
     if (konly && p.only_bailed) return hipGetLastError();

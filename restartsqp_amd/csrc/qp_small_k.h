@@ -234,13 +234,11 @@ struct EngineK {
             for (int b = 0; b < CV; b++) {
                 const int c = bj * CV + b;
                 Hb[a][b] = (r < nV && c < nV) ? Hd[r + c * nV] : 0.0;
-                Mvv[a][b] = 0.0;
             }
 #pragma unroll
             for (int c_ = 0; c_ < CC; c_++) {
                 const int i = bj * CC + c_;                             // A' block: variable rows of bi, constraint columns of bj
                 Tb[a][c_] = (i < nC && r < nV) ? Ad[i + r * nC] : 0.0;
-                Mvc[a][c_] = 0.0;
             }
         }
 #pragma unroll
@@ -250,10 +248,7 @@ struct EngineK {
             for (int b = 0; b < CV; b++) {
                 const int v = bj * CV + b;                              // A block: constraint rows of bi, variable columns of bj
                 Ab[c_][b] = (i < nC && v < nV) ? Ad[i + v * nC] : 0.0;
-                Mcv[c_][b] = 0.0;
             }
-#pragma unroll
-            for (int d_ = 0; d_ < CC; d_++) Mcc[c_][d_] = 0.0;
         }
         double hm = 0.0;
         for (int v = tid & 63; v < nV; v += 64) hm = fmax(hm, fabs(Hd[v + v * nV]));
@@ -734,9 +729,9 @@ struct EngineK {
             const int r = bi * RV + a;
             if (r < nV) {
 #pragma unroll
-                for (int b = 0; b < CV; b++) { const int c = bj * CV + b; if (c < nV) pm[r + (long long)c * N] = Mvv[a][b]; }
+                for (int b = 0; b < CV; b++) { const int c = bj * CV + b; if (c < nV) pm[r + c * N] = Mvv[a][b]; }
 #pragma unroll
-                for (int c_ = 0; c_ < CC; c_++) { const int c = bj * CC + c_; if (c < nC) pm[r + (long long)(nV + c) * N] = Mvc[a][c_]; }
+                for (int c_ = 0; c_ < CC; c_++) { const int c = bj * CC + c_; if (c < nC) pm[r + (nV + c) * N] = Mvc[a][c_]; }
             }
         }
 #pragma unroll
@@ -744,10 +739,33 @@ struct EngineK {
             const int r = bi * RC + c_;
             if (r < nC) {
 #pragma unroll
-                for (int b = 0; b < CV; b++) { const int c = bj * CV + b; if (c < nV) pm[nV + r + (long long)c * N] = Mcv[c_][b]; }
+                for (int b = 0; b < CV; b++) { const int c = bj * CV + b; if (c < nV) pm[nV + r + c * N] = Mcv[c_][b]; }
 #pragma unroll
-                for (int d_ = 0; d_ < CC; d_++) { const int c = bj * CC + d_; if (c < nC) pm[nV + r + (long long)(nV + c) * N] = Mcc[c_][d_]; }
+                for (int d_ = 0; d_ < CC; d_++) { const int c = bj * CC + d_; if (c < nC) pm[nV + r + (nV + c) * N] = Mcc[c_][d_]; }
             }
+        }
+    }
+    // M: zero (cold start) or the stored factor (hot start; pm = the extension behind the null-space image). ONE definition
+    // site for the register blocks: with a second one (zeros in stage(), loads in load_state()) the register allocator kept
+    // 204 instead of ~100 AGPRs busy through the whole kernel
+    __device__ __forceinline__ void init_M(const double *pm) {
+        const int N = nV + nC;
+        const bool ld_ = pm != nullptr;
+#pragma unroll
+        for (int a = 0; a < RV; a++) {
+            const int r = bi * RV + a;
+#pragma unroll
+            for (int b = 0; b < CV; b++) { const int c = bj * CV + b; Mvv[a][b] = (ld_ && r < nV && c < nV) ? pm[r + c * N] : 0.0; }
+#pragma unroll
+            for (int c_ = 0; c_ < CC; c_++) { const int c = bj * CC + c_; Mvc[a][c_] = (ld_ && r < nV && c < nC) ? pm[r + (nV + c) * N] : 0.0; }
+        }
+#pragma unroll
+        for (int c_ = 0; c_ < RC; c_++) {
+            const int r = bi * RC + c_;
+#pragma unroll
+            for (int b = 0; b < CV; b++) { const int c = bj * CV + b; Mcv[c_][b] = (ld_ && r < nC && c < nV) ? pm[nV + r + c * N] : 0.0; }
+#pragma unroll
+            for (int d_ = 0; d_ < CC; d_++) { const int c = bj * CC + d_; Mcc[c_][d_] = (ld_ && r < nC && c < nC) ? pm[nV + r + (nV + c) * N] : 0.0; }
         }
     }
     // hot start: false = the stored state is not one this kernel wrote (the caller bails: the null-space kernel takes the member)
@@ -762,24 +780,6 @@ struct EngineK {
         if (tid >= NT / 2 && tid - NT / 2 < nC) {
             const int i = tid - NT / 2;
             Ax[i] = pv[4 * nV + i]; lbA[i] = pv[4 * nV + nC + i]; ubA[i] = pv[4 * nV + 2 * nC + i]; yC[i] = pv[5 * nV + 3 * nC + i]; Sc[i] = pi[nV + i];
-        }
-        const double *pm = img + rsqp_image_bytes(nV, nC) / 8;
-        const int N = nV + nC;
-#pragma unroll
-        for (int a = 0; a < RV; a++) {
-            const int r = bi * RV + a;
-#pragma unroll
-            for (int b = 0; b < CV; b++) { const int c = bj * CV + b; Mvv[a][b] = (r < nV && c < nV) ? pm[r + (long long)c * N] : 0.0; }
-#pragma unroll
-            for (int c_ = 0; c_ < CC; c_++) { const int c = bj * CC + c_; Mvc[a][c_] = (r < nV && c < nC) ? pm[r + (long long)(nV + c) * N] : 0.0; }
-        }
-#pragma unroll
-        for (int c_ = 0; c_ < RC; c_++) {
-            const int r = bi * RC + c_;
-#pragma unroll
-            for (int b = 0; b < CV; b++) { const int c = bj * CV + b; Mcv[c_][b] = (r < nC && c < nV) ? pm[nV + r + (long long)c * N] : 0.0; }
-#pragma unroll
-            for (int d_ = 0; d_ < CC; d_++) { const int c = bj * CC + d_; Mcc[c_][d_] = (r < nC && c < nC) ? pm[nV + r + (long long)(nV + c) * N] : 0.0; }
         }
         KSYNC();
         // (as the homotopy of the other engines begins) an inactive side that was infinite and now has a finite target only has
@@ -815,8 +815,11 @@ struct EngineK {
     }
 };
 
-template <int RV, int RC, int CV, int CC, int GJ_>
-__global__ void __launch_bounds__(32 * GJ_, 1) small_qpk_kernel(QPPools P, int nq, int mode, int maxWSR) {
+// STATEFUL = false: cold starts of batches that keep no hot-start state -- a build without the state I/O (not instantiated:
+// it measures the same); true: cold starts that may leave a state behind, and hot starts on it
+template <int RV, int RC, int CV, int CC, int GJ_, bool STATEFUL>
+__global__ void __launch_bounds__(32 * GJ_, 1) small_qpk_kernel(QPPools P, int nq, int mode_in, int maxWSR) {
+    const int mode = STATEFUL ? mode_in : 0;
     extern __shared__ __attribute__((aligned(16))) char smem_generic[];
     const int q = (int)blockIdx.x;
     if (q >= nq) return;
@@ -836,17 +839,21 @@ __global__ void __launch_bounds__(32 * GJ_, 1) small_qpk_kernel(QPPools P, int n
     } else {
         E.stage(P.Ajc + d.offAjc, P.Air + d.offAnz, P.Aval + d.offAnz, P.Hjc + d.offHjc, P.Hir + d.offHnz, P.Hval + d.offHnz,
                 P.g + d.offV, P.lb + d.offV, P.ub + d.offV, P.lbA + d.offC, P.ubA + d.offC);
+        E.init_M((STATEFUL && mode != 0) ? P.state + d.offState + rsqp_image_bytes(d.nV, d.nC) / 8 : nullptr);
         if (!(E.hscale > 0.0)) { rcode = RET_BAIL; E.bail_reason = 10; }
-        else if (mode != 0 && !E.load_state(P.state + d.offState)) { rcode = RET_BAIL; E.bail_reason = 12; }   // not this kernel's state
+        else if (STATEFUL && mode != 0 && !E.load_state(P.state + d.offState)) { rcode = RET_BAIL; E.bail_reason = 12; }   // not this kernel's state
         else if (E.bounds_inconsistent()) {
             // (a hot start keeps the stored iterate: what the null-space kernels return in that case)
             E.infeasible = 1; rcode = RET_INFEASIBLE;
-        } else if (mode != 0) {
-            rcode = E.homotopy(maxWSR, nWSR, true);
         } else {
-            E.status = QPS_PREPARINGAUXILIARYQP;
-            rcode = E.setup_cold();
-            if (rcode == RET_OK) { E.status = QPS_AUXILIARYQPSOLVED; rcode = E.homotopy(maxWSR, nWSR, false); }
+            // (ONE call site of the homotopy: inlined twice -- hot and cold -- the kernel doubled in code and in AGPR traffic)
+            const bool hot = STATEFUL && mode != 0;
+            if (!hot) {
+                E.status = QPS_PREPARINGAUXILIARYQP;
+                rcode = E.setup_cold();
+                if (rcode == RET_OK) E.status = QPS_AUXILIARYQPSOLVED;
+            }
+            if (rcode == RET_OK) rcode = E.homotopy(maxWSR, nWSR, hot);
         }
         if (rcode != RET_BAIL) obj = E.objective();
     }
@@ -864,12 +871,12 @@ __global__ void __launch_bounds__(32 * GJ_, 1) small_qpk_kernel(QPPools P, int n
         P.nwsr[q] = nWSR;
         P.nflips[q] = 0;
         P.obj[q] = obj;
-        if (!P.keep_state) {
+        if (!STATEFUL || !P.keep_state) {
             // no hot-start state wanted: mark the persistent image "not initialised" (layout of the explicit-inverse engine:
             // persist_doubles doubles, then the integer image Sb | Sc | AC | posAC | iscal, status in iscal[3])
             const long long xnp = EngineX<256, true>::persist_doubles(d.nV, d.nC);
             reinterpret_cast<int *>(P.state + d.offState + xnp)[d.nV + 3 * d.nC + 3] = QPS_NOTINITIALISED;
         }
     }
-    if (P.keep_state) E.store_state(P.state + d.offState);
+    if constexpr (STATEFUL) { if (P.keep_state) E.store_state(P.state + d.offState); }
 }
