@@ -338,6 +338,65 @@ __global__ void __launch_bounds__(NT) k_ger_v(double *__restrict__ M, long long 
     }
 }
 
+// The rank-1 update M += coef t v' and the transposed product out = M'x of the UPDATED matrix in one pass (the
+// reflection of Z by an incoming constraint followed by the step direction's Z'(H xY + g~): one read + one write of Z
+// instead of read + write + read). Structure, element expression and summation order are those of k_ger_v and
+// gemv_t_body's 16-byte path (leading dimension even, M / x / t 16-byte aligned: checked by the launcher).
+__global__ void __launch_bounds__(NT) k_ger_gemv_t(double *__restrict__ M, long long ld, int nrows, int ncols,
+                                                   const double *__restrict__ ut, const double *__restrict__ uv,
+                                                   const double *__restrict__ scal, int ci, double cs,
+                                                   const double *__restrict__ x, const double *__restrict__ addv,
+                                                   double *__restrict__ out) {
+    __shared__ double sh[4];
+    const int c0 = blockIdx.x * GT_COLS;
+    const double coef = cs * scal[ci];
+    double s[GT_COLS], vc[GT_COLS];
+#pragma unroll
+    for (int k = 0; k < GT_COLS; k++) { s[k] = 0.0; vc[k] = c0 + k < ncols ? uv[c0 + k] : 0.0; }
+    const int n2 = nrows >> 1;
+#pragma unroll 2
+    for (int r = threadIdx.x; r < n2; r += NT) {
+        const double2 xv = reinterpret_cast<const double2 *>(x)[r];
+        const double2 tv = reinterpret_cast<const double2 *>(ut)[r];
+        const double a0 = coef * tv.x, a1 = coef * tv.y;
+        double2 m[GT_COLS];
+#pragma unroll
+        for (int k = 0; k < GT_COLS; k++)
+            if (c0 + k < ncols) m[k] = reinterpret_cast<const double2 *>(M + (c0 + k) * ld)[r];
+#pragma unroll
+        for (int k = 0; k < GT_COLS; k++)
+            if (c0 + k < ncols) {
+                m[k].x += a0 * vc[k]; m[k].y += a1 * vc[k];
+                reinterpret_cast<double2 *>(M + (c0 + k) * ld)[r] = m[k];
+                s[k] += m[k].x * xv.x + m[k].y * xv.y;
+            }
+    }
+    if ((nrows & 1) && threadIdx.x == 0) {
+        const int r = nrows - 1;
+        const double a0 = coef * ut[r];
+#pragma unroll
+        for (int k = 0; k < GT_COLS; k++)
+            if (c0 + k < ncols) {
+                double *p = M + (c0 + k) * ld + r;
+                const double m = *p + a0 * vc[k];
+                *p = m;
+                s[k] += m * x[r];
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < GT_COLS; k++) {
+        const double v = block_sum(s[k], sh);
+        if (threadIdx.x == 0 && c0 + k < ncols) out[c0 + k] = addv ? v + addv[c0 + k] : v;
+    }
+}
+// what a deferred reflection needs later: the Householder vector and its beta out of the way of the next products
+__global__ void k_keep_reflector(const double *__restrict__ v, int n, double *__restrict__ keep, double *__restrict__ scal, int from,
+                                 int to) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keep[i] = v[i];
+    if (i == 0) scal[to] = scal[from];
+}
+
 // scal[slot] = sum_i a[i]*b[i]
 __global__ void __launch_bounds__(NT) k_dot(const double *__restrict__ a, const double *__restrict__ b, int n,
                                             double *__restrict__ scal, int slot) {
@@ -463,6 +522,78 @@ __global__ void __launch_bounds__(NT) k_wz_shrink_v(double *__restrict__ Wz, lon
             *reinterpret_cast<double2 *>(p) = m;
         } else {
             p[0] += -beta * sa0 * vb - beta * va0 * sbv + beta * beta * theta * va0 * vb - ca0 * cb / w22;
+        }
+    }
+}
+// k_wz_shrink_v and the product out = alpha * Wz' w of the SHRUNK matrix in one pass (the elimination of the null-space
+// column an incoming constraint takes, followed by the step direction's Wz (Z'g~)): one read + one write of Wz instead
+// of read + write + read. A workgroup owns 128 rows (a lane two consecutive ones) and a chunk of columns, its four waves
+// stride the chunk as in k_gemv_n_part; partial sums [chunk][row] go through k_gemv_n_reduce (gridDim.y > 1).
+__global__ void __launch_bounds__(NT) k_wz_shrink_gemv(double *__restrict__ Wz, long long ld, int nZ, const double *__restrict__ s,
+                                                       const double *__restrict__ v, const double *__restrict__ col,
+                                                       const double *__restrict__ scal, int sb, int st, int chunk,
+                                                       const double *__restrict__ w, double alpha, double *__restrict__ part,
+                                                       double *__restrict__ out) {
+    __shared__ double sh[4][128];
+    const int lane = threadIdx.x & 63, cl = threadIdx.x >> 6;
+    const int l = nZ - 1;
+    const int a = (blockIdx.x * 64 + lane) * 2;
+    const int c0 = blockIdx.y * chunk, c1 = min(c0 + chunk, l);
+    const double beta = scal[sb], theta = scal[st], w22 = col[l];
+    double acc0 = 0.0, acc1 = 0.0;
+    if (a < l) {
+        const bool two = a + 1 < l;
+        const double sa0 = s[a], va0 = v[a], ca0 = col[a];
+        const double sa1 = two ? s[a + 1] : 0.0, va1 = two ? v[a + 1] : 0.0, ca1 = two ? col[a + 1] : 0.0;
+        if (two) {
+            double2 t[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+            auto upd = [&](double2 &m, double vb, double sbv, double cb) {
+                m.x += -beta * sa0 * vb - beta * va0 * sbv + beta * beta * theta * va0 * vb - ca0 * cb / w22;
+                m.y += -beta * sa1 * vb - beta * va1 * sbv + beta * beta * theta * va1 * vb - ca1 * cb / w22;
+            };
+            int b = c0 + cl;
+            for (; b + 12 < c1; b += 16) {
+                double2 m[4];
+                double vb[4], sbv[4], cb[4], wb[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) m[k] = *reinterpret_cast<double2 *>(Wz + (long long)(b + 4 * k) * ld + a);
+#pragma unroll
+                for (int k = 0; k < 4; k++) { vb[k] = v[b + 4 * k]; sbv[k] = s[b + 4 * k]; cb[k] = col[b + 4 * k]; wb[k] = w[b + 4 * k]; }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    upd(m[k], vb[k], sbv[k], cb[k]);
+                    *reinterpret_cast<double2 *>(Wz + (long long)(b + 4 * k) * ld + a) = m[k];
+                    t[k].x += m[k].x * wb[k]; t[k].y += m[k].y * wb[k];
+                }
+            }
+            for (; b < c1; b += 4) {
+                double *p0 = Wz + (long long)b * ld + a;
+                double2 m0 = *reinterpret_cast<double2 *>(p0);
+                upd(m0, v[b], s[b], col[b]);
+                *reinterpret_cast<double2 *>(p0) = m0;
+                t[0].x += m0.x * w[b]; t[0].y += m0.y * w[b];
+            }
+            acc0 = (t[0].x + t[1].x) + (t[2].x + t[3].x); acc1 = (t[0].y + t[1].y) + (t[2].y + t[3].y);
+        } else {
+            for (int b = c0 + cl; b < c1; b += 4) {
+                double *p0 = Wz + (long long)b * ld + a;
+                const double m = *p0 + (-beta * sa0 * v[b] - beta * va0 * s[b] + beta * beta * theta * va0 * v[b] - ca0 * col[b] / w22);
+                *p0 = m;
+                acc0 += m * w[b];
+            }
+        }
+    }
+    sh[cl][2 * lane] = acc0; sh[cl][2 * lane + 1] = acc1;
+    __syncthreads();
+    if (cl == 0) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int rr = a + k, li = 2 * lane + k;
+            if (rr < l) {
+                const double t = (sh[0][li] + sh[1][li]) + (sh[2][li] + sh[3][li]);
+                if (gridDim.y == 1) out[rr] = alpha * t;
+                else part[(long long)blockIdx.y * l + rr] = t;
+            }
         }
     }
 }
@@ -1169,6 +1300,7 @@ struct RsqpLargeEngine::Impl {
     double *Z = nullptr, *Y = nullptr, *Minv = nullptr, *Wz = nullptr;
     // vectors (nV)
     double *x, *g, *lb, *ub, *gN, *lbN, *ubN, *dx, *w1, *w2, *w3, *w4, *w5, *w6, *wz1, *wz2, *wz3;
+    double *pz_t = nullptr, *pz_v = nullptr, *pw_s = nullptr, *pw_col = nullptr;   // operands of a deferred reflection (z_reflect_and_shrink)
     // vectors (nC)
     double *Ax, *lbA, *ubA, *lbAN, *ubAN, *dAx, *c1, *c2, *c3, *a1, *a2, *a3, *a4;
     double *y, *dy, *part, *scal, *pt, *res_t;
@@ -1239,7 +1371,7 @@ struct RsqpLargeEngine::Impl {
 
     ~Impl() {
         double *dv[] = {Z, Y, Minv, Wz, x, g, lb, ub, gN, lbN, ubN, dx, w1, w2, w3, w4, w5, w6, wz1, wz2, wz3, Ax, lbA, ubA,
-                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy};
+                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col};
         for (double *p : dv) if (p) (void)hipFree(p);
         if (big) (void)hipFree(big);
         rsqp_dense_work_free(&dw);
@@ -1268,8 +1400,8 @@ struct RsqpLargeEngine::Impl {
     }
     void preport() {
         if (!profile) return;
-        const char *nm[8] = {"gemv_n", "gemv_t", "ger", "wz_shrink", "wz_grow", "spmv", "", ""};
-        for (int k = 0; k < 6; k++)
+        const char *nm[8] = {"gemv_n", "gemv_t", "ger", "wz_shrink", "wz_grow", "spmv", "ger_gemv_t", "shrink_gemv"};
+        for (int k = 0; k < 8; k++)
             if (prof[k].calls) fprintf(stderr, "[rsqp profile] %-9s calls %8lld  time %9.3f ms  bytes %10.3f GB  => %7.1f GB/s  (avg %.1f us)\n", nm[k], prof[k].calls, prof[k].ms, prof[k].bytes / 1e9, prof[k].bytes / (prof[k].ms * 1e-3) / 1e9, 1e3 * prof[k].ms / prof[k].calls);
     }
     void chk(const char *what) {
@@ -1423,24 +1555,88 @@ struct RsqpLargeEngine::Impl {
     // ---- working-set operations -------------------------------------------------------
     // reflection of Z that puts the direction Z w (w in wz1, length nZ) into the last column;
     // Wz follows; the last column is then taken out of the null space. scal[0..3] = house.
-    void z_reflect_and_shrink() {
+    // DEFERRED form (defer = true, the incoming constraint of a homotopy step): only the last column of Z is reflected now
+    // (it becomes the new Y column); the update of the other columns and the shrinking of Wz wait for the step direction,
+    // whose first products with Z and Wz apply them on the way (k_ger_gemv_t, k_wz_shrink_gemv) -- flush_pending() applies
+    // them on their own if anything else wants Z or Wz first.
+    struct { bool on = false; int ncols = 0; } pendZ;
+    struct { bool on = false; int nZold = 0; } pendW;
+    bool fuse_passes = getenv("RSQP_LARGE_NO_FUSE") == nullptr;
+    static constexpr int S_KEEP_BETA = 40, S_KEEP_THETA = 41;
+    bool can_defer() const {
+        return fuse_passes && wz_enabled && (ld & 1) == 0 && nZ > 1 && pz_t &&
+               (((reinterpret_cast<unsigned long long>(Z) | reinterpret_cast<unsigned long long>(Wz)) & 15) == 0);
+    }
+    void flush_pending() {
+        if (pendZ.on) { pendZ.on = false; ger(Z, ld, nV, pendZ.ncols, pz_t, pz_v, S_KEEP_BETA, -1.0); }
+        if (pendW.on) { pendW.on = false; wz_shrink_now(pendW.nZold, pw_s, pz_v, pw_col, S_KEEP_BETA, S_KEEP_THETA); }
+    }
+    void wz_shrink_now(int nZo, const double *s_, const double *v_, const double *col_, int sb, int stheta) {
+        pbegin();
+        if (nZo > 1) {
+            if ((ld & 1) == 0)
+                hipLaunchKernelGGL(k_wz_shrink_v, dim3((nZo - 1 + 2 * NT - 1) / (2 * NT), (nZo - 1 + WZ_COLS - 1) / WZ_COLS), dim3(NT), 0, st, Wz,
+                                   ld, nZo, s_, v_, col_, scal, sb, stheta);
+            else
+                hipLaunchKernelGGL(k_wz_shrink, dim3((nZo - 1 + NT - 1) / NT, nZo - 1), dim3(NT), 0, st, Wz, ld, nZo, s_, v_, col_,
+                                   scal, sb, stheta);
+        }
+        pend(3, 16.0 * (double)nZo * nZo);
+    }
+    void z_reflect_and_shrink(bool defer = false) {
+        flush_pending();
         if (!house_done) hipLaunchKernelGGL(k_house, dim3(1), dim3(NT), 0, st, wz1, nZ, wz2, scal, 0);   // v -> wz2 (else: done by the products' kernel)
         house_done = false;
-        gemv_n(Z, ld, nV, nZ, wz2, 1.0, 0.0, nullptr, w5);                               // t = Z v
-        ger(Z, ld, nV, nZ, w5, wz2, 1, -1.0);                                            // Z -= beta t v'
+        const bool dz = defer && can_defer();
+        gemv_n(Z, ld, nV, nZ, wz2, 1.0, 0.0, nullptr, dz ? pz_t : w5);                   // t = Z v
+        if (dz) {
+            hipLaunchKernelGGL(k_keep_reflector, g1(nZ), dim3(NT), 0, st, wz2, nZ, pz_v, scal, 1, S_KEEP_BETA);
+            ger(Zc(nZ - 1), ld, nV, 1, pz_t, pz_v + (nZ - 1), S_KEEP_BETA, -1.0);       // the column that moves to Y: now
+            pendZ.on = true; pendZ.ncols = nZ - 1;
+        } else ger(Z, ld, nV, nZ, w5, wz2, 1, -1.0);                                     // Z -= beta t v'
         if (!wz_enabled) return;
-        gemv_n(Wz, ld, nZ, nZ, wz2, 1.0, 0.0, nullptr, wz3);                             // s = Wz v
-        hipLaunchKernelGGL(k_wz_lastcol, g1(nZ), dim3(NT), 0, st, Wz, ld, nZ, wz3, wz2, scal, 1, 4, w6);   // theta = v's -> scal[4]
-        pbegin();
-        if (nZ > 1) {
-            if ((ld & 1) == 0)
-                hipLaunchKernelGGL(k_wz_shrink_v, dim3((nZ - 1 + 2 * NT - 1) / (2 * NT), (nZ - 1 + WZ_COLS - 1) / WZ_COLS), dim3(NT), 0, st, Wz,
-                                   ld, nZ, wz3, wz2, w6, scal, 1, 4);
-            else
-                hipLaunchKernelGGL(k_wz_shrink, dim3((nZ - 1 + NT - 1) / NT, nZ - 1), dim3(NT), 0, st, Wz, ld, nZ, wz3, wz2, w6,
-                                   scal, 1, 4);
+        double *s_ = dz ? pw_s : wz3, *col_ = dz ? pw_col : w6;
+        gemv_n(Wz, ld, nZ, nZ, wz2, 1.0, 0.0, nullptr, s_);                              // s = Wz v
+        hipLaunchKernelGGL(k_wz_lastcol, g1(nZ), dim3(NT), 0, st, Wz, ld, nZ, s_, wz2, scal, 1, dz ? S_KEEP_THETA : 4, col_);   // theta = v's
+        if (dz) { pendW.on = true; pendW.nZold = nZ; }
+        else wz_shrink_now(nZ, wz3, wz2, w6, 1, 4);
+    }
+    // the step direction's  out = Z'x + addv  and  out = alpha Wz w  with the deferred updates applied on the way
+    void gemv_t_Z_pending(const double *xv, const double *addv, double *out) {
+        const bool ok = pendZ.on && pendZ.ncols == nZ && nZ > 0 &&
+                        (((reinterpret_cast<unsigned long long>(xv) | reinterpret_cast<unsigned long long>(pz_t)) & 15) == 0);
+        if (!ok) {
+            flush_pending();
+            GtTask t = gt_task(Z, ld, nV, nZ, xv, out);
+            t.addv = addv;
+            gemv_t_task(t);
+            return;
         }
-        pend(3, 16.0 * (double)nZ * nZ);
+        pendZ.on = false;
+        pbegin();
+        hipLaunchKernelGGL(k_ger_gemv_t, dim3((nZ + GT_COLS - 1) / GT_COLS), dim3(NT), 0, st, Z, ld, nV, nZ, pz_t, pz_v, scal, S_KEEP_BETA, -1.0, xv,
+                           addv, out);
+        pend(6, 16.0 * nV * (double)nZ);
+        chk("ger_gemv_t");
+    }
+    void gemv_n_Wz_pending(const double *wv, double alpha, double *out) {
+        if (!(pendW.on && pendW.nZold - 1 == nZ && nZ > 0)) {
+            if (pendW.on) { pendW.on = false; wz_shrink_now(pendW.nZold, pw_s, pz_v, pw_col, S_KEEP_BETA, S_KEEP_THETA); }
+            gemv_n(Wz, ld, nZ, nZ, wv, alpha, 0.0, nullptr, out);
+            return;
+        }
+        pendW.on = false;
+        pbegin();
+        const int rb = (nZ + 127) / 128;
+        int nch = std::max(1, std::min(std::min((gemv_wgs + rb - 1) / rb, 32), (nZ + 15) / 16));
+        while ((long long)nch * nZ > part_cap) nch = (nch + 1) / 2;
+        const int chunk = (nZ + nch - 1) / nch;
+        nch = (nZ + chunk - 1) / chunk;
+        hipLaunchKernelGGL(k_wz_shrink_gemv, dim3(rb, nch), dim3(NT), 0, st, Wz, ld, nZ + 1, pw_s, pz_v, pw_col, scal, S_KEEP_BETA, S_KEEP_THETA, chunk,
+                           wv, alpha, part, out);
+        if (nch > 1) hipLaunchKernelGGL(k_gemv_n_reduce, dim3((nZ + 63) / 64), dim3(NT), 0, st, part, nZ, nch, alpha, 0.0, (const double *)nullptr, out);
+        pend(7, 16.0 * nZ * (double)nZ);
+        chk("wz_shrink_gemv");
     }
 
     // append the Y column `ycol` (already stored at Y[:, nAC]) for constraint r whose products
@@ -1452,14 +1648,15 @@ struct RsqpLargeEngine::Impl {
                            AC, posAC, Sc, r, side);
     }
 
-    int add_constraint(int r, int side, bool skipZ) {
+    int add_constraint(int r, int side, bool skipZ, bool defer = false) {
         // a (free part) in w1; wZ in wz1; wY in a1 were computed by the caller (li_test_constraint)
         if (!skipZ) {
-            z_reflect_and_shrink();
+            z_reflect_and_shrink(defer);
             // new Y column = last column of the reflected Z; eta = a'y_new = image sign * alpha
             copy(Zc(nZ - 1), Yc(nAC), nV);
         } else {
             // exchange / flip: the row is orthogonal to all null-space columns but the last
+            flush_pending();
             house_done = false;
             copy(Zc(nZ - 1), Yc(nAC), nV);
             dot(w1, Zc(nZ - 1), nV, 5);
@@ -1664,6 +1861,7 @@ struct RsqpLargeEngine::Impl {
     }
 
     int change_active_set(int kind, int idx, int side) {
+        flush_pending();
         if (kind == 1) return remove_with_guard(false, idx, nullptr, nullptr);
         if (kind == 2) return remove_with_guard(true, idx, nullptr, nullptr);
         double ynew = 0.0;
@@ -1688,7 +1886,7 @@ struct RsqpLargeEngine::Impl {
             if (kind == 3) constraint_products(idx); else bound_products(idx);
         }
         if (kind == 3) {
-            add_constraint(idx, side, !full);
+            add_constraint(idx, side, !full, true);      // (the last operation of the change: the step direction follows)
             hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, y, nV + idx, ynew);
         } else {
             add_bound(idx, side, !full);
@@ -1714,8 +1912,8 @@ struct RsqpLargeEngine::Impl {
         gemv_n(Y, ld, nV, nAC, a2, 1.0, 0.0, nullptr, w3);                 // xY
         // null space: wZ = -Wz Z'(tmpg + H xY) ; dx_FR = xY + Z wZ
         H_times(w3, w2, w1);                                               // w2 = H xY + tmpg
-        gemv_t(Z, ld, nV, nZ, w2, wz1);
-        gemv_n(Wz, ld, nZ, nZ, wz1, -1.0, 0.0, nullptr, wz2);
+        gemv_t_Z_pending(w2, nullptr, wz1);                               // (+ the deferred reflection of Z)
+        gemv_n_Wz_pending(wz1, -1.0, wz2);                                 // (+ the deferred shrinking of Wz)
         gemv_n(Z, ld, nV, nZ, wz2, 1.0, 1.0, w3, w4, Sb, dx);              // xY + Z wZ, merged into dx on the free variables
         // multipliers: dyAC = Minv' Y'(H dx + dg); A dx (for the ratio tests) rides along with H dx
         AH_times(dx, dAx, Hdx);
@@ -1797,6 +1995,7 @@ struct RsqpLargeEngine::Impl {
         if ((profile || getenv("RSQP_LARGE_WAITSTAT")) && iter > 0)
             fprintf(stderr, "[rsqp profile] homotopy: %d changes, mean nFR %.1f nAC %.1f nZ %.1f (nV %d nC %d); host waited %.3f s in %lld round trips\n", iter,
                     sum_nFR / iter, sum_nAC / iter, sum_nZ / iter, nV, nC, wait_seconds, wait_calls);
+        flush_pending();
         *nWSR = iter;
         return rcode;
     }
@@ -2007,6 +2206,7 @@ hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
     DA(Z, (size_t)P.ld * nV); DA(Wz, (size_t)P.ld * nV); DA(Y, (size_t)P.ld * std::max(P.nAmax, 1)); DA(Minv, (size_t)P.ldm * P.ldm);
     DA(x, nV); DA(g, nV); DA(lb, nV); DA(ub, nV); DA(gN, nV); DA(lbN, nV); DA(ubN, nV); DA(dx, nV);
     DA(w1, nV); DA(w2, nV); DA(w3, nV); DA(w4, nV); DA(w5, nV); DA(w6, nV); DA(wz1, nV); DA(wz2, nV); DA(wz3, nV);
+    DA(pz_t, nV); DA(pz_v, nV); DA(pw_s, nV); DA(pw_col, nV);
     DA(Ax, nC); DA(lbA, nC); DA(ubA, nC); DA(lbAN, nC); DA(ubAN, nC); DA(dAx, nC); DA(c1, nC); DA(c2, nC); DA(c3, nC);
     DA(a1, P.nAmax + 2); DA(a2, P.nAmax + 2); DA(a3, P.nAmax + 2); DA(a4, P.nAmax + 2);
     DA(y, nV + nC); DA(dy, nV + nC);
@@ -2142,7 +2342,7 @@ int RsqpLargeEngine::status_word() const {
 int RsqpLargeEngine::nflips() const { return p_->nflips; }
 hipError_t RsqpLargeEngine::last_error() const { return p_->err_; }
 const char *RsqpLargeEngine::profile_name(int k) {
-    static const char *nm[PROFILE_CLASSES] = {"gemv_n", "gemv_t", "ger", "wz_shrink", "wz_grow", "spmv", "", ""};
+    static const char *nm[PROFILE_CLASSES] = {"gemv_n", "gemv_t", "ger", "wz_shrink", "wz_grow", "spmv", "ger_gemv_t", "shrink_gemv"};
     return k >= 0 && k < PROFILE_CLASSES ? nm[k] : "";
 }
 void RsqpLargeEngine::profile_enable(bool on) { p_->profile = on; }
