@@ -144,10 +144,15 @@ static hipError_t dgemm_ws(bool transA, bool transB, int m, int n, int k, double
         TM = m <= 64 || (long long)((m + 63) / 64) * ((n + 127) / 128) < 512 ? 64 : 128;
         TN = n <= 64 || (long long)((m + TM - 1) / TM) * ((n + 127) / 128) < 512 ? 64 : 128;
     }
+    // a block of reflectors against a wide matrix (W = V'C: 256 x n with an inner dimension of thousands): the large tile,
+    // and K split so that the chip has work -- 64 x 64 tiles ran these at 29-35 TFLOP/s (RSQP_GEMM_SKINNY=0: as before)
+    static const int skinny = getenv("RSQP_GEMM_SKINNY") ? atoi(getenv("RSQP_GEMM_SKINNY")) : 1;
+    const bool skinny_case = skinny && ws && m <= 256 && m >= 128 && n >= 1024 && k >= 2048 && ws_cap >= 2LL * m * n;
+    if (skinny_case) { TM = 128; TN = skinny == 2 ? 64 : 128; }
     const int bx = (m + TM - 1) / TM, by = (n + TN - 1) / TN;
     // a long inner dimension over few output tiles: split K so that the chip has work
     int splits = 1;
-    if (ws && (long long)bx * by < 200 && k >= 1024) {
+    if (ws && ((long long)bx * by < 200 || skinny_case) && k >= 1024) {
         splits = (int)std::min<long long>(std::min<long long>((511 + (long long)bx * by) / ((long long)bx * by), k / 256), ws_cap / ((long long)m * n));
         if (splits < 2) splits = 1;
     }
