@@ -346,6 +346,255 @@ __global__ void k_panel_writeback(double *__restrict__ B, long long ldb, int m, 
     B[i + (long long)(k0 + c) * ldb] = i == k0 + c ? rdiag[k0 + c] : V[(i - k0) + (long long)c * ldv];
 }
 
+// =====================================================================================
+// Panel factorisation without a launch per column: Cholesky-QR twice, then the Householder representation of
+// the orthonormal factor (Ballard, Demmel, Grigori, Jacquelin, Nguyen, Solomonik 2014: the LU factorisation of
+// Q - [D; 0] with the signs D_k = -sgn(pivot) chosen on the way IS the set of reflectors the column-by-column
+// algorithm produces: V = L, T = -U D L_1^-T, R = D R_chol -- tools/proto_qr/cholqr_hr.py checks it against LAPACK).
+// All 64 x 64 work of a panel runs in two single-workgroup kernels; everything that touches the tall panel is a GEMM:
+//   G1 = P'P, [R1, X1 = R1^-1] (k_cholqr_pass1), Q1 = P X1, G2 = Q1'Q1, k_cholqr_pass2 (R2, X2; Q_top = Q1_top X2;
+//   L U = Q_top - D; T; M = (U R2)^-1; R = D R2 R1), V_bottom = Q1_bottom M.
+// A panel whose Gram matrix loses more than ten digits in the Cholesky pivots (flag[2]) is not decided here: the
+// caller repeats the factorisation with the column kernel (w->panel_cholqr = false).
+//
+// The 64 x 64 factorisations are ONE routine: elimination without pivoting on the augmented matrix [A | I] -> [U | L^-1],
+// 256 threads, a thread owning a 4 x 8 block of the 64 x 128 array in registers; per step the pivot row and the pivot
+// column go through a double-buffered LDS line (one barrier per step, 64 steps ~ 10 us). Cholesky: R = diag(u)^-1/2 U,
+// R^-1 = (L^-1)' diag(u)^-1/2; inverse of a triangular matrix: eliminate its transpose, [W' | I] -> [Lambda | F],
+// W^-1 = F' Lambda^-1.
+constexpr int EB = 64, ES = EB + 2;     // block order; LDS row stride (even: rows 16-byte aligned, 4 consecutive rows on distinct banks)
+typedef double EMat[EB][ES];
+struct ElimLds { double row[2][2][2 * EB]; double col[2][2][EB]; double dsign[EB]; double g0[EB]; int bad; };
+enum { EL_PLAIN = 0, EL_CHOL = 1, EL_SIGNLU = 2 };
+__device__ __forceinline__ double fast_rcp(double p) {      // v_rcp_f64 + two Newton steps (the IEEE division is ~3x the dependent chain)
+    double r = __builtin_amdgcn_rcp(p), e = fma(-p, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-p, r, 1.0);
+    return fma(r, e, r);
+}
+
+template <class F> __device__ __forceinline__ void el_init(double (&a)[4][8], F left) {
+    const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int row = 4 * tr + r, col = 8 * tc + c;
+            a[r][c] = col < EB ? left(row, col < EB ? col : 0) : (col - EB == row ? 1.0 : 0.0);
+        }
+}
+__device__ __forceinline__ void el_dump(const double (&a)[4][8], EMat &Lh, EMat &Rh) {
+    const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int row = 4 * tr + r, col = 8 * tc + c;
+            if (col < EB) Lh[row][col] = a[r][c]; else Rh[row][col - EB] = a[r][c];
+        }
+}
+// Two pivots per barrier: the owners publish rows k, k + 1 and columns k, k + 1 as the steps < k left them; every thread
+// derives the second pivot row / multipliers itself (a few redundant operations instead of a second round trip through LDS).
+template <int MODE>
+__device__ __forceinline__ void elim64(double (&a)[4][8], ElimLds &E, double tol_rel) {
+    const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
+    auto publish = [&](int k, int par, int rs, int cs) {      // par, rs, cs: compile-time at the call sites (k even)
+        const bool orow = tr == (k >> 2), ocol = tc == (k >> 3);
+        if (MODE == EL_SIGNLU && orow && ocol) {
+            const double d = a[rs][cs] >= 0.0 ? -1.0 : 1.0;      // |pivot| = 1 + |q_kk| >= 1
+            a[rs][cs] -= d;
+            E.dsign[k] = d;
+        }
+        if (orow) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) { E.row[par][0][8 * tc + c] = a[rs][c]; E.row[par][1][8 * tc + c] = a[rs + 1][c]; }
+        }
+        if (ocol) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) { E.col[par][0][4 * tr + r] = a[r][cs]; E.col[par][1][4 * tr + r] = a[r][cs + 1]; }
+        }
+    };
+    publish(0, 0, 0, 0);
+    for (int kb = 0; kb < EB / 8; kb++) {
+#pragma unroll
+        for (int kk = 0; kk < 8; kk += 2) {
+            const int k = 8 * kb + kk, par = (kk >> 1) & 1;
+            __syncthreads();
+            const double p0 = E.row[par][0][k], x01 = E.row[par][0][k + 1];
+            double rp0, rp1, d1 = 0.0;
+            if (MODE == EL_CHOL) {
+                const bool ok = p0 > tol_rel * E.g0[k];
+                if (!ok && tid == 0) E.bad = 1;
+                rp0 = ok ? fast_rcp(p0) : 0.0;
+            } else rp0 = fast_rcp(p0);
+            const double m = E.col[par][0][k + 1] * rp0;                  // row k + 1 loses its entry in column k
+            double p1 = fma(-m, x01, E.row[par][1][k + 1]);
+            if (MODE == EL_SIGNLU) { d1 = p1 >= 0.0 ? -1.0 : 1.0; p1 -= d1; }
+            if (MODE == EL_CHOL) {
+                const bool ok = p1 > tol_rel * E.g0[k + 1];
+                if (!ok && tid == 0) E.bad = 1;
+                rp1 = ok ? fast_rcp(p1) : 0.0;
+            } else rp1 = fast_rcp(p1);
+            double c0[4], c1[4], u0[8], u1[8];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 4 * tr + r;
+                c0[r] = row > k ? E.col[par][0][row] * rp0 : 0.0;
+                c1[r] = row > k + 1 ? fma(-c0[r], x01, E.col[par][1][row]) * rp1 : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int col = 8 * tc + c;
+                u0[c] = E.row[par][0][col];
+                if (MODE == EL_SIGNLU && col < k) u0[c] = 0.0;            // (left of the pivot a row holds its own multipliers)
+                u1[c] = fma(-m, u0[c], E.row[par][1][col]);
+                if (MODE == EL_SIGNLU && col <= k) u1[c] = 0.0;          // (elsewhere: zeros and rounding dust that only reaches columns k, k + 1, rewritten below)
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int c = 0; c < 8; c++) a[r][c] = fma(-c1[r], u1[c], fma(-c0[r], u0[c], a[r][c]));
+            if (tc == kb) {      // columns k, k + 1: the multipliers (LU) or exact zeros instead of rounding dust; the second sign
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = 4 * tr + r;
+                    if (row > k) a[r][kk] = MODE == EL_SIGNLU ? c0[r] : 0.0;
+                    if (row > k + 1) a[r][kk + 1] = MODE == EL_SIGNLU ? c1[r] : 0.0;
+                }
+                if (MODE == EL_SIGNLU && tr == ((k + 1) >> 2)) { a[(kk + 1) & 3][kk + 1] = p1; E.dsign[k + 1] = d1; }
+            }
+            if (k + 2 < EB) publish(k + 2, ((kk + 2) >> 1) & 1, (kk + 2) & 3, (kk + 2) & 7);
+        }
+    }
+    __syncthreads();
+}
+// acc (the thread's 4 x 4 block of a 64 x 64 product) = sum_k A(i, k) B(k, j), operands through accessors
+template <class FA, class FB> __device__ __forceinline__ void mm64(double (&acc)[4][4], FA A, FB B) {
+    const int bi = threadIdx.x >> 4, bj = threadIdx.x & 15;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[r][c] = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < EB; k++) {
+        double ar[4], bc[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) ar[r] = A(4 * bi + r, k);
+#pragma unroll
+        for (int c = 0; c < 4; c++) bc[c] = B(k, 4 * bj + c);
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[r][c] = fma(ar[r], bc[c], acc[r][c]);
+    }
+}
+template <class F> __device__ __forceinline__ void mm64_store(const double (&acc)[4][4], F put) {
+    const int bi = threadIdx.x >> 4, bj = threadIdx.x & 15;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) put(4 * bi + r, 4 * bj + c, acc[r][c]);
+}
+constexpr size_t CHOLQR_LDS1 = 2 * sizeof(EMat) + sizeof(ElimLds);
+constexpr size_t CHOLQR_LDS2 = 4 * sizeof(EMat) + sizeof(ElimLds);
+
+// G (64 x 64, symmetric, column-major ld 64) = R'R:  R1 and X1 = R1^-1 (upper, ld 64)
+__global__ void __launch_bounds__(256) k_cholqr_pass1(const double *__restrict__ G, double *__restrict__ X1, double *__restrict__ R1,
+                                                      int *__restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) double cq_lds[];
+    EMat &U = *reinterpret_cast<EMat *>(cq_lds), &Li = *reinterpret_cast<EMat *>(cq_lds + EB * ES);
+    ElimLds &E = *reinterpret_cast<ElimLds *>(cq_lds + 2 * EB * ES);
+    const int tid = threadIdx.x;
+    if (tid < EB) E.g0[tid] = G[tid + EB * tid];
+    if (tid == 0) E.bad = 0;
+    double a[4][8];
+    el_init(a, [&](int r, int c) { return G[r + EB * c]; });
+    __syncthreads();
+    elim64<EL_CHOL>(a, E, 1e-10);
+    el_dump(a, U, Li);
+    __syncthreads();
+    for (int e = tid; e < EB * EB; e += 256) {
+        const int i = e & (EB - 1), j = e >> 6;
+        R1[e] = i <= j ? U[i][j] / sqrt(U[i][i]) : 0.0;
+        X1[e] = i <= j ? Li[j][i] / sqrt(U[j][j]) : 0.0;
+    }
+    if (tid == 0 && E.bad) atomicAdd(flag + 2, 1);
+}
+
+// second pass + Householder reconstruction of one panel (see the header comment): G2 = Q1'Q1, Q1t = the first 64 rows of Q1
+__global__ void __launch_bounds__(256)
+k_cholqr_pass2(const double *__restrict__ G2, const double *__restrict__ Q1t, long long ldq, const double *__restrict__ R1,
+               const double *__restrict__ norm2, double eps_li, double *__restrict__ Mx, double *__restrict__ Vtop, long long ldv,
+               double *__restrict__ Bblk, long long ldb, double *__restrict__ rdiag, double *__restrict__ tau, double *__restrict__ Tout,
+               int *__restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) double cq_lds[];
+    EMat &b0 = *reinterpret_cast<EMat *>(cq_lds), &b1 = *reinterpret_cast<EMat *>(cq_lds + EB * ES),
+         &b2 = *reinterpret_cast<EMat *>(cq_lds + 2 * EB * ES), &b3 = *reinterpret_cast<EMat *>(cq_lds + 3 * EB * ES);
+    ElimLds &E = *reinterpret_cast<ElimLds *>(cq_lds + 4 * EB * ES);
+    const int tid = threadIdx.x;
+    double a[4][8], acc[4][4];
+    // 1. G2 = R2'R2 (G2 = I + O(eps cond^2): any pivot below 1/100 means the first pass was useless)
+    if (tid < EB) E.g0[tid] = G2[tid + EB * tid];
+    if (tid == 0) E.bad = 0;
+    el_init(a, [&](int r, int c) { return G2[r + EB * c]; });
+    __syncthreads();
+    elim64<EL_CHOL>(a, E, 1e-2);
+    el_dump(a, b1, b2);
+    __syncthreads();
+    for (int e = tid; e < EB * EB; e += 256) {
+        const int i = e & (EB - 1), j = e >> 6;
+        b0[i][j] = i <= j ? b1[i][j] / sqrt(b1[i][i]) : 0.0;        // R2
+        b3[i][j] = i <= j ? b2[j][i] / sqrt(b1[j][j]) : 0.0;        // X2 = R2^-1
+    }
+    __syncthreads();
+    // 2. Q_top = Q1_top X2
+    for (int e = tid; e < EB * EB; e += 256) { const int i = e & (EB - 1), j = e >> 6; b1[i][j] = Q1t[i + j * ldq]; }
+    __syncthreads();
+    mm64(acc, [&](int i, int k) { return b1[i][k]; }, [&](int k, int j) { return b3[k][j]; });
+    mm64_store(acc, [&](int i, int j, double v) { b2[i][j] = v; });
+    __syncthreads();
+    // 3. L U = Q_top - D, and L^-1 beside it
+    el_init(a, [&](int r, int c) { return b2[r][c]; });
+    __syncthreads();
+    elim64<EL_SIGNLU>(a, E, 0.0);
+    el_dump(a, b1, b2);           // b1: U (upper) and the multipliers (strictly lower); b2: L^-1
+    __syncthreads();
+    for (int e = tid; e < EB * EB; e += 256) {
+        const int i = e & (EB - 1), j = e >> 6;
+        Vtop[i + j * ldv] = i > j ? b1[i][j] : (i == j ? 1.0 : 0.0);
+    }
+    // T = -U D L^-T
+    mm64(acc, [&](int i, int k) { return i <= k ? b1[i][k] * E.dsign[k] : 0.0; }, [&](int k, int j) { return b2[j][k]; });
+    mm64_store(acc, [&](int i, int j, double v) {
+        const double t = i <= j ? -v : 0.0;
+        Tout[i + j * NB] = t;
+        if (i == j) tau[i] = t;
+    });
+    // M = (U R2)^-1: W = U R2 into b3, eliminate W'
+    mm64(acc, [&](int i, int k) { return i <= k ? b1[i][k] : 0.0; }, [&](int k, int j) { return b0[k][j]; });
+    mm64_store(acc, [&](int i, int j, double v) { b3[i][j] = i <= j ? v : 0.0; });
+    __syncthreads();             // (also: every thread is done with b1, b2)
+    el_init(a, [&](int r, int c) { return b3[c][r]; });
+    __syncthreads();
+    elim64<EL_PLAIN>(a, E, 0.0);
+    el_dump(a, b2, b3);           // b2: Lambda (diagonal), b3: F with F W' = Lambda
+    // R = D R2 R1 (R1 into b1 meanwhile)
+    for (int e = tid; e < EB * EB; e += 256) { const int i = e & (EB - 1), j = e >> 6; b1[i][j] = R1[e]; }
+    __syncthreads();
+    for (int e = tid; e < EB * EB; e += 256) { const int i = e & (EB - 1), j = e >> 6; Mx[e] = i <= j ? b3[j][i] / b2[j][j] : 0.0; }
+    mm64(acc, [&](int i, int k) { return b0[i][k]; }, [&](int k, int j) { return b1[k][j]; });
+    mm64_store(acc, [&](int i, int j, double v) {
+        const double r = E.dsign[i] * v;
+        if (i < j) Bblk[i + j * ldb] = r;
+        else if (i == j) {
+            Bblk[i + j * ldb] = r;
+            rdiag[i] = r;
+            if (!(fabs(r) > eps_li * sqrt(norm2[i]))) atomicAdd(flag, 1);
+        }
+    });
+    if (tid == 0 && E.bad) atomicAdd(flag + 2, 1);
+}
+
 // explicit reflectors of a stored panel (for rsqp_dorgqr)
 __global__ void k_build_V(const double *__restrict__ B, long long ldb, int m, int k0, int jb, double *__restrict__ V, long long ldv) {
     const int c = blockIdx.y;
@@ -472,6 +721,7 @@ hipError_t rsqp_dense_work_alloc(RsqpDenseWork *w, long long mmax) {
     if ((e = hipMalloc((void **)&w->dblk, sizeof(double) * 66 * NB * NB)) != hipSuccess) return e;   // S, Uinv + split-K slabs
     w->ws_cap = 4LL * OB * mmax;
     if ((e = hipMalloc((void **)&w->ws, sizeof(double) * w->ws_cap)) != hipSuccess) return e;
+    if ((e = hipMalloc((void **)&w->hr, sizeof(double) * 3 * NB * NB)) != hipSuccess) return e;
     if ((e = hipMalloc((void **)&w->flag, sizeof(int) * 4)) != hipSuccess) return e;
     if ((e = hipMemset(w->flag, 0, sizeof(int) * 4)) != hipSuccess) return e;
     w->mmax = mmax;
@@ -479,7 +729,7 @@ hipError_t rsqp_dense_work_alloc(RsqpDenseWork *w, long long mmax) {
 }
 
 void rsqp_dense_work_free(RsqpDenseWork *w) {
-    double *d[] = {w->V, w->T, w->W, w->W2, w->T2, w->Tout, w->tau, w->norm2, w->dblk, w->ws};
+    double *d[] = {w->V, w->T, w->W, w->W2, w->T2, w->Tout, w->tau, w->norm2, w->dblk, w->ws, w->hr};
     for (double *p : d) if (p) (void)hipFree(p);
     if (w->flag) (void)hipFree(w->flag);
     *w = RsqpDenseWork();
@@ -510,12 +760,31 @@ hipError_t rsqp_dgeqrf(int m, int n, double *B, long long ldb, double eps_li, Rs
             //  at a few per cent of anything (64 x 192 results from an inner dimension of 10 000): 149 ms instead of 138 ms for
             //  10 000 x 7 670, the column launches turn bandwidth-bound at ~15 us)
             static const bool wide = getenv("RSQP_QR_WIDE_PANEL") != nullptr;
-            for (int j = k0; j < k0 + jb; j++)
-                hipLaunchKernelGGL(k_qr_col, dim3((wide ? K0 + ob : k0 + jb) - j), dim3(QC), 0, st, B, ldb, m, j, k0, Vp, ldv, w->tau, rdiag,
-                                   w->norm2, eps_li, w->flag);
-            // S = V'V (jb x jb, long inner dimension: split K), T factor, reflectors back into B
-            DCHK(dgemm_ws(true, false, jb, jb, mt, 1.0, Vp, ldv, Vp, ldv, 0.0, S, jb, ws, 64LL * NB * NB, st));
-            hipLaunchKernelGGL(k_qr_T_merge, dim3(1), dim3(256), 0, st, jb, S, w->tau + k0, w->T + (long long)p * NB * NB);
+            static const bool no_cholqr = getenv("RSQP_QR_NO_CHOLQR") != nullptr;
+            double *Tp = w->T + (long long)p * NB * NB;
+            if (w->panel_cholqr && !no_cholqr && !wide && jb == NB && mt >= 2 * NB) {
+                // the panel in a dozen launches (see k_cholqr_pass2): Q1 lives in w->W (free until the panel is applied)
+                double *P = B + k0 + (long long)k0 * ldb, *Q1 = w->W, *X1 = w->hr, *R1 = w->hr + NB * NB, *Mx = w->hr + 2 * NB * NB;
+                const long long ldq = w->mmax;
+                static std::atomic<unsigned long long> set1{0}, set2{0};
+                rsqp_allow_full_lds(reinterpret_cast<const void *>(&k_cholqr_pass1), set1, (int)CHOLQR_LDS1);
+                rsqp_allow_full_lds(reinterpret_cast<const void *>(&k_cholqr_pass2), set2, (int)CHOLQR_LDS2);
+                DCHK(dgemm_ws(true, false, NB, NB, mt, 1.0, P, ldb, P, ldb, 0.0, S, NB, ws, 64LL * NB * NB, st));           // G1 = P'P
+                hipLaunchKernelGGL(k_cholqr_pass1, dim3(1), dim3(256), CHOLQR_LDS1, st, S, X1, R1, w->flag);
+                DCHK(rsqp_dgemm(false, false, mt, NB, NB, 1.0, P, ldb, X1, NB, 0.0, Q1, ldq, st));                            // Q1 = P R1^-1
+                DCHK(dgemm_ws(true, false, NB, NB, mt, 1.0, Q1, ldq, Q1, ldq, 0.0, S, NB, ws, 64LL * NB * NB, st));         // G2 = Q1'Q1
+                hipLaunchKernelGGL(k_cholqr_pass2, dim3(1), dim3(256), CHOLQR_LDS2, st, S, Q1, ldq, R1, w->norm2 + k0, eps_li, Mx, Vp, ldv, P,
+                                   ldb, rdiag + k0, w->tau + k0, Tp, w->flag);
+                DCHK(rsqp_dgemm(false, false, mt - NB, NB, NB, 1.0, Q1 + NB, ldq, Mx, NB, 0.0, Vp + NB, ldv, st));          // V below the block
+            } else {
+                for (int j = k0; j < k0 + jb; j++)
+                    hipLaunchKernelGGL(k_qr_col, dim3((wide ? K0 + ob : k0 + jb) - j), dim3(QC), 0, st, B, ldb, m, j, k0, Vp, ldv, w->tau, rdiag,
+                                       w->norm2, eps_li, w->flag);
+                // S = V'V (jb x jb, long inner dimension: split K), T factor
+                DCHK(dgemm_ws(true, false, jb, jb, mt, 1.0, Vp, ldv, Vp, ldv, 0.0, S, jb, ws, 64LL * NB * NB, st));
+                hipLaunchKernelGGL(k_qr_T_merge, dim3(1), dim3(256), 0, st, jb, S, w->tau + k0, Tp);
+            }
+            // reflectors back into B
             hipLaunchKernelGGL(k_panel_writeback, dim3((mt + 255) / 256, jb), dim3(256), 0, st, B, ldb, m, k0, jb, Vp, ldv, rdiag);
             if (nin > 0 && !wide) {      // the rest of the outer block
                 double *Ct = B + k0 + (long long)(k0 + jb) * ldb;
@@ -675,6 +944,16 @@ extern "C" int rsqp_dense_qr(int m, int n, double *B, double *Q, double *Rinv, d
     Stopwatch sw;
     sw.start();
     hipError_t e = rsqp_dgeqrf(m, n, dB.p, m, eps_li, &w, nullptr);
+    {   // an ill-conditioned panel (flag[2]): once more with the column kernel, as the engine does
+        int f2 = 0;
+        if (e == hipSuccess) e = hipMemcpy(&f2, w.flag + 2, sizeof(int), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && f2 != 0) {
+            w.panel_cholqr = false;
+            e = hipMemset(w.flag, 0, sizeof(int) * 4);
+            if (e == hipSuccess) e = hipMemcpy(dB.p, B, sizeof(double) * (size_t)m * n, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = rsqp_dgeqrf(m, n, dB.p, m, eps_li, &w, nullptr);
+        }
+    }
     if (e == hipSuccess) e = rsqp_dtrtri_upper(n, dB.p, m, dX.p, n, &w, nullptr);
     if (e == hipSuccess) e = rsqp_dorgqr(m, n, dB.p, m, dQ.p, m, &w, nullptr);
     const float t = sw.stop();

@@ -2025,12 +2025,19 @@ struct RsqpLargeEngine::Impl {
         double *B = Y;            // m x n, ld lb_ <= ld (Y is rewritten at the end)
         double *X = big;          // n x n  R^-1
         double *Q = big + (size_t)ld * ld;   // m x m
-        LCHK(hipMemsetAsync(B, 0, sizeof(double) * (size_t)lb_ * n, st));
-        LCHK(hipMemsetAsync(dw.flag, 0, sizeof(int) * 4, st));
-        hipLaunchKernelGGL(k_build_B, dim3(n), dim3(NT), 0, st, M.Arp, M.Aci, M.Arv, d_cand, d_fpos, B, lb_);
-        LCHK(rsqp_dgeqrf(m, n, B, lb_, RSQP_EPS_LI, &dw, st));
-        LCHK(hipMemcpyAsync(h_pinned_i, dw.flag, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
-        LCHK(hipStreamSynchronize(st));
+        for (int attempt = 0; attempt < 2; attempt++) {
+            LCHK(hipMemsetAsync(B, 0, sizeof(double) * (size_t)lb_ * n, st));
+            LCHK(hipMemsetAsync(dw.flag, 0, sizeof(int) * 4, st));
+            hipLaunchKernelGGL(k_build_B, dim3(n), dim3(NT), 0, st, M.Arp, M.Aci, M.Arv, d_cand, d_fpos, B, lb_);
+            LCHK(rsqp_dgeqrf(m, n, B, lb_, RSQP_EPS_LI, &dw, st));
+            LCHK(hipMemcpyAsync(h_pinned_i, dw.flag, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+            LCHK(hipStreamSynchronize(st));
+            // a panel too ill-conditioned for the Cholesky-QR panel factorisation: once more with the column kernel, which decides
+            // the independence of every column on its own
+            if (h_pinned_i[2] == 0 || !dw.panel_cholqr) break;
+            dw.panel_cholqr = false;
+        }
+        dw.panel_cholqr = true;
         if (h_pinned_i[0] != 0) {   // dependent rows in the guess: start over, one constraint at a time
             if (nZ > 0) {
                 LCHK(hipMemsetAsync(Z, 0, sizeof(double) * (size_t)ld * nZ, st));

@@ -25,7 +25,10 @@ struct RsqpDenseWork {
     double *dblk = nullptr;  // NB x NB     diagonal block scratch
     double *ws = nullptr;    // split-K slabs of the tall-skinny products (V'C with a long inner dimension)
     long long ws_cap = 0;
-    int *flag = nullptr;     // [0] = number of dependent columns found, [1] = not positive definite
+    int *flag = nullptr;     // [0] = number of dependent columns found, [1] = not positive definite, [2] = a panel was too ill-conditioned
+                             //       for the Cholesky-QR panel factorisation: repeat rsqp_dgeqrf with panel_cholqr = false
+    double *hr = nullptr;    // 3 NB x NB   R1^-1, R1, (U R2)^-1 of the panel being factorised
+    bool panel_cholqr = true;   // panels by Cholesky-QR + Householder reconstruction (a few launches) instead of one launch per column
     long long mmax = 0;
 };
 hipError_t rsqp_dense_work_alloc(RsqpDenseWork *w, long long mmax);

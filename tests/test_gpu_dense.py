@@ -65,6 +65,44 @@ def test_blocked_qr(m, n):
     assert np.max(np.abs(np.tril(Ri, -1))) == 0.0
 
 
+@pytest.mark.parametrize("m,n,scale", [(700, 450, 1.0), (1500, 1000, 1.0), (2100, 640, 1e3), (1000, 1000, 1.0)])
+def test_blocked_qr_panels_by_cholesky_qr(m, n, scale):
+    """Panels of 64 columns with at least 128 rows below their diagonal are factorised by Cholesky-QR twice + Householder
+    reconstruction (dense_la.hip k_cholqr_pass1/2) instead of one launch per column: the SAME reflectors, so R agrees with
+    LAPACK's column-by-column Householder R (same sign rule) entry by entry, not only up to row signs. `scale` spreads the
+    column norms over three decades."""
+    import scipy.linalg as sl
+    rng = np.random.default_rng(m * n)
+    B0 = rng.normal(size=(m, n)) * np.logspace(0, np.log10(scale), n)[None, :]
+    B = np.asfortranarray(B0.copy()); Q = np.zeros((m, m), order="F"); Ri = np.zeros((n, n), order="F")
+    ndep = C.c_int(-1)
+    assert capi.lib().rsqp_dense_qr(m, n, _dp(B), _dp(Q), _dp(Ri), 1e-9, C.byref(ndep), None) == 0
+    assert ndep.value == 0
+    R = np.triu(B[:n, :])
+    Rl = sl.qr(B0, mode="r")[0][:n]
+    assert np.max(np.abs(R - Rl) / np.abs(np.diag(Rl))[:, None]) < 1e-10
+    assert np.max(np.abs(Q.T @ Q - np.eye(m))) < 1e-12
+    assert np.max(np.abs(Q[:, :n] @ R - B0) / np.abs(B0).max(axis=0)[None, :]) < 1e-12 * m
+    assert np.max(np.abs(Ri @ R - np.eye(n))) < 1e-9
+
+
+def test_blocked_qr_ill_conditioned_panel_takes_the_column_kernel():
+    """A panel whose columns agree to seven digits: the Gram matrix cannot resolve it (pivot ratio 1e-14 < 1e-10), the
+    factorisation is repeated with the column kernel and stays accurate; the columns are independent at eps_li = 1e-9."""
+    rng = np.random.default_rng(77)
+    m, n = 900, 200
+    B0 = rng.normal(size=(m, n))
+    B0[:, 70] = B0[:, 66] + 1e-7 * rng.normal(size=m)
+    B = np.asfortranarray(B0.copy()); Q = np.zeros((m, m), order="F"); Ri = np.zeros((n, n), order="F")
+    ndep = C.c_int(-1)
+    assert capi.lib().rsqp_dense_qr(m, n, _dp(B), _dp(Q), _dp(Ri), 1e-9, C.byref(ndep), None) == 0
+    assert ndep.value == 0
+    R = np.triu(B[:n, :])
+    assert np.max(np.abs(Q.T @ Q - np.eye(m))) < 1e-12
+    assert np.max(np.abs(Q[:, :n] @ R - B0)) < 1e-12 * m
+    assert 1e-8 < abs(R[70, 70]) < 1e-4
+
+
 def test_blocked_qr_flags_dependent_columns():
     rng = np.random.default_rng(9)
     B0 = rng.normal(size=(120, 70))

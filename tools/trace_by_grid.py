@@ -21,3 +21,7 @@ for n, t in sorted(byname.items(), key=lambda x: -x[1]): print("%-60s %10.1f us 
 print()
 for (n, g), a in sorted(agg.items(), key=lambda x: -x[1][1]):
     if a[1] >= lim: print("%-44s grid %-18s calls %5d total %10.1f us mean %9.2f us" % (n[:44], g, a[0], a[1], a[1] / a[0]))
+if len(sys.argv) > 3:      # every duration of the kernels whose name contains argv[3], in dispatch order
+    rows = csv.DictReader(open(files[-1]))
+    d = [(int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows if sys.argv[3] in r["Kernel_Name"]]
+    print(" ".join("%.1f" % t for _, t in sorted(d)[:60]))
