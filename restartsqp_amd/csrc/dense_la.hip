@@ -357,14 +357,17 @@ __global__ void k_panel_writeback(double *__restrict__ B, long long ldb, int m, 
 // A panel whose Gram matrix loses more than ten digits in the Cholesky pivots (flag[2]) is not decided here: the
 // caller repeats the factorisation with the column kernel (w->panel_cholqr = false).
 //
-// The 64 x 64 factorisations are ONE routine: elimination without pivoting on the augmented matrix [A | I] -> [U | L^-1],
-// 256 threads, a thread owning a 4 x 8 block of the 64 x 128 array in registers; per step the pivot row and the pivot
-// column go through a double-buffered LDS line (one barrier per step, 64 steps ~ 10 us). Cholesky: R = diag(u)^-1/2 U,
-// R^-1 = (L^-1)' diag(u)^-1/2; inverse of a triangular matrix: eliminate its transpose, [W' | I] -> [Lambda | F],
-// W^-1 = F' Lambda^-1.
+// The 64 x 64 factorisations are ONE routine: elimination without pivoting, IN PLACE -- the row operations that turn A into
+// U are the rows of L^-1, and the column a step eliminates is exactly the slot its column of L^-1 needs: afterwards the upper
+// triangle holds U, the strictly lower one L^-1 (unit diagonal implied). 256 threads, a thread owning a 4 x 4 block in
+// registers; per PAIR of pivots the two pivot rows and columns go through a double-buffered LDS line (one barrier, every
+// thread derives the second pivot row / multipliers itself). Cholesky: R = diag(u)^-1/2 U, R^-1 = (L^-1)' diag(u)^-1/2;
+// inverse of a triangular matrix: eliminate its transpose, W' -> (Lambda, F), W^-1 = F' Lambda^-1.
+// (Measured: the routine is instruction-bound, one wave per SIMD -- two pivots per barrier instead of one changed nothing,
+// halving the arithmetic by the in-place form did.)
 constexpr int EB = 64, ES = EB + 2;     // block order; LDS row stride (even: rows 16-byte aligned, 4 consecutive rows on distinct banks)
 typedef double EMat[EB][ES];
-struct ElimLds { double row[2][2][2 * EB]; double col[2][2][EB]; double dsign[EB]; double g0[EB]; int bad; };
+struct ElimLds { double row[2][2][EB]; double col[2][2][EB]; double dsign[EB]; double g0[EB]; int bad, skip2; };
 enum { EL_PLAIN = 0, EL_CHOL = 1, EL_SIGNLU = 2 };
 __device__ __forceinline__ double fast_rcp(double p) {      // v_rcp_f64 + two Newton steps (the IEEE division is ~3x the dependent chain)
     double r = __builtin_amdgcn_rcp(p), e = fma(-p, r, 1.0);
@@ -372,58 +375,64 @@ __device__ __forceinline__ double fast_rcp(double p) {      // v_rcp_f64 + two N
     e = fma(-p, r, 1.0);
     return fma(r, e, r);
 }
-
-template <class F> __device__ __forceinline__ void el_init(double (&a)[4][8], F left) {
+template <class F> __device__ __forceinline__ void el_init(double (&a)[4][4], F elem) {
     const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const int row = 4 * tr + r, col = 8 * tc + c;
-            a[r][c] = col < EB ? left(row, col < EB ? col : 0) : (col - EB == row ? 1.0 : 0.0);
-        }
+        for (int c = 0; c < 4; c++) a[r][c] = elem(4 * tr + r, 4 * tc + c);
 }
-__device__ __forceinline__ void el_dump(const double (&a)[4][8], EMat &Lh, EMat &Rh) {
+__device__ __forceinline__ void el_dump(const double (&a)[4][4], EMat &Mo) {
     const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const int row = 4 * tr + r, col = 8 * tc + c;
-            if (col < EB) Lh[row][col] = a[r][c]; else Rh[row][col - EB] = a[r][c];
+        for (int c = 0; c < 4; c++) Mo[4 * tr + r][4 * tc + c] = a[r][c];
+}
+// the same, split: U (zeros below the diagonal) and L^-1 (unit diagonal, zeros above) as two clean matrices
+__device__ __forceinline__ void el_dump2(const double (&a)[4][4], EMat &Uo, EMat &Lo) {
+    const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int row = 4 * tr + r, col = 4 * tc + c;
+            Uo[row][col] = row <= col ? a[r][c] : 0.0;
+            Lo[row][col] = row > col ? a[r][c] : (row == col ? 1.0 : 0.0);
         }
 }
-// Two pivots per barrier: the owners publish rows k, k + 1 and columns k, k + 1 as the steps < k left them; every thread
-// derives the second pivot row / multipliers itself (a few redundant operations instead of a second round trip through LDS).
+// MODE EL_CHOL: a pivot p must pass p > tol_rel (|g0| + max(g0 - p, 0)) + tol_abs, the engine's definiteness test (else E.bad); EL_SIGNLU: the pivot is shifted by D_k = -sgn(pivot) first (E.dsign)
+// and the multipliers (the strictly lower triangle of L) go to Lm
 template <int MODE>
-__device__ __forceinline__ void elim64(double (&a)[4][8], ElimLds &E, double tol_rel) {
+__device__ __forceinline__ void elim64(double (&a)[4][4], ElimLds &E, double tol_rel, EMat *Lm, double tol_abs = 0.0) {
     const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
-    auto publish = [&](int k, int par, int rs, int cs) {      // par, rs, cs: compile-time at the call sites (k even)
-        const bool orow = tr == (k >> 2), ocol = tc == (k >> 3);
+    auto publish = [&](int kb, int par, int kk) {      // rows / columns k, k + 1 (k = 4 kb + kk; par, kk compile-time at the call sites)
+        const bool orow = tr == kb, ocol = tc == kb;
         if (MODE == EL_SIGNLU && orow && ocol) {
-            const double d = a[rs][cs] >= 0.0 ? -1.0 : 1.0;      // |pivot| = 1 + |q_kk| >= 1
-            a[rs][cs] -= d;
-            E.dsign[k] = d;
+            const double d = a[kk][kk] >= 0.0 ? -1.0 : 1.0;      // |pivot| = 1 + |q_kk| >= 1
+            a[kk][kk] -= d;
+            E.dsign[4 * kb + kk] = d;
         }
         if (orow) {
 #pragma unroll
-            for (int c = 0; c < 8; c++) { E.row[par][0][8 * tc + c] = a[rs][c]; E.row[par][1][8 * tc + c] = a[rs + 1][c]; }
+            for (int c = 0; c < 4; c++) { E.row[par][0][4 * tc + c] = a[kk][c]; E.row[par][1][4 * tc + c] = a[kk + 1][c]; }
         }
         if (ocol) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) { E.col[par][0][4 * tr + r] = a[r][cs]; E.col[par][1][4 * tr + r] = a[r][cs + 1]; }
+            for (int r = 0; r < 4; r++) { E.col[par][0][4 * tr + r] = a[r][kk]; E.col[par][1][4 * tr + r] = a[r][kk + 1]; }
         }
     };
-    publish(0, 0, 0, 0);
-    for (int kb = 0; kb < EB / 8; kb++) {
+    publish(0, 0, 0);
+    for (int kb = 0; kb < EB / 4; kb++) {
 #pragma unroll
-        for (int kk = 0; kk < 8; kk += 2) {
-            const int k = 8 * kb + kk, par = (kk >> 1) & 1;
+        for (int kk = 0; kk < 4; kk += 2) {
+            const int k = 4 * kb + kk, par = kk >> 1;
             __syncthreads();
             const double p0 = E.row[par][0][k], x01 = E.row[par][0][k + 1];
             double rp0, rp1, d1 = 0.0;
             if (MODE == EL_CHOL) {
-                const bool ok = p0 > tol_rel * E.g0[k];
+                const double g0k = E.g0[k], ex0 = g0k - p0;
+                const bool ok = p0 > tol_rel * (fabs(g0k) + (ex0 > 0.0 ? ex0 : 0.0)) + tol_abs;
                 if (!ok && tid == 0) E.bad = 1;
                 rp0 = ok ? fast_rcp(p0) : 0.0;
             } else rp0 = fast_rcp(p0);
@@ -431,11 +440,12 @@ __device__ __forceinline__ void elim64(double (&a)[4][8], ElimLds &E, double tol
             double p1 = fma(-m, x01, E.row[par][1][k + 1]);
             if (MODE == EL_SIGNLU) { d1 = p1 >= 0.0 ? -1.0 : 1.0; p1 -= d1; }
             if (MODE == EL_CHOL) {
-                const bool ok = p1 > tol_rel * E.g0[k + 1];
+                const double g0k = E.g0[k + 1], ex1 = g0k - p1;
+                const bool ok = p1 > tol_rel * (fabs(g0k) + (ex1 > 0.0 ? ex1 : 0.0)) + tol_abs;
                 if (!ok && tid == 0) E.bad = 1;
                 rp1 = ok ? fast_rcp(p1) : 0.0;
             } else rp1 = fast_rcp(p1);
-            double c0[4], c1[4], u0[8], u1[8];
+            double c0[4], c1[4], u0[4], u1[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = 4 * tr + r;
@@ -443,40 +453,47 @@ __device__ __forceinline__ void elim64(double (&a)[4][8], ElimLds &E, double tol
                 c1[r] = row > k + 1 ? fma(-c0[r], x01, E.col[par][1][row]) * rp1 : 0.0;
             }
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const int col = 8 * tc + c;
-                u0[c] = E.row[par][0][col];
-                if (MODE == EL_SIGNLU && col < k) u0[c] = 0.0;            // (left of the pivot a row holds its own multipliers)
-                u1[c] = fma(-m, u0[c], E.row[par][1][col]);
-                if (MODE == EL_SIGNLU && col <= k) u1[c] = 0.0;          // (elsewhere: zeros and rounding dust that only reaches columns k, k + 1, rewritten below)
+            for (int c = 0; c < 4; c++) {
+                u0[c] = E.row[par][0][4 * tc + c];                        // (left of the pivot: the row of L^-1 built so far)
+                u1[c] = fma(-m, u0[c], E.row[par][1][4 * tc + c]);
             }
 #pragma unroll
             for (int r = 0; r < 4; r++)
 #pragma unroll
-                for (int c = 0; c < 8; c++) a[r][c] = fma(-c1[r], u1[c], fma(-c0[r], u0[c], a[r][c]));
-            if (tc == kb) {      // columns k, k + 1: the multipliers (LU) or exact zeros instead of rounding dust; the second sign
+                for (int c = 0; c < 4; c++) a[r][c] = fma(-c1[r], u1[c], fma(-c0[r], u0[c], a[r][c]));
+            if (tc == kb) {
+                // columns k, k + 1 below the pivots: the new columns of L^-1 (the identity's 1 of rows k, k + 1 took part as
+                // u0[k] = 1, u1[k] = -m, u1[k + 1] = 1); the multipliers themselves are L
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int row = 4 * tr + r;
-                    if (row > k) a[r][kk] = MODE == EL_SIGNLU ? c0[r] : 0.0;
-                    if (row > k + 1) a[r][kk + 1] = MODE == EL_SIGNLU ? c1[r] : 0.0;
+                    if (row == k + 1) { a[r][kk] = -m; if (MODE == EL_SIGNLU) (*Lm)[row][k] = m; }
+                    if (row > k + 1) {
+                        a[r][kk] = fma(c1[r], m, -c0[r]);
+                        a[r][kk + 1] = -c1[r];
+                        if (MODE == EL_SIGNLU) { (*Lm)[row][k] = c0[r]; (*Lm)[row][k + 1] = c1[r]; }
+                    }
                 }
-                if (MODE == EL_SIGNLU && tr == ((k + 1) >> 2)) { a[(kk + 1) & 3][kk + 1] = p1; E.dsign[k + 1] = d1; }
+                if (MODE == EL_SIGNLU && tr == kb) { a[kk + 1][kk + 1] = p1; E.dsign[k + 1] = d1; }
             }
-            if (k + 2 < EB) publish(k + 2, ((kk + 2) >> 1) & 1, (kk + 2) & 3, (kk + 2) & 7);
+            if (kk == 0) publish(kb, 1, 2);
+            else if (kb + 1 < EB / 4) publish(kb + 1, 0, 0);
         }
     }
     __syncthreads();
 }
-// acc (the thread's 4 x 4 block of a 64 x 64 product) = sum_k A(i, k) B(k, j), operands through accessors
-template <class FA, class FB> __device__ __forceinline__ void mm64(double (&acc)[4][4], FA A, FB B) {
+// acc (the thread's 4 x 4 block of a 64 x 64 product) = sum_k A(i, k) B(k, j), operands through accessors. TRI: both factors
+// are upper triangular (or A is and B has nothing below its block's last row): only k in [first row of the block, last
+// column of the block] contributes
+template <bool TRI, class FA, class FB> __device__ __forceinline__ void mm64(double (&acc)[4][4], FA A, FB B) {
     const int bi = threadIdx.x >> 4, bj = threadIdx.x & 15;
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int c = 0; c < 4; c++) acc[r][c] = 0.0;
+    const int k0 = TRI ? 4 * bi : 0, k1 = TRI ? 4 * bj + 4 : EB;
 #pragma unroll 4
-    for (int k = 0; k < EB; k++) {
+    for (int k = k0; k < k1; k++) {
         double ar[4], bc[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) ar[r] = A(4 * bi + r, k);
@@ -495,30 +512,61 @@ template <class F> __device__ __forceinline__ void mm64_store(const double (&acc
 #pragma unroll
         for (int c = 0; c < 4; c++) put(4 * bi + r, 4 * bj + c, acc[r][c]);
 }
-constexpr size_t CHOLQR_LDS1 = 2 * sizeof(EMat) + sizeof(ElimLds);
+constexpr size_t CHOLQR_LDS1 = sizeof(EMat) + sizeof(ElimLds);
 constexpr size_t CHOLQR_LDS2 = 4 * sizeof(EMat) + sizeof(ElimLds);
 
 // G (64 x 64, symmetric, column-major ld 64) = R'R:  R1 and X1 = R1^-1 (upper, ld 64)
 __global__ void __launch_bounds__(256) k_cholqr_pass1(const double *__restrict__ G, double *__restrict__ X1, double *__restrict__ R1,
                                                       int *__restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) double cq_lds[];
-    EMat &U = *reinterpret_cast<EMat *>(cq_lds), &Li = *reinterpret_cast<EMat *>(cq_lds + EB * ES);
-    ElimLds &E = *reinterpret_cast<ElimLds *>(cq_lds + 2 * EB * ES);
+    EMat &U = *reinterpret_cast<EMat *>(cq_lds);
+    ElimLds &E = *reinterpret_cast<ElimLds *>(cq_lds + EB * ES);
     const int tid = threadIdx.x;
     if (tid < EB) E.g0[tid] = G[tid + EB * tid];
     if (tid == 0) E.bad = 0;
-    double a[4][8];
+    double a[4][4];
     el_init(a, [&](int r, int c) { return G[r + EB * c]; });
     __syncthreads();
-    elim64<EL_CHOL>(a, E, 1e-10);
-    el_dump(a, U, Li);
+    elim64<EL_CHOL>(a, E, 1e-10, nullptr);
+    el_dump(a, U);
+    __syncthreads();
+    if (tid < EB) E.g0[tid] = 1.0 / sqrt(U[tid][tid]);      // 1 / r_kk
     __syncthreads();
     for (int e = tid; e < EB * EB; e += 256) {
         const int i = e & (EB - 1), j = e >> 6;
-        R1[e] = i <= j ? U[i][j] / sqrt(U[i][i]) : 0.0;
-        X1[e] = i <= j ? Li[j][i] / sqrt(U[j][j]) : 0.0;
+        R1[e] = i <= j ? U[i][j] * E.g0[i] : 0.0;
+        X1[e] = i < j ? U[j][i] * E.g0[j] : (i == j ? E.g0[j] : 0.0);
     }
     if (tid == 0 && E.bad) atomicAdd(flag + 2, 1);
+}
+
+// unblocked Cholesky (upper, G = U'U) of one NB x NB diagonal block of the blocked factorisation, by the same elimination:
+// the engine's definiteness test against the ORIGINAL diagonal diag0; also returns the inverse of the block's factor
+__global__ void __launch_bounds__(256) k_potf2_elim(int nb, double *__restrict__ G, long long ldg, const double *__restrict__ diag0,
+                                                    double pd_rel, double pd_abs, double *__restrict__ Uinv, int *__restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) double cq_lds[];
+    EMat &U = *reinterpret_cast<EMat *>(cq_lds);
+    ElimLds &E = *reinterpret_cast<ElimLds *>(cq_lds + EB * ES);
+    const int tid = threadIdx.x;
+    if (tid < EB) E.g0[tid] = tid < nb ? diag0[tid] : 1.0;
+    if (tid == 0) E.bad = 0;
+    double a[4][4];
+    el_init(a, [&](int r, int c) {        // (the upper triangle holds the block: mirrored)
+        const int i = r < c ? r : c, j = r < c ? c : r;
+        return j < nb ? G[i + (long long)j * ldg] : (r == c ? 1.0 : 0.0);
+    });
+    __syncthreads();
+    elim64<EL_CHOL>(a, E, pd_rel, nullptr, pd_abs);
+    el_dump(a, U);
+    __syncthreads();
+    if (tid < EB) E.g0[tid] = 1.0 / sqrt(U[tid][tid]);
+    __syncthreads();
+    for (int e = tid; e < EB * EB; e += 256) {
+        const int i = e & (EB - 1), j = e >> 6;
+        if (i < nb && j < nb) G[i + (long long)j * ldg] = i <= j ? U[i][j] * E.g0[i] : 0.0;
+        Uinv[e] = i < j ? U[j][i] * E.g0[j] : (i == j ? E.g0[j] : 0.0);
+    }
+    if (tid == 0 && E.bad) atomicAdd(flag, 1);
 }
 
 // second pass + Householder reconstruction of one panel (see the header comment): G2 = Q1'Q1, Q1t = the first 64 rows of Q1
@@ -532,58 +580,81 @@ k_cholqr_pass2(const double *__restrict__ G2, const double *__restrict__ Q1t, lo
          &b2 = *reinterpret_cast<EMat *>(cq_lds + 2 * EB * ES), &b3 = *reinterpret_cast<EMat *>(cq_lds + 3 * EB * ES);
     ElimLds &E = *reinterpret_cast<ElimLds *>(cq_lds + 4 * EB * ES);
     const int tid = threadIdx.x;
-    double a[4][8], acc[4][4];
-    // 1. G2 = R2'R2 (G2 = I + O(eps cond^2): any pivot below 1/100 means the first pass was useless)
-    if (tid < EB) E.g0[tid] = G2[tid + EB * tid];
-    if (tid == 0) E.bad = 0;
-    el_init(a, [&](int r, int c) { return G2[r + EB * c]; });
+    double a[4][4], acc[4][4];
+    // 1. G2 = R2'R2. G2 = I + O(eps cond^2): a well-conditioned panel leaves nothing to correct (|G2 - I| <= 3e-14: R2 = I),
+    //    and any pivot below 1/100 means the first pass was useless
+    if (tid == 0) { E.bad = 0; E.skip2 = 1; }
     __syncthreads();
-    elim64<EL_CHOL>(a, E, 1e-2);
-    el_dump(a, b1, b2);
-    __syncthreads();
-    for (int e = tid; e < EB * EB; e += 256) {
-        const int i = e & (EB - 1), j = e >> 6;
-        b0[i][j] = i <= j ? b1[i][j] / sqrt(b1[i][i]) : 0.0;        // R2
-        b3[i][j] = i <= j ? b2[j][i] / sqrt(b1[j][j]) : 0.0;        // X2 = R2^-1
+    {
+        bool off = false;
+        for (int e = tid; e < EB * EB; e += 256) { const int i = e & (EB - 1), j = e >> 6; off = off || fabs(G2[e] - (i == j ? 1.0 : 0.0)) > 3e-14; }
+        if (off) E.skip2 = 0;
     }
     __syncthreads();
+    const bool skip2 = E.skip2 != 0;      // (workgroup-uniform)
+    if (!skip2) {
+        if (tid < EB) E.g0[tid] = G2[tid + EB * tid];
+        el_init(a, [&](int r, int c) { return G2[r + EB * c]; });
+        __syncthreads();
+        elim64<EL_CHOL>(a, E, 1e-2, nullptr);
+        el_dump(a, b1);
+        __syncthreads();
+        if (tid < EB) E.g0[tid] = 1.0 / sqrt(b1[tid][tid]);
+        __syncthreads();
+        for (int e = tid; e < EB * EB; e += 256) {
+            const int i = e & (EB - 1), j = e >> 6;
+            b0[i][j] = i <= j ? b1[i][j] * E.g0[i] : 0.0;                                    // R2
+            b3[i][j] = i < j ? b1[j][i] * E.g0[j] : (i == j ? E.g0[j] : 0.0);                // X2 = R2^-1
+        }
+        __syncthreads();
+    }
     // 2. Q_top = Q1_top X2
-    for (int e = tid; e < EB * EB; e += 256) { const int i = e & (EB - 1), j = e >> 6; b1[i][j] = Q1t[i + j * ldq]; }
+    for (int e = tid; e < EB * EB; e += 256) { const int i = e & (EB - 1), j = e >> 6; (skip2 ? b2 : b1)[i][j] = Q1t[i + j * ldq]; }
     __syncthreads();
-    mm64(acc, [&](int i, int k) { return b1[i][k]; }, [&](int k, int j) { return b3[k][j]; });
-    mm64_store(acc, [&](int i, int j, double v) { b2[i][j] = v; });
-    __syncthreads();
-    // 3. L U = Q_top - D, and L^-1 beside it
+    if (!skip2) {
+        mm64<false>(acc, [&](int i, int k) { return b1[i][k]; }, [&](int k, int j) { return b3[k][j]; });
+        mm64_store(acc, [&](int i, int j, double v) { b2[i][j] = v; });
+        __syncthreads();
+    }
+    // 3. L U = Q_top - D: U into b1, L^-1 into b2, the multipliers L into b3
     el_init(a, [&](int r, int c) { return b2[r][c]; });
     __syncthreads();
-    elim64<EL_SIGNLU>(a, E, 0.0);
-    el_dump(a, b1, b2);           // b1: U (upper) and the multipliers (strictly lower); b2: L^-1
+    elim64<EL_SIGNLU>(a, E, 0.0, &b3);
+    el_dump2(a, b1, b2);
     __syncthreads();
     for (int e = tid; e < EB * EB; e += 256) {
         const int i = e & (EB - 1), j = e >> 6;
-        Vtop[i + j * ldv] = i > j ? b1[i][j] : (i == j ? 1.0 : 0.0);
+        Vtop[i + j * ldv] = i > j ? b3[i][j] : (i == j ? 1.0 : 0.0);
     }
     // T = -U D L^-T
-    mm64(acc, [&](int i, int k) { return i <= k ? b1[i][k] * E.dsign[k] : 0.0; }, [&](int k, int j) { return b2[j][k]; });
+    mm64<true>(acc, [&](int i, int k) { return b1[i][k] * E.dsign[k]; }, [&](int k, int j) { return b2[j][k]; });
     mm64_store(acc, [&](int i, int j, double v) {
         const double t = i <= j ? -v : 0.0;
         Tout[i + j * NB] = t;
         if (i == j) tau[i] = t;
     });
-    // M = (U R2)^-1: W = U R2 into b3, eliminate W'
-    mm64(acc, [&](int i, int k) { return i <= k ? b1[i][k] : 0.0; }, [&](int k, int j) { return b0[k][j]; });
-    mm64_store(acc, [&](int i, int j, double v) { b3[i][j] = i <= j ? v : 0.0; });
-    __syncthreads();             // (also: every thread is done with b1, b2)
-    el_init(a, [&](int r, int c) { return b3[c][r]; });
+    __syncthreads();             // (b2, b3 are rewritten below)
+    // M = (U R2)^-1: W = U R2 into b2, eliminate W'
+    if (!skip2) {
+        mm64<true>(acc, [&](int i, int k) { return b1[i][k]; }, [&](int k, int j) { return b0[k][j]; });
+        mm64_store(acc, [&](int i, int j, double v) { b2[i][j] = i <= j ? v : 0.0; });
+        __syncthreads();
+    }
+    el_init(a, [&](int r, int c) { return (skip2 ? b1 : b2)[c][r]; });
+    // R1 into b3 meanwhile
+    for (int e = tid; e < EB * EB; e += 256) { const int i = e & (EB - 1), j = e >> 6; b3[i][j] = R1[e]; }
     __syncthreads();
-    elim64<EL_PLAIN>(a, E, 0.0);
-    el_dump(a, b2, b3);           // b2: Lambda (diagonal), b3: F with F W' = Lambda
-    // R = D R2 R1 (R1 into b1 meanwhile)
-    for (int e = tid; e < EB * EB; e += 256) { const int i = e & (EB - 1), j = e >> 6; b1[i][j] = R1[e]; }
+    elim64<EL_PLAIN>(a, E, 0.0, nullptr);
+    el_dump(a, b2);               // diagonal: Lambda; strictly lower: F (unit diagonal) with F W' = Lambda
     __syncthreads();
-    for (int e = tid; e < EB * EB; e += 256) { const int i = e & (EB - 1), j = e >> 6; Mx[e] = i <= j ? b3[j][i] / b2[j][j] : 0.0; }
-    mm64(acc, [&](int i, int k) { return b0[i][k]; }, [&](int k, int j) { return b1[k][j]; });
-    mm64_store(acc, [&](int i, int j, double v) {
+    if (tid < EB) E.g0[tid] = 1.0 / b2[tid][tid];
+    __syncthreads();
+    for (int e = tid; e < EB * EB; e += 256) {
+        const int i = e & (EB - 1), j = e >> 6;
+        Mx[e] = i < j ? b2[j][i] * E.g0[j] : (i == j ? E.g0[j] : 0.0);
+    }
+    // R = D R2 R1
+    auto putR = [&](int i, int j, double v) {
         const double r = E.dsign[i] * v;
         if (i < j) Bblk[i + j * ldb] = r;
         else if (i == j) {
@@ -591,7 +662,13 @@ k_cholqr_pass2(const double *__restrict__ G2, const double *__restrict__ Q1t, lo
             rdiag[i] = r;
             if (!(fabs(r) > eps_li * sqrt(norm2[i]))) atomicAdd(flag, 1);
         }
-    });
+    };
+    if (skip2) {
+        for (int e = tid; e < EB * EB; e += 256) { const int i = e & (EB - 1), j = e >> 6; putR(i, j, b3[i][j]); }
+    } else {
+        mm64<true>(acc, [&](int i, int k) { return b0[i][k]; }, [&](int k, int j) { return b3[k][j]; });
+        mm64_store(acc, putR);
+    }
     if (tid == 0 && E.bad) atomicAdd(flag + 2, 1);
 }
 
@@ -879,7 +956,9 @@ hipError_t rsqp_dpotrf_upper(int n, double *G, long long ldg, double pd_rel, dou
     for (int k0 = 0; k0 < n; k0 += NB) {
         const int jb = std::min(NB, n - k0), nt = n - k0 - jb;
         double *Gd = G + k0 + (long long)k0 * ldg;
-        hipLaunchKernelGGL(k_potf2, dim3(1), dim3(64), 0, st, jb, Gd, ldg, w->norm2 + k0, pd_rel, pd_abs, Uinv, w->flag + 1);
+        static const bool old_potf2 = getenv("RSQP_POTF2_OLD") != nullptr;
+        if (old_potf2) hipLaunchKernelGGL(k_potf2, dim3(1), dim3(64), 0, st, jb, Gd, ldg, w->norm2 + k0, pd_rel, pd_abs, Uinv, w->flag + 1);
+        else hipLaunchKernelGGL(k_potf2_elim, dim3(1), dim3(256), CHOLQR_LDS1, st, jb, Gd, ldg, w->norm2 + k0, pd_rel, pd_abs, Uinv, w->flag + 1);
         if (nt > 0) {
             double *G12 = G + k0 + (long long)(k0 + jb) * ldg;
             // U12 = Ujj^-T G12  (jb x nt): via W, then copied back
