@@ -21,7 +21,10 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int GK16 = 16;   // K step of the GEMM (32 for the 8-wave 128 x 128 tile)
-constexpr int GPAD = 4;   // LDS row padding (doubles): row stride = 8 words mod 64 banks
+#ifndef RSQP_GPAD
+#define RSQP_GPAD 4
+#endif
+constexpr int GPAD = RSQP_GPAD;   // LDS row padding (doubles): row stride = 8 words mod 64 banks (tools/gemm_pad_variants.sh builds others)
 
 // one operand tile (GK x T) -> registers. kcontig: element (kk, t) at X[kk + t * ld], else X[t + kk * ld]
 template <int T, int NTHR, int GK>

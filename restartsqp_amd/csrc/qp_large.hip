@@ -1620,7 +1620,9 @@ struct RsqpLargeEngine::Impl {
         chk("ger_gemv_t");
     }
     void gemv_n_Wz_pending(const double *wv, double alpha, double *out) {
-        if (!(pendW.on && pendW.nZold - 1 == nZ && nZ > 0)) {
+        // (below ~3000 columns the fused pass is launch-bound -- partial sums + reduction, 35 us at nZ = 2300 -- and the separate
+        //  kernels, 19 + 9 us, are faster)
+        if (!(pendW.on && pendW.nZold - 1 == nZ && nZ >= 3072)) {
             if (pendW.on) { pendW.on = false; wz_shrink_now(pendW.nZold, pw_s, pz_v, pw_col, S_KEEP_BETA, S_KEEP_THETA); }
             gemv_n(Wz, ld, nZ, nZ, wv, alpha, 0.0, nullptr, out);
             return;
