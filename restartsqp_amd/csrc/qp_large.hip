@@ -1959,6 +1959,7 @@ struct RsqpLargeEngine::Impl {
         double sum_nFR = 0.0, sum_nAC = 0.0, sum_nZ = 0.0;      // reported by RSQP_PROFILE: the sizes the products run on
         status = QPS_PERFORMINGHOMOTOPY;
         dx_ready = false;
+        pendZ.on = pendW.on = false;      // (nothing is deferred across solves; a solve that failed half-way leaves nothing behind)
         refresh_products();
         hipLaunchKernelGGL(k_rerelax, g1(nV), dim3(NT), 0, st, nV, Sb, x, lbN, ubN, lb, ub);
         if (nC > 0) hipLaunchKernelGGL(k_rerelax, g1(nC), dim3(NT), 0, st, nC, Sc, Ax, lbAN, ubAN, lbA, ubA);
