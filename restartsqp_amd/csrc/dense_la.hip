@@ -24,6 +24,9 @@ constexpr int GK16 = 16;   // K step of the GEMM (32 for the 8-wave 128 x 128 ti
 #ifndef RSQP_GPAD
 #define RSQP_GPAD 4
 #endif
+#ifndef RSQP_GEMM_DB
+#define RSQP_GEMM_DB 0
+#endif
 constexpr int GPAD = RSQP_GPAD;   // LDS row padding (doubles): row stride = 8 words mod 64 banks (tools/gemm_pad_variants.sh builds others)
 
 // one operand tile (GK x T) -> registers. kcontig: element (kk, t) at X[kk + t * ld], else X[t + kk * ld]
@@ -62,8 +65,11 @@ __global__ void __launch_bounds__(NW * 64, MINW)
 k_dgemm(int ta, int tb, int m, int n, int kfull, int kc, double alpha, const double *__restrict__ A, long long lda,
         const double *__restrict__ B, long long ldb, double beta, double *__restrict__ C, long long ldc) {
     extern __shared__ __attribute__((aligned(16))) double gemm_lds[];
-    double (*As)[TM + GPAD] = reinterpret_cast<double (*)[TM + GPAD]>(gemm_lds);
-    double (*Bs)[TN + GPAD] = reinterpret_cast<double (*)[TN + GPAD]>(gemm_lds + GK * (TM + GPAD));
+    // RSQP_GEMM_DB=1 (tuning build, tools/gemm_pad_variants.sh): two LDS buffers, the tiles of step i + 1 stored while step i is
+    // still being multiplied, one barrier per K step instead of two -- measured SLOWER (51.3 vs 53.1 TFLOP/s on 4096^3, QR
+    // 100.4 vs 97.8 ms): the barriers are not what keeps the MFMA pipe at 67 % busy. Row paddings 2 .. 20 doubles: no difference.
+    constexpr int NBUF = RSQP_GEMM_DB ? 2 : 1;
+    constexpr int TILE_DOUBLES = GK * ((TM + GPAD) + (TN + GPAD));
     constexpr int NTHR = NW * 64, WN = NW / 2;
     constexpr int MI = TM / 32, NJ = TN / (16 * WN);   // 16x16 blocks per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -81,11 +87,22 @@ k_dgemm(int ta, int tb, int m, int n, int kfull, int kc, double alpha, const dou
     double ra[GK * TM / NTHR], rb[GK * TN / NTHR];
     load_tile<TM, NTHR, GK>(ra, A, lda, akc, kbeg, i0, k, m);
     load_tile<TN, NTHR, GK>(rb, B, ldb, bkc, kbeg, j0, k, n);
-    for (int k0 = kbeg; k0 < k; k0 += GK) {
-        store_tile<TM, NTHR, GK>(ra, As, akc);
-        store_tile<TN, NTHR, GK>(rb, Bs, bkc);
+    if (NBUF == 2) {
+        store_tile<TM, NTHR, GK>(ra, reinterpret_cast<double (*)[TM + GPAD]>(gemm_lds), akc);
+        store_tile<TN, NTHR, GK>(rb, reinterpret_cast<double (*)[TN + GPAD]>(gemm_lds + GK * (TM + GPAD)), bkc);
         __syncthreads();
-        if (k0 + GK < k) {
+    }
+    int buf = 0;
+    for (int k0 = kbeg; k0 < k; k0 += GK) {
+        double (*As)[TM + GPAD] = reinterpret_cast<double (*)[TM + GPAD]>(gemm_lds + buf * TILE_DOUBLES);
+        double (*Bs)[TN + GPAD] = reinterpret_cast<double (*)[TN + GPAD]>(gemm_lds + buf * TILE_DOUBLES + GK * (TM + GPAD));
+        if (NBUF == 1) {
+            store_tile<TM, NTHR, GK>(ra, As, akc);
+            store_tile<TN, NTHR, GK>(rb, Bs, bkc);
+            __syncthreads();
+        }
+        const bool more = k0 + GK < k;
+        if (more) {
             load_tile<TM, NTHR, GK>(ra, A, lda, akc, k0 + GK, i0, k, m);
             load_tile<TN, NTHR, GK>(rb, B, ldb, bkc, k0 + GK, j0, k, n);
         }
@@ -100,6 +117,13 @@ k_dgemm(int ta, int tb, int m, int n, int kfull, int kc, double alpha, const dou
             for (int a = 0; a < NJ; a++)
 #pragma unroll
                 for (int b = 0; b < MI; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[a], af[b], acc[a][b], 0, 0, 0);
+        }
+        if (NBUF == 2) {
+            if (more) {
+                buf ^= 1;
+                store_tile<TM, NTHR, GK>(ra, reinterpret_cast<double (*)[TM + GPAD]>(gemm_lds + buf * TILE_DOUBLES), akc);
+                store_tile<TN, NTHR, GK>(rb, reinterpret_cast<double (*)[TN + GPAD]>(gemm_lds + buf * TILE_DOUBLES + GK * (TM + GPAD)), bkc);
+            }
         }
         __syncthreads();
     }
@@ -168,7 +192,7 @@ static hipError_t dgemm_ws(bool transA, bool transB, int m, int n, int k, double
     static const int nw_big = getenv("RSQP_GEMM_WAVES") ? atoi(getenv("RSQP_GEMM_WAVES")) : 8;
 #define GEMM_LAUNCH(a, b, nw, mw, gk)                                                                              \
     do {                                                                                                           \
-        const size_t lds_ = sizeof(double) * gk * ((a + GPAD) + (b + GPAD));                                       \
+        const size_t lds_ = sizeof(double) * gk * ((a + GPAD) + (b + GPAD)) * (RSQP_GEMM_DB ? 2 : 1);               \
         static std::atomic<unsigned long long> set_{0};                                                            \
         rsqp_allow_full_lds(reinterpret_cast<const void *>(&k_dgemm<a, b, nw, mw, gk>), set_, (int)lds_);          \
         hipLaunchKernelGGL((k_dgemm<a, b, nw, mw, gk>), grid, dim3(nw * 64), lds_, st, ta, tb, m, n, k, kc, al, A, \
