@@ -1228,7 +1228,14 @@ hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCma
                                     : (shape82 ? Engine<8, true, true>::image_doubles(nVmax, nCmax) : Engine<64, true>::image_doubles(nVmax, nCmax));
     const long long imgi = eng == 1 ? EngineX<64, true>::image_ints(nVmax, nCmax) : Engine<64, true>::image_ints(nVmax, nCmax);
     const long long img = (8 * imgd + 2 * imgi + 7) & ~7LL;
-    const bool mat_lds = mat_bytes_max >= 0 && align16(img + mat_bytes_max) <= kMaxLds;
+#if defined(RSQP_SMALL_EXPERIMENT) && RSQP_SMALL_EXPERIMENT == 1
+    // tuning build only: the 8-lane shape kernel with the matrices left in global memory (L2) -- a smaller LDS image per problem,
+    // more resident waves (RSQP_EXP_MATGLOBAL=1 with RSQP_SMALL_WAVES=3)
+    static const int exp_nomat = env_int("RSQP_EXP_MATGLOBAL", 0);
+#else
+    constexpr int exp_nomat = 0;
+#endif
+    const bool mat_lds = mat_bytes_max >= 0 && align16(img + mat_bytes_max) <= kMaxLds && !exp_nomat;
     // LDS of one problem: image, then its staged matrices, 16-byte granular.
     long long stride = align16(img + (mat_lds ? mat_bytes_max : 0));
     // (an odd number of 16-byte units would spread the problems of a wave over the banks, but the LDS is
@@ -1241,7 +1248,7 @@ hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCma
     int L = nmax <= 8 ? 8 : (nmax <= 16 ? 16 : (nmax <= 32 ? 32 : 64));
     if ((forcedL == 8 || forcedL == 16 || forcedL == 32 || forcedL == 64) && forcedL >= L) L = forcedL;   // never fewer lanes than entries
     if (eng == 1 && L < 16) L = 16;   // the explicit-inverse build has no 8-lane instantiation
-    if (!mat_lds) L = 64;
+    if (!mat_lds && !exp_nomat) L = 64;
     while (L < 64 && (64 / L) * stride > kMaxLds) L *= 2;
     if (L == 64 && stride > kMaxLds) stride = align16(mat_lds ? img + mat_bytes_max : img);
     static const int forcedWide0 = env_int("RSQP_SMALL_WIDE", -1);
@@ -1348,6 +1355,18 @@ hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCma
         // SIMD = 80 VGPRs with ~180 spilled values; kept reachable only here, for the root-cause hunt
         if (L == 16 && eng == 0 && mat_lds) { SQ_LAUNCH_U(Engine, 16, true, 6, 0); return hipGetLastError(); }
 #endif
+        if (exp_nomat && L == 8 && eng == 0 && fixed) {
+#define SQ_LAUNCH_SHAPE_G(W)                                                                                                  \
+            do {                                                                                                              \
+                static std::atomic<unsigned long long> set_{0};                                                               \
+                rsqp_allow_full_lds(reinterpret_cast<const void *>(&small_qp_kernel<Engine<8, false, true>, 8, false, W, 8 * 256 + 2>), set_, (int)kMaxLds); \
+                hipLaunchKernelGGL((small_qp_kernel<Engine<8, false, true>, 8, false, W, 8 * 256 + 2>), dim3(nblk), dim3(64), lds, stream, p, nq, \
+                                   (int)stride, mode, maxWSR);                                                                \
+            } while (0)
+            switch (waves) { case 3: SQ_LAUNCH_SHAPE_G(3); break; case 4: SQ_LAUNCH_SHAPE_G(4); break; default: SQ_LAUNCH_SHAPE_G(2); }
+#undef SQ_LAUNCH_SHAPE_G
+            return hipGetLastError();
+        }
         if (L != 8 || eng != 0 || !mat_lds) return hipErrorInvalidValue;
         if (fixed) { switch (waves) { case 3: SQ_LAUNCH_SHAPE(8, 3, 8, 2); break; case 4: SQ_LAUNCH_SHAPE(8, 4, 8, 2); break; default: SQ_LAUNCH_SHAPE(8, 2, 8, 2); } }
         else { switch (waves) { case 3: SQ_LAUNCH_U(Engine, 8, true, 3, 0); break; case 4: SQ_LAUNCH_U(Engine, 8, true, 4, 0); break; default: SQ_LAUNCH_U(Engine, 8, true, 2, 0); } }
