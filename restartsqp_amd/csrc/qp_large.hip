@@ -1562,6 +1562,7 @@ struct RsqpLargeEngine::Impl {
     struct { bool on = false; int ncols = 0; } pendZ;
     struct { bool on = false; int nZold = 0; } pendW;
     bool fuse_passes = getenv("RSQP_LARGE_NO_FUSE") == nullptr;
+    int fuse_wz_min = getenv("RSQP_LARGE_FUSE_WZ_MIN") ? atoi(getenv("RSQP_LARGE_FUSE_WZ_MIN")) : 3072;   // (tests force 0: both fused kernels on small problems)
     static constexpr int S_KEEP_BETA = 40, S_KEEP_THETA = 41;
     bool can_defer() const {
         return fuse_passes && wz_enabled && (ld & 1) == 0 && nZ > 1 && pz_t &&
@@ -1622,7 +1623,7 @@ struct RsqpLargeEngine::Impl {
     void gemv_n_Wz_pending(const double *wv, double alpha, double *out) {
         // (below ~3000 columns the fused pass is launch-bound -- partial sums + reduction, 35 us at nZ = 2300 -- and the separate
         //  kernels, 19 + 9 us, are faster)
-        if (!(pendW.on && pendW.nZold - 1 == nZ && nZ >= 3072)) {
+        if (!(pendW.on && pendW.nZold - 1 == nZ && nZ >= fuse_wz_min && nZ > 0)) {
             if (pendW.on) { pendW.on = false; wz_shrink_now(pendW.nZold, pw_s, pz_v, pw_col, S_KEEP_BETA, S_KEEP_THETA); }
             gemv_n(Wz, ld, nZ, nZ, wv, alpha, 0.0, nullptr, out);
             return;

@@ -130,6 +130,30 @@ def test_hot_start_modes(capi, oracle):
         same_as_oracle(s, n, qp, n_or)
 
 
+def test_deferred_reflection_kernels_match_oracle(capi, oracle, monkeypatch):
+    """An incoming constraint's reflection of Z and the shrinking of Wz ride on the step direction's products (k_ger_gemv_t,
+    k_wz_shrink_gemv); the second one only from 3 072 null-space columns on. Forced on for every size here (the engine reads
+    the knob when a solver is created), and switched off altogether: the same decisions as the oracle either way, cold and
+    hot start."""
+    rng = np.random.default_rng(4711)
+    cases = [problems.random_qp(rng, 64, 40, 0.5), problems.random_qp(rng, 150, 120, 0.3), problems.random_qp(rng, 96, 200, 0.4)]
+    for knob, val in (("RSQP_LARGE_FUSE_WZ_MIN", "0"), ("RSQP_LARGE_NO_FUSE", "1")):
+        monkeypatch.setenv(knob, val)
+        for q in cases:
+            s = load(capi, q)
+            n = s.solve(capi.MODE_COLD, 20000)
+            qp, rc, n_or = oracle_cold(oracle, q, 20000)
+            same_as_oracle(s, n, qp, n_or)
+            q2 = problems.perturb(np.random.default_rng(5), q)
+            for w, v in zip(range(5), (q2.g, q2.lb, q2.ub, q2.lbA, q2.ubA)):
+                s.set_vector(w, v)
+            n = s.solve(capi.MODE_HOT_VECTORS, 20000)
+            rc, n_or = qp.hotstart(q2.g, q2.lb, q2.ub, q2.lbA, q2.ubA, 20000)
+            same_as_oracle(s, n, qp, n_or)
+            s.close()
+        monkeypatch.delenv(knob)
+
+
 def test_mid_size_dense_matches_oracle(capi, oracle):
     q = problems.dense_qp(300, 600, seed=20260101)
     s = load(capi, q, engine=0)
