@@ -654,7 +654,10 @@ def main():
     cdev = "cpu" if rehearsal else "cuda"          # where the tensors of the collectives live
     from restartsqp_amd import build, capi, parallel, problems
     if not NO_BUILD:
-        build.build_lib()
+        if rank == 0:
+            build.build_lib()      # (a no-op when the library is up to date; never N ranks compiling into one file)
+        if dist is not None:
+            dist.barrier()
     if capi.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
 
