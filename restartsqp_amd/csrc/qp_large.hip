@@ -945,6 +945,29 @@ __global__ void k_sd_prep(int nAC, const int *__restrict__ AC, const int *__rest
     }
     if (i < nV) tmpg[i] = Hdxfx[i] + (gN[i] - g[i]);
 }
+// The range-space part of the step direction behind an ADDED constraint, carried instead of recomputed: the right-hand sides of
+// the constraints that were active before have (1 - tau) of their way left, the new row of Minv is -xi/eta | 1/eta (minv_append):
+//   wY[0..k) *= (1 - tau);  wY[k] = (bA[k] - xi'bA[0..k)) / eta   (one workgroup; the new entry also into scal[sl])
+__global__ void __launch_bounds__(NT) k_carry_wY(int k, double om, const double *__restrict__ bA, const double *__restrict__ xi,
+                                                 double *__restrict__ wY, double *__restrict__ scal, int se, int sl) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int j = threadIdx.x; j < k; j += NT) { s += xi[j] * bA[j]; wY[j] *= om; }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) { const double w = (bA[k] - s) / scal[se]; wY[k] = w; scal[sl] = w; }
+}
+//   xY = (1 - tau) xY + wY[k] y_k   (y_k = the column the constraint added to Y)
+__global__ void k_carry_xY(int n, double om, const double *__restrict__ yk, const double *__restrict__ scal, int sl, double *__restrict__ xY) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) xY[i] = om * xY[i] + scal[sl] * yk[i];
+}
+// what that needs from the border of Minv: the row xi and eta, out of the way of the next products
+__global__ void k_keep_border(int k, const double *__restrict__ row, double *__restrict__ keep, double *__restrict__ scal, int es,
+                              int eta_from_house, int se) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < k) keep[j] = row[j];
+    if (j == 0) scal[se] = eta_from_house ? scal[2] * scal[0] : scal[es];
+}
 // dy on the fixed variables: (H dx + (gN - g)) - A'dy_C, zero on the free ones
 __global__ void k_dy_fixed2(int nV, const int *__restrict__ Sb, const double *__restrict__ Hdx, const double *__restrict__ gN,
                             const double *__restrict__ g, const double *__restrict__ ATdy, double *__restrict__ dy) {
@@ -1301,6 +1324,7 @@ struct RsqpLargeEngine::Impl {
     // vectors (nV)
     double *x, *g, *lb, *ub, *gN, *lbN, *ubN, *dx, *w1, *w2, *w3, *w4, *w5, *w6, *wz1, *wz2, *wz3;
     double *pz_t = nullptr, *pz_v = nullptr, *pw_s = nullptr, *pw_col = nullptr;   // operands of a deferred reflection (z_reflect_and_shrink)
+    double *c_wY = nullptr, *c_xY = nullptr, *c_xi = nullptr;                    // range-space part of the step direction, carried over an added constraint
     // vectors (nC)
     double *Ax, *lbA, *ubA, *lbAN, *ubAN, *dAx, *c1, *c2, *c3, *a1, *a2, *a3, *a4;
     double *y, *dy, *part, *scal, *pt, *res_t;
@@ -1371,7 +1395,7 @@ struct RsqpLargeEngine::Impl {
 
     ~Impl() {
         double *dv[] = {Z, Y, Minv, Wz, x, g, lb, ub, gN, lbN, ubN, dx, w1, w2, w3, w4, w5, w6, wz1, wz2, wz3, Ax, lbA, ubA,
-                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col};
+                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col, c_wY, c_xY, c_xi};
         for (double *p : dv) if (p) (void)hipFree(p);
         if (big) (void)hipFree(big);
         rsqp_dense_work_free(&dw);
@@ -1644,9 +1668,21 @@ struct RsqpLargeEngine::Impl {
 
     // append the Y column `ycol` (already stored at Y[:, nAC]) for constraint r whose products
     // with the old Y are in a1 (wY) and with the new column in scal[eta_slot]
-    void minv_append(int eta_slot, bool eta_from_house, int r, int side) {
+    // The step direction's wY = Minv bA and xY = Y wY are CARRIED over an incoming constraint (k_carry_wY / k_carry_xY: two
+    // O(n) kernels instead of one pass over Minv and one over Y) and recomputed exactly after any other change, at the first
+    // step, and every CARRY_REFRESH carried steps (RSQP_LARGE_NO_CARRY=1: always exactly).
+    static constexpr int S_KEEP_ETA = 43, S_KEEP_WLAST = 42, CARRY_REFRESH = 8;
+    bool carry_enabled = getenv("RSQP_LARGE_NO_CARRY") == nullptr;
+    bool carry_valid = false;        // c_wY / c_xY are those of the last step direction, nothing but a homotopy step since
+    bool carry_pending = false;      // ... and the change behind it was a plain added constraint (border kept in c_xi, S_KEEP_ETA)
+    int carried = 0;
+    bool plain_add = false;          // the change is ONE added constraint (no exchange partner removed first)
+    double last_tau = 0.0;
+    void minv_append(int eta_slot, bool eta_from_house, int r, int side, bool keep_for_carry = false) {
         // new row nAC: -(wY' Minv)/eta ; new column nAC: 0 ; corner 1/eta ; working set: constraint r at position nAC
         gemv_t(Minv, ldm, nAC, nAC, a1, a2);  // a2[j] = sum_i wY[i] Minv[i][j]
+        if (keep_for_carry)
+            hipLaunchKernelGGL(k_keep_border, g1(std::max(nAC, 1)), dim3(NT), 0, st, nAC, a2, c_xi, scal, eta_slot, eta_from_house ? 1 : 0, S_KEEP_ETA);
         hipLaunchKernelGGL(k_minv_border, g1(nAC + 1), dim3(NT), 0, st, Minv, ldm, nAC, a2, scal, eta_slot, eta_from_house ? 1 : 0,
                            AC, posAC, Sc, r, side);
     }
@@ -1665,7 +1701,9 @@ struct RsqpLargeEngine::Impl {
             dot(w1, Zc(nZ - 1), nV, 5);
         }
         nZ--;
-        minv_append(5, !skipZ, r, side);
+        const bool keep = defer && !skipZ && plain_add && carry_enabled && carry_valid && carried < CARRY_REFRESH;
+        minv_append(5, !skipZ, r, side, keep);
+        carry_pending = keep;
         hAC[nAC] = r; hSc[r] = side;
         nAC++;
         return RET_OK;
@@ -1865,6 +1903,7 @@ struct RsqpLargeEngine::Impl {
 
     int change_active_set(int kind, int idx, int side) {
         flush_pending();
+        carry_pending = false;       // (set again by a plain added constraint, the last operation below)
         if (kind == 1) return remove_with_guard(false, idx, nullptr, nullptr);
         if (kind == 2) return remove_with_guard(true, idx, nullptr, nullptr);
         double ynew = 0.0;
@@ -1889,7 +1928,9 @@ struct RsqpLargeEngine::Impl {
             if (kind == 3) constraint_products(idx); else bound_products(idx);
         }
         if (kind == 3) {
+            plain_add = li;
             add_constraint(idx, side, !full, true);      // (the last operation of the change: the step direction follows)
+            plain_add = false;
             hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, y, nV + idx, ynew);
         } else {
             add_bound(idx, side, !full);
@@ -1911,8 +1952,19 @@ struct RsqpLargeEngine::Impl {
         hipLaunchKernelGGL(k_sd_prep, g1(std::max(nAC, nV)), dim3(NT), 0, st, nAC, AC, Sc, lbA, ubA, lbAN, ubAN, c1, a1, nV, w2, gN, g,
                            w1);                                            // bA -> a1, tmpg -> w1
         // range space: wY = Minv bA ; xY = Y wY
-        gemv_n(Minv, ldm, nAC, nAC, a1, 1.0, 0.0, nullptr, a2);
-        gemv_n(Y, ld, nV, nAC, a2, 1.0, 0.0, nullptr, w3);                 // xY
+        if (carry_pending && carry_valid && nAC > 0) {
+            const double om = 1.0 - last_tau;
+            hipLaunchKernelGGL(k_carry_wY, dim3(1), dim3(NT), 0, st, nAC - 1, om, a1, c_xi, c_wY, scal, S_KEEP_ETA, S_KEEP_WLAST);
+            hipLaunchKernelGGL(k_carry_xY, g1(nV), dim3(NT), 0, st, nV, om, Yc(nAC - 1), scal, S_KEEP_WLAST, c_xY);
+            carried++;
+        } else {
+            gemv_n(Minv, ldm, nAC, nAC, a1, 1.0, 0.0, nullptr, c_wY);
+            gemv_n(Y, ld, nV, nAC, c_wY, 1.0, 0.0, nullptr, c_xY);         // xY
+            carried = 0;
+        }
+        carry_pending = false;
+        carry_valid = true;
+        double *const w3 = c_xY;                                           // (xY lives in its own buffer: the next step may scale it)
         // null space: wZ = -Wz Z'(tmpg + H xY) ; dx_FR = xY + Z wZ
         H_times(w3, w2, w1);                                               // w2 = H xY + tmpg
         gemv_t_Z_pending(w2, nullptr, wz1);                               // (+ the deferred reflection of Z)
@@ -1961,6 +2013,8 @@ struct RsqpLargeEngine::Impl {
         status = QPS_PERFORMINGHOMOTOPY;
         dx_ready = false;
         pendZ.on = pendW.on = false;      // (nothing is deferred across solves; a solve that failed half-way leaves nothing behind)
+        carry_valid = carry_pending = false;
+        carried = 0;
         refresh_products();
         hipLaunchKernelGGL(k_rerelax, g1(nV), dim3(NT), 0, st, nV, Sb, x, lbN, ubN, lb, ub);
         if (nC > 0) hipLaunchKernelGGL(k_rerelax, g1(nC), dim3(NT), 0, st, nC, Sc, Ax, lbAN, ubAN, lbA, ubA);
@@ -1988,7 +2042,9 @@ struct RsqpLargeEngine::Impl {
             if (extra_sync) (void)hipStreamSynchronize(st);      // tuning: what one more host round trip per change costs
             if (done) { A_times(x, Ax); status = QPS_SOLVED; break; }
             if (iter >= maxit) { rcode = RET_MAX_NWSR; break; }
+            last_tau = tau;
             rcode = change_active_set(kind, idx, side);
+            if (!carry_pending) carry_valid = false;          // anything but a plain added constraint: exact products next
             if (rcode == RET_INFEASIBLE) { infeasible = 1; break; }
             if (rcode == RET_UNBOUNDED) { unbounded = 1; break; }
             if (rcode != RET_OK) break;
@@ -2218,6 +2274,7 @@ hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
     DA(x, nV); DA(g, nV); DA(lb, nV); DA(ub, nV); DA(gN, nV); DA(lbN, nV); DA(ubN, nV); DA(dx, nV);
     DA(w1, nV); DA(w2, nV); DA(w3, nV); DA(w4, nV); DA(w5, nV); DA(w6, nV); DA(wz1, nV); DA(wz2, nV); DA(wz3, nV);
     DA(pz_t, nV); DA(pz_v, nV); DA(pw_s, nV); DA(pw_col, nV);
+    DA(c_wY, P.nAmax + 2); DA(c_xY, nV); DA(c_xi, P.nAmax + 2);
     DA(Ax, nC); DA(lbA, nC); DA(ubA, nC); DA(lbAN, nC); DA(ubAN, nC); DA(dAx, nC); DA(c1, nC); DA(c2, nC); DA(c3, nC);
     DA(a1, P.nAmax + 2); DA(a2, P.nAmax + 2); DA(a3, P.nAmax + 2); DA(a4, P.nAmax + 2);
     DA(y, nV + nC); DA(dy, nV + nC);

@@ -134,10 +134,11 @@ def test_deferred_reflection_kernels_match_oracle(capi, oracle, monkeypatch):
     """An incoming constraint's reflection of Z and the shrinking of Wz ride on the step direction's products (k_ger_gemv_t,
     k_wz_shrink_gemv); the second one only from 3 072 null-space columns on. Forced on for every size here (the engine reads
     the knob when a solver is created), and switched off altogether: the same decisions as the oracle either way, cold and
-    hot start."""
+    hot start. Third knob: the range-space part of the step direction recomputed at every step instead of carried over an
+    added constraint (k_carry_wY / k_carry_xY, the default)."""
     rng = np.random.default_rng(4711)
     cases = [problems.random_qp(rng, 64, 40, 0.5), problems.random_qp(rng, 150, 120, 0.3), problems.random_qp(rng, 96, 200, 0.4)]
-    for knob, val in (("RSQP_LARGE_FUSE_WZ_MIN", "0"), ("RSQP_LARGE_NO_FUSE", "1")):
+    for knob, val in (("RSQP_LARGE_FUSE_WZ_MIN", "0"), ("RSQP_LARGE_NO_FUSE", "1"), ("RSQP_LARGE_NO_CARRY", "1")):
         monkeypatch.setenv(knob, val)
         for q in cases:
             s = load(capi, q)
