@@ -31,4 +31,4 @@ for m, b, cond in ((10000, 64, 1.0), (2330, 64, 1e3), (300, 64, 1e5), (64, 64, 1
     H = np.eye(m) - V @ T @ V.T
     print("m %5d b %2d cond %.0e: |V - V_lapack| %.1e  |tau - tau_lapack| %.1e  |R - R_lapack|/|R| %.1e  |H'H - I| %.1e  |H'P - [R;0]|/|P| %.1e" % (
         m, b, np.linalg.cond(P), np.abs(V - Vl).max(), np.abs(np.diag(T) - tau).max(), np.abs(R - Rl).max() / np.abs(Rl).max(),
-        np.abs(H.T @ H - np.eye(m)).max() if m <= 2500 else -1, np.abs((P - V @ (T.T @ (V.T @ P)))[b:]).max() / np.abs(P).max()))
+        np.abs(H.T @ H - np.eye(m)).max() if m <= 2500 else -1, (np.abs((P - V @ (T.T @ (V.T @ P)))[b:]).max() if m > b else 0.0) / np.abs(P).max()))
