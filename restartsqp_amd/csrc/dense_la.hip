@@ -24,6 +24,9 @@ constexpr int GK16 = 16;   // K step of the GEMM (32 for the 8-wave 128 x 128 ti
 #ifndef RSQP_GPAD
 #define RSQP_GPAD 4
 #endif
+#ifndef RSQP_GEMM_GK
+#define RSQP_GEMM_GK 16     // K step of the 128 x 128 tile (tuning builds: 32)
+#endif
 #ifndef RSQP_GEMM_DB
 #define RSQP_GEMM_DB 0
 #endif
@@ -46,6 +49,36 @@ __device__ __forceinline__ void load_tile(double (&r)[GK * T / NTHR], const doub
         r[e] = v;
     }
 }
+// the same tile through per-thread pointers that step along K: one load and one 64-bit add per element instead of the index
+// arithmetic, bounds tests and selects of load_tile (~350 VALU instructions per K step of a wave against its 32 MFMAs -- they
+// kept the matrix pipe at 67 % busy). Valid while the whole K range of the tile is inside the slice (the last, partial step of
+// a slice takes load_tile); a tile index past the edge of the matrix is CLAMPED to the last one: what it loads only reaches
+// rows / columns of C that are never stored.
+template <int T, int NTHR, int GK> struct TilePtr {
+    static constexpr int E = GK * T / NTHR;
+    const double *p[E];
+    long long step;
+    __device__ __forceinline__ void init(const double *X, long long ld, bool kcontig, int k0, int t0, int tmax) {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            int kk, t;
+            if (kcontig) { kk = tid & (GK - 1); t = tid / GK + (NTHR / GK) * e; }
+            else { t = tid % T; kk = tid / T + (NTHR / T) * e; }
+            const int gt = min(t0 + t, tmax - 1);
+            p[e] = kcontig ? X + (k0 + kk) + (long long)gt * ld : X + gt + (long long)(k0 + kk) * ld;
+        }
+        step = kcontig ? (long long)GK : (long long)GK * ld;
+    }
+    __device__ __forceinline__ void load(double (&r)[E]) {
+#pragma unroll
+        for (int e = 0; e < E; e++) { r[e] = *p[e]; p[e] += step; }
+    }
+    __device__ __forceinline__ void skip() {
+#pragma unroll
+        for (int e = 0; e < E; e++) p[e] += step;
+    }
+};
 template <int T, int NTHR, int GK>
 __device__ __forceinline__ void store_tile(const double (&r)[GK * T / NTHR], double (*S)[T + GPAD], bool kcontig) {
     constexpr int E = GK * T / NTHR;
@@ -85,8 +118,15 @@ k_dgemm(int ta, int tb, int m, int n, int kfull, int kc, double alpha, const dou
 #pragma unroll
         for (int b = 0; b < MI; b++) acc[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
     double ra[GK * TM / NTHR], rb[GK * TN / NTHR];
-    load_tile<TM, NTHR, GK>(ra, A, lda, akc, kbeg, i0, k, m);
-    load_tile<TN, NTHR, GK>(rb, B, ldb, bkc, kbeg, j0, k, n);
+    TilePtr<TM, NTHR, GK> pa;
+    TilePtr<TN, NTHR, GK> pb;
+    pa.init(A, lda, akc, kbeg, i0, m);
+    pb.init(B, ldb, bkc, kbeg, j0, n);
+    if (kbeg + GK <= k) { pa.load(ra); pb.load(rb); }
+    else {
+        load_tile<TM, NTHR, GK>(ra, A, lda, akc, kbeg, i0, k, m);
+        load_tile<TN, NTHR, GK>(rb, B, ldb, bkc, kbeg, j0, k, n);
+    }
     if (NBUF == 2) {
         store_tile<TM, NTHR, GK>(ra, reinterpret_cast<double (*)[TM + GPAD]>(gemm_lds), akc);
         store_tile<TN, NTHR, GK>(rb, reinterpret_cast<double (*)[TN + GPAD]>(gemm_lds + GK * (TM + GPAD)), bkc);
@@ -103,8 +143,11 @@ k_dgemm(int ta, int tb, int m, int n, int kfull, int kc, double alpha, const dou
         }
         const bool more = k0 + GK < k;
         if (more) {
-            load_tile<TM, NTHR, GK>(ra, A, lda, akc, k0 + GK, i0, k, m);
-            load_tile<TN, NTHR, GK>(rb, B, ldb, bkc, k0 + GK, j0, k, n);
+            if (k0 + 2 * GK <= k) { pa.load(ra); pb.load(rb); }      // (uniform: the next tile lies inside the slice)
+            else {
+                load_tile<TM, NTHR, GK>(ra, A, lda, akc, k0 + GK, i0, k, m);
+                load_tile<TN, NTHR, GK>(rb, B, ldb, bkc, k0 + GK, j0, k, n);
+            }
         }
 #pragma unroll
         for (int k4 = 0; k4 < GK; k4 += 4) {
@@ -201,7 +244,7 @@ static hipError_t dgemm_ws(bool transA, bool transB, int m, int n, int k, double
     if (TM == 128 && TN == 128) {
         // measured on 4096^3: 8 waves (4 resident per SIMD, 122 VGPRs) 53.5 TFLOP/s; 4 waves x 2 resident
         // 51.5; 4 waves x 1 resident (the compiler's default allocation) 37.8; K step 32 is slower (spills)
-        if (nw_big == 8) GEMM_LAUNCH(128, 128, 8, 4, 16);
+        if (nw_big == 8) GEMM_LAUNCH(128, 128, 8, 4, RSQP_GEMM_GK);
         else GEMM_LAUNCH(128, 128, 4, 2, 16);
     }
     else if (TM == 64 && TN == 128) GEMM_LAUNCH(64, 128, 4, 3, 16);
