@@ -217,7 +217,7 @@ static hipError_t dgemm_ws(bool transA, bool transB, int m, int n, int k, double
     // a block of reflectors against a wide matrix (W = V'C: 256 x n with an inner dimension of thousands): the large tile,
     // and K split so that the chip has work -- 64 x 64 tiles ran these at 29-35 TFLOP/s (RSQP_GEMM_SKINNY=0: as before)
     static const int skinny = getenv("RSQP_GEMM_SKINNY") ? atoi(getenv("RSQP_GEMM_SKINNY")) : 1;
-    const bool skinny_case = skinny && ws && m <= 256 && m >= 128 && n >= 1024 && k >= 2048 && ws_cap >= 2LL * m * n;
+    const bool skinny_case = skinny && ws && m <= 512 && m >= 128 && n >= 1024 && k >= 2048 && ws_cap >= 2LL * m * n;
     if (skinny_case) { TM = 128; TN = skinny == 2 ? 64 : 128; }
     const int bx = (m + TM - 1) / TM, by = (n + TN - 1) / TN;
     // a long inner dimension over few output tiles: split K so that the chip has work
@@ -269,7 +269,10 @@ hipError_t rsqp_dgemm(bool transA, bool transB, int m, int n, int k, double alph
 namespace {
 
 constexpr int NB = 64;
-constexpr int OB = 256;    // outer block of the QR: the trailing matrix is updated once per OB columns (aggregated reflector)
+#ifndef RSQP_QR_OB
+#define RSQP_QR_OB 256
+#endif
+constexpr int OB = RSQP_QR_OB;    // outer block of the QR: the trailing matrix is updated once per OB columns (aggregated reflector)
 
 template <int NTHR>
 __device__ __forceinline__ double block_sum(double v, double *red) {
