@@ -100,7 +100,8 @@ k_dgemm(int ta, int tb, int m, int n, int kfull, int kc, double alpha, const dou
     extern __shared__ __attribute__((aligned(16))) double gemm_lds[];
     // RSQP_GEMM_DB=1 (tuning build, tools/gemm_pad_variants.sh): two LDS buffers, the tiles of step i + 1 stored while step i is
     // still being multiplied, one barrier per K step instead of two -- measured SLOWER (51.3 vs 53.1 TFLOP/s on 4096^3, QR
-    // 100.4 vs 97.8 ms): the barriers are not what keeps the MFMA pipe at 67 % busy. Row paddings 2 .. 20 doubles: no difference.
+    // 100.4 vs 97.8 ms): the barriers are not what keeps the MFMA pipe at 67 % busy. Row paddings 2 .. 20 doubles: no difference. Other tile shapes (RSQP_GEMM_TILE), K step 32
+    // (spills), the AGPR form of the MFMAs (a 64 / 64 register split: spills, 16 TFLOP/s): all slower or equal.
     constexpr int NBUF = RSQP_GEMM_DB ? 2 : 1;
     constexpr int TILE_DOUBLES = GK * ((TM + GPAD) + (TN + GPAD));
     constexpr int NTHR = NW * 64, WN = NW / 2;
@@ -219,6 +220,8 @@ static hipError_t dgemm_ws(bool transA, bool transB, int m, int n, int k, double
     static const int skinny = getenv("RSQP_GEMM_SKINNY") ? atoi(getenv("RSQP_GEMM_SKINNY")) : 1;
     const bool skinny_case = skinny && ws && m <= 512 && m >= 128 && n >= 1024 && k >= 2048 && ws_cap >= 2LL * m * n;
     if (skinny_case) { TM = 128; TN = skinny == 2 ? 64 : 128; }
+    static const int force_tile = getenv("RSQP_GEMM_TILE") ? atoi(getenv("RSQP_GEMM_TILE")) : 0;      // tuning: 12864 / 64128 / 6464
+    if (force_tile == 12864) { TM = 128; TN = 64; } else if (force_tile == 64128) { TM = 64; TN = 128; } else if (force_tile == 6464) { TM = 64; TN = 64; }
     const int bx = (m + TM - 1) / TM, by = (n + TN - 1) / TN;
     // a long inner dimension over few output tiles: split K so that the chip has work
     int splits = 1;
