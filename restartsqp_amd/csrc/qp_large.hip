@@ -961,6 +961,24 @@ __global__ void k_carry_xY(int n, double om, const double *__restrict__ yk, cons
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) xY[i] = om * xY[i] + scal[sl] * yk[i];
 }
+// ... and over a REMOVED constraint (remove_constraint_tq: Y <- Y P, Minv <- P Minv with P = I - beta v v', then the last column of
+// Y moves to Z): wY <- (1 - tau) (P wY)[0..k), xY <- (1 - tau) (xY - omega z_new) with omega = (P wY)[k]  (one workgroup; omega
+// into scal[sl])
+__global__ void __launch_bounds__(NT) k_carry_remove_wY(int k, double om, const double *__restrict__ v, double *__restrict__ wY,
+                                                        double *__restrict__ scal, int sb, int sl) {
+    __shared__ double sh[4];
+    double d = 0.0;
+    for (int i = threadIdx.x; i <= k; i += NT) d += v[i] * wY[i];
+    d = block_sum(d, sh);
+    const double c = scal[sb] * d;
+    if (threadIdx.x == 0) scal[sl] = wY[k] - c * v[k];
+    for (int i = threadIdx.x; i < k; i += NT) wY[i] = om * (wY[i] - c * v[i]);
+}
+__global__ void k_carry_remove_xY(int n, double om, const double *__restrict__ znew, const double *__restrict__ scal, int sl,
+                                  double *__restrict__ xY) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) xY[i] = om * (xY[i] - scal[sl] * znew[i]);
+}
 // what that needs from the border of Minv: the row xi and eta, out of the way of the next products
 __global__ void k_keep_border(int k, const double *__restrict__ row, double *__restrict__ keep, double *__restrict__ scal, int es,
                               int eta_from_house, int se) {
@@ -1675,6 +1693,8 @@ struct RsqpLargeEngine::Impl {
     bool carry_enabled = getenv("RSQP_LARGE_NO_CARRY") == nullptr;
     bool carry_valid = false;        // c_wY / c_xY are those of the last step direction, nothing but a homotopy step since
     bool carry_pending = false;      // ... and the change behind it was a plain added constraint (border kept in c_xi, S_KEEP_ETA)
+    bool carry_ready = false;        // ... or a plain removed constraint: c_wY / c_xY already transformed (remove_constraint_tq)
+    bool plain_removal = false;      // the change is ONE removed constraint (not the partner of an exchange)
     int carried = 0;
     bool plain_add = false;          // the change is ONE added constraint (no exchange partner removed first)
     double last_tau = 0.0;
@@ -1782,6 +1802,12 @@ struct RsqpLargeEngine::Impl {
         gemv_t(Minv, ldm, nAC, nAC, a2, a3);                             // s' = v' Minv
         ger(Minv, ldm, nAC, nAC, a2, a3, 1, -1.0);                       // Minv -= beta v s'
         copy(Yc(nAC - 1), Zc(nZ), nV);                                   // new null-space column
+        if (plain_removal && carry_enabled && carry_valid && carried < CARRY_REFRESH && nAC > 1) {
+            const double om = 1.0 - last_tau;
+            hipLaunchKernelGGL(k_carry_remove_wY, dim3(1), dim3(NT), 0, st, nAC - 1, om, a2, c_wY, scal, 1, S_KEEP_WLAST);
+            hipLaunchKernelGGL(k_carry_remove_xY, g1(nV), dim3(NT), 0, st, nV, om, Zc(nZ), scal, S_KEEP_WLAST, c_xY);
+            carry_ready = true;
+        }
         // delete row (nAC-1) [implicit] and column k: move the last column into k
         if (k != nAC - 1) {
             copy(Minv + (long long)(nAC - 1) * ldm, Minv + k * ldm, nAC);
@@ -1903,8 +1929,15 @@ struct RsqpLargeEngine::Impl {
 
     int change_active_set(int kind, int idx, int side) {
         flush_pending();
-        carry_pending = false;       // (set again by a plain added constraint, the last operation below)
-        if (kind == 1) return remove_with_guard(false, idx, nullptr, nullptr);
+        carry_pending = carry_ready = false;       // (set again by a plain added / removed constraint below)
+        if (kind == 1) {
+            plain_removal = true;
+            const int flips_before_change = nflips;
+            const int rc = remove_with_guard(false, idx, nullptr, nullptr);
+            plain_removal = false;
+            if (nflips != flips_before_change) carry_ready = false;     // the constraint came back on its other side: not a plain removal
+            return rc;
+        }
         if (kind == 2) return remove_with_guard(true, idx, nullptr, nullptr);
         double ynew = 0.0;
         bool li = false, full = true;
@@ -1952,7 +1985,9 @@ struct RsqpLargeEngine::Impl {
         hipLaunchKernelGGL(k_sd_prep, g1(std::max(nAC, nV)), dim3(NT), 0, st, nAC, AC, Sc, lbA, ubA, lbAN, ubAN, c1, a1, nV, w2, gN, g,
                            w1);                                            // bA -> a1, tmpg -> w1
         // range space: wY = Minv bA ; xY = Y wY
-        if (carry_pending && carry_valid && nAC > 0) {
+        if (carry_ready && carry_valid) {
+            carried++;                                                     // (transformed by remove_constraint_tq already)
+        } else if (carry_pending && carry_valid && nAC > 0) {
             const double om = 1.0 - last_tau;
             hipLaunchKernelGGL(k_carry_wY, dim3(1), dim3(NT), 0, st, nAC - 1, om, a1, c_xi, c_wY, scal, S_KEEP_ETA, S_KEEP_WLAST);
             hipLaunchKernelGGL(k_carry_xY, g1(nV), dim3(NT), 0, st, nV, om, Yc(nAC - 1), scal, S_KEEP_WLAST, c_xY);
@@ -1962,7 +1997,7 @@ struct RsqpLargeEngine::Impl {
             gemv_n(Y, ld, nV, nAC, c_wY, 1.0, 0.0, nullptr, c_xY);         // xY
             carried = 0;
         }
-        carry_pending = false;
+        carry_pending = carry_ready = false;
         carry_valid = true;
         double *const w3 = c_xY;                                           // (xY lives in its own buffer: the next step may scale it)
         // null space: wZ = -Wz Z'(tmpg + H xY) ; dx_FR = xY + Z wZ
@@ -2013,7 +2048,7 @@ struct RsqpLargeEngine::Impl {
         status = QPS_PERFORMINGHOMOTOPY;
         dx_ready = false;
         pendZ.on = pendW.on = false;      // (nothing is deferred across solves; a solve that failed half-way leaves nothing behind)
-        carry_valid = carry_pending = false;
+        carry_valid = carry_pending = carry_ready = false;
         carried = 0;
         refresh_products();
         hipLaunchKernelGGL(k_rerelax, g1(nV), dim3(NT), 0, st, nV, Sb, x, lbN, ubN, lb, ub);
@@ -2044,7 +2079,7 @@ struct RsqpLargeEngine::Impl {
             if (iter >= maxit) { rcode = RET_MAX_NWSR; break; }
             last_tau = tau;
             rcode = change_active_set(kind, idx, side);
-            if (!carry_pending) carry_valid = false;          // anything but a plain added constraint: exact products next
+            if (!carry_pending && !carry_ready) carry_valid = false;      // anything but a plain added / removed constraint: exact products next
             if (rcode == RET_INFEASIBLE) { infeasible = 1; break; }
             if (rcode == RET_UNBOUNDED) { unbounded = 1; break; }
             if (rcode != RET_OK) break;
