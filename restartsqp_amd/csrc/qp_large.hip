@@ -300,6 +300,65 @@ __global__ void __launch_bounds__(NTH) k_gemv_n1(const double *__restrict__ M, l
     }
 }
 
+// The rank-1 update M += coef t v' and out = beta * base + alpha * M w of the UPDATED matrix in one pass, in the single-launch
+// form of k_gemv_n1 (a workgroup owns 16 consecutive rows and all columns, 16-byte accesses; leading dimension even, M 16-byte
+// aligned): the deferred reflection of Z riding on the step direction's LAST product when its first one is carried (k_carry_wZ).
+template <int NTH>
+__global__ void __launch_bounds__(NTH) k_ger_gemv_n1(double *__restrict__ M, long long ld, int nrows, int ncols,
+                                                     const double *__restrict__ ut, const double *__restrict__ uv,
+                                                     const double *__restrict__ scal, int ci, double cs,
+                                                     const double *__restrict__ w, double alpha, double beta,
+                                                     const double *__restrict__ base, double *__restrict__ out,
+                                                     const int *__restrict__ mSb, double *__restrict__ mdst) {
+    constexpr int NG = NTH / 8;          // column groups
+    __shared__ double sh[NG][17];
+    const int rl = threadIdx.x & 7, cg = threadIdx.x >> 3;
+    const int r = (blockIdx.x * 8 + rl) * 2;
+    const double coef = cs * scal[ci];
+    double a0 = 0.0, a1 = 0.0;
+    if (r + 1 < nrows) {
+        const double2 tv = *reinterpret_cast<const double2 *>(ut + r);
+        const double t0 = coef * tv.x, t1 = coef * tv.y;
+        double2 s0 = {0, 0}, s1 = {0, 0};
+        int c = cg;
+        for (; c + NG < ncols; c += 2 * NG) {
+            double *p0 = M + c * ld + r, *p1 = M + (c + NG) * ld + r;
+            double2 m0 = *reinterpret_cast<double2 *>(p0), m1 = *reinterpret_cast<double2 *>(p1);
+            const double v0 = uv[c], v1 = uv[c + NG], w0 = w[c], w1 = w[c + NG];
+            m0.x += t0 * v0; m0.y += t1 * v0; m1.x += t0 * v1; m1.y += t1 * v1;
+            *reinterpret_cast<double2 *>(p0) = m0; *reinterpret_cast<double2 *>(p1) = m1;
+            s0.x += m0.x * w0; s0.y += m0.y * w0; s1.x += m1.x * w1; s1.y += m1.y * w1;
+        }
+        for (; c < ncols; c += NG) {
+            double *p0 = M + c * ld + r;
+            double2 m0 = *reinterpret_cast<double2 *>(p0);
+            const double v0 = uv[c], w0 = w[c];
+            m0.x += t0 * v0; m0.y += t1 * v0;
+            *reinterpret_cast<double2 *>(p0) = m0;
+            s0.x += m0.x * w0; s0.y += m0.y * w0;
+        }
+        a0 = s0.x + s1.x; a1 = s0.y + s1.y;
+    } else if (r < nrows) {
+        const double t0 = coef * ut[r];
+        for (int c = cg; c < ncols; c += NG) { double *p0 = M + c * ld + r; const double m = *p0 + t0 * uv[c]; *p0 = m; a0 += m * w[c]; }
+    }
+    sh[cg][2 * rl] = a0; sh[cg][2 * rl + 1] = a1;
+    __syncthreads();
+    if ((int)threadIdx.x < 16) {
+        const int rr = blockIdx.x * 16 + threadIdx.x;
+        if (rr < nrows) {
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+            for (int g = 0; g < NG; g += 4) {
+                t0 += sh[g][threadIdx.x]; t1 += sh[g + 1][threadIdx.x]; t2 += sh[g + 2][threadIdx.x]; t3 += sh[g + 3][threadIdx.x];
+            }
+            const double v = (base ? beta * base[rr] : 0.0) + alpha * ((t0 + t1) + (t2 + t3));
+            out[rr] = v;
+            if (mSb && mSb[rr] == 0) mdst[rr] = v;
+        }
+    }
+}
+
 // M[c*ld + r] += coef * t[r] * v[c]   (coef = scal[ci] * cs)
 __global__ void __launch_bounds__(NT) k_ger(double *__restrict__ M, long long ld, int nrows, int ncols,
                                             const double *__restrict__ t, const double *__restrict__ v,
@@ -979,6 +1038,24 @@ __global__ void k_carry_remove_xY(int n, double om, const double *__restrict__ z
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) xY[i] = om * (xY[i] - scal[sl] * znew[i]);
 }
+// The NULL-space part behind an added constraint, carried as well: with P = I - beta v v' the reflection of Z, wZ' = P wZ,
+// col = the last column of P Wz P (k_wz_lastcol), kappa = col[0..l) / col[l], wY_k the new entry of wY:
+//   wZ[0..l) <- (1 - tau) (wZ'[0..l) - kappa wZ'[l]) + wY_k kappa
+// (block elimination of the last null-space column from Z'HZ wZ = -Z'(g~ + H xY), whose right-hand side gained wY_k Z'H y_k;
+// DESIGN 4.1). One workgroup.
+__global__ void __launch_bounds__(NT) k_carry_wZ(int l, double om, const double *__restrict__ v, const double *__restrict__ col,
+                                                 double *__restrict__ wZ, const double *__restrict__ scal, int sb, int sl) {
+    __shared__ double sh[4];
+    double d = 0.0;
+    for (int i = threadIdx.x; i <= l; i += NT) d += v[i] * wZ[i];
+    d = block_sum(d, sh);
+    const double c = scal[sb] * d, wl = wZ[l] - c * v[l], wyk = scal[sl], rc = 1.0 / col[l];
+    __syncthreads();
+    for (int i = threadIdx.x; i < l; i += NT) {
+        const double kap = col[i] * rc;
+        wZ[i] = om * ((wZ[i] - c * v[i]) - kap * wl) + wyk * kap;
+    }
+}
 // what that needs from the border of Minv: the row xi and eta, out of the way of the next products
 __global__ void k_keep_border(int k, const double *__restrict__ row, double *__restrict__ keep, double *__restrict__ scal, int es,
                               int eta_from_house, int se) {
@@ -1342,7 +1419,7 @@ struct RsqpLargeEngine::Impl {
     // vectors (nV)
     double *x, *g, *lb, *ub, *gN, *lbN, *ubN, *dx, *w1, *w2, *w3, *w4, *w5, *w6, *wz1, *wz2, *wz3;
     double *pz_t = nullptr, *pz_v = nullptr, *pw_s = nullptr, *pw_col = nullptr;   // operands of a deferred reflection (z_reflect_and_shrink)
-    double *c_wY = nullptr, *c_xY = nullptr, *c_xi = nullptr;                    // range-space part of the step direction, carried over an added constraint
+    double *c_wY = nullptr, *c_xY = nullptr, *c_xi = nullptr, *c_wZ = nullptr;                    // range-space part of the step direction, carried over an added constraint
     // vectors (nC)
     double *Ax, *lbA, *ubA, *lbAN, *ubAN, *dAx, *c1, *c2, *c3, *a1, *a2, *a3, *a4;
     double *y, *dy, *part, *scal, *pt, *res_t;
@@ -1413,7 +1490,7 @@ struct RsqpLargeEngine::Impl {
 
     ~Impl() {
         double *dv[] = {Z, Y, Minv, Wz, x, g, lb, ub, gN, lbN, ubN, dx, w1, w2, w3, w4, w5, w6, wz1, wz2, wz3, Ax, lbA, ubA,
-                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col, c_wY, c_xY, c_xi};
+                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col, c_wY, c_xY, c_xi, c_wZ};
         for (double *p : dv) if (p) (void)hipFree(p);
         if (big) (void)hipFree(big);
         rsqp_dense_work_free(&dw);
@@ -1430,7 +1507,7 @@ struct RsqpLargeEngine::Impl {
     // RSQP_PROFILE=1: per kernel class, HIP-event time and algorithmic bytes (serialises the stream)
     bool profile = getenv("RSQP_PROFILE") != nullptr;
     struct Prof { double ms = 0, bytes = 0; long long calls = 0; };
-    Prof prof[8];
+    Prof prof[10];
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     void pbegin() { if (profile) { if (!pe0) { (void)hipEventCreate(&pe0); (void)hipEventCreate(&pe1); } (void)hipEventRecord(pe0, st); } }
@@ -1442,8 +1519,8 @@ struct RsqpLargeEngine::Impl {
     }
     void preport() {
         if (!profile) return;
-        const char *nm[8] = {"gemv_n", "gemv_t", "ger", "wz_shrink", "wz_grow", "spmv", "ger_gemv_t", "shrink_gemv"};
-        for (int k = 0; k < 8; k++)
+        const char *nm[10] = {"gemv_n", "gemv_t", "ger", "wz_shrink", "wz_grow", "spmv", "ger_gemv_t", "shrink_gemv", "ger_gemv_n", ""};
+        for (int k = 0; k < 10; k++)
             if (prof[k].calls) fprintf(stderr, "[rsqp profile] %-9s calls %8lld  time %9.3f ms  bytes %10.3f GB  => %7.1f GB/s  (avg %.1f us)\n", nm[k], prof[k].calls, prof[k].ms, prof[k].bytes / 1e9, prof[k].bytes / (prof[k].ms * 1e-3) / 1e9, 1e3 * prof[k].ms / prof[k].calls);
     }
     void chk(const char *what) {
@@ -1691,6 +1768,7 @@ struct RsqpLargeEngine::Impl {
     // step, and every CARRY_REFRESH carried steps (RSQP_LARGE_NO_CARRY=1: always exactly).
     static constexpr int S_KEEP_ETA = 43, S_KEEP_WLAST = 42, CARRY_REFRESH = 8;
     bool carry_enabled = getenv("RSQP_LARGE_NO_CARRY") == nullptr;
+    bool carry_null_enabled = getenv("RSQP_LARGE_NO_CARRY_NULL") == nullptr;   // (the null-space part as well, k_carry_wZ)
     bool carry_valid = false;        // c_wY / c_xY are those of the last step direction, nothing but a homotopy step since
     bool carry_pending = false;      // ... and the change behind it was a plain added constraint (border kept in c_xi, S_KEEP_ETA)
     bool carry_ready = false;        // ... or a plain removed constraint: c_wY / c_xY already transformed (remove_constraint_tq)
@@ -1985,6 +2063,7 @@ struct RsqpLargeEngine::Impl {
         hipLaunchKernelGGL(k_sd_prep, g1(std::max(nAC, nV)), dim3(NT), 0, st, nAC, AC, Sc, lbA, ubA, lbAN, ubAN, c1, a1, nV, w2, gN, g,
                            w1);                                            // bA -> a1, tmpg -> w1
         // range space: wY = Minv bA ; xY = Y wY
+        bool carry_null = false;      // the null-space part is carried too (needs the deferred reflection's v / col / beta)
         if (carry_ready && carry_valid) {
             carried++;                                                     // (transformed by remove_constraint_tq already)
         } else if (carry_pending && carry_valid && nAC > 0) {
@@ -1992,6 +2071,13 @@ struct RsqpLargeEngine::Impl {
             hipLaunchKernelGGL(k_carry_wY, dim3(1), dim3(NT), 0, st, nAC - 1, om, a1, c_xi, c_wY, scal, S_KEEP_ETA, S_KEEP_WLAST);
             hipLaunchKernelGGL(k_carry_xY, g1(nV), dim3(NT), 0, st, nV, om, Yc(nAC - 1), scal, S_KEEP_WLAST, c_xY);
             carried++;
+            carry_null = carry_null_enabled && pendZ.on && pendZ.ncols == nZ && pendW.on && pendW.nZold - 1 == nZ && nZ > 0 && nV <= 16384 &&
+                         (((reinterpret_cast<unsigned long long>(pz_t)) & 15) == 0);
+            if (carry_null) {
+                hipLaunchKernelGGL(k_carry_wZ, dim3(1), dim3(NT), 0, st, nZ, om, pz_v, pw_col, c_wZ, scal, S_KEEP_BETA, S_KEEP_WLAST);
+                pendW.on = false;
+                wz_shrink_now(pendW.nZold, pw_s, pz_v, pw_col, S_KEEP_BETA, S_KEEP_THETA);        // (no product with Wz to ride on)
+            }
         } else {
             gemv_n(Minv, ldm, nAC, nAC, a1, 1.0, 0.0, nullptr, c_wY);
             gemv_n(Y, ld, nV, nAC, c_wY, 1.0, 0.0, nullptr, c_xY);         // xY
@@ -2001,10 +2087,20 @@ struct RsqpLargeEngine::Impl {
         carry_valid = true;
         double *const w3 = c_xY;                                           // (xY lives in its own buffer: the next step may scale it)
         // null space: wZ = -Wz Z'(tmpg + H xY) ; dx_FR = xY + Z wZ
-        H_times(w3, w2, w1);                                               // w2 = H xY + tmpg
-        gemv_t_Z_pending(w2, nullptr, wz1);                               // (+ the deferred reflection of Z)
-        gemv_n_Wz_pending(wz1, -1.0, wz2);                                 // (+ the deferred shrinking of Wz)
-        gemv_n(Z, ld, nV, nZ, wz2, 1.0, 1.0, w3, w4, Sb, dx);              // xY + Z wZ, merged into dx on the free variables
+        if (carry_null) {
+            // wZ carried (k_carry_wZ above): the deferred reflection of Z rides on the product Z wZ instead of on Z'w
+            pendZ.on = false;
+            pbegin();
+            hipLaunchKernelGGL((k_ger_gemv_n1<NT>), dim3((nV + 15) / 16), dim3(NT), 0, st, Z, ld, nV, nZ, pz_t, pz_v, scal, S_KEEP_BETA, -1.0,
+                               c_wZ, 1.0, 1.0, w3, w4, Sb, dx);
+            pend(8, 16.0 * nV * (double)nZ);
+            chk("ger_gemv_n1");
+        } else {
+            H_times(w3, w2, w1);                                           // w2 = H xY + tmpg
+            gemv_t_Z_pending(w2, nullptr, wz1);                           // (+ the deferred reflection of Z)
+            gemv_n_Wz_pending(wz1, -1.0, c_wZ);                            // (+ the deferred shrinking of Wz)
+            gemv_n(Z, ld, nV, nZ, c_wZ, 1.0, 1.0, w3, w4, Sb, dx);         // xY + Z wZ, merged into dx on the free variables
+        }
         // multipliers: dyAC = Minv' Y'(H dx + dg); A dx (for the ratio tests) rides along with H dx
         AH_times(dx, dAx, Hdx);
         {
@@ -2309,7 +2405,7 @@ hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
     DA(x, nV); DA(g, nV); DA(lb, nV); DA(ub, nV); DA(gN, nV); DA(lbN, nV); DA(ubN, nV); DA(dx, nV);
     DA(w1, nV); DA(w2, nV); DA(w3, nV); DA(w4, nV); DA(w5, nV); DA(w6, nV); DA(wz1, nV); DA(wz2, nV); DA(wz3, nV);
     DA(pz_t, nV); DA(pz_v, nV); DA(pw_s, nV); DA(pw_col, nV);
-    DA(c_wY, P.nAmax + 2); DA(c_xY, nV); DA(c_xi, P.nAmax + 2);
+    DA(c_wY, P.nAmax + 2); DA(c_xY, nV); DA(c_xi, P.nAmax + 2); DA(c_wZ, nV);
     DA(Ax, nC); DA(lbA, nC); DA(ubA, nC); DA(lbAN, nC); DA(ubAN, nC); DA(dAx, nC); DA(c1, nC); DA(c2, nC); DA(c3, nC);
     DA(a1, P.nAmax + 2); DA(a2, P.nAmax + 2); DA(a3, P.nAmax + 2); DA(a4, P.nAmax + 2);
     DA(y, nV + nC); DA(dy, nV + nC);
@@ -2445,7 +2541,7 @@ int RsqpLargeEngine::status_word() const {
 int RsqpLargeEngine::nflips() const { return p_->nflips; }
 hipError_t RsqpLargeEngine::last_error() const { return p_->err_; }
 const char *RsqpLargeEngine::profile_name(int k) {
-    static const char *nm[PROFILE_CLASSES] = {"gemv_n", "gemv_t", "ger", "wz_shrink", "wz_grow", "spmv", "ger_gemv_t", "shrink_gemv"};
+    static const char *nm[PROFILE_CLASSES] = {"gemv_n", "gemv_t", "ger", "wz_shrink", "wz_grow", "spmv", "ger_gemv_t", "shrink_gemv", "ger_gemv_n", ""};
     return k >= 0 && k < PROFILE_CLASSES ? nm[k] : "";
 }
 void RsqpLargeEngine::profile_enable(bool on) { p_->profile = on; }

@@ -41,7 +41,7 @@ public:
     hipError_t last_error() const;
     // per-kernel-class accounting (HIP events around every launch of the class: serialises the stream, so
     // only for measurement runs). Classes: names(); get() fills {calls, ms, algorithmic bytes, 0} per class.
-    static constexpr int PROFILE_CLASSES = 8;
+    static constexpr int PROFILE_CLASSES = 10;
     static const char *profile_name(int k);
     void profile_enable(bool on);
     void set_reinit_from_y0(bool on);   // warm start without guessed constraints: from A x0 (default, the reference) or sides from sign(y0) (opt-in)
