@@ -1774,6 +1774,7 @@ struct RsqpLargeEngine::Impl {
     bool carry_ready = false;        // ... or a plain removed constraint: c_wY / c_xY already transformed (remove_constraint_tq)
     bool plain_removal = false;      // the change is ONE removed constraint (not the partner of an exchange)
     int carried = 0;
+    long long stat_carried = 0, stat_carried_null = 0;
     bool plain_add = false;          // the change is ONE added constraint (no exchange partner removed first)
     double last_tau = 0.0;
     void minv_append(int eta_slot, bool eta_from_house, int r, int side, bool keep_for_carry = false) {
@@ -2065,15 +2066,16 @@ struct RsqpLargeEngine::Impl {
         // range space: wY = Minv bA ; xY = Y wY
         bool carry_null = false;      // the null-space part is carried too (needs the deferred reflection's v / col / beta)
         if (carry_ready && carry_valid) {
-            carried++;                                                     // (transformed by remove_constraint_tq already)
+            carried++; stat_carried++;                                     // (transformed by remove_constraint_tq already)
         } else if (carry_pending && carry_valid && nAC > 0) {
             const double om = 1.0 - last_tau;
             hipLaunchKernelGGL(k_carry_wY, dim3(1), dim3(NT), 0, st, nAC - 1, om, a1, c_xi, c_wY, scal, S_KEEP_ETA, S_KEEP_WLAST);
             hipLaunchKernelGGL(k_carry_xY, g1(nV), dim3(NT), 0, st, nV, om, Yc(nAC - 1), scal, S_KEEP_WLAST, c_xY);
-            carried++;
+            carried++; stat_carried++;
             carry_null = carry_null_enabled && pendZ.on && pendZ.ncols == nZ && pendW.on && pendW.nZold - 1 == nZ && nZ > 0 && nV <= 16384 &&
                          (((reinterpret_cast<unsigned long long>(pz_t)) & 15) == 0);
             if (carry_null) {
+                stat_carried_null++;
                 hipLaunchKernelGGL(k_carry_wZ, dim3(1), dim3(NT), 0, st, nZ, om, pz_v, pw_col, c_wZ, scal, S_KEEP_BETA, S_KEEP_WLAST);
                 pendW.on = false;
                 wz_shrink_now(pendW.nZold, pw_s, pz_v, pw_col, S_KEEP_BETA, S_KEEP_THETA);        // (no product with Wz to ride on)
@@ -2140,6 +2142,8 @@ struct RsqpLargeEngine::Impl {
 
     int homotopy(int maxit, int *nWSR) {
         int iter = 0, rcode = RET_OK;
+        long long kind_count[5] = {0, 0, 0, 0, 0};   // (RSQP_PROFILE: changes by kind)
+        stat_carried = stat_carried_null = 0;
         double sum_nFR = 0.0, sum_nAC = 0.0, sum_nZ = 0.0;      // reported by RSQP_PROFILE: the sizes the products run on
         status = QPS_PERFORMINGHOMOTOPY;
         dx_ready = false;
@@ -2174,6 +2178,7 @@ struct RsqpLargeEngine::Impl {
             if (done) { A_times(x, Ax); status = QPS_SOLVED; break; }
             if (iter >= maxit) { rcode = RET_MAX_NWSR; break; }
             last_tau = tau;
+            kind_count[kind]++;
             rcode = change_active_set(kind, idx, side);
             if (!carry_pending && !carry_ready) carry_valid = false;      // anything but a plain added / removed constraint: exact products next
             if (rcode == RET_INFEASIBLE) { infeasible = 1; break; }
@@ -2186,6 +2191,9 @@ struct RsqpLargeEngine::Impl {
         if ((profile || getenv("RSQP_LARGE_WAITSTAT")) && iter > 0)
             fprintf(stderr, "[rsqp profile] homotopy: %d changes, mean nFR %.1f nAC %.1f nZ %.1f (nV %d nC %d); host waited %.3f s in %lld round trips\n", iter,
                     sum_nFR / iter, sum_nAC / iter, sum_nZ / iter, nV, nC, wait_seconds, wait_calls);
+        if (profile && iter > 0)
+            fprintf(stderr, "[rsqp profile] changes by kind: constraint out %lld, bound out %lld, constraint in %lld, bound in %lld; step directions with the range-space part carried %lld, null-space part too %lld\n",
+                    kind_count[1], kind_count[2], kind_count[3], kind_count[4], stat_carried, stat_carried_null);
         flush_pending();
         *nWSR = iter;
         return rcode;
