@@ -405,7 +405,9 @@ __global__ void __launch_bounds__(NT) k_ger_gemv_t(double *__restrict__ M, long 
                                                    const double *__restrict__ ut, const double *__restrict__ uv,
                                                    const double *__restrict__ scal, int ci, double cs,
                                                    const double *__restrict__ x, const double *__restrict__ addv,
-                                                   double *__restrict__ out) {
+                                                   double *__restrict__ out, const double *__restrict__ xa = nullptr,
+                                                   const double *__restrict__ xb = nullptr, const int *__restrict__ omap = nullptr) {
+    // (xa / xb: the x-prologue x + (xa - xb) of gemv_t_body; omap: its scatter epilogue)
     __shared__ double sh[4];
     const int c0 = blockIdx.x * GT_COLS;
     const double coef = cs * scal[ci];
@@ -415,7 +417,11 @@ __global__ void __launch_bounds__(NT) k_ger_gemv_t(double *__restrict__ M, long 
     const int n2 = nrows >> 1;
 #pragma unroll 2
     for (int r = threadIdx.x; r < n2; r += NT) {
-        const double2 xv = reinterpret_cast<const double2 *>(x)[r];
+        double2 xv = reinterpret_cast<const double2 *>(x)[r];
+        if (xa) {
+            const double2 a = reinterpret_cast<const double2 *>(xa)[r], b = reinterpret_cast<const double2 *>(xb)[r];
+            xv.x += a.x - b.x; xv.y += a.y - b.y;
+        }
         const double2 tv = reinterpret_cast<const double2 *>(ut)[r];
         const double a0 = coef * tv.x, a1 = coef * tv.y;
         double2 m[GT_COLS];
@@ -439,14 +445,22 @@ __global__ void __launch_bounds__(NT) k_ger_gemv_t(double *__restrict__ M, long 
                 double *p = M + (c0 + k) * ld + r;
                 const double m = *p + a0 * vc[k];
                 *p = m;
-                s[k] += m * x[r];
+                s[k] += m * (x[r] + (xa ? xa[r] - xb[r] : 0.0));
             }
     }
 #pragma unroll
     for (int k = 0; k < GT_COLS; k++) {
         const double v = block_sum(s[k], sh);
-        if (threadIdx.x == 0 && c0 + k < ncols) out[c0 + k] = addv ? v + addv[c0 + k] : v;
+        if (threadIdx.x == 0 && c0 + k < ncols) out[omap ? omap[c0 + k] : c0 + k] = addv ? v + addv[c0 + k] : v;
     }
+}
+// what the deferred reflections of Y and Minv behind a removed constraint need later (remove_constraint_tq): v twice (Y's column
+// coefficients = Minv's row coefficients), s = v'Minv with the entry of the column that is refilled zeroed, beta
+__global__ void k_keep_removal(int n, const double *__restrict__ v, const double *__restrict__ srow, int kzero, double *__restrict__ keep_v,
+                               double *__restrict__ keep_s, double *__restrict__ scal, int from, int to) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { keep_v[i] = v[i]; keep_s[i] = i == kzero ? 0.0 : srow[i]; }
+    if (i == 0) scal[to] = scal[from];
 }
 // what a deferred reflection needs later: the Householder vector and its beta out of the way of the next products
 __global__ void k_keep_reflector(const double *__restrict__ v, int n, double *__restrict__ keep, double *__restrict__ scal, int from,
@@ -1419,7 +1433,8 @@ struct RsqpLargeEngine::Impl {
     // vectors (nV)
     double *x, *g, *lb, *ub, *gN, *lbN, *ubN, *dx, *w1, *w2, *w3, *w4, *w5, *w6, *wz1, *wz2, *wz3;
     double *pz_t = nullptr, *pz_v = nullptr, *pw_s = nullptr, *pw_col = nullptr;   // operands of a deferred reflection (z_reflect_and_shrink)
-    double *c_wY = nullptr, *c_xY = nullptr, *c_xi = nullptr, *c_wZ = nullptr;                    // range-space part of the step direction, carried over an added constraint
+    double *c_wY = nullptr, *c_xY = nullptr, *c_xi = nullptr, *c_wZ = nullptr;
+    double *py_t = nullptr, *py_v = nullptr, *pm_s = nullptr;                     // operands of the deferred reflections of Y / Minv (removed constraint)                    // range-space part of the step direction, carried over an added constraint
     // vectors (nC)
     double *Ax, *lbA, *ubA, *lbAN, *ubAN, *dAx, *c1, *c2, *c3, *a1, *a2, *a3, *a4;
     double *y, *dy, *part, *scal, *pt, *res_t;
@@ -1490,7 +1505,7 @@ struct RsqpLargeEngine::Impl {
 
     ~Impl() {
         double *dv[] = {Z, Y, Minv, Wz, x, g, lb, ub, gN, lbN, ubN, dx, w1, w2, w3, w4, w5, w6, wz1, wz2, wz3, Ax, lbA, ubA,
-                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col, c_wY, c_xY, c_xi, c_wZ};
+                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col, c_wY, c_xY, c_xi, c_wZ, py_t, py_v, pm_s};
         for (double *p : dv) if (p) (void)hipFree(p);
         if (big) (void)hipFree(big);
         rsqp_dense_work_free(&dw);
@@ -1680,6 +1695,8 @@ struct RsqpLargeEngine::Impl {
     // them on their own if anything else wants Z or Wz first.
     struct { bool on = false; int ncols = 0; } pendZ;
     struct { bool on = false; int nZold = 0; } pendW;
+    struct { bool on = false; int n = 0; } pendY, pendM;      // reflections of Y (n columns) / Minv (n x n) behind a removed constraint
+    static constexpr int S_KEEP_BETA2 = 44;
     bool fuse_passes = getenv("RSQP_LARGE_NO_FUSE") == nullptr;
     int fuse_wz_min = getenv("RSQP_LARGE_FUSE_WZ_MIN") ? atoi(getenv("RSQP_LARGE_FUSE_WZ_MIN")) : 3072;   // (tests force 0: both fused kernels on small problems)
     static constexpr int S_KEEP_BETA = 40, S_KEEP_THETA = 41;
@@ -1687,9 +1704,14 @@ struct RsqpLargeEngine::Impl {
         return fuse_passes && wz_enabled && (ld & 1) == 0 && nZ > 1 && pz_t &&
                (((reinterpret_cast<unsigned long long>(Z) | reinterpret_cast<unsigned long long>(Wz)) & 15) == 0);
     }
-    void flush_pending() {
+    void flush_pending_ZW() {
         if (pendZ.on) { pendZ.on = false; ger(Z, ld, nV, pendZ.ncols, pz_t, pz_v, S_KEEP_BETA, -1.0); }
         if (pendW.on) { pendW.on = false; wz_shrink_now(pendW.nZold, pw_s, pz_v, pw_col, S_KEEP_BETA, S_KEEP_THETA); }
+    }
+    void flush_pending() {
+        flush_pending_ZW();
+        if (pendY.on) { pendY.on = false; ger(Y, ld, nV, pendY.n, py_t, py_v, S_KEEP_BETA2, -1.0); }
+        if (pendM.on) { pendM.on = false; ger(Minv, ldm, pendM.n, pendM.n, py_v, pm_s, S_KEEP_BETA2, -1.0); }
     }
     void wz_shrink_now(int nZo, const double *s_, const double *v_, const double *col_, int sb, int stheta) {
         pbegin();
@@ -1726,7 +1748,7 @@ struct RsqpLargeEngine::Impl {
         const bool ok = pendZ.on && pendZ.ncols == nZ && nZ > 0 &&
                         (((reinterpret_cast<unsigned long long>(xv) | reinterpret_cast<unsigned long long>(pz_t)) & 15) == 0);
         if (!ok) {
-            flush_pending();
+            flush_pending_ZW();
             GtTask t = gt_task(Z, ld, nV, nZ, xv, out);
             t.addv = addv;
             gemv_t_task(t);
@@ -1876,12 +1898,26 @@ struct RsqpLargeEngine::Impl {
         const int r = hAC[k];
         copy(Minv + k * ldm, a1, nAC);                                   // u = Minv[:, k]
         hipLaunchKernelGGL(k_house, dim3(1), dim3(NT), 0, st, a1, nAC, a2, scal, 0);  // v -> a2
-        gemv_n(Y, ld, nV, nAC, a2, 1.0, 0.0, nullptr, w5);               // t = Y v
-        ger(Y, ld, nV, nAC, w5, a2, 1, -1.0);                            // Y -= beta t v'
+        // a plain removal whose step direction will be carried (below) does not need Y and Minv before that step direction's LAST
+        // two products (Y'r, Minv'(Y'r)): their reflections wait and ride on those (k_ger_gemv_t) -- only the last column of each is
+        // reflected now (it moves to Z / into the slot of the removed constraint)
+        const bool will_carry = plain_removal && carry_enabled && carry_valid && carried < CARRY_REFRESH && nAC > 1;
+        const bool dfr = will_carry && fuse_passes && (ld & 1) == 0 && (ldm & 1) == 0 &&
+                         (((reinterpret_cast<unsigned long long>(Y) | reinterpret_cast<unsigned long long>(Minv)) & 15) == 0);
+        gemv_n(Y, ld, nV, nAC, a2, 1.0, 0.0, nullptr, dfr ? py_t : w5);  // t = Y v
         gemv_t(Minv, ldm, nAC, nAC, a2, a3);                             // s' = v' Minv
-        ger(Minv, ldm, nAC, nAC, a2, a3, 1, -1.0);                       // Minv -= beta v s'
+        if (dfr) {
+            hipLaunchKernelGGL(k_keep_removal, g1(nAC), dim3(NT), 0, st, nAC, a2, a3, k, py_v, pm_s, scal, 1, S_KEEP_BETA2);
+            ger(Yc(nAC - 1), ld, nV, 1, py_t, a2 + (nAC - 1), 1, -1.0);
+            ger(Minv + (long long)(nAC - 1) * ldm, ldm, nAC, 1, a2, a3 + (nAC - 1), 1, -1.0);
+            pendY.on = true; pendY.n = nAC - 1;
+            pendM.on = true; pendM.n = nAC - 1;
+        } else {
+            ger(Y, ld, nV, nAC, w5, a2, 1, -1.0);                        // Y -= beta t v'
+            ger(Minv, ldm, nAC, nAC, a2, a3, 1, -1.0);                   // Minv -= beta v s'
+        }
         copy(Yc(nAC - 1), Zc(nZ), nV);                                   // new null-space column
-        if (plain_removal && carry_enabled && carry_valid && carried < CARRY_REFRESH && nAC > 1) {
+        if (will_carry) {
             const double om = 1.0 - last_tau;
             hipLaunchKernelGGL(k_carry_remove_wY, dim3(1), dim3(NT), 0, st, nAC - 1, om, a2, c_wY, scal, 1, S_KEEP_WLAST);
             hipLaunchKernelGGL(k_carry_remove_xY, g1(nV), dim3(NT), 0, st, nV, om, Zc(nZ), scal, S_KEEP_WLAST, c_xY);
@@ -1943,6 +1979,7 @@ struct RsqpLargeEngine::Impl {
             remove_bound_tq(idx);   // (zeroes y[idx] as well)
             if (wz_grow(&pd) != RET_OK) return RET_SETUP_FAILED;
             if (pd) return RET_OK;
+            flush_pending();          // (the flip below reads Y / Minv: deferred reflections first)
             // flip: put the variable back on the opposite side (or the same if that one is infinite)
             double b[2];
             LCHK(hipMemcpyAsync(h_pinned, lbN + idx, 8, hipMemcpyDeviceToHost, st));
@@ -1962,6 +1999,7 @@ struct RsqpLargeEngine::Impl {
             remove_constraint_tq(k);   // (zeroes y[nV + idx] as well)
             if (wz_grow(&pd) != RET_OK) return RET_SETUP_FAILED;
             if (pd) return RET_OK;
+            flush_pending();          // (the flip below reads Y / Minv: deferred reflections first)
             LCHK(hipMemcpyAsync(h_pinned, lbAN + idx, 8, hipMemcpyDeviceToHost, st));
             LCHK(hipMemcpyAsync(h_pinned + 1, ubAN + idx, 8, hipMemcpyDeviceToHost, st));
             LCHK(hipStreamSynchronize(st));
@@ -2081,6 +2119,8 @@ struct RsqpLargeEngine::Impl {
                 wz_shrink_now(pendW.nZold, pw_s, pz_v, pw_col, S_KEEP_BETA, S_KEEP_THETA);        // (no product with Wz to ride on)
             }
         } else {
+            if (pendY.on) { pendY.on = false; ger(Y, ld, nV, pendY.n, py_t, py_v, S_KEEP_BETA2, -1.0); }      // (a removal whose step
+            if (pendM.on) { pendM.on = false; ger(Minv, ldm, pendM.n, pendM.n, py_v, pm_s, S_KEEP_BETA2, -1.0); }   //  direction is exact after all)
             gemv_n(Minv, ldm, nAC, nAC, a1, 1.0, 0.0, nullptr, c_wY);
             gemv_n(Y, ld, nV, nAC, c_wY, 1.0, 0.0, nullptr, c_xY);         // xY
             carried = 0;
@@ -2106,12 +2146,32 @@ struct RsqpLargeEngine::Impl {
         // multipliers: dyAC = Minv' Y'(H dx + dg); A dx (for the ratio tests) rides along with H dx
         AH_times(dx, dAx, Hdx);
         {
-            GtTask t = gt_task(Y, ld, nV, nAC, Hdx, a1);                   // a1 = Y'(H dx + (gN - g))
-            t.xa = gN; t.xb = g;
-            gemv_t_task(t);
-            GtTask u = gt_task(Minv, ldm, nAC, nAC, a1, dy + nV);          // dy[nV + AC[j]] = sum_i Minv[i][j] a1[i]
-            u.omap = AC;
-            gemv_t_task(u);
+            const bool al = (((reinterpret_cast<unsigned long long>(Hdx) | reinterpret_cast<unsigned long long>(gN) |
+                               reinterpret_cast<unsigned long long>(g) | reinterpret_cast<unsigned long long>(a1)) & 15) == 0);
+            if (pendY.on && pendY.n == nAC && nAC > 0 && al) {            // (+ the deferred reflection of Y behind a removed constraint)
+                pendY.on = false;
+                pbegin();
+                hipLaunchKernelGGL(k_ger_gemv_t, dim3((nAC + GT_COLS - 1) / GT_COLS), dim3(NT), 0, st, Y, ld, nV, nAC, py_t, py_v, scal, S_KEEP_BETA2,
+                                   -1.0, Hdx, (const double *)nullptr, a1, gN, g, (const int *)nullptr);
+                pend(6, 16.0 * nV * (double)nAC);
+            } else {
+                if (pendY.on) { pendY.on = false; ger(Y, ld, nV, pendY.n, py_t, py_v, S_KEEP_BETA2, -1.0); }
+                GtTask t = gt_task(Y, ld, nV, nAC, Hdx, a1);               // a1 = Y'(H dx + (gN - g))
+                t.xa = gN; t.xb = g;
+                gemv_t_task(t);
+            }
+            if (pendM.on && pendM.n == nAC && nAC > 0 && al) {            // (+ the deferred reflection of Minv)
+                pendM.on = false;
+                pbegin();
+                hipLaunchKernelGGL(k_ger_gemv_t, dim3((nAC + GT_COLS - 1) / GT_COLS), dim3(NT), 0, st, Minv, ldm, nAC, nAC, py_v, pm_s, scal,
+                                   S_KEEP_BETA2, -1.0, a1, (const double *)nullptr, dy + nV, (const double *)nullptr, (const double *)nullptr, AC);
+                pend(6, 16.0 * nAC * (double)nAC);
+            } else {
+                if (pendM.on) { pendM.on = false; ger(Minv, ldm, pendM.n, pendM.n, py_v, pm_s, S_KEEP_BETA2, -1.0); }
+                GtTask u = gt_task(Minv, ldm, nAC, nAC, a1, dy + nV);      // dy[nV + AC[j]] = sum_i Minv[i][j] a1[i]
+                u.omap = AC;
+                gemv_t_task(u);
+            }
         }
         AT_times(dy + nV, ATdy);
         // (dy of the fixed variables: formed by k_ratio1, which is the next kernel)
@@ -2147,7 +2207,7 @@ struct RsqpLargeEngine::Impl {
         double sum_nFR = 0.0, sum_nAC = 0.0, sum_nZ = 0.0;      // reported by RSQP_PROFILE: the sizes the products run on
         status = QPS_PERFORMINGHOMOTOPY;
         dx_ready = false;
-        pendZ.on = pendW.on = false;      // (nothing is deferred across solves; a solve that failed half-way leaves nothing behind)
+        pendZ.on = pendW.on = pendY.on = pendM.on = false;      // (nothing is deferred across solves; a solve that failed half-way leaves nothing behind)
         carry_valid = carry_pending = carry_ready = false;
         carried = 0;
         refresh_products();
@@ -2414,6 +2474,7 @@ hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
     DA(w1, nV); DA(w2, nV); DA(w3, nV); DA(w4, nV); DA(w5, nV); DA(w6, nV); DA(wz1, nV); DA(wz2, nV); DA(wz3, nV);
     DA(pz_t, nV); DA(pz_v, nV); DA(pw_s, nV); DA(pw_col, nV);
     DA(c_wY, P.nAmax + 2); DA(c_xY, nV); DA(c_xi, P.nAmax + 2); DA(c_wZ, nV);
+    DA(py_t, nV); DA(py_v, P.nAmax + 2); DA(pm_s, P.nAmax + 2);
     DA(Ax, nC); DA(lbA, nC); DA(ubA, nC); DA(lbAN, nC); DA(ubAN, nC); DA(dAx, nC); DA(c1, nC); DA(c2, nC); DA(c3, nC);
     DA(a1, P.nAmax + 2); DA(a2, P.nAmax + 2); DA(a3, P.nAmax + 2); DA(a4, P.nAmax + 2);
     DA(y, nV + nC); DA(dy, nV + nC);
