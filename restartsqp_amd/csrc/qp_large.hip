@@ -1070,6 +1070,23 @@ __global__ void __launch_bounds__(NT) k_carry_wZ(int l, double om, const double 
         wZ[i] = om * ((wZ[i] - c * v[i]) - kap * wl) + wyk * kap;
     }
 }
+// ... and behind a REMOVED constraint (the null space gained the column z, Wz its border with u = Wz Z'Hz and rho^2, wz_grow): with
+// s = z'(H dx_old + (gN - g)_old) -- the reduced gradient of the previous step along z, (gN - g)_old = (gN - g) / (1 - tau) -- and
+// omega the component xY lost (k_carry_remove_wY):
+//   wZ[0..n) <- (1 - tau) (wZ + (s / rho^2) u),   wZ[n] = (1 - tau) (omega - s / rho^2)
+// (block solve of the bordered system). One workgroup.
+__global__ void __launch_bounds__(NT) k_carry_wZ_grow(int n, int nV, double om, const double *__restrict__ z, const double *__restrict__ Hdx,
+                                                      const double *__restrict__ gN, const double *__restrict__ g, const double *__restrict__ u,
+                                                      double *__restrict__ wZ, const double *__restrict__ scal, int srho, int somega) {
+    __shared__ double sh[4];
+    const double iom = 1.0 / om;
+    double d = 0.0;
+    for (int i = threadIdx.x; i < nV; i += NT) d += z[i] * (Hdx[i] + (gN[i] - g[i]) * iom);
+    d = block_sum(d, sh);
+    const double c = d / scal[srho];
+    for (int i = threadIdx.x; i < n; i += NT) wZ[i] = om * (wZ[i] + c * u[i]);
+    if (threadIdx.x == 0) wZ[n] = om * (scal[somega] - c);
+}
 // what that needs from the border of Minv: the row xi and eta, out of the way of the next products
 __global__ void k_keep_border(int k, const double *__restrict__ row, double *__restrict__ keep, double *__restrict__ scal, int es,
                               int eta_from_house, int se) {
@@ -2103,6 +2120,7 @@ struct RsqpLargeEngine::Impl {
                            w1);                                            // bA -> a1, tmpg -> w1
         // range space: wY = Minv bA ; xY = Y wY
         bool carry_null = false;      // the null-space part is carried too (needs the deferred reflection's v / col / beta)
+        const bool was_ready = carry_ready && carry_valid;
         if (carry_ready && carry_valid) {
             carried++; stat_carried++;                                     // (transformed by remove_constraint_tq already)
         } else if (carry_pending && carry_valid && nAC > 0) {
@@ -2129,7 +2147,14 @@ struct RsqpLargeEngine::Impl {
         carry_valid = true;
         double *const w3 = c_xY;                                           // (xY lives in its own buffer: the next step may scale it)
         // null space: wZ = -Wz Z'(tmpg + H xY) ; dx_FR = xY + Z wZ
-        if (carry_null) {
+        const bool carry_null_grow = was_ready && carry_null_enabled && nZ > 0 && 1.0 - last_tau > 1e-6;
+        if (carry_null_grow) {
+            // a removed constraint: wZ from the bordered system (the new null-space column is Z[:, nZ - 1], u / rho^2 are wz_grow's)
+            stat_carried_null++;
+            hipLaunchKernelGGL(k_carry_wZ_grow, dim3(1), dim3(NT), 0, st, nZ - 1, nV, 1.0 - last_tau, Zc(nZ - 1), Hdx, gN, g, wz2, c_wZ, scal, 13,
+                               S_KEEP_WLAST);
+            gemv_n(Z, ld, nV, nZ, c_wZ, 1.0, 1.0, w3, w4, Sb, dx);
+        } else if (carry_null) {
             // wZ carried (k_carry_wZ above): the deferred reflection of Z rides on the product Z wZ instead of on Z'w
             pendZ.on = false;
             pbegin();
