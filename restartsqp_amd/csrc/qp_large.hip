@@ -1710,6 +1710,16 @@ struct RsqpLargeEngine::Impl {
     // (it becomes the new Y column); the update of the other columns and the shrinking of Wz wait for the step direction,
     // whose first products with Z and Wz apply them on the way (k_ger_gemv_t, k_wz_shrink_gemv) -- flush_pending() applies
     // them on their own if anything else wants Z or Wz first.
+    // INVARIANTS of the deferred updates and the carried step direction:
+    //  * pendZ / pendW (added constraint) and pendY / pendM (removed constraint) are only ever set by the LAST operation of a
+    //    working-set change and consumed by the step direction that follows; change_active_set() starts with flush_pending(), the
+    //    homotopy ends with it, a solve starts with all four off: a matrix is never read while its update is pending, except by
+    //    the fused kernel that applies it;
+    //  * c_wY / c_xY / c_wZ are the wY, xY, wZ of the LAST step direction (carry_valid); a change keeps them alive only if it is one
+    //    plain added (carry_pending) or removed (carry_ready) constraint -- no exchange, no flip, no bound -- and at most
+    //    CARRY_REFRESH steps in a row; everything else recomputes them from the matrices;
+    //  * the operands a deferred update needs later live in their own buffers (pz_*, pw_*, py_*, pm_s, c_xi, scal[40..44]): the work
+    //    vectors they were computed in are reused by the next products.
     struct { bool on = false; int ncols = 0; } pendZ;
     struct { bool on = false; int nZold = 0; } pendW;
     struct { bool on = false; int n = 0; } pendY, pendM;      // reflections of Y (n columns) / Minv (n x n) behind a removed constraint
