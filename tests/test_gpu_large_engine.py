@@ -156,6 +156,20 @@ def test_deferred_reflection_kernels_match_oracle(capi, oracle, monkeypatch):
         monkeypatch.delenv(knob)
 
 
+def test_deferred_and_carried_paths_are_taken(capi):
+    """Guard against a refactoring that silently switches the round-3 paths off: with the engine's own accounting on, a cold
+    start of a mid-size problem (even leading dimension) must show launches of both fused kernels of the deferred reflections."""
+    q = problems.random_qp(np.random.default_rng(4712), 150, 120, 0.3)
+    s = load(capi, q)
+    s.set_engine_profiling(True)
+    s.solve(capi.MODE_COLD, 20000)
+    prof = s.engine_profile()
+    s.close()
+    assert prof is not None
+    assert prof.get("ger_gemv_n", {}).get("calls", 0) > 0        # reflection of Z riding on Z wZ (null-space part carried)
+    assert prof.get("ger_gemv_t", {}).get("calls", 0) > 0        # reflection of Z riding on Z'w, or of Y / Minv behind a removal
+
+
 def test_mid_size_dense_matches_oracle(capi, oracle):
     q = problems.dense_qp(300, 600, seed=20260101)
     s = load(capi, q, engine=0)
