@@ -240,6 +240,11 @@ struct rsqp_solver {
     // kernels read / write directly (zero-copy): a solve costs one launch and one sync
     void *io_host = nullptr;
     int *d_done = nullptr, *h_done = nullptr;   // host-mapped completion word of single-QP solves (spun on by rsqp_solve)
+    // the certificate of a single LDS-scale QP is launched right BEHIND its solve (QPhandler::solveQP always asks for it): by the time
+    // rsqp_test_optimality is called it has run, and the call only waits for its completion value -- no launch on the critical path.
+    // Dropped by every setter (the certificate then runs on demand, as before).
+    bool spec_cert = false;
+    int spec_cert_val = 0;
     int done_seq = 0;
     bool lp_mode = false;   // optimizeLP: H ignored, H := hreg*I
     double hreg = 0.0;
@@ -360,7 +365,8 @@ int wait_done(rsqp_solver *s, int val) {
         // (a plain volatile read orders nothing on non-x86 hosts and lets the compiler hoist the result reads)
         // (raising the word is the kernel's last action; a hipStreamQuery here measured +4 us per call, 8 us per solveQP --
         //  a fault is reported by the next HIP call of the handle, as for any asynchronous launch)
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == val) return RSQP_OK;
+        // (>=: the word is a sequence number; the certificate launched behind a solve may have raised it further already)
+        if ((int)(__atomic_load_n(flag, __ATOMIC_ACQUIRE) - val) >= 0) return RSQP_OK;
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
@@ -450,6 +456,7 @@ extern "C" int rsqp_create(int nV, int nC, int device, rsqp_solver **out) {
 extern "C" void rsqp_destroy(rsqp_solver *s) { delete s; }
 
 extern "C" int rsqp_set_engine(rsqp_solver *s, int engine) {
+    if (s) s->spec_cert = false;
     if (!s || engine < 0 || engine > 2) return fail(RSQP_ERR_ARG, "rsqp_set_engine");
     if (engine == 1 && !s->fits_small)
         return fail(RSQP_ERR_TOO_LARGE, "rsqp_set_engine: problem image exceeds the 160 KiB LDS-resident engine");
@@ -500,6 +507,7 @@ extern "C" int rsqp_set_options(rsqp_solver *s, int qp_maxiter, int lp_maxiter) 
 extern "C" int rsqp_set_A_triplet(rsqp_solver *s, int nnz, const int *irow, const int *jcol, const double *val,
                                   int n_ident, const int *id_irow, const int *id_jcol, const int *id_size,
                                   const double *id_value) {
+    if (s) s->spec_cert = false;
     if (!s || nnz < 0 || (nnz > 0 && (!irow || !jcol || !val))) return fail(RSQP_ERR_ARG, "rsqp_set_A_triplet");
     if (s->firstQPsolved && !s->upd_A) s->upd_A = true;  // qpOASESInterface.cpp:427-429
     DevMatrix &M = s->A;
@@ -537,6 +545,7 @@ extern "C" int rsqp_set_A_triplet(rsqp_solver *s, int nnz, const int *irow, cons
 
 extern "C" int rsqp_set_H_triplet(rsqp_solver *s, int nnz, const int *irow, const int *jcol, const double *val,
                                   int is_symmetric) {
+    if (s) s->spec_cert = false;
     if (!s || nnz < 0 || (nnz > 0 && (!irow || !jcol || !val))) return fail(RSQP_ERR_ARG, "rsqp_set_H_triplet");
     if (s->firstQPsolved && !s->upd_H) s->upd_H = true;  // :407-409
     DevMatrix &M = s->H;
@@ -620,10 +629,12 @@ int get_csc(const DevMatrix &M, int *jc, int *ir, double *val, int *order) {
 }  // namespace
 
 extern "C" int rsqp_set_A_csc(rsqp_solver *s, const int *jc, const int *ir, const double *val) {
+    if (s) s->spec_cert = false;
     if (!s) return fail(RSQP_ERR_ARG, "null solver");
     return set_csc(s, s->A, s->nC, s->nV, jc, ir, val, true, &s->upd_A);
 }
 extern "C" int rsqp_set_H_csc(rsqp_solver *s, const int *jc, const int *ir, const double *val) {
+    if (s) s->spec_cert = false;
     if (!s) return fail(RSQP_ERR_ARG, "null solver");
     return set_csc(s, s->H, s->nV, s->nV, jc, ir, val, false, &s->upd_H);
 }
@@ -659,6 +670,7 @@ extern "C" int rsqp_get_vector(const rsqp_solver *s, int which, double *v) {
     return RSQP_OK;
 }
 extern "C" int rsqp_reset_constraints(rsqp_solver *s) {
+    if (s) s->spec_cert = false;
     if (!s) return fail(RSQP_ERR_ARG, "null solver");
     for (int k = RSQP_VEC_LB; k <= RSQP_VEC_UBA; k++) std::fill(s->h_vec[k].begin(), s->h_vec[k].end(), 0.0);
     s->vec_dirty = true;
@@ -729,9 +741,12 @@ int solve_large(rsqp_solver *s, int mode, int *nWSR, const double *x0, const dou
 }
 }  // namespace
 
+namespace { void launch_speculative_certificate(rsqp_solver *s, const QPPools &p); }
+
 extern "C" int rsqp_solve(rsqp_solver *s, int mode, int *nWSR, const double *x0, const double *y0,
                           const int *guess_b) {
     if (!s || !nWSR || mode < 0 || mode > 3) return fail(RSQP_ERR_ARG, "rsqp_solve");
+    s->spec_cert = false;
     if (!s->A.initialised && s->nC > 0) return fail(RSQP_ERR_ARG, "rsqp_solve: A not set");
     HIPCHK(hipSetDevice(s->device));
     int rc = flush_vectors(s);
@@ -750,6 +765,7 @@ extern "C" int rsqp_solve(rsqp_solver *s, int mode, int *nWSR, const double *x0,
                                         rsqp_mat_lds_bytes(s->nV, s->nC, s->A.initialised ? s->A.nnz : 0, s->H.initialised ? s->H.nnz : 0),
                                         mode, *nWSR, s->stream);
     if (e != hipSuccess) return fail(RSQP_ERR_DEVICE, std::string("QP kernel launch: ") + hipGetErrorString(e));
+    launch_speculative_certificate(s, p);
     // the results live in host-mapped memory and the kernel raises a host-mapped flag behind them: spinning on it saves
     // the ~10 us a blocking hipStreamSynchronize takes to wake up (a single hs071-scale solve is ~30 us end to end)
     if (p.done_flag) { if ((rc = wait_done(s, p.done_val)) != RSQP_OK) return rc; }
@@ -952,8 +968,47 @@ int spmv_csr(rsqp_solver *s, DevMatrix &M, const double *in, double *out) {  // 
     return RSQP_OK;
 }
 
+int collect_certificate(rsqp_solver *s, rsqp_optimality_status *out, int *W_c, int *W_b, int *invalid) {
+    double o[6];
+    HIPCHK(s->d_kkt.download(o, 6));
+    if (out) {
+        out->primal_violation = o[0]; out->dual_violation = o[1]; out->compl_violation = o[2];
+        out->stationarity_violation = o[3]; out->KKT_error = o[4];
+    }
+    *invalid = o[5] != 0.0;
+    if (W_b) HIPCHK(s->d_Wb.download(W_b, s->nV));
+    if (W_c) HIPCHK(s->d_Wc.download(W_c, s->nC));
+    return RSQP_OK;
+}
+void fill_kkt_args(rsqp_solver *s, RsqpKktArgs &a) {
+    std::memset(&a, 0, sizeof(a));
+    a.nV1 = s->nV; a.nC1 = s->nC;
+    a.x = s->d_x.p; a.y = s->d_y.p; a.g = s->d_vec[RSQP_VEC_G].p; a.lb = s->d_vec[RSQP_VEC_LB].p;
+    a.ub = s->d_vec[RSQP_VEC_UB].p; a.lbA = s->d_vec[RSQP_VEC_LBA].p; a.ubA = s->d_vec[RSQP_VEC_UBA].p;
+    a.Ax = s->d_Ax.p; a.ATy = s->d_ATy.p; a.Hx = s->d_Hx.p;
+    a.ws_b = s->d_wsb.p; a.ws_c = s->d_wsc.p; a.W_b = s->d_Wb.p; a.W_c = s->d_Wc.p; a.out = s->d_kkt.p;
+}
+bool spec_cert_enabled() { static const bool on = getenv("RSQP_NO_SPEC_CERT") == nullptr; return on; }
+// the fused products + certificate kernel of an LDS-scale QP right behind its solve kernel (same stream), see rsqp_solver::spec_cert
+void launch_speculative_certificate(rsqp_solver *s, const QPPools &p) {
+    s->spec_cert = false;
+    if (!spec_cert_enabled() || s->lp_mode || !p.done_flag || !(s->fits_small && s->A.initialised == (s->nC > 0))) return;
+    RsqpKktArgs a;
+    fill_kkt_args(s, a);
+    a.done_flag = s->d_done; a.done_val = ++s->done_seq;
+    if (rsqp_launch_small_certificate(p, a, 1, s->d_Ax.p, s->d_ATy.p, s->d_Hx.p, s->stream) != hipSuccess) return;
+    s->spec_cert = true; s->spec_cert_val = a.done_val;
+}
+
 int run_certificate(rsqp_solver *s, rsqp_optimality_status *out, int *W_c, int *W_b, int *invalid) {
     HIPCHK(hipSetDevice(s->device));
+    if (s->spec_cert && !s->vec_dirty) {      // launched behind the solve, nothing changed since: only wait for it
+        s->spec_cert = false;
+        int rcw = wait_done(s, s->spec_cert_val);
+        if (rcw != RSQP_OK) return rcw;
+        return collect_certificate(s, out, W_c, W_b, invalid);
+    }
+    s->spec_cert = false;
     int rc = flush_vectors(s);
     if (rc != RSQP_OK) return rc;
     const bool fused = s->fits_small && s->A.initialised == (s->nC > 0);
@@ -973,12 +1028,7 @@ int run_certificate(rsqp_solver *s, rsqp_optimality_status *out, int *W_c, int *
         HIPCHK(hipMemsetAsync(s->d_Hx.p, 0, sizeof(double) * s->nV, s->stream));
     }
     RsqpKktArgs a;
-    std::memset(&a, 0, sizeof(a));
-    a.nV1 = s->nV; a.nC1 = s->nC;
-    a.x = s->d_x.p; a.y = s->d_y.p; a.g = s->d_vec[RSQP_VEC_G].p; a.lb = s->d_vec[RSQP_VEC_LB].p;
-    a.ub = s->d_vec[RSQP_VEC_UB].p; a.lbA = s->d_vec[RSQP_VEC_LBA].p; a.ubA = s->d_vec[RSQP_VEC_UBA].p;
-    a.Ax = s->d_Ax.p; a.ATy = s->d_ATy.p; a.Hx = s->d_Hx.p;
-    a.ws_b = s->d_wsb.p; a.ws_c = s->d_wsc.p; a.W_b = s->d_Wb.p; a.W_c = s->d_Wc.p; a.out = s->d_kkt.p;
+    fill_kkt_args(s, a);
     if (s->d_done && spin_enabled()) { a.done_flag = s->d_done; a.done_val = ++s->done_seq; }
     if (fused) {
         QPPools p = pools_of(s);
@@ -987,16 +1037,7 @@ int run_certificate(rsqp_solver *s, rsqp_optimality_status *out, int *W_c, int *
     } else if (rsqp_launch_kkt(a, 1, s->stream) != hipSuccess) return fail(RSQP_ERR_DEVICE, "kkt launch failed");
     if (a.done_flag) { if ((rc = wait_done(s, a.done_val)) != RSQP_OK) return rc; }
     else HIPCHK(hipStreamSynchronize(s->stream));
-    double o[6];
-    HIPCHK(s->d_kkt.download(o, 6));
-    if (out) {
-        out->primal_violation = o[0]; out->dual_violation = o[1]; out->compl_violation = o[2];
-        out->stationarity_violation = o[3]; out->KKT_error = o[4];
-    }
-    *invalid = o[5] != 0.0;
-    if (W_b) HIPCHK(s->d_Wb.download(W_b, s->nV));
-    if (W_c) HIPCHK(s->d_Wc.download(W_c, s->nC));
-    return RSQP_OK;
+    return collect_certificate(s, out, W_c, W_b, invalid);
 }
 }  // namespace
 
