@@ -859,7 +859,8 @@ __global__ void __launch_bounds__(32 * GJ_, 1) small_qpk_kernel(QPPools P, int n
     }
     const int tid = (int)threadIdx.x;
     if (rcode == RET_BAIL) {
-        if (tid == 0) { P.ret[q] = RET_BAIL; P.nflips[q] = E.bail_reason; }    // the null-space kernel takes this member over
+        if (tid == 0) { P.ret[q] = RET_BAIL; P.nflips[q] = E.bail_reason; P.nwsr[q] = 1000 + E.bail_reason; }    // the null-space kernel takes this member over
+        //                                  (nwsr: overwritten by it; read by tools/bail_hist.py under RSQP_SMALL_KKT_ONLY=1)
         return;
     }
     for (int v = tid; v < d.nV; v += ENG::NT) { P.x[d.offV + v] = E.x[v]; P.ws_b[d.offV + v] = E.Sb[v]; P.y[d.offV + d.offC + v] = E.yB[v]; }
