@@ -68,6 +68,26 @@ def pmc_traffic(substr, fetch_factor):
     return None, None
 
 
+def pmc_fetch_calibration():
+    """How FETCH_SIZE has to be read for NARROW coalesced loads (MI355X_MICROARCH.md calibrates the x2 only for 16 B per lane and
+    says to calibrate other widths on a known byte count): scatter_values in the same committed PMC file reads exactly
+    12 B per entry (a 4-byte index and an 8-byte value per lane, both coalesced, 200 000 entries) -- known bytes / reported bytes
+    is the factor. Returns (factor, text) or (None, None)."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+    if not paths:
+        return None, None
+    d = json.load(open(paths[-1]))
+    for k, v in d.items():
+        if k.startswith("scatter_values(") and "FETCH_SIZE" in v:
+            rep = v["FETCH_SIZE"]["mean_per_dispatch"] * 1024
+            known = 12.0 * 200000
+            if rep > 0:
+                return known / rep, ("scatter_values (200 000 entries, 4 B + 8 B per lane, coalesced): %.0f B read, FETCH_SIZE reports %.0f B "
+                                     "-> factor %.2f (%s)" % (known, rep, known / rep, os.path.basename(paths[-1])))
+    return None, None
+
+
 def pmc_issue_roofline(substr, n_cus=256, n_simd=1024, n_xcd=8):
     """What actually bounds the LDS-resident QP kernel ("achieved LDS / VALU utilisation"), from the
     committed rocprofv3 --pmc passes of `bench.py --no-extras` (tools/pmc_small.sh): LDS-array busy cycles
@@ -135,7 +155,10 @@ def spmv_roofline(capi, problems, nbatch, repeats):
         traffic, tfile = pmc_traffic(ksub + "<true, false>", 2.0) if best["kernel_variant"] == 40 else (None, None)
         if traffic is None:
             traffic, tfile = pmc_traffic(ksub, 2.0)
-    res = {"kernel": kname + " (A'y on CSC = SpHbMat::transposed_times; input vector resident in LDS; "
+    res = {"consumer": "NONE on a solver path: this batched kernel is reached only through rsqp_spmv_plan_* (this bench leg and the parity "
+                       "tests) -- the batched micro-benchmark SURVEY 7 asks for (one 2.7 MB matrix is launch-bound and cache-resident). "
+                       "The engines call csx_stream_spmv (single matrix, entry order, bit-exact) and small_certificate_kernel",
+           "kernel": kname + " (A'y on CSC = SpHbMat::transposed_times; input vector resident in LDS; "
                      "parity: tests/test_gpu_parity.py::test_roofline_spmv_kernels_match_the_oracle, "
                      "test_entry_parallel_spmv_edge_patterns)",
            "bound": "hbm", "achieved": best["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -163,10 +186,16 @@ def value_refresh_roofline(capi, problems):
     s.set_A_triplet(ir + 1, cols + 1, rng.normal(size=nnz), ident)
     s.set_A_triplet(ir + 1, cols + 1, rng.normal(size=nnz), ident)      # value refresh: stages the triplet values
     ms_s, ms_g = s.time_value_refresh(200)
+    ms_f = s.time_value_refresh_fused(200)
     t_struct = s.structure_seconds(0)
     s.close()
     bs, bg = 20.0 * nnz, 20.0 * (nnz + 2 * m)
-    return {"scatter_values": {"entries": nnz, "algorithmic_bytes": bs, "ms_per_launch": ms_s, "achieved": bs / (ms_s * 1e-3) / 1e9,
+    bf = 32.0 * nnz          # 8 B value + 2 x 4 B index read, 2 x 8 B written
+    return {"fused_csc_csr": {"kernel": "scatter_values_csc_csr (what rsqp_set_A_triplet launches on a known pattern: ONE launch)",
+                              "entries": nnz, "algorithmic_bytes": bf, "ms_per_launch": ms_f, "achieved": bf / (ms_f * 1e-3) / 1e9,
+                              "frac": bf / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "survey_bytes_20_per_entry_frac": bs / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "scatter_values": {"entries": nnz, "algorithmic_bytes": bs, "ms_per_launch": ms_s, "achieved": bs / (ms_s * 1e-3) / 1e9,
                                "frac": bs / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "gather_values": {"entries": nnz + 2 * m, "algorithmic_bytes": bg, "ms_per_launch": ms_g,
                               "achieved": bg / (ms_g * 1e-3) / 1e9, "frac": bg / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBS},
@@ -175,9 +204,11 @@ def value_refresh_roofline(capi, problems):
             "set_structure_note": "one-off SpHbMat::setStructure equivalent of the first set_A ([J I -I], 240 000 entries, 50 000 "
                                   "columns: host sort by (col, row), CSC + CSR copy + SpMV plan, upload), timed apart from the "
                                   "per-iteration value refresh (SURVEY 8(d))",
-            "note": "4.8 MB per launch = 0.6 us at peak: a single refresh is launch-latency bound, not HBM bound"}
+            "note": "4.8 MB per launch = 0.6 us at peak: a single refresh is launch-latency bound, not HBM bound; scatter_values / "
+                    "gather_values are the two separate kernels of rounds 1-3 (the gather still refreshes the CSR copy on the CSC setter)"}
 
 
+HEADLINE_PMC_KEY = "Engine<8"     # substring of the headline kernel's name in the committed PMC files
 MFMA_F64_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: dense f64 matrix (v_mfma_f64_16x16x4_f64) peak
 
 
@@ -331,7 +362,7 @@ def large_configs(capi, problems, seq_steps=50, ref_rule_steps=4, cpu_seconds=10
                                         "tflops": sp["flops_qr_q_rinv"] / (sp["ms_qr_q_rinv"] * 1e-3) / 1e12},
                           "zhz_chol_inv": {"ms": sp["ms_zhz_chol_inv"], "flops": sp["flops_zhz_chol_inv"],
                                            "tflops": sp["flops_zhz_chol_inv"] / max(sp["ms_zhz_chol_inv"] * 1e-3, 1e-9) / 1e12}},
-                "step": {"mode": "hotstart with new matrices (VARIED after VARIED)", "wall_ms": 1e3 * t, "nWSR": nk, "certified": bool(okk)},
+                "step": {"mode": capi.Solver.MODE_NAMES.get(s.last_mode(), "?"), "mode_id": s.last_mode(), "wall_ms": 1e3 * t, "nWSR": nk, "certified": bool(okk)},
                 "note": "algorithmic flops: QR 2n^2(m-n/3) + explicit Q 4(m^2 n - m n^2 + n^3/3) + R^-1 n^3/3 (m = nFR, n = nAC); "
                         "Z'HZ nV nZ^2 + Cholesky, inverse and U^-1 U^-T nZ^3; time = HIP events on the engine's stream; "
                         "MFMA-busy counters: profiles/r03_*_pmc_mfma_blocked_setup.json"}
@@ -440,6 +471,49 @@ def hs_batch_scaling(capi, problems, parallel, torch, dist, rank, world, local_r
             "n_gpus": world, "steps": reps}
 
 
+def native_rccl_gather(capi, torch, dist, batch, B, rank, world, local_rank, ksteps):
+    """the gather of the result records through the C ABI's own RCCL call site (rsqp_batch_allgather_records: pack on the
+    device, in-place ncclAllGather on the batch's stream) -- what a C++ host without Python calls. The communicator is
+    created through the C ABI as well; only the 128-byte unique id travels over the existing process group (world > 1)."""
+    uid = capi.rccl_unique_id() if rank == 0 else bytes(128)
+    if dist is not None:
+        t = torch.tensor(list(uid), dtype=torch.uint8, device="cuda")
+        dist.broadcast(t, 0)
+        uid = bytes(t.cpu().tolist())
+    comm = capi.RcclComm(uid, rank, world, local_rank)
+    stride = batch.record_stride
+    allrec = torch.zeros(world * B * stride, dtype=torch.float64, device="cuda")
+    batch.solve(capi.MODE_COLD, 1000, sync=False)
+    batch.allgather_records(comm, B, allrec.data_ptr())          # warm-up (RCCL builds its channels on the first call)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0, only = time.perf_counter(), 0.0
+    for _ in range(ksteps):
+        batch.solve(capi.MODE_COLD, 1000, sync=False)
+        capi.check(capi.lib().rsqp_batch_sync(batch._h))
+        tc = time.perf_counter()
+        batch.allgather_records(comm, B, allrec.data_ptr())
+        only += time.perf_counter() - tc
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    tg = time.perf_counter() - t0
+    got = allrec.view(world * B, stride)
+    seen = int((got[::B, 0] == 20).sum().item())
+    comm.close()
+    if dist is not None:
+        tt = torch.tensor([tg, only], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tg, only = (float(v) for v in tt.tolist())
+    if seen != world:
+        raise SystemExit("bench.py: native RCCL all-gather returned the records of %d ranks, %d expected" % (seen, world))
+    return {"entry": "rsqp_batch_allgather_records (C ABI: pack + in-place ncclAllGather on the batch's stream; communicator from "
+                     "rsqp_rccl_comm_create)", "steps": ksteps, "ms_per_step": 1e3 * tg / ksteps, "pack_plus_all_gather_ms": 1e3 * only / ksteps,
+            "value": world * B * ksteps / tg, "unit": "QP solves/s", "ranks_seen": seen, "world": world,
+            "bytes_gathered_per_rank": 8 * world * B * stride}
+
+
 def trajectory_batch(capi, problems, nq=16384, reps=20):
     """The headline kernel on a REPRESENTATIVE mix: the QPs of a whole hs071 SQP run (tests/golden/sqp_traces.json: the
     iterates, multipliers, radii and penalties of the trajectory that tests/sqp_driver.py walks to the optimum), each with
@@ -502,6 +576,54 @@ def hs071_single_qp_latency(problems, iters=3000):
         res["gpu_over_cpu_latency"] = res["gpu_us_solveQP"] / res["cpu_oracle_us_solveQP"]
     res["note"] = ("one 8-variable QP at a time is launch / host-sync latency bound on the GPU: the CPU oracle (same loop in C, one "
                    "core) is FASTER per solve; the GPU wins only on batches (the headline line)")
+    return res
+
+
+def hs071_trajectory_latency(reps=300):
+    """"Wall-clock per SQP iteration (hs071)" as the reference clocks it (src/Algorithm.cpp:57,138-139), QP side: the WHOLE 6-QP
+    trajectory of tests/golden/sqp_traces.json through the C++ boundary (host_replay --trajectory: setupQP with set_A / set_H
+    refreshes and the per-element update_* storm, solveQP = optimizeQP + certificate, getters) and the same loop in C over the
+    CPU oracle (oracle/traj_oracle.c) on one core."""
+    import tempfile
+    import oracle as O
+    path = os.path.join(ROOT, "tests", "golden", "sqp_traces.json")
+    if not os.path.exists(path):
+        return None
+    tr = json.load(open(path))["hs071"]["qps"]
+    traj = [[q["delta"], q["rho"]] + list(q["x"]) + list(q["lam"]) for q in tr]
+    host = os.path.join(ROOT, "restartsqp_amd", "csrc", "host")
+    res = {"sqp_iterations": len(traj), "reps": reps}
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        for row in traj:
+            f.write(" ".join(repr(float(v)) for v in row) + "\n")
+        tpath = f.name
+    try:
+        out = subprocess.run([os.path.join(host, "host_replay"), "--trajectory", tpath, str(reps)], capture_output=True, text=True,
+                             timeout=300).stdout
+    finally:
+        os.unlink(tpath)
+    gx = None
+    for line in out.splitlines():
+        tok = line.split()
+        if line.startswith("trajectory sqp_iterations"):
+            kv = dict(zip(tok[1::2], tok[2::2]))
+            res["gpu"] = float(kv["us_per_sqp_iteration"]); res["gpu_first_iteration"] = float(kv["us_first_iteration"])
+            res["gpu_later_iterations"] = float(kv["us_later_iterations"]); res["gpu_qp_iter"] = int(kv["qp_iter"])
+        elif line.startswith("trajectory_last_x"):
+            gx = np.array([float(v) for v in tok[1:]])
+    cpu = O.hs071_trajectory_replay(traj, 50 * reps)
+    res["cpu_oracle"] = cpu["us_per_sqp_iteration"]; res["cpu_oracle_first_iteration"] = cpu["us_first_iteration"]
+    res["cpu_oracle_later_iterations"] = cpu["us_later_iterations"]; res["cpu_oracle_qp_iter"] = cpu["qp_iter"]
+    res["cpu_oracle_all_certified"] = cpu["failed_iteration"] == 0
+    gold = np.array(tr[-1]["x_qp"])
+    if gx is not None:
+        res["gpu_last_qp_max_abs_dx_vs_trace"] = float(np.abs(gx - gold).max())
+    res["cpu_last_qp_max_abs_dx_vs_trace"] = float(np.abs(cpu["x"] - gold).max())
+    if "gpu" in res:
+        res["gpu_over_cpu_latency"] = res["gpu"] / res["cpu_oracle"]
+    res["unit"] = "microseconds per SQP iteration (QP side: setupQP + solveQP + getters; NLP evaluation closed form)"
+    res["note"] = ("one 8-variable QP at a time is launch / host-sync latency bound on a GPU; ubA is refreshed in update_bounds "
+                   "(the reference's stale ubA, QPhandler.cpp:358-360, makes its own hs071 run infeasible after the first step)")
     return res
 
 
@@ -637,6 +759,13 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import torch
+    # fail loudly BEFORE any GPU call when the job cannot be the N-GPU job that was asked for (device_count() does not
+    # initialise the GPU): every rank needs a device of its own
+    if not rehearsal:
+        have = torch.cuda.device_count()
+        if have < world or local_rank >= have:
+            raise SystemExit("bench.py: --gpus %d but rank %d (local rank %d) sees %d GPU(s): refusing to run a smaller job "
+                             "under the name of a larger one" % (args.gpus, rank, local_rank, have))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -729,6 +858,12 @@ def main():
                   "ranks_seen": int((got[::B, 0] == 20).sum().item()),
                   "note": "solve + device-side record packing + all_gather_into_tensor over RCCL; not part of `value`"}
 
+        if gather["ranks_seen"] != world:
+            # every rank's first record carries Exitflag 20: fewer means a rank's shard never arrived -- not a result to report
+            raise SystemExit("bench.py: the all-gather returned the records of %d ranks, %d expected" % (gather["ranks_seen"], world))
+        if not rehearsal:
+            gather["native_rccl"] = native_rccl_gather(capi, torch, dist, batch, B, rank, world, local_rank, max(3, ksteps // 5))
+
     # BASELINE configs[4] (512 hs0xx QPs) as a weak- and a strong-scaling figure, on every rank, for every N
     scaling5 = hs_batch_scaling(capi, problems, parallel, torch, dist, rank, world, local_rank, cdev)
 
@@ -746,7 +881,9 @@ def main():
         k_ms = kernel_ms_total / args.steps   # average launch duration over the timed region
         bytes_launch = float(sum(qp_algorithmic_bytes(q) for q in probs))
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9
-        traffic, tfile = pmc_traffic("Engine<8", 1.0) if B == 65536 else (None, None)
+        fcal, fcal_note = pmc_fetch_calibration()
+        ffac = 2.0 if (fcal is not None and fcal > 1.5) else 1.0     # (the guide's x2 or nothing: the calibration decides which)
+        traffic, tfile = pmc_traffic(HEADLINE_PMC_KEY, ffac) if B == 65536 else (None, None)
         line = {
             "metric": "QP-subproblem solves/sec", "value": total / elapsed, "unit": "QP solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -758,8 +895,12 @@ def main():
                        "mean_nWSR": float(np.mean([r["nWSR"] for r in res])), "unsolved_or_kkt_fail": n_bad},
             "roofline": {"kernel": "small_qp_kernel<Engine<8>>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tfile,
-                         "traffic_note": "from the committed rocprofv3 --pmc passes of this command (FETCH_SIZE uncorrected: "
-                                         "narrow loads; + WRITE_SIZE), not measured in this run",
+                         "traffic_note": "from the committed rocprofv3 --pmc passes of this command, not measured in this run: "
+                                         "FETCH_SIZE x %.0f + WRITE_SIZE. The x2 of MI355X_MICROARCH.md (FETCH_SIZE tallies 128-B requests at "
+                                         "64 B) is calibrated there for 16-B-per-lane loads only; this kernel stages its inputs with 4- and "
+                                         "8-byte-per-lane coalesced loads, so the factor is calibrated on a kernel of the same file with a "
+                                         "known byte count: %s" % (ffac, fcal_note or "no calibration entry found: FETCH_SIZE taken as is"),
+                         "fetch_size_factor": ffac,
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_launch,
                          "note": "latency/LDS-bound kernel: HBM fraction is not its limiter; see roofline_issue in DESIGN.md 6"},
             "kernel_ms_stats": quartiles(per_launch),
@@ -777,13 +918,42 @@ def main():
                 O.use_native_build()
             line["cpu_baseline"] = cpu_baseline(probs[:256], args.cpu_seconds)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+            try:
+                line["native_rccl_1_rank"] = native_rccl_gather(capi, torch, None, batch, B, 0, 1, local_rank, 5)
+            except capi.RsqpError as e:     # informational at N = 1 (no librccl on the host): say so, never hide it
+                line["native_rccl_1_rank"] = {"error": str(e)}
             line["roofline_spmv"] = spmv_roofline(capi, problems, args.spmv_batch, 40)
             line["roofline_value_refresh"] = value_refresh_roofline(capi, problems)
             line["hs071_single_qp"] = hs071_single_qp_latency(problems)
+            traj = hs071_trajectory_latency()
+            if traj:
+                line["hs071_trajectory_latency"] = traj
+                # (the driver keeps `config` whole and drops other extras: the two per-SQP-iteration figures of BASELINE's
+                #  metric -- "wall-clock per SQP iteration (hs071; n=10k sparse)" -- go there)
+                line["config"]["hs071_us_per_sqp_iteration"] = {k: traj.get(k) for k in ("gpu", "cpu_oracle", "sqp_iterations",
+                                                                                         "gpu_later_iterations", "cpu_oracle_later_iterations")}
             line["hs071_trajectory_batch"] = trajectory_batch(capi, problems)
             line["hs0xx_batch_512"] = hs_batch_config(capi, problems, parallel)
             if not args.no_large:
                 line["large_engine"] = large_configs(capi, problems)
+                le = line["large_engine"]
+                ref, y0 = le.get("sparse_10000x20000_warm_sequence_reference_rule"), le.get("sparse_10000x20000_warm_sequence_y0_rule")
+                if ref:
+                    line["config"]["sparse10k_s_per_sqp_iteration_reference_rule"] = {
+                        "mean": 1e-3 * ref["wall_ms_per_sqp_iteration_mean"],
+                        "fixed": 1e-3 * ref["fixed_matrix_steps"]["wall_ms_mean"] if ref.get("fixed_matrix_steps") else None,
+                        "varied": 1e-3 * ref["varied_matrix_steps"]["wall_ms_mean"] if ref.get("varied_matrix_steps") else None,
+                        "steps": ref["qps"], "all_certified": ref["all_certified"]}
+                if y0:
+                    line["config"]["sparse10k_s_per_sqp_iteration_y0_rule_opt_in"] = 1e-3 * y0["wall_ms_per_sqp_iteration_mean"]
+                d2 = le.get("dense_2048x4096_cold")
+                if d2:
+                    line["config"]["dense_2048x4096_cold_s"] = d2["seconds"]
+                if "roofline_mfma" in le:
+                    line["config"]["roofline_mfma_frac"] = le["roofline_mfma"]["frac"]
+            line["config"]["roofline_spmv_frac"] = line["roofline_spmv"]["frac"]
+            line["config"]["hs0xx_batch_512_ms"] = line["hs0xx_batch_512"]["512_qps"]["ms_per_batch"]
+            line["config"]["hs0xx_batch_64_shard_ms"] = line["hs0xx_batch_512"]["64_qps_shard_of_8_gpus"]["ms_per_batch"]
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

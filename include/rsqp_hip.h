@@ -70,6 +70,8 @@ typedef struct rsqp_batch rsqp_batch;
 /* library                                                                               */
 /* ------------------------------------------------------------------------------------ */
 const char *rsqp_version(void);
+/* sha256 of the sources, headers and flags this library was built from (restartsqp_amd/build.py rebuilds on a mismatch) */
+const char *rsqp_build_hash(void);
 /* number of visible HIP devices (0 when there is none); never initialises a context */
 int rsqp_device_count(void);
 const char *rsqp_last_error(void);
@@ -97,6 +99,9 @@ int rsqp_get_setup_profile(const rsqp_solver *s, double *out8);
  * sort, CSC + CSR copy + SpMV plan, upload), timed apart from the per-solve cost; which: 0 = A, 1 = H;
  * < 0 when the matrix has not been set. */
 double rsqp_get_structure_seconds(const rsqp_solver *s, int which);
+/* RSQP_MODE_* the dispatch of the last rsqp_optimize_qp / _lp (or the caller of rsqp_solve) used: which of the four call
+ * shapes of qpOASESInterface.cpp:155,180-206 ran; -1 before the first solve */
+int rsqp_get_last_mode(const rsqp_solver *s);
 int rsqp_get_nV(const rsqp_solver *s);
 int rsqp_get_nC(const rsqp_solver *s);
 /* engine selection: 0 = automatic (the LDS-resident kernel when the problem image fits the
@@ -145,6 +150,9 @@ int rsqp_get_vector(const rsqp_solver *s, int which, double *v);
  * SpHbMat::setMatVal (SpHbMat.cpp:368-380): the scatter through `order` (20 B per entry) and the
  * refresh of the CSR copy -- on the values staged by the last rsqp_set_A_triplet */
 int rsqp_time_value_refresh(rsqp_solver *s, int repeats, float *ms_scatter, float *ms_gather);
+/* the product path since round 4: ONE launch that writes every refreshed triplet value to its CSC slot and to its slot of
+ * the CSR copy (set_A on a known pattern, SpHbMat.cpp:368-380); average ms per launch */
+int rsqp_time_value_refresh_fused(rsqp_solver *s, int repeats, float *ms);
 /* tuning aid for the HBM-resident engine (no reference counterpart): device ms per call of one of its streaming
  * kernel classes -- kind 0: y = M w (column-major), 1: y = M'x, 2: rank-1 update -- on an nrows x ncols block of an
  * n x n buffer (leading dimension n), exactly as the engine launches them */
@@ -268,6 +276,23 @@ int rsqp_batch_pack_records_host(rsqp_batch *b, double *rec_host);
  * Both are the partitions restartsqp_amd/parallel.py uses (shard_range, balanced_shards). */
 int rsqp_shard_range(int nq, int rank, int world, int *lo, int *hi);
 int rsqp_balanced_shard(int nq, const int *nV, const int *nC, int rank, int world, int *idx, int *count);
+/* The two exchange steps of the sharded batch as NATIVE RCCL calls (the reference itself has no collective:
+ * it is single-threaded, test/simple_test.cpp:72). librccl.so is bound at first use, so hosts that never shard need none.
+ *   rsqp_rccl_unique_id / rsqp_rccl_comm_create / _destroy: ncclGetUniqueId on one rank (the host ships the 128 bytes to
+ *       the others by whatever it has: MPI, a file, torch.distributed), ncclCommInitRank on every rank with its device.
+ *       A host that already owns an ncclComm_t passes it instead -- `comm` is an ncclComm_t everywhere below.
+ *   rsqp_rccl_broadcast_dev: ncclBroadcast of `bytes` bytes of device memory from rank `root` (shared structure of a
+ *       parameter scan: patterns, values, vectors) on `hip_stream` (NULL = the null stream); returns when it has completed.
+ *   rsqp_batch_allgather_records: packs this rank's fixed-stride records (rsqp_batch_pack_records_dev) straight into its
+ *       slot of all_dev and all-gathers in place over RCCL / xGMI. all_dev: DEVICE buffer of world * count_per_rank * stride
+ *       doubles; count_per_rank >= the member count of every rank, the same on all ranks (ranks with fewer members pad
+ *       with zero records: Exitflag 0). Enqueued on the batch's stream behind the solve; returns when it has completed. */
+#define RSQP_RCCL_UNIQUE_ID_BYTES 128
+int rsqp_rccl_unique_id(char id[RSQP_RCCL_UNIQUE_ID_BYTES]);
+int rsqp_rccl_comm_create(const char id[RSQP_RCCL_UNIQUE_ID_BYTES], int rank, int world, int device, void **comm);
+int rsqp_rccl_comm_destroy(void *comm);
+int rsqp_rccl_broadcast_dev(void *comm, void *buf_dev, long long bytes, int root, void *hip_stream);
+int rsqp_batch_allgather_records(rsqp_batch *b, void *comm, int count_per_rank, double *all_dev);
 
 /* ------------------------------------------------------------------------------------ */
 /* batched sparse products, device resident -- the SpMV the roofline target names        */

@@ -23,7 +23,7 @@ c_dbl_p = C.POINTER(C.c_double)
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("sphb_oracle.c", "kkt_oracle.c", "qp_oracle.c", "rsqp_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("sphb_oracle.c", "kkt_oracle.c", "qp_oracle.c", "traj_oracle.c", "rsqp_oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
     return so
@@ -77,6 +77,8 @@ def lib():
                   "orc_qp_nflips", "orc_exitflag"):
             getattr(L, f).argtypes = [C.c_void_p]
             getattr(L, f).restype = C.c_int
+        L.orc_hs071_trajectory_replay.argtypes = [C.c_int, c_dbl_p, C.c_int, c_dbl_p, c_dbl_p, c_dbl_p, c_int_p, c_int_p]
+        L.orc_hs071_trajectory_replay.restype = C.c_int
         L.orc_one_norm.restype = C.c_double
         L.orc_inf_norm.restype = C.c_double
         _LIB = L
@@ -406,3 +408,17 @@ class OracleInterface:
                 self.new = self.old = 0
         self.upd_A = self.upd_H = False
         return used
+
+
+def hs071_trajectory_replay(traj, reps=1):
+    """traj: rows of (delta, rho, x[4], lam[2]) -- the iterates of an hs071 SQP run. The QP side of every iteration (assembly,
+    handler formulas, optimizeQP dispatch, certificate, getters) in ONE C loop (traj_oracle.c): the CPU leg of
+    "wall-clock per SQP iteration (hs071)". Returns dict(us_per_sqp_iteration, us_first_iteration, us_later_iterations, x, y,
+    qp_iter, modes, failed_iteration)."""
+    t = np.ascontiguousarray(traj, dtype=np.float64).reshape(-1, 8)
+    nit = t.shape[0]
+    us = np.zeros(3); x = np.zeros(8); y = np.zeros(10); it = C.c_int(0); modes = np.zeros(nit, np.int32)
+    bad = lib().orc_hs071_trajectory_replay(nit, t.ctypes.data_as(c_dbl_p), reps, us.ctypes.data_as(c_dbl_p), x.ctypes.data_as(c_dbl_p),
+                                            y.ctypes.data_as(c_dbl_p), C.byref(it), modes.ctypes.data_as(c_int_p))
+    return dict(us_per_sqp_iteration=float(us[0]), us_first_iteration=float(us[1]), us_later_iterations=float(us[2]), x=x, y=y,
+                qp_iter=it.value, modes=modes.tolist(), failed_iteration=bad)

@@ -178,6 +178,11 @@ int orc_qp_nflips(const orc_qp *qp);
 /* qpOASESInterface::get_status src/qpOASESInterface.cpp:332-357 -> Exitflag value */
 int orc_exitflag(const orc_qp *qp);
 
+/* bench.py / tests only (traj_oracle.c): the QP side of every iteration of an hs071 SQP run in one C loop -- setupQP
+ * (src/Algorithm.cpp:645-697), solveQP (src/QPhandler.cpp:470-499), getters; traj = nit rows {delta, rho, x[4], lam[2]} */
+int orc_hs071_trajectory_replay(int nit, const double *traj, int reps, double *out_us, double *x_last, double *y_last,
+                                int *qp_iter, int *modes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,12 +32,14 @@ SYMBOLS = {
     "rsqp_dense_chol_inverse": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double,
                                           C.POINTER(C.c_int), fp]),
     "rsqp_version": (C.c_char_p, []),
+    "rsqp_build_hash": (C.c_char_p, []),
     "rsqp_device_count": (C.c_int, []),
     "rsqp_last_error": (C.c_char_p, []),
     "rsqp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "rsqp_destroy": (None, [C.c_void_p]),
     "rsqp_set_options": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rsqp_set_reinit_guess": (C.c_int, [C.c_void_p, C.c_int]),
+    "rsqp_get_last_mode": (C.c_int, [C.c_void_p]),
     "rsqp_get_nV": (C.c_int, [C.c_void_p]),
     "rsqp_get_nC": (C.c_int, [C.c_void_p]),
     "rsqp_write_qp_dump": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, ip, ip, dp, ip, ip, dp]),
@@ -94,7 +96,13 @@ SYMBOLS = {
     "rsqp_batch_pack_records_host": (C.c_int, [C.c_void_p, dp]),
     "rsqp_shard_range": (C.c_int, [C.c_int, C.c_int, C.c_int, ip, ip]),
     "rsqp_balanced_shard": (C.c_int, [C.c_int, ip, ip, C.c_int, C.c_int, ip, ip]),
+    "rsqp_rccl_unique_id": (C.c_int, [C.c_char_p]),
+    "rsqp_rccl_comm_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "rsqp_rccl_comm_destroy": (C.c_int, [C.c_void_p]),
+    "rsqp_rccl_broadcast_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),
+    "rsqp_batch_allgather_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "rsqp_time_value_refresh": (C.c_int, [C.c_void_p, C.c_int, fp, fp]),
+    "rsqp_time_value_refresh_fused": (C.c_int, [C.c_void_p, C.c_int, fp]),
     "rsqp_time_large_kernel": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp]),
     "rsqp_spmv_plan_create": (C.c_int, [C.c_int, C.c_int, ip, ip, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "rsqp_spmv_plan_destroy": (None, [C.c_void_p]),
@@ -246,6 +254,11 @@ class Solver:
         check(lib().rsqp_time_value_refresh(self._h, repeats, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def time_value_refresh_fused(self, repeats=50):
+        a = C.c_float(0)
+        check(lib().rsqp_time_value_refresh_fused(self._h, repeats, C.byref(a)))
+        return a.value
+
     def set_engine(self, engine):
         """0 automatic, 1 LDS-resident kernel, 2 HBM-resident engine."""
         check(lib().rsqp_set_engine(self._h, engine))
@@ -254,10 +267,18 @@ class Solver:
     def engine(self):
         return lib().rsqp_get_engine(self._h)
 
-    def set_reinit_guess(self, from_y0=True):
-        """warm re-initialisation without guessed constraints: as qpOASES, from A x0 (library default) or -- opt-in,
-        from_y0=True -- sides from sign(y0)"""
+    def set_reinit_guess(self, from_y0):
+        """warm re-initialisation without guessed constraints: from_y0=False as qpOASES, from A x0 (the library default, the
+        reference's behaviour) or -- opt-in, from_y0=True -- sides from sign(y0). No default argument: a bare call must not
+        silently leave the reference's rule"""
         check(lib().rsqp_set_reinit_guess(self._h, int(bool(from_y0))))
+
+    MODE_NAMES = {-1: "none", 0: "init (cold)", 1: "hotstart(g, lb, ub, lbA, ubA)", 2: "hotstart(H, g, A, ..) -- new matrices",
+                  3: "init(.., x_qp, y_qp, &bounds) -- status flip"}
+
+    def last_mode(self):
+        """RSQP_MODE_* the dispatch of the last optimize_qp / optimize_lp chose"""
+        return lib().rsqp_get_last_mode(self._h)
 
     def set_options(self, qp_maxiter=1000, lp_maxiter=100):
         check(lib().rsqp_set_options(self._h, qp_maxiter, lp_maxiter))
@@ -476,6 +497,35 @@ class Batch:
         ok = np.zeros(self.nq, np.int32)
         check(lib().rsqp_batch_test_optimality(self._h, C.cast(st, C.c_void_p), _ip(ok)))
         return ok, [st[q].KKT_error for q in range(self.nq)]
+
+    def allgather_records(self, comm, count_per_rank, all_dev_ptr):
+        """native RCCL: pack this rank's records into its slot of the DEVICE buffer at `all_dev_ptr`
+        (world * count_per_rank * record_stride doubles) and all-gather in place; returns when done"""
+        check(lib().rsqp_batch_allgather_records(self._h, comm._c, int(count_per_rank), C.c_void_p(all_dev_ptr)))
+
+
+def rccl_unique_id():
+    """ncclGetUniqueId through the C ABI: 128 bytes that rank 0 ships to every other rank"""
+    buf = C.create_string_buffer(128)
+    check(lib().rsqp_rccl_unique_id(buf))
+    return buf.raw
+
+
+class RcclComm:
+    """an ncclComm_t created through the C ABI (rsqp_rccl_comm_create): one per rank, bound to `device`"""
+
+    def __init__(self, uid, rank, world, device):
+        c = C.c_void_p()
+        check(lib().rsqp_rccl_comm_create(C.create_string_buffer(bytes(uid), 128), rank, world, device, C.byref(c)))
+        self._c, self.rank, self.world = c, rank, world
+
+    def broadcast_dev(self, dev_ptr, nbytes, root=0, stream=None):
+        check(lib().rsqp_rccl_broadcast_dev(self._c, C.c_void_p(dev_ptr), int(nbytes), root, C.c_void_p(stream or 0)))
+
+    def close(self):
+        if getattr(self, "_c", None):
+            lib().rsqp_rccl_comm_destroy(self._c)
+            self._c = None
 
 
 class SpmvPlan:

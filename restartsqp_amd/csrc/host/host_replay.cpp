@@ -26,7 +26,7 @@ struct Hs071 {
     static constexpr double x_l[4] = {1, 1, 1, 1}, x_u[4] = {5, 5, 5, 5};
     static constexpr double c_l[2] = {25, 40};
     double c_u[2] = {std::numeric_limits<double>::infinity(), 40};
-    explicit Hs071(const double *xk) {
+    explicit Hs071(const double *xk, const double *lam = nullptr) {
         for (int i = 0; i < 4; i++) x[i] = xk[i];
         const double x1 = x[0], x2 = x[1], x3 = x[2], x4 = x[3];
         c[0] = x1 * x2 * x3 * x4; c[1] = x1 * x1 + x2 * x2 + x3 * x3 + x4 * x4;
@@ -39,6 +39,12 @@ struct Hs071 {
         H->RowNum = H->ColNum = 4; H->isSymmetric = true;
         H->RowIndex = {1, 2, 2, 3, 3, 3, 4, 4, 4, 4}; H->ColIndex = {1, 1, 2, 1, 2, 3, 1, 2, 3, 4};
         H->MatVal = {2 * x4, x4, 0, x4, 0, 0, 2 * x1 + x2 + x3, x1, x1, 0};
+        if (lam) {   // Hessian of the Lagrangian f - lam'c (SQPTNLP::Eval_Hessian negates lambda, src/SQPTNLP.cpp:124-126)
+            const double l1 = lam[0], l2 = lam[1];
+            const double hc1[10] = {0, x3 * x4, 0, x2 * x4, x1 * x4, 0, x2 * x3, x1 * x3, x1 * x2, 0};
+            const bool diag[10] = {true, false, true, false, false, true, false, false, false, true};
+            for (int e = 0; e < 10; e++) H->MatVal[e] -= l1 * hc1[e] + (diag[e] ? 2.0 * l2 : 0.0);
+        }
     }
 };
 constexpr double Hs071::x_l[4], Hs071::x_u[4], Hs071::c_l[2];
@@ -66,9 +72,14 @@ struct Handler {
         }
         for (int i = 0; i < 2 * m; i++) solver->set_ub(n + i, INF_REF);
     }
+    // refresh_ubA: NOT the reference (its qpOASES branch leaves ubA stale, :358-360, which turns its own run infeasible after the
+    // first accepted step when a constraint is an equality); the whole-trajectory replay needs the value and passes c_u
     void update_bounds(double delta, const double *x_l, const double *x_u, const double *x_k, const double *c_l,
-                       const double *c_k) {                                             // :342-368 (ubA is not refreshed)
-        for (int i = 0; i < m; i++) solver->set_lbA(i, c_l[i] - c_k[i]);
+                       const double *c_k, const double *refresh_ubA_c_u = nullptr) {    // :342-368 (ubA is not refreshed)
+        for (int i = 0; i < m; i++) {
+            solver->set_lbA(i, c_l[i] - c_k[i]);
+            if (refresh_ubA_c_u) solver->set_ubA(i, refresh_ubA_c_u[i] - c_k[i]);
+        }
         for (int i = 0; i < n; i++) {
             solver->set_lb(i, std::fmax(x_l[i] - x_k[i], -delta));
             solver->set_ub(i, std::fmin(x_u[i] - x_k[i], delta));
@@ -163,6 +174,69 @@ int penalty_soc_trace() {
     return 0;
 }
 
+// "wall-clock per SQP iteration (hs071)" as the reference clocks it (src/Algorithm.cpp:57,138-139: one clock() pair per pass of
+// the while loop): the QP side of EVERY iteration of a whole hs071 run -- Algorithm::setupQP (:645-697: iteration 0 set_A,
+// set_H, set_bounds, set_g; later update_A / update_H / update_bounds / update_penalty / update_grad through the per-element
+// setters), QPhandler::solveQP (optimizeQP + mandatory certificate, src/QPhandler.cpp:470-499) and the getters the loop
+// reads (:609-622). The iterates (delta, rho, x_k, lambda_k per iteration) come from the committed trajectory
+// (tests/golden/sqp_traces.json, written to a text file by the caller); NLP evaluation is closed form and not timed apart.
+int trajectory_bench(const char *path, int reps) {
+    std::vector<double> tr;
+    {
+        FILE *f = std::fopen(path, "r");
+        if (!f) { std::printf("cannot open %s\n", path); return 2; }
+        double v;
+        while (std::fscanf(f, "%lf", &v) == 1) tr.push_back(v);
+        std::fclose(f);
+    }
+    const int nit = (int)tr.size() / 8;
+    if (nit < 1 || reps < 1) { std::printf("empty trajectory\n"); return 2; }
+    NLPInfo info{2, 4, 8, 10};
+    auto options = std::make_shared<Options>();
+    double us_all = 0.0, us_first = 0.0, xlast[8] = {0}, ylast[10] = {0};
+    int qp_iter_last = 0;
+    for (int r = 0; r < reps; r++) {
+        auto stats = std::make_shared<Stats>();
+        Handler myQP(info, QP, options, nullptr);          // (Algorithm::allocate_memory: outside the reference's clock as well)
+        double rho_prev = 0.0;
+        for (int k = 0; k < nit; k++) {
+            const double *t = &tr[8 * k];
+            const double delta = t[0], rho = t[1];
+            const auto t0 = std::chrono::steady_clock::now();
+            Hs071 nlp(t + 2, t + 6);
+            if (k == 0) {
+                myQP.set_A(nlp.J); myQP.set_H(nlp.H);
+                myQP.set_bounds(delta, nlp.x_l, nlp.x_u, nlp.x, nlp.c_l, nlp.c_u, nlp.c);
+                myQP.set_g(nlp.grad, rho);
+            } else {
+                myQP.set_A(nlp.J); myQP.set_H(nlp.H);      // update_A / update_H (QPhandler.cpp:508-531): value refresh
+                myQP.update_bounds(delta, nlp.x_l, nlp.x_u, nlp.x, nlp.c_l, nlp.c, nlp.c_u);
+                if (rho != rho_prev) myQP.update_penalty(rho);
+                myQP.update_grad(nlp.grad);
+            }
+            rho_prev = rho;
+            myQP.solveQP(stats);
+            const double *x = myQP.solver->get_optimal_solution();
+            const double *yb = myQP.solver->get_multipliers_bounds(), *yc = myQP.solver->get_multipliers_constr();
+            for (int i = 0; i < 8; i++) { xlast[i] = x[i]; ylast[i] = yb[i]; }
+            ylast[8] = yc[0]; ylast[9] = yc[1];
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            us_all += us;
+            if (k == 0) us_first += us;
+        }
+        qp_iter_last = stats->qp_iter;
+    }
+    std::printf("trajectory sqp_iterations %d reps %d us_per_sqp_iteration %.3f us_first_iteration %.3f us_later_iterations %.3f qp_iter %d\n",
+                nit, reps, us_all / (reps * (double)nit), us_first / reps, nit > 1 ? (us_all - us_first) / (reps * (double)(nit - 1)) : 0.0,
+                qp_iter_last);
+    std::printf("trajectory_last_x");
+    for (int i = 0; i < 8; i++) std::printf(" %.15g", xlast[i]);
+    std::printf("\ntrajectory_last_y");
+    for (int i = 0; i < 10; i++) std::printf(" %.15g", ylast[i]);
+    std::printf("\n");
+    return 0;
+}
+
 // plain-QP ctor with data (reference src/qpOASESInterface.cpp:54-94, as test/QPsolvers_testers.cpp:220 uses
 // it on the dumps of test/unsolved_QP_data), the data getters QPhandler::get_active_set reads
 // (src/QPhandler.cpp:596-650) and WriteQPDataToFile in both layouts
@@ -213,6 +287,7 @@ int main(int argc, char **argv) {
     try {
         if (argc > 1 && std::strcmp(argv[1], "--penalty") == 0) return penalty_soc_trace();
         if (argc > 3 && std::strcmp(argv[1], "--dump") == 0) return dump_replay(argv[2], argv[3]);
+        if (argc > 3 && std::strcmp(argv[1], "--trajectory") == 0) return trajectory_bench(argv[2], std::atoi(argv[3]));
     } catch (const std::exception &e) {
         std::printf("EXCEPTION %s\n", e.what());
         return 2;

@@ -1490,6 +1490,14 @@ struct RsqpLargeEngine::Impl {
         LCHK(hipStreamSynchronize(st));
         return RET_OK;
     }
+    // a publication that never arrived (device error): the deferred rank-1 updates of Z / Wz / Y / Minv were not applied
+    // while nZ / nAC already count the change -- the stored factors are inconsistent, so the handle forgets them and the
+    // next hot start falls back to a full set-up
+    int wait_failed() {
+        status = QPS_NOTINITIALISED;
+        pendZ.on = pendW.on = pendY.on = pendM.on = false;
+        return RET_SETUP_FAILED;
+    }
     double *h_pinned = nullptr;  // small pinned read-back buffer
     int *h_pinned_i = nullptr;
     int nblk_ratio = 0;
@@ -1914,7 +1922,7 @@ struct RsqpLargeEngine::Impl {
         else
             hipLaunchKernelGGL(k_wz_grow, dim3((nZ + 1 + NT - 1) / NT, nZ + 1), dim3(NT), 0, st, Wz, ld, nZ, wz2, scal, 13);
         pend(4, 16.0 * (double)nZ * nZ);
-        if (wait_ctl() != RET_OK) return RET_SETUP_FAILED;
+        if (wait_ctl() != RET_OK) return wait_failed();
         *pd = h_ctl[4] > h_ctl[5];
         if (*pd) nZ++;
         return RET_OK;
@@ -2052,7 +2060,7 @@ struct RsqpLargeEngine::Impl {
         const double sgn = side == 1 ? -1.0 : 1.0;
         hipLaunchKernelGGL(k_partner1, dim3(nblk_ratio), dim3(NT), 0, st, nV, nC, Sb, Sc, y, c1, w3, sgn, pt, pid);
         hipLaunchKernelGGL(k_argmin2, dim3(1), dim3(NT), 0, st, nblk_ratio, pt, pid, d_ctl, next_seq(), (double *)nullptr);
-        if (wait_ctl() != RET_OK) return RET_SETUP_FAILED;
+        if (wait_ctl() != RET_OK) return wait_failed();
         const double t = h_ctl[0];
         const int id = (int)h_ctl[1];
         if (id == 0x7fffffff) return RET_INFEASIBLE;
@@ -2065,7 +2073,7 @@ struct RsqpLargeEngine::Impl {
     }
 
     int li_decision(bool *li) {
-        if (wait_ctl() != RET_OK) return RET_SETUP_FAILED;
+        if (wait_ctl() != RET_OK) return wait_failed();
         const double a2 = h_ctl[2], w2n = h_ctl[3];
         *li = nZ > 0 && a2 > 0.0 && std::sqrt(w2n) > RSQP_EPS_LI * std::sqrt(a2);
         return RET_OK;
@@ -2255,7 +2263,7 @@ struct RsqpLargeEngine::Impl {
             // the homotopy step decodes the winner on the device and runs while the host waits for its own copy
             hipLaunchKernelGGL(k_step_all, g1(nV + nC), dim3(NT), 0, st, nV, nC, scal + 30, iter < maxit ? 1 : 0, Sb, x, g, lb, ub, gN, lbN,
                                ubN, dx, ATdy, ATy, Hdx, Hx, lbA, ubA, lbAN, ubAN, dAx, Ax, dy, y);
-            if (wait_ctl() != RET_OK) return RET_SETUP_FAILED;
+            if (wait_ctl() != RET_OK) return wait_failed();
             double tau = h_ctl[0];
             const int bid = (int)h_ctl[1];
             int kind = 0, idx = -1, side = 0;

@@ -203,7 +203,7 @@ struct DevMatrix {
     DevBuf<int> jc, ir, order, tmap;                 // CSC
     DevBuf<int4> blk_c, blk_r;
     DevBuf<double> val, tv;                          // tv: staging for triplet values
-    DevBuf<int> rp, ci, perm;                        // CSR copy (A only)
+    DevBuf<int> rp, ci, perm, rorder;                // CSR copy (A only); rorder[i] = CSR position of triplet entry i (fused value refresh)
     DevBuf<double> rval;
     int nblk_c = 0, nblk_r = 0;
     bool have_csr = false;
@@ -253,6 +253,7 @@ struct rsqp_solver {
     bool fits_small = true;
     RsqpLargeEngine *large = nullptr;
     bool large_ready = false, profile_large = false;
+    int last_mode = -1;           // RSQP_MODE_* of the last rsqp_solve (what the dispatch of optimizeQP / optimizeLP chose): rsqp_get_last_mode
     bool reinit_from_y0 = false;  // rsqp_set_reinit_guess: default = the reference rule (qpOASESInterface.cpp:199-207); 1 = opt-in shortcut
     DevBuf<double> denseA, denseAT, denseH;   // dense copies for the HBM-resident engine (dense matrices only)
     ~rsqp_solver() {
@@ -289,6 +290,12 @@ int upload_matrix(DevMatrix &M, const Compressed &c, bool want_csr) {
         HIPCHK(M.ci.alloc(M.nnz + 2, true)); HIPCHK(M.ci.upload(r.ci.data(), r.ci.size()));
         HIPCHK(M.perm.alloc(std::max(M.nnz, 1), true)); HIPCHK(M.perm.upload(r.perm.data(), r.perm.size()));
         HIPCHK(M.rval.alloc(M.nnz + 2, true));
+        {   // rorder = (CSC slot -> CSR slot) o order: where a refreshed triplet value lands in the CSR copy
+            std::vector<int> inv(std::max(M.nnz, 1), 0), ro(std::max(M.nnz, 1), 0);
+            for (int k = 0; k < M.nnz; k++) inv[r.perm[k]] = k;
+            for (size_t i = 0; i < c.order.size(); i++) ro[i] = inv[c.order[i]];
+            HIPCHK(M.rorder.from(ro));
+        }
         std::vector<int4> blr = build_blocks(M.nrow, r.rp.data(), rsqp_spmv_chunk());
         M.nblk_r = (int)blr.size();
         HIPCHK(M.blk_r.from(blr));
@@ -489,6 +496,7 @@ extern "C" double rsqp_get_structure_seconds(const rsqp_solver *s, int which) {
     const DevMatrix &M = which == 0 ? s->A : s->H;
     return M.initialised ? M.structure_seconds : -1.0;
 }
+extern "C" int rsqp_get_last_mode(const rsqp_solver *s) { return s ? s->last_mode : -1; }
 extern "C" int rsqp_get_nV(const rsqp_solver *s) { return s ? s->nV : -1; }
 extern "C" int rsqp_get_nC(const rsqp_solver *s) { return s ? s->nC : -1; }
 
@@ -529,7 +537,7 @@ extern "C" int rsqp_set_A_triplet(rsqp_solver *s, int nnz, const int *irow, cons
         M.from_triplet = true; M.n_triplet = nnz; M.n_ident_entries = nid;
         int rc = upload_matrix(M, cs, true);
         if (rc != RSQP_OK) return rc;
-        (void)hipDeviceSynchronize();
+        (void)hipStreamSynchronize(s->stream);   // this handle's stream only (the uploads are blocking copies): other handles keep running
         M.structure_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         s->desc_ready = false;
         return RSQP_OK;
@@ -537,8 +545,9 @@ extern "C" int rsqp_set_A_triplet(rsqp_solver *s, int nnz, const int *irow, cons
     if (!M.from_triplet || nnz != M.n_triplet) return fail(RSQP_ERR_ARG, "rsqp_set_A_triplet: pattern changed");
     // SpHbMat::setMatVal(rhs, I_info): only the first nnz(J) entries are rewritten
     HIPCHK(M.tv.upload(val, nnz));
-    if (rsqp_launch_scatter(nnz, M.order.p, nullptr, M.tv.p, M.val.p, s->stream) != hipSuccess ||
-        rsqp_launch_gather(M.nnz, M.perm.p, M.val.p, M.rval.p, s->stream) != hipSuccess)
+    // one launch: every refreshed value goes to its CSC slot and to its slot of the CSR copy (the identity entries of [J I -I]
+    // keep their values in both, SpHbMat.cpp:368-380)
+    if (rsqp_launch_scatter_csc_csr(nnz, M.order.p, M.rorder.p, M.tv.p, M.val.p, M.rval.p, s->stream) != hipSuccess)
         return fail(RSQP_ERR_DEVICE, "value refresh launch failed");
     return RSQP_OK;
 }
@@ -567,7 +576,7 @@ extern "C" int rsqp_set_H_triplet(rsqp_solver *s, int nnz, const int *irow, cons
         M.from_triplet = true; M.n_triplet = nnz; M.symmetric = is_symmetric != 0;
         int rc = upload_matrix(M, cs, false);
         if (rc != RSQP_OK) return rc;
-        (void)hipDeviceSynchronize();
+        (void)hipStreamSynchronize(s->stream);   // this handle's stream only (the uploads are blocking copies): other handles keep running
         M.structure_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         s->desc_ready = false;
         return RSQP_OK;
@@ -610,18 +619,18 @@ int set_csc(rsqp_solver *s, DevMatrix &M, int nrow, int ncol, const int *jc, con
     int rc = upload_matrix(M, cs, want_csr);
     s->desc_ready = false;
     if (rc == RSQP_OK) {
-        (void)hipDeviceSynchronize();
+        (void)hipStreamSynchronize(s->stream);   // this handle's stream only (the uploads are blocking copies): other handles keep running
         M.structure_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     return rc;
 }
-int get_csc(const DevMatrix &M, int *jc, int *ir, double *val, int *order) {
+int get_csc(const DevMatrix &M, hipStream_t stream, int *jc, int *ir, double *val, int *order) {
     if (!M.initialised) return fail(RSQP_ERR_ARG, "matrix not set");
     if (jc) std::copy(M.h_jc.begin(), M.h_jc.end(), jc);
     if (ir) std::copy(M.h_ir.begin(), M.h_ir.end(), ir);
     if (order) std::copy(M.h_order.begin(), M.h_order.end(), order);
     if (val) {
-        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipStreamSynchronize(stream));   // the value refresh kernels of this handle
         HIPCHK(M.val.download(val, M.nnz));
     }
     return RSQP_OK;
@@ -642,11 +651,11 @@ extern "C" int rsqp_get_A_nnz(const rsqp_solver *s) { return s && s->A.initialis
 extern "C" int rsqp_get_H_nnz(const rsqp_solver *s) { return s && s->H.initialised ? s->H.nnz : -1; }
 extern "C" int rsqp_get_A_csc(const rsqp_solver *s, int *jc, int *ir, double *val, int *order) {
     if (!s) return fail(RSQP_ERR_ARG, "null solver");
-    return get_csc(s->A, jc, ir, val, order);
+    return get_csc(s->A, s->stream, jc, ir, val, order);
 }
 extern "C" int rsqp_get_H_csc(const rsqp_solver *s, int *jc, int *ir, double *val, int *order) {
     if (!s) return fail(RSQP_ERR_ARG, "null solver");
-    return get_csc(s->H, jc, ir, val, order);
+    return get_csc(s->H, s->stream, jc, ir, val, order);
 }
 
 extern "C" int rsqp_set_vector(rsqp_solver *s, int which, const double *v) {
@@ -747,6 +756,7 @@ extern "C" int rsqp_solve(rsqp_solver *s, int mode, int *nWSR, const double *x0,
                           const int *guess_b) {
     if (!s || !nWSR || mode < 0 || mode > 3) return fail(RSQP_ERR_ARG, "rsqp_solve");
     s->spec_cert = false;
+    s->last_mode = mode;
     if (!s->A.initialised && s->nC > 0) return fail(RSQP_ERR_ARG, "rsqp_solve: A not set");
     HIPCHK(hipSetDevice(s->device));
     int rc = flush_vectors(s);
@@ -1407,8 +1417,32 @@ extern "C" int rsqp_batch_pack_records_host(rsqp_batch *b, double *rec_host) {
     return RSQP_OK;
 }
 
+// (rsqp_rccl.cpp: the native RCCL call sites reach the batch through these)
+int rsqp_fail_msg(int code, const char *msg) { return fail(code, msg ? msg : ""); }
+hipStream_t rsqp_batch_stream_internal(rsqp_batch *b) { return b->stream; }
+int rsqp_batch_device_internal(const rsqp_batch *b) { return b->device; }
+int rsqp_batch_nq_internal(const rsqp_batch *b) { return b ? b->nq : 0; }
+
 // setMatVal on the device (SpHbMat.cpp:368-393): time `repeats` launches of the scatter through `order`
 // and of the CSR-copy gather on the values already staged by rsqp_set_A_triplet (no host transfer inside)
+extern "C" int rsqp_time_value_refresh_fused(rsqp_solver *s, int repeats, float *ms) {
+    if (!s || repeats <= 0 || !ms || !s->A.initialised || !s->A.from_triplet || !s->A.have_csr) return fail(RSQP_ERR_ARG, "rsqp_time_value_refresh_fused");
+    HIPCHK(hipSetDevice(s->device));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    DevMatrix &M = s->A;
+    HIPCHK(hipEventRecord(e0, s->stream));
+    for (int r = 0; r < repeats; r++)
+        if (rsqp_launch_scatter_csc_csr(M.n_triplet, M.order.p, M.rorder.p, M.tv.p, M.val.p, M.rval.p, s->stream) != hipSuccess)
+            return fail(RSQP_ERR_DEVICE, "value refresh launch failed");
+    HIPCHK(hipEventRecord(e1, s->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    HIPCHK(hipEventElapsedTime(ms, e0, e1));
+    *ms /= repeats;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return RSQP_OK;
+}
+
 extern "C" int rsqp_time_value_refresh(rsqp_solver *s, int repeats, float *ms_scatter, float *ms_gather) {
     if (!s || repeats <= 0 || !s->A.initialised || !s->A.from_triplet) return fail(RSQP_ERR_ARG, "rsqp_time_value_refresh");
     HIPCHK(hipSetDevice(s->device));

@@ -107,3 +107,17 @@ def test_gpu_replays_the_trajectory(capi, name):
         assert same_path, (name, g["it"], g["mode"], n, g["nWSR"])
         assert np.abs(y - gy).max() <= 1e-9 * max(1.0, np.abs(gy).max()), (name, g["it"], g["mode"])
     assert ties <= 3, ties
+
+
+def test_c_loop_of_the_hs071_trajectory_matches_the_trace(oracle):
+    """bench.py's CPU leg of "wall-clock per SQP iteration (hs071)" (oracle/traj_oracle.c: assembly, handler formulas, dispatch,
+    certificate and getters of all six QPs in one C loop) walks the committed trajectory: same modes, working-set changes and
+    last QP as the trace."""
+    gold = trace()["hs071"]["qps"]
+    traj = [[g["delta"], g["rho"]] + g["x"] + g["lam"] for g in gold]
+    r = oracle.hs071_trajectory_replay(traj, 3)
+    assert r["failed_iteration"] == 0
+    assert r["modes"] == [{"cold": 0, "hot_vectors": 1, "hot_matrices": 2, "reinit": 3}[g["mode"]] for g in gold]
+    assert r["qp_iter"] == sum(g["nWSR"] for g in gold)
+    assert np.abs(r["x"] - np.array(gold[-1]["x_qp"])).max() <= 1e-12 and np.abs(r["y"] - np.array(gold[-1]["y_qp"])).max() <= 1e-12
+    assert 0.0 < r["us_per_sqp_iteration"] < 1e4
