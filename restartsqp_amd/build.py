@@ -50,8 +50,26 @@ def source_hash():
     return _sha([os.path.join(CSRC, f) for f in _sources() + [STAMP]] + _headers(), " ".join(FLAGS + LINK_LIBS))
 
 
-def _tu_hash(f, hdr_hash):
-    return _sha([os.path.join(CSRC, f)], hdr_hash + " ".join(FLAGS))
+def _includes(path, seen=None):
+    """the quoted includes of a source, transitively (paths relative to the including file)"""
+    import re
+    seen = seen if seen is not None else []
+    try:
+        txt = open(path).read()
+    except OSError:
+        return seen
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', txt, flags=re.M):
+        q = os.path.normpath(os.path.join(os.path.dirname(path), inc))
+        if q not in seen and os.path.exists(q):
+            seen.append(q)
+            _includes(q, seen)
+    return seen
+
+
+def _tu_hash(f, hdr_hash=None):
+    """content hash of one translation unit: the source, every header it includes (transitively), the flags"""
+    src = os.path.join(CSRC, f)
+    return _sha([src] + sorted(_includes(src)), " ".join(FLAGS))
 
 
 def stamped_hash(path=None):

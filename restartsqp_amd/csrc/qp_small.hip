@@ -181,7 +181,7 @@ struct Engine {
     long long tlast;
 
     // ------------------------------------------------------------------ carve
-    static constexpr bool K_IMAGE = false;      // (only batches of the explicit-inverse engine are shared with qp_small_k.h)
+    static constexpr bool K_IMAGE = false;      // (only batches of the explicit-inverse engine are shared with qp_small_g.h)
     // doubles of this formulation's image (<= rsqp_image_doubles, the size of the persistent copy)
     __host__ __device__ static long long image_doubles(int nV, int nC) {
         const long long ld = rsqp_ld(nV), sT = nV < nC ? nV : nC;
@@ -1046,7 +1046,7 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
     const int grp = L >= 64 ? 0 : (int)threadIdx.x / L;  // L >= 64: everything below stays workgroup-uniform
     const int q = L >= 64 ? (int)blockIdx.x : blockIdx.x * (64 / L) + grp;
     if (q >= nq) return;  // no workgroup barrier anywhere below: idle groups may leave
-    if (P.only_bailed && P.ret[q] != RET_BAIL) return;   // second pass behind the explicit-KKT-inverse kernel (qp_small_k.h)
+    if (P.only_bailed && P.ret[q] != RET_BAIL) return;   // second pass behind the tableau kernel (qp_small_g.h)
     lchar *smem = (lchar *)smem_generic + grp * stride;
     QPDesc d = P.desc[q];
     if constexpr (SHAPE > 0) { d.nV = NVC; d.nC = NCC; }
@@ -1148,7 +1148,7 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
         if constexpr (ENG::K_IMAGE) {
             // the state is one the explicit-KKT-inverse kernel wrote (and then bailed out of this hot start): its factors
             // are not this engine's -- rebuild them for the stored working set, keep the homotopy data
-            if (E.iscal[4] == 1) {
+            if (E.iscal[4] != 0) {     // (1: round 3, M = K^-1; 2: the tableau of qp_small_g.h -- either way not this engine's factors)
                 rcode = E.rebuild_factors();
                 if (rcode != RET_OK) rcode = E.setup_aux(false, false, false, false);
             }
@@ -1185,7 +1185,7 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
     STAMP(9);
 }
 
-#include "qp_small_k.h"
+#include "qp_small_g.h"
 
 }  // namespace
 
@@ -1286,30 +1286,23 @@ hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCma
     // Packed builds with W=6 (80 VGPRs, ~180 spilled) returned wrong results and are not built.
     int waves = L == 64 ? (nVmax <= 16 ? 6 : 4) : 2;
     if (forcedW >= 2 && forcedW <= (L == 64 ? 6 : 4)) waves = forcedW;
-    // ---- cold-start-only batches of mid-size problems: the explicit-KKT-inverse kernel first (qp_small_k.h: ~10 phases per
-    // working-set change instead of ~50); members it cannot carry (non-convex, LP, undecidable tests) come back with
+    // ---- batches of mid-size problems (cold starts and hot starts on new vectors): the tableau kernel first (qp_small_g.h: 3 phases
+    // per working-set change instead of ~50); members it cannot carry (non-symmetric H, LP, undecidable tests) come back with
     // ret == RET_BAIL and are solved by the null-space kernel launched right behind it, which skips everybody else
     static const int noK = env_int("RSQP_SMALL_NO_KKT", 0);
     // 32 row blocks x 8 column blocks of lanes: up to 72 variables x 32 constraints -- the 69 x 28 class of the hs0xx batch.
-    // (The 512-lane build EngineK<3, 1, 5, 2, 16> -- half the registers per lane, no AGPRs, two waves per SIMD -- measured
-    //  1.01 ms against 0.91 ms on the 512-QP batch: its 4-step reductions and 8-wave barriers cost more than the overlap gains.)
-    typedef EngineK<3, 1, 9, 4, 8> EK;      // up to 72 variables x 32 constraints
-    typedef EngineK<2, 2, 8, 8, 8> EK2;     // up to 64 variables x 64 constraints
+    typedef EngineG<3, 1, 9, 4> EK;      // up to 72 variables x 32 constraints
+    typedef EngineG<2, 2, 8, 8> EK2;     // up to 64 variables x 64 constraints
     // (only where the null-space kernel would give a problem four waves as well: batches of SMALL problems are throughput-bound
     //  and better served by 16 / 32 lanes per problem, several problems per wave)
     if (!noK && forcedE < 0 && eng == 1 && (nVmax > 32 || nCmax > 32) && (mode == 0 || mode == 1) && !p.done_flag) {
-        const bool stateful = mode != 0 || p.keep_state;
-#define KK_LAUNCH(RV_, RC_, CV_, CC_, ST_)                                                                                       \
+#define KK_LAUNCH(RV_, RC_, CV_, CC_)                                                                                            \
         do {                                                                                                                     \
-            static std::atomic<unsigned long long> set_{0};                                                                      \
-            rsqp_allow_full_lds(reinterpret_cast<const void *>(&small_qpk_kernel<RV_, RC_, CV_, CC_, 8, ST_>), set_, (int)kMaxLds); \
-            const size_t kl = (size_t)EngineK<RV_, RC_, CV_, CC_, 8>::lds_bytes(nVmax, nCmax);                                     \
-            hipLaunchKernelGGL((small_qpk_kernel<RV_, RC_, CV_, CC_, 8, ST_>), dim3(nq), dim3(256), kl, stream, p, nq, mode, maxWSR); \
+            hipLaunchKernelGGL((small_qpg_kernel<RV_, RC_, CV_, CC_>), dim3(nq), dim3(256), 0, stream, p, nq, mode, maxWSR);     \
             p.only_bailed = 1;                                                                                                   \
         } while (0)
-        (void)stateful;     // (a build without the state I/O exists as a template parameter; it measured the same once the homotopy had ONE call site)
-        if (nVmax <= EK::MAXV && nCmax <= EK::MAXC) KK_LAUNCH(3, 1, 9, 4, true);
-        else if (nVmax <= EK2::MAXV && nCmax <= EK2::MAXC) KK_LAUNCH(2, 2, 8, 8, true);
+        if (nVmax <= EK::MAXV && nCmax <= EK::MAXC) KK_LAUNCH(3, 1, 9, 4);
+        else if (nVmax <= EK2::MAXV && nCmax <= EK2::MAXC) KK_LAUNCH(2, 2, 8, 8);
 #undef KK_LAUNCH
     }
     static const int konly = env_int("RSQP_SMALL_KKT_ONLY", 0);     // diagnostics: no second pass (bailed members keep ret = 9, nflips = reason)

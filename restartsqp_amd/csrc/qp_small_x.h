@@ -933,8 +933,8 @@ struct EngineX {
         return RET_OK;
     }
 
-    // A hot start on a state the explicit-KKT-inverse kernel left behind (qp_small_k.h wrote iterate, multipliers, homotopy
-    // data and working set in this engine's layout, its own factor M = K^-1 elsewhere) that that kernel could not finish:
+    // A hot start on a state the tableau kernel left behind (qp_small_g.h wrote iterate, multipliers, homotopy
+    // data and working set in this engine's layout, its own tableau G elsewhere) that that kernel could not finish:
     // build Z, Y, Minv, Wz for the stored working set and leave everything else -- x, y, g, lb, ub, lbA, ubA, A x -- as it is,
     // so that the homotopy continues exactly where a hot start of this engine would (the bases differ, the step directions
     // do not depend on them). Mirrors the factor part of setup_aux.

@@ -1,6 +1,6 @@
-"""Which members of the 512-QP hs0xx batch the explicit-KKT-inverse kernel hands to the null-space kernel, and why: with
+"""Which members of the 512-QP hs0xx batch the tableau kernel (qp_small_g.h) hands to the null-space kernel, and why: with
 RSQP_SMALL_KKT_ONLY=1 the second pass is not launched, a bailed member keeps status 25 and nWSR = 1000 + bail reason
-(qp_small_k.h: 2 / 5 = a freed bound -- direct / exchange partner -- would leave Z'HZ without curvature, ...).   (GPU box)"""
+(qp_small_g.h: 1 / 2 pivot inside the rounding band, 3 independence undecidable, 5 singular block pivot, 8 exchange without partner, 10 not eligible, 11 free variable in the cold working set, ...).   (GPU box)"""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["RSQP_SMALL_KKT_ONLY"] = "1"

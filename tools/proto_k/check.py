@@ -13,8 +13,9 @@ import oracle as O  # noqa: E402
 from restartsqp_amd import problems  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", os.path.join(HERE, "libprotok.so"), os.path.join(HERE, "proto_k.cpp")])
-L = C.CDLL(os.path.join(HERE, "libprotok.so"))
+WHICH = os.environ.get("PROTO", "g")      # g: the tableau formulation of round 4 (proto_g.cpp); k: the explicit KKT inverse of round 3
+subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", os.path.join(HERE, "libproto%s.so" % WHICH), os.path.join(HERE, "proto_%s.cpp" % WHICH)])
+L = C.CDLL(os.path.join(HERE, "libproto%s.so" % WHICH))
 dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
 L.protok_solve.argtypes = [C.c_int, C.c_int] + [dp] * 7 + [C.c_int, dp, dp, ip, ip, ip, ip]
 
