@@ -1215,6 +1215,8 @@ hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCma
     // 5x1 0.14 / 0.16, 8x2 0.045 / 0.051, 8x3 0.25 / 0.21, 12x4 0.49 / 0.42, 16x6 0.73 / 0.55,
     // 23x6 1.26 / 1.01, 37x14 2.57 / 1.51, 69x28 10.8 / 4.1 -- the chains of the TQ form grow with nZ.
     static const int forcedE = env_int("RSQP_SMALL_ENGINE", -1);
+    // hs071-scale problems: the register-resident tableau kernel (qp_tiny.hip) serves every call shape
+    if (forcedE < 0 && p.tiny_ok && rsqp_tiny_fits(nVmax, nCmax)) return rsqp_launch_tiny_qp(p, nq, nVmax, nCmax, mode, maxWSR, stream);
     const int eng = forcedE == 0 || forcedE == 1 ? forcedE : (nVmax > 8 ? 1 : 0);
     if (eng == 1 && mat_bytes_max >= 0) mat_bytes_max = 8LL * ((long long)nVmax * nVmax + (long long)nCmax * nVmax);
     // uniform hs071-scale batches (8 x 2 through the QPhandler formulation; parameter scans of one NLP iterate) run

@@ -253,6 +253,7 @@ struct rsqp_solver {
     bool fits_small = true;
     RsqpLargeEngine *large = nullptr;
     bool large_ready = false, profile_large = false;
+    bool h_sym = true;            // H symmetric value by value (or absent): the tableau kernel of qp_tiny.hip may take the handle
     int last_mode = -1;           // RSQP_MODE_* of the last rsqp_solve (what the dispatch of optimizeQP / optimizeLP chose): rsqp_get_last_mode
     bool reinit_from_y0 = false;  // rsqp_set_reinit_guess: default = the reference rule (qpOASESInterface.cpp:199-207); 1 = opt-in shortcut
     DevBuf<double> denseA, denseAT, denseH;   // dense copies for the HBM-resident engine (dense matrices only)
@@ -306,6 +307,21 @@ int upload_matrix(DevMatrix &M, const Compressed &c, bool want_csr) {
     return RSQP_OK;
 }
 
+// is the CSC matrix (n <= 8 columns) symmetric, value by value? (eligibility of the tableau kernel of qp_tiny.hip)
+bool small_csc_symmetric(int n, const int *jc, const int *ir, const double *val) {
+    if (n > 8) return false;
+    double d[64] = {0.0};
+    for (int c = 0; c < n; c++)
+        for (int k = jc[c]; k < jc[c + 1]; k++) {
+            if (ir[k] < 0 || ir[k] >= n) return false;
+            d[ir[k] * 8 + c] = val[k];
+        }
+    for (int r = 0; r < n; r++)
+        for (int c = 0; c < r; c++)
+            if (d[r * 8 + c] != d[c * 8 + r]) return false;
+    return true;
+}
+
 int flush_vectors(rsqp_solver *s) {
     if (!s->vec_dirty) return RSQP_OK;
     for (int k = 0; k < 5; k++) HIPCHK(s->d_vec[k].upload(s->h_vec[k].data(), s->h_vec[k].size()));
@@ -348,6 +364,7 @@ QPPools pools_of(rsqp_solver *s) {
     p.keep_state = 1;
     p.done_flag = nullptr; p.done_val = 0;
     p.reinit_from_y0 = s->reinit_from_y0 ? 1 : 0;
+    p.tiny_ok = (s->h_sym || !s->H.initialised || s->lp_mode) ? 1 : 0;
     return p;
 }
 
@@ -573,6 +590,7 @@ extern "C" int rsqp_set_H_triplet(rsqp_solver *s, int nnz, const int *irow, cons
         Compressed cs;
         csc_from_entries(s->nV, s->nV, r, c, v, cs);
         cs.tmap = tmap;
+        s->h_sym = is_symmetric != 0 || (s->nV <= 8 && small_csc_symmetric(s->nV, cs.jc.data(), cs.ir.data(), cs.val.data()));
         M.from_triplet = true; M.n_triplet = nnz; M.symmetric = is_symmetric != 0;
         int rc = upload_matrix(M, cs, false);
         if (rc != RSQP_OK) return rc;
@@ -582,6 +600,7 @@ extern "C" int rsqp_set_H_triplet(rsqp_solver *s, int nnz, const int *irow, cons
         return RSQP_OK;
     }
     if (!M.from_triplet || nnz != M.n_triplet) return fail(RSQP_ERR_ARG, "rsqp_set_H_triplet: pattern changed");
+    if (!M.symmetric) s->h_sym = false;       // (values of a general triplet matrix: not re-examined)
     HIPCHK(M.tv.upload(val, nnz));
     if (rsqp_launch_scatter(M.nnz, M.order.p, M.tmap.p, M.tv.p, M.val.p, s->stream) != hipSuccess)
         return fail(RSQP_ERR_DEVICE, "value refresh launch failed");
@@ -645,6 +664,7 @@ extern "C" int rsqp_set_A_csc(rsqp_solver *s, const int *jc, const int *ir, cons
 extern "C" int rsqp_set_H_csc(rsqp_solver *s, const int *jc, const int *ir, const double *val) {
     if (s) s->spec_cert = false;
     if (!s) return fail(RSQP_ERR_ARG, "null solver");
+    if (jc && (jc[s->nV] == 0 || (ir && val))) s->h_sym = s->nV <= 8 && small_csc_symmetric(s->nV, jc, ir, val);
     return set_csc(s, s->H, s->nV, s->nV, jc, ir, val, false, &s->upd_H);
 }
 extern "C" int rsqp_get_A_nnz(const rsqp_solver *s) { return s && s->A.initialised ? s->A.nnz : -1; }
@@ -1104,6 +1124,8 @@ struct rsqp_batch {
     int nq = 0, device = 0, nVmax = 0, nCmax = 0, uniV = -1, uniC = -1;
     long long sumV = 0, sumC = 0, sumAnz = 0, sumHnz = 0, mat_bytes_max = 0;
     bool haveH = false;
+    bool h_sym = true;                    // every H symmetric value by value (the tableau kernel of qp_tiny.hip may take the batch)
+    std::vector<int> h_Hjc, h_Hir;        // host copy of the H patterns (re-examined when the values change), small batches only
     std::vector<QPDesc> desc;
     std::vector<int> h_csr_perm;
     hipStream_t stream = nullptr;
@@ -1144,6 +1166,7 @@ QPPools pools_of(rsqp_batch *b) {
     p.uniV = b->uniV; p.uniC = b->uniC;
     p.keep_state = b->keep_state ? 1 : 0;
     p.done_flag = nullptr; p.done_val = 0;
+    p.tiny_ok = (b->h_sym || !b->haveH) ? 1 : 0;
     return p;
 }
 }  // namespace
@@ -1194,6 +1217,13 @@ extern "C" int rsqp_batch_create(int nq, const int *nV, const int *nC, const int
     }
     if (!rsqp_small_qp_fits(b->nVmax, b->nCmax))
         return fail(RSQP_ERR_TOO_LARGE, "rsqp_batch_create: a problem exceeds the LDS-resident engine");
+    if (b->haveH && b->nVmax <= 8) {
+        b->h_Hjc.assign(Hjc, Hjc + offHjc); b->h_Hir.assign(Hir, Hir + offHnz);
+        for (int q = 0; q < nq && b->h_sym; q++) {
+            const QPDesc &d = b->desc[q];
+            b->h_sym = small_csc_symmetric(d.nV, Hjc + d.offHjc, Hir + d.offHnz, Hval + d.offHnz);
+        }
+    } else if (b->haveH) b->h_sym = false;
     b->sumV = offV; b->sumC = offC; b->sumAnz = offAnz; b->sumHnz = offHnz;
     HIPCHK(hipStreamCreate(&b->stream));
     HIPCHK(hipEventCreate(&b->ev0)); HIPCHK(hipEventCreate(&b->ev1));
@@ -1243,7 +1273,16 @@ extern "C" int rsqp_batch_set_matrix_values(rsqp_batch *b, const double *Aval, c
         if (rsqp_launch_gather((int)b->sumAnz, b->perm.p, b->Aval.p, b->Arv.p, b->stream) != hipSuccess)
             return fail(RSQP_ERR_DEVICE, "gather launch failed");
     }
-    if (Hval && b->haveH) HIPCHK(b->Hval.upload(Hval, b->sumHnz));
+    if (Hval && b->haveH) {
+        HIPCHK(b->Hval.upload(Hval, b->sumHnz));
+        if (!b->h_Hjc.empty()) {
+            b->h_sym = true;
+            for (int q = 0; q < b->nq && b->h_sym; q++) {
+                const QPDesc &d = b->desc[q];
+                b->h_sym = small_csc_symmetric(d.nV, b->h_Hjc.data() + d.offHjc, b->h_Hir.data() + d.offHnz, Hval + d.offHnz);
+            }
+        }
+    }
     HIPCHK(hipStreamSynchronize(b->stream));
     return RSQP_OK;
 }

@@ -49,6 +49,8 @@ struct QPPools {
     int done_val;     //   on it instead of sleeping in hipStreamSynchronize); nullptr for batches
     int k_debug_bail; // test hook (RSQP_K_DEBUG_BAIL=n): the explicit-KKT-inverse kernel bails out of a HOT start before its n-th change; -1 off
     int only_bailed;  // 1: the null-space kernel runs only the members the explicit-KKT-inverse kernel left with ret == RET_BAIL
+    int tiny_ok;      // 1: every H of the batch is symmetric (or absent): problems of <= 8 variables may take the register-resident
+                      //    tableau kernel (qp_tiny.hip), which keeps K symmetric by construction
     int keep_state;   // 1: write the hot-start part of the engine image back to HBM at the end of a solve (what the
                       //    SQProblem object keeps between calls); 0: cold-start-only batches skip that write --
                       //    the image is marked "not initialised", a later hot start falls back to a cold start
@@ -71,7 +73,11 @@ __host__ __device__ inline long long rsqp_image_bytes(int nV, int nC) {
 // persistent state of one problem in HBM: the image of the null-space engines, followed by the extension of the
 // explicit-KKT-inverse kernel (qp_small_k.h): M = K^-1 with one slot per variable and constraint, (nV + nC)^2 doubles
 __host__ __device__ inline long long rsqp_state_bytes(int nV, int nC) {
-    return rsqp_image_bytes(nV, nC) + 8LL * (long long)(nV + nC) * (nV + nC);
+    long long b = rsqp_image_bytes(nV, nC) + 8LL * (long long)(nV + nC) * (nV + nC);
+    // hs071-scale problems (qp_tiny.hip): the register-resident tableau engine keeps a fixed-slot state of (8 + MC)^2 + 80
+    // doubles + 24 ints whatever the problem's own sizes are (MC = 2 / 4 / 8 by the batch's largest nC)
+    if (nV <= 8 && nC <= 8 && b < 2816) b = 2816;
+    return b;
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: set it once per
@@ -91,3 +97,6 @@ hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, 
                                 int maxWSR, hipStream_t stream);
 long long rsqp_mat_lds_bytes(int nV, int nC, int annz, int hnnz);
 int rsqp_small_qp_fits(int nVmax, int nCmax);
+// qp_tiny.hip: the register-resident tableau kernel for problems of at most 8 variables and 8 constraints
+int rsqp_tiny_fits(int nVmax, int nCmax);
+hipError_t rsqp_launch_tiny_qp(const QPPools &p, int nq, int nVmax, int nCmax, int mode, int maxWSR, hipStream_t stream);
