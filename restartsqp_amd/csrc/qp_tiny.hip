@@ -40,6 +40,26 @@ typedef LDS char lchar;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
     } while (0)
 
+// diagnostic build only (-DRSQP_STAMPS, tools/stamp_tiny_kernel.py): cycles per phase of wave 0 of block 0
+#ifdef RSQP_STAMPS
+__device__ unsigned long long g_tiny_stamps[16];
+#define TSTAMP(k)                                                                                        \
+    do {                                                                                                 \
+        long long t_ = clock64();                                                                        \
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_tiny_stamps[k], (unsigned long long)(t_ - tlast)); \
+        tlast = t_;                                                                                      \
+    } while (0)
+extern "C" void rsqp_debug_tiny_stamps(unsigned long long *out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tiny_stamps), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tiny_stamps), z, sizeof(z));
+    }
+}
+#else
+#define TSTAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 // ---- exchanges inside a group of 8 lanes by DPP permutations (xor 1, xor 2, i <-> 7 - i): see qp_small.hip
@@ -85,11 +105,13 @@ struct EngineT {
     double xv, lo, up, loN, upN, yv, g, gN, gy, inV;
     double ax, loA, upA, cloN, cupN, yc, inC;
     int sv, sc;
+    double dV, dC;                      // the diagonal entries of my two rows (G_ll, G_{8+l,8+l}): the pivot of a change is one of them
     // ---- group-uniform
     int nV, nC, l, fmask, amask;        // free variables / active constraints as bit masks (replicated in every lane)
     int status, infeasible, unbounded, nflips, since_refresh;
     double hscale, hreg;
     ldouble *Kd;                        // dense K of my problem in LDS, row major N x N (H + hreg I | A' ; A | 0)
+    long long tlast;                    // (-DRSQP_STAMPS builds)
 
     __device__ __forceinline__ bool vV() const { return l < nV; }
     __device__ __forceinline__ bool vC() const { return l < nC; }
@@ -101,6 +123,20 @@ struct EngineT {
 #pragma unroll
         for (int k = 0; k < N; k++) v = fma(u[k], opaque(k == slot ? 1.0 : 0.0), v);
         return v;
+    }
+    // entry q (uniform over the group, not a compile-time constant) of my two rows = G_lq, G_{8+l,q}: by symmetry the entries of
+    // ROW q that belong to my slots. A chain of selects on wave masks (k == q): no register-array indexing, no extra registers
+    __device__ __forceinline__ void my_entries(int q, double &ev, double &ec) const {
+        ev = 0.0; ec = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; k++) { const bool h = k == q; ev = h ? GV[k] : ev; ec = h ? GC[k] : ec; }
+    }
+    // G_pq for uniform slots p, q: the lane that owns slot p looks up entry q of its row, the group fetches it
+    __device__ __forceinline__ double entry_pq(int p, int q) const {
+        double ev, ec;
+        my_entries(q, ev, ec);
+        const bool pc = p >= MV;
+        return fetch8(pc ? ec : ev, pc ? p - MV : p);
     }
     // the whole slot vector (variable part from the lanes' `a`, constraint part from their `b`) into every lane
     __device__ __forceinline__ void gather(double a, double b, double (&all)[N]) const {
@@ -119,23 +155,41 @@ struct EngineT {
     __device__ __forceinline__ void stage(const QPPools &P, const QPDesc &d) {
         const int *gAjc = P.Ajc + d.offAjc, *gAir = P.Air + d.offAnz, *gHjc = P.Hjc + d.offHjc, *gHir = P.Hir + d.offHnz;
         const double *gAval = P.Aval + d.offAnz, *gHval = P.Hval + d.offHnz;
+        // every load that does not depend on another one first: the vectors and the column pointers travel together
+        const bool v = vV(), c = vC();
+        const int hb = (v && d.haveH) ? gHjc[l] : 0, he = (v && d.haveH) ? gHjc[l + 1] : 0, ab = v ? gAjc[l] : 0, ae = v ? gAjc[l + 1] : 0;
+        const double g_ = v ? P.g[d.offV + l] : 0.0, lb_ = v ? P.lb[d.offV + l] : 0.0, ub_ = v ? P.ub[d.offV + l] : 0.0;
+        const double la_ = c ? P.lbA[d.offC + l] : -RSQP_INFTY, ua_ = c ? P.ubA[d.offC + l] : RSQP_INFTY;
         for (int k = l; k < N * N; k += 8) Kd[k] = 0.0;
         TSYNC();
-        if (vV()) {          // column l of H and of A (CSC): K is symmetric, so the A entries go to both triangles
-            if (d.haveH) for (int k = gHjc[l]; k < gHjc[l + 1]; k++) Kd[gHir[k] * N + l] = gHval[k];
-            for (int k = gAjc[l]; k < gAjc[l + 1]; k++) { const int i = gAir[k]; const double v = gAval[k]; Kd[(MV + i) * N + l] = v; Kd[l * N + MV + i] = v; }
+        // column l of H and of A (CSC), four entries per trip: their index / value loads are in flight together (a loop of one entry
+        // per trip pays a full memory round trip per entry). K is symmetric, so the A entries go to both triangles
+        for (int k0 = hb; k0 < he; k0 += 4) {
+            int r[4]; double w[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) { const bool in = k0 + t < he; r[t] = in ? gHir[k0 + t] : -1; w[t] = in ? gHval[k0 + t] : 0.0; }
+#pragma unroll
+            for (int t = 0; t < 4; t++) if (r[t] >= 0) Kd[r[t] * N + l] = w[t];
+        }
+        for (int k0 = ab; k0 < ae; k0 += 4) {
+            int r[4]; double w[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) { const bool in = k0 + t < ae; r[t] = in ? gAir[k0 + t] : -1; w[t] = in ? gAval[k0 + t] : 0.0; }
+#pragma unroll
+            for (int t = 0; t < 4; t++) if (r[t] >= 0) { Kd[(MV + r[t]) * N + l] = w[t]; Kd[l * N + MV + r[t]] = w[t]; }
         }
         TSYNC();
-        if (vV() && hreg != 0.0) Kd[l * N + l] += hreg;
+        if (v && hreg != 0.0) Kd[l * N + l] += hreg;
         TSYNC();
-        hscale = max8(vV() ? fabs(Kd[l * N + l]) : 0.0);
-        gN = vV() ? P.g[d.offV + l] : 0.0;
-        loN = vV() ? clampinf(P.lb[d.offV + l]) : 0.0; upN = vV() ? clampinf(P.ub[d.offV + l]) : 0.0;
-        cloN = vC() ? clampinf(P.lbA[d.offC + l]) : -RSQP_INFTY; cupN = vC() ? clampinf(P.ubA[d.offC + l]) : RSQP_INFTY;
+        hscale = max8(v ? fabs(Kd[l * N + l]) : 0.0);
+        gN = g_;
+        loN = v ? clampinf(lb_) : 0.0; upN = v ? clampinf(ub_) : 0.0;
+        cloN = c ? clampinf(la_) : -RSQP_INFTY; cupN = c ? clampinf(ua_) : RSQP_INFTY;
     }
     __device__ __forceinline__ void g_from_K() {     // S empty: G = -K
 #pragma unroll
         for (int k = 0; k < N; k++) { GV[k] = -Kd[l * N + k]; GC[k] = l < MC ? -Kd[(MV + (l < MC ? l : 0)) * N + k] : 0.0; }
+        dV = -Kd[l * N + l]; dC = 0.0;
     }
     __device__ __forceinline__ bool bounds_inconsistent() const {
         return or8(((vV() && loN > upN + RSQP_EPS) || (vC() && cloN > cupN + RSQP_EPS)) ? 1 : 0) != 0;
@@ -159,22 +213,28 @@ struct EngineT {
     __device__ __forceinline__ void pivot1(const double (&u)[N], int q, double sgn, double pi) {
         const double c = -recip(pi);
         const bool rv = l == q, rc = MV + l == q;                                  // my row IS row q: it starts from zero
-        const double tv = c * (rv ? sgn : pick(u, l)), tc = c * (rc ? sgn : pick(u, MV + l));
+        double ev, ec;
+        my_entries(q, ev, ec);                                                     // = u at my slots (G is symmetric)
+        const double uv = rv ? sgn : ev, uc = rc ? sgn : ec;
+        const double tv = c * uv, tc = c * uc;
         const double kv = rv ? 0.0 : 1.0, kc = rc ? 0.0 : 1.0;
 #pragma unroll
         for (int k = 0; k < N; k++) {
             const bool h = k == q;
-            const double ut = h ? sgn : u[k], kk = h ? 0.0 : 1.0;
-            GV[k] = fma(tv, ut, GV[k] * (kk * kv));
-            GC[k] = fma(tc, ut, GC[k] * (kk * kc));
+            const double ut = h ? sgn : u[k];
+            GV[k] = fma(tv, ut, GV[k] * (h ? 0.0 : kv));
+            GC[k] = fma(tc, ut, GC[k] * (h ? 0.0 : kc));
         }
+        dV = fma(tv, uv, dV * kv); dC = fma(tc, uc, dC * kc);
     }
     // 2 x 2 block pivot on (p, q) with W = [G_pp G_pq; G_pq G_qq]^-1: G <- G00 - U~ W U~', U~ = [u_p u_q], rows p, q = diag(sp, sq)
     __device__ __forceinline__ void pivot2(const double (&up_)[N], const double (&uq)[N], int p, double sp, int q, double sq,
                                            double w11, double w12, double w22) {
         const bool vp = l == p, vq = l == q, cp_ = MV + l == p, cq_ = MV + l == q;
-        const double av = vp ? sp : (vq ? 0.0 : pick(up_, l)), bv = vq ? sq : (vp ? 0.0 : pick(uq, l));
-        const double ac = cp_ ? sp : (cq_ ? 0.0 : pick(up_, MV + l)), bc = cq_ ? sq : (cp_ ? 0.0 : pick(uq, MV + l));
+        double epv, epc, eqv, eqc;
+        my_entries(p, epv, epc); my_entries(q, eqv, eqc);
+        const double av = vp ? sp : (vq ? 0.0 : epv), bv = vq ? sq : (vp ? 0.0 : eqv);
+        const double ac = cp_ ? sp : (cq_ ? 0.0 : epc), bc = cq_ ? sq : (cp_ ? 0.0 : eqc);
         const double kv = (vp || vq) ? 0.0 : 1.0, kc = (cp_ || cq_) ? 0.0 : 1.0;
 #pragma unroll
         for (int k = 0; k < N; k++) {
@@ -184,6 +244,8 @@ struct EngineT {
             GV[k] = fma(-av, cp, fma(-bv, cq, GV[k] * (kk * kv)));
             GC[k] = fma(-ac, cp, fma(-bc, cq, GC[k] * (kk * kc)));
         }
+        dV = fma(-av, fma(w11, av, w12 * bv), fma(-bv, fma(w12, av, w22 * bv), dV * kv));
+        dC = fma(-ac, fma(w11, ac, w12 * bc), fma(-bc, fma(w12, ac, w22 * bc), dC * kc));
     }
     // sum of u_v^2 over the free variables; sum of a_v^2 over them for the row `arow` of A (>= 0), e_v (arow = -2 - v), nothing (-1)
     __device__ __forceinline__ void free_norms(const double (&u)[N], int arow, double &pn2, double &na2) const {
@@ -211,16 +273,16 @@ struct EngineT {
                 if ((pf >> v) & 1) {
                     double u[N];
                     fetch_row(false, v, u);
-                    const double pi = pick(u, v);
+                    const double pi = fetch8(dV, v);
                     if (-pi > 1e-8 * hscale) { pivot1(u, v, 1.0, pi); fmask |= 1 << v; pf &= ~(1 << v); progress = true; }
                 }
             for (int i = 0; i < MC; i++)
                 if ((pa >> i) & 1) {
                     double u[N], pn2, na2;
                     fetch_row(true, i, u);
-                    const double pi = pick(u, MV + i);
+                    const double pi = fetch8(dC, i);
                     free_norms(u, i, pn2, na2);
-                    if (nFR() - nAC() > 0 && na2 > 0.0 && hscale * sqrt(pn2 / na2) > 1e-9 && pi > 1e-10 * na2 / hscale) {
+                    if (nFR() - nAC() > 0 && na2 > 0.0 && hscale * hscale * pn2 > 1e-18 * na2 && pi * hscale > 1e-10 * na2) {
                         pivot1(u, MV + i, 1.0, pi); amask |= 1 << i; pa &= ~(1 << i); progress = true;
                     }
                 }
@@ -231,7 +293,7 @@ struct EngineT {
                             if ((pa >> i) & 1) {
                                 double uv[N], ui[N];
                                 fetch_row(false, v, uv); fetch_row(true, i, ui);
-                                const double pp = pick(uv, v), qq = pick(ui, MV + i), pq = pick(ui, v);
+                                const double pp = fetch8(dV, v), qq = fetch8(dC, i), pq = entry_pq(v, MV + i);
                                 const double det = pp * qq - pq * pq;
                                 if (det < 0.0 && -det > 1e-10 * fmax(fabs(pp * qq), pq * pq) && pq * pq > 1e-16 * hscale * hscale) {
                                     const double rd = recip(det);
@@ -267,8 +329,9 @@ struct EngineT {
         g_from_K();
         fmask = amask = 0;
         // A x of the guess and the constraints' sides (qpOASES: from the guess, else from y0, else from A x0)
-        double gyx, axx, hxx;
-        exact_products(gyx, axx, hxx);
+        const bool cold = !have_x0 && !have_y0;          // x = 0, y = 0: every product with the data is zero
+        double gyx = 0.0, axx = 0.0, hxx = 0.0;
+        if (!cold) exact_products(gyx, axx, hxx);
         ax = vC() ? axx : 0.0;
         int sgc = 0;
         if (have_gc) sgc = gc;
@@ -285,7 +348,7 @@ struct EngineT {
         yv = sv == 0 ? 0.0 : ((sv == -1 && yv < 0.0) || (sv == 1 && yv > 0.0) ? 0.0 : yv);
         yc = sc == 0 ? 0.0 : ((sc == -1 && yc < 0.0) || (sc == 1 && yc > 0.0) ? 0.0 : yc);
         // gradient of the auxiliary QP from stationarity, its limits around the iterate
-        exact_products(gyx, axx, hxx);
+        if (!cold) exact_products(gyx, axx, hxx);
         gy = gyx; g = gyx + yv;
         lo = sv == -1 ? xv : fmin(loN, xv - RSQP_BOUND_RELAXATION);
         up = sv == 1 ? xv : fmax(upN, xv + RSQP_BOUND_RELAXATION);
@@ -303,7 +366,7 @@ struct EngineT {
         const int q = isc ? MV + idx : idx;
         double u[N];
         fetch_row(isc, idx, u);
-        const double pi = pick(u, q);
+        const double pi = fetch8(isc ? dC : dV, idx);
         const bool myV = !isc && l == idx, myC = isc && l == idx;
         bool flip = false;
         if (kind == 1) {
@@ -331,8 +394,9 @@ struct EngineT {
             int li;
             if (nFR() - nAC() <= 0 || !(na2 > 0.0)) li = 0;
             else {
-                const double rel = hscale * sqrt(pn2 / na2);
-                li = rel > 1e-6 ? 1 : (rel < 1e-12 ? 0 : -1);
+                // rel = hscale |P a| / |a_FR| against 1e-6 / 1e-12, squared: no square root, no division
+                const double p2 = hscale * hscale * pn2;
+                li = p2 > 1e-12 * na2 ? 1 : (p2 < 1e-24 * na2 ? 0 : -1);
             }
             if (li < 0) {
                 // the band: the residual of the row's representation by the active rows decides (qp_small_g.h)
@@ -340,12 +404,14 @@ struct EngineT {
 #pragma unroll
                 for (int i = 0; i < MC; i++) r = ((amask >> i) & 1) ? fma(-Kd[(MV + i) * N + l], sg * u[MV + i], r) : r;
                 const double rn2 = sum8((vV() && sv == 0) ? r * r : 0.0);
-                li = sqrt(rn2 / na2) > 3e-8 ? 1 : 0;
+                li = rn2 > 9e-16 * na2 ? 1 : 0;                 // |r| / |a_FR| > 3e-8
             }
             if (li == 0) {
                 // ---- exchange: shift the multipliers along the dependency until one of them reaches zero; that one leaves
                 const double sgn = side == 1 ? -1.0 : 1.0;
-                const double xiv = (vV() && sv != 0) ? sgn * sg * pick(u, l) : 0.0, xic = (vC() && sc != 0) ? sgn * sg * pick(u, MV + l) : 0.0;
+                double ev, ec;
+                my_entries(q, ev, ec);
+                const double xiv = (vV() && sv != 0) ? sgn * sg * ev : 0.0, xic = (vC() && sc != 0) ? sgn * sg * ec : 0.0;
                 double bt = RSQP_INFTY;
                 int bid = 0x7fffffff;
                 if (vC() && sc != 0) {
@@ -369,15 +435,15 @@ struct EngineT {
                 const int p = pk == 1 ? MV + pidx : pidx;
                 double u2[N];
                 fetch_row(pk == 1, pidx, u2);
-                const double pp = pick(u2, p), qq = pi, pq = pick(u, p);
+                const double pp = fetch8(pk == 1 ? dC : dV, pidx), qq = pi, pq = entry_pq(p, q);
                 const double det = pp * qq - pq * pq;
                 if (!(det < 0.0) || !(-det > 1e-10 * fmax(fabs(pp * qq), pq * pq))) return RET_SETUP_FAILED;
                 const double rd = recip(det);
                 pivot2(u2, u, p, pk == 1 ? -1.0 : 1.0, q, kind == 3 ? 1.0 : -1.0, qq * rd, -pq * rd, pp * rd);
                 since_refresh = REFRESH;
             } else {
-                if (kind == 3) { if (!(pi > 1e-10 * na2 / hscale)) return RET_SETUP_FAILED; }
-                else if (!(pi > 1e-10 / hscale)) return RET_SETUP_FAILED;
+                if (kind == 3) { if (!(pi * hscale > 1e-10 * na2)) return RET_SETUP_FAILED; }
+                else if (!(pi * hscale > 1e-10)) return RET_SETUP_FAILED;
             }
         }
         if (pk == 0) pivot1(u, q, (kind == 2 || kind == 3) ? 1.0 : -1.0, pi);
@@ -419,6 +485,7 @@ struct EngineT {
                 loA = (!keep && sc == -1) ? ax : loA; upA = (!keep && sc == 1) ? ax : upA;
                 inC = sc == 0 ? 0.0 : (sc == -1 ? cloN - loA : cupN - upA);
             }
+            TSTAMP(5);
             // ---- out = G in; dx / dy / A dx and the ratio-test candidates of my rows
             double dxv, dyv, hd, dax, dyc;
             double bt = 1.0;
@@ -433,6 +500,7 @@ struct EngineT {
                 dxv = sv == 0 ? ov : inV; dyv = sv == 0 ? 0.0 : dg - ov; hd = sv == 0 ? -dg : -ov;
                 dax = sc != 0 ? inC : -oc; dyc = sc != 0 ? -oc : 0.0;
             }
+            TSTAMP(6);
             {
                 // candidates in the order of their ids (ties go to the lowest id)
                 auto cand = [&](double num, double den, int id, bool ok) {
@@ -453,6 +521,7 @@ struct EngineT {
                 }
             }
             if (!(bt < 1.0)) { bt = 1.0; bid = 0x7fffffff; }
+            TSTAMP(7);
             argmin8(bt, bid);
             int kind = 0, idx = -1, side = 0;
             if (bid != 0x7fffffff) {
@@ -479,12 +548,14 @@ struct EngineT {
                 lo = done ? loN : ((hitV && side == -1) ? xn : l1); up = done ? upN : ((hitV && side == 1) ? xn : u1);
                 loA = done ? cloN : ((hitC && side == -1) ? an : l2); upA = done ? cupN : ((hitC && side == 1) ? an : u2);
             }
+            TSTAMP(8);
             if (done || cap) {
                 if (done) status = QPS_SOLVED; else rcode = RET_MAX_NWSR;
                 break;
             }
             bool treat_done = false;
             rcode = change(kind, idx, side, tau, treat_done);
+            TSTAMP(9);
             if (treat_done) {      // (see change: no exchange partner at the very end of the homotopy)
                 g = gN; lo = loN; up = upN; loA = cloN; upA = cupN;
                 if (sv != 0) xv = sv == -1 ? loN : upN;
@@ -526,7 +597,7 @@ struct EngineT {
 
 // persistent state of one problem (hot starts), in the problem's state block: [N*N tableau by slot][10 doubles per variable
 // lane][7 per constraint lane][ints: sv, sc per lane, status, masks, magic]
-template <int MC> __device__ __forceinline__ long long tiny_state_doubles() { return (long long)(MV + MC) * (MV + MC) + 8LL * 6 + 8LL * 4; }
+template <int MC> __device__ __forceinline__ long long tiny_state_doubles() { return (long long)(MV + MC) * (MV + MC) + 8LL * 6 + 8LL * 4 + 8LL * 2; }
 constexpr int TINY_MAGIC = 0x7a11e;
 
 template <int MC, int W>
@@ -543,7 +614,12 @@ __global__ void __launch_bounds__(256, W) tiny_qp_kernel(QPPools P, int nq, int 
     E.Kd = (ldouble *)kd_all + grp * N * N;
     E.nflips = 0; E.infeasible = E.unbounded = 0; E.status = QPS_NOTINITIALISED; E.fmask = E.amask = 0; E.since_refresh = 0;
     const int l = E.l;
+#ifdef RSQP_STAMPS
+    E.tlast = clock64();
+    long long &tlast = E.tlast;
+#endif
     E.stage(P, d);
+    TSTAMP(0);
     int mode = mode_in;
     double *sd = P.state + d.offState;
     int *si = reinterpret_cast<int *>(sd + tiny_state_doubles<MC>());
@@ -560,6 +636,7 @@ __global__ void __launch_bounds__(256, W) tiny_qp_kernel(QPPools P, int nq, int 
                 E.xv = px; E.g = pr[l * 6 + 1]; E.lo = pr[l * 6 + 2]; E.up = pr[l * 6 + 3]; E.gy = pr[l * 6 + 4]; E.yv = pyv;
                 E.ax = pr[48 + l * 4 + 0]; E.loA = pr[48 + l * 4 + 1]; E.upA = pr[48 + l * 4 + 2]; E.yc = pyc;
                 E.sv = psv; E.sc = psc; E.status = si[16]; E.fmask = si[17] & 0xff; E.amask = (si[17] >> 8) & 0xff;
+                E.dV = pr[80 + l * 2]; E.dC = pr[80 + l * 2 + 1];
             }
         }
     }
@@ -587,10 +664,13 @@ __global__ void __launch_bounds__(256, W) tiny_qp_kernel(QPPools P, int nq, int 
             ok = E.setup(hx, hy, hg, hc, P.reinit_from_y0 != 0, x0, y0v, y0c, gb, gc);
             hx = hy = hg = hc = false;
         }
+        TSTAMP(1);
         if (!ok) rcode = RET_SETUP_FAILED;
         else rcode = E.homotopy(maxWSR, nWSR, mode == 1);
+        TSTAMP(2);
     }
     const double obj = E.finish(rcode == RET_OK);
+    TSTAMP(3);
     // ---- results (x, y = [bounds; constraints], working set, status / nWSR / objective)
     if (l < d.nV) { P.x[d.offV + l] = E.xv; P.ws_b[d.offV + l] = E.sv; P.y[d.offV + d.offC + l] = E.yv; }
     if (l < d.nC) { P.y[d.offV + d.offC + d.nV + l] = E.yc; P.ws_c[d.offC + l] = E.sc; }
@@ -605,9 +685,11 @@ __global__ void __launch_bounds__(256, W) tiny_qp_kernel(QPPools P, int nq, int 
         double *pr = sd + N * N;
         pr[l * 6 + 0] = E.xv; pr[l * 6 + 1] = E.g; pr[l * 6 + 2] = E.lo; pr[l * 6 + 3] = E.up; pr[l * 6 + 4] = E.gy; pr[l * 6 + 5] = E.yv;
         pr[48 + l * 4 + 0] = E.ax; pr[48 + l * 4 + 1] = E.loA; pr[48 + l * 4 + 2] = E.upA; pr[48 + l * 4 + 3] = E.yc;
+        pr[80 + l * 2] = E.dV; pr[80 + l * 2 + 1] = E.dC;
         si[l] = E.sv; si[8 + l] = E.sc;
         if (l == 0) { si[16] = E.status; si[17] = (E.fmask & 0xff) | ((E.amask & 0xff) << 8); si[18] = TINY_MAGIC; }
     } else if (l == 0) { si[16] = QPS_NOTINITIALISED; si[18] = TINY_MAGIC; }
+    TSTAMP(4);
     if (P.done_flag) {
         __threadfence_system();      // the results above are in host-mapped memory: visible before the flag
         if (q == 0 && l == 0) *reinterpret_cast<volatile int *>(P.done_flag) = P.done_val;
@@ -619,7 +701,7 @@ __global__ void __launch_bounds__(256, W) tiny_qp_kernel(QPPools P, int nq, int 
 // bytes of the state block the kernel needs (the caller's blocks are sized by rsqp_state_bytes: checked by the launcher)
 long long rsqp_tiny_state_bytes(int nCmax) {
     const long long N = MV + (nCmax <= 2 ? 2 : (nCmax <= 4 ? 4 : 8));
-    return 8 * (N * N + 48 + 32) + 4 * 24;
+    return 8 * (N * N + 48 + 32 + 16) + 4 * 24;
 }
 // 1 if the batch shape is served by this engine
 int rsqp_tiny_fits(int nVmax, int nCmax) {

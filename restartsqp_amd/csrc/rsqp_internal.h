@@ -74,9 +74,9 @@ __host__ __device__ inline long long rsqp_image_bytes(int nV, int nC) {
 // explicit-KKT-inverse kernel (qp_small_k.h): M = K^-1 with one slot per variable and constraint, (nV + nC)^2 doubles
 __host__ __device__ inline long long rsqp_state_bytes(int nV, int nC) {
     long long b = rsqp_image_bytes(nV, nC) + 8LL * (long long)(nV + nC) * (nV + nC);
-    // hs071-scale problems (qp_tiny.hip): the register-resident tableau engine keeps a fixed-slot state of (8 + MC)^2 + 80
-    // doubles + 24 ints whatever the problem's own sizes are (MC = 2 / 4 / 8 by the batch's largest nC)
-    if (nV <= 8 && nC <= 8 && b < 2816) b = 2816;
+    // hs071-scale problems (qp_tiny.hip): the register-resident tableau engine keeps a fixed-slot state of (8 + MC)^2 + 96
+    // doubles + 24 ints (<= 2912 B) whatever the problem's own sizes are (MC = 2 / 4 / 8 by the batch's largest nC)
+    if (nV <= 8 && nC <= 8 && b < 2944) b = 2944;
     return b;
 }
 
