@@ -28,6 +28,7 @@
 #include <cstdlib>
 
 #include "rsqp_internal.h"
+#include "rsqp_kkt.h"
 
 #define LDS __attribute__((address_space(3)))
 typedef LDS double ldouble;
@@ -690,6 +691,37 @@ __global__ void __launch_bounds__(256, W) tiny_qp_kernel(QPPools P, int nq, int 
         if (l == 0) { si[16] = E.status; si[17] = (E.fmask & 0xff) | ((E.amask & 0xff) << 8); si[18] = TINY_MAGIC; }
     } else if (l == 0) { si[16] = QPS_NOTINITIALISED; si[18] = TINY_MAGIC; }
     TSTAMP(4);
+    if (P.cert_out) {
+        // the reference's certificate (qpOASESInterface::test_optimality, src/qpOASESInterface.cpp:498-684) on the answer just
+        // written, from the rows this lane holds: A x, A'y_C - H x of the final iterate are exact products of finish()
+        const double lraw = l < d.nV ? P.lb[d.offV + l] : 0.0, uraw = l < d.nV ? P.ub[d.offV + l] : 0.0;
+        const double laraw = l < d.nC ? P.lbA[d.offC + l] : 0.0, uaraw = l < d.nC ? P.ubA[d.offC + l] : 0.0;
+        double gyx, axx, hxx;
+        E.exact_products(gyx, axx, hxx);
+        double primal = 0.0, dual = 0.0, compl_ = 0.0, stat = 0.0;
+        int bad = 0;
+        if (l < d.nV) {
+            const double lo_ = fmax(lraw, -RSQP_K_INFTY), up_ = fmin(uraw, RSQP_K_INFTY);
+            const int Wm = map_bound(E.sv, E.xv, lo_, up_);
+            P.cert_Wb[d.offV + l] = Wm;
+            primal += fmax(0.0, lo_ - E.xv) + -fmin(0.0, up_ - E.xv);
+            kkt_terms(Wm, E.yv, E.xv, lo_, up_, dual, compl_, bad);
+            stat += fabs(gyx + E.yv - E.gN);                         // A'y_C + y_B - g - H x
+        }
+        if (l < d.nC) {
+            const double lo_ = fmax(laraw, -RSQP_K_INFTY), up_ = fmin(uaraw, RSQP_K_INFTY);
+            const int Wm = map_constr(E.sc, axx, lo_, up_);
+            P.cert_Wc[d.offC + l] = Wm;
+            primal += fmax(0.0, lo_ - axx) + -fmin(0.0, up_ - axx);
+            kkt_terms(Wm, E.yc, axx, lo_, up_, dual, compl_, bad);
+        }
+        primal = sum8(primal); dual = sum8(dual); compl_ = sum8(compl_); stat = sum8(stat);
+        bad = or8(bad);
+        if (l == 0) {
+            double *o = P.cert_out + 6LL * q;
+            o[0] = primal; o[1] = dual; o[2] = compl_; o[3] = stat; o[4] = compl_ + stat + dual + primal; o[5] = (double)bad;
+        }
+    }
     if (P.done_flag) {
         __threadfence_system();      // the results above are in host-mapped memory: visible before the flag
         if (q == 0 && l == 0) *reinterpret_cast<volatile int *>(P.done_flag) = P.done_val;

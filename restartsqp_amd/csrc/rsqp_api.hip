@@ -207,6 +207,14 @@ struct DevMatrix {
     DevBuf<double> rval;
     int nblk_c = 0, nblk_r = 0;
     bool have_csr = false;
+    // LDS-scale single-QP handles: the VALUES (CSC and CSR copy) live in host-mapped pinned memory that the kernels read
+    // directly -- a value refresh (SpHbMat::setMatVal through order_) is then a host loop over a few dozen entries, no copy
+    // and no launch (a blocking hipMemcpy + a scatter launch cost ~15 us per matrix per SQP iteration of hs071)
+    void *pin = nullptr;
+    std::vector<int> h_rorder, h_tmap, h_perm;
+    ~DevMatrix() {
+        if (pin) { val.release(); rval.release(); (void)hipHostFree(pin); }
+    }
 };
 
 struct rsqp_solver {
@@ -245,6 +253,7 @@ struct rsqp_solver {
     // Dropped by every setter (the certificate then runs on demand, as before).
     bool spec_cert = false;
     int spec_cert_val = 0;
+    bool cert_pending = false;   // a speculative certificate kernel may still be reading the (host-mapped) matrix values
     int done_seq = 0;
     bool lp_mode = false;   // optimizeLP: H ignored, H := hreg*I
     double hreg = 0.0;
@@ -271,12 +280,24 @@ struct rsqp_solver {
 
 namespace {
 
-int upload_matrix(DevMatrix &M, const Compressed &c, bool want_csr) {
+int upload_matrix(DevMatrix &M, const Compressed &c, bool want_csr, bool zero_copy = false) {
     M.nrow = c.nrow; M.ncol = c.ncol; M.nnz = c.nnz();
-    M.h_jc = c.jc; M.h_ir = c.ir; M.h_order = c.order;
+    M.h_jc = c.jc; M.h_ir = c.ir; M.h_order = c.order; M.h_tmap = c.tmap;
+    if (M.pin) { M.val.release(); M.rval.release(); (void)hipHostFree(M.pin); M.pin = nullptr; }
     HIPCHK(M.jc.from(c.jc));
     HIPCHK(M.ir.alloc(M.nnz + 2, true)); HIPCHK(M.ir.upload(c.ir.data(), c.ir.size()));
-    HIPCHK(M.val.alloc(M.nnz + 2, true)); HIPCHK(M.val.upload(c.val.data(), c.val.size()));
+    if (zero_copy) {
+        const size_t n = (size_t)M.nnz + 2;
+        HIPCHK(hipHostMalloc(&M.pin, 2 * n * sizeof(double), hipHostMallocMapped));
+        std::memset(M.pin, 0, 2 * n * sizeof(double));
+        void *dev = nullptr;
+        HIPCHK(hipHostGetDevicePointer(&dev, M.pin, 0));
+        M.val.map(static_cast<double *>(dev), static_cast<double *>(M.pin), n);
+        M.rval.map(static_cast<double *>(dev) + n, static_cast<double *>(M.pin) + n, n);
+        HIPCHK(M.val.upload(c.val.data(), c.val.size()));
+    } else {
+        HIPCHK(M.val.alloc(M.nnz + 2, true)); HIPCHK(M.val.upload(c.val.data(), c.val.size()));
+    }
     HIPCHK(M.order.alloc(std::max(M.nnz, 1), true)); HIPCHK(M.order.upload(c.order.data(), c.order.size()));
     if (!c.tmap.empty()) { HIPCHK(M.tmap.from(c.tmap)); }
     HIPCHK(M.tv.alloc(std::max(M.nnz, 1), true));
@@ -290,17 +311,19 @@ int upload_matrix(DevMatrix &M, const Compressed &c, bool want_csr) {
         HIPCHK(M.rp.from(r.rp));
         HIPCHK(M.ci.alloc(M.nnz + 2, true)); HIPCHK(M.ci.upload(r.ci.data(), r.ci.size()));
         HIPCHK(M.perm.alloc(std::max(M.nnz, 1), true)); HIPCHK(M.perm.upload(r.perm.data(), r.perm.size()));
-        HIPCHK(M.rval.alloc(M.nnz + 2, true));
+        if (!M.pin) HIPCHK(M.rval.alloc(M.nnz + 2, true));
         {   // rorder = (CSC slot -> CSR slot) o order: where a refreshed triplet value lands in the CSR copy
             std::vector<int> inv(std::max(M.nnz, 1), 0), ro(std::max(M.nnz, 1), 0);
             for (int k = 0; k < M.nnz; k++) inv[r.perm[k]] = k;
             for (size_t i = 0; i < c.order.size(); i++) ro[i] = inv[c.order[i]];
             HIPCHK(M.rorder.from(ro));
+            M.h_rorder = ro; M.h_perm = r.perm;
         }
         std::vector<int4> blr = build_blocks(M.nrow, r.rp.data(), rsqp_spmv_chunk());
         M.nblk_r = (int)blr.size();
         HIPCHK(M.blk_r.from(blr));
-        if (rsqp_launch_gather(M.nnz, M.perm.p, M.val.p, M.rval.p, nullptr) != hipSuccess)
+        if (M.pin) { for (int k = 0; k < M.nnz; k++) M.rval.host[k] = M.val.host[r.perm[k]]; }
+        else if (rsqp_launch_gather(M.nnz, M.perm.p, M.val.p, M.rval.p, nullptr) != hipSuccess)
             return fail(RSQP_ERR_DEVICE, "gather launch failed");
     }
     M.initialised = true;
@@ -552,7 +575,7 @@ extern "C" int rsqp_set_A_triplet(rsqp_solver *s, int nnz, const int *irow, cons
         Compressed cs;
         csc_from_entries(s->nC, s->nV, r, c, v, cs);
         M.from_triplet = true; M.n_triplet = nnz; M.n_ident_entries = nid;
-        int rc = upload_matrix(M, cs, true);
+        int rc = upload_matrix(M, cs, true, s->fits_small);
         if (rc != RSQP_OK) return rc;
         (void)hipStreamSynchronize(s->stream);   // this handle's stream only (the uploads are blocking copies): other handles keep running
         M.structure_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -561,6 +584,14 @@ extern "C" int rsqp_set_A_triplet(rsqp_solver *s, int nnz, const int *irow, cons
     }
     if (!M.from_triplet || nnz != M.n_triplet) return fail(RSQP_ERR_ARG, "rsqp_set_A_triplet: pattern changed");
     // SpHbMat::setMatVal(rhs, I_info): only the first nnz(J) entries are rewritten
+    if (M.pin) {
+        // host-mapped values: the scatter through order_ is a host loop (no kernel of this handle is running: every solve and
+        // certificate of the single-QP boundary is waited for before its call returns)
+        if (s->cert_pending) { HIPCHK(hipStreamSynchronize(s->stream)); s->cert_pending = false; }
+        double *v = M.val.host, *rv = M.rval.host;
+        for (int i = 0; i < nnz; i++) { v[M.h_order[i]] = val[i]; rv[M.h_rorder[i]] = val[i]; }
+        return RSQP_OK;
+    }
     HIPCHK(M.tv.upload(val, nnz));
     // one launch: every refreshed value goes to its CSC slot and to its slot of the CSR copy (the identity entries of [J I -I]
     // keep their values in both, SpHbMat.cpp:368-380)
@@ -592,7 +623,7 @@ extern "C" int rsqp_set_H_triplet(rsqp_solver *s, int nnz, const int *irow, cons
         cs.tmap = tmap;
         s->h_sym = is_symmetric != 0 || (s->nV <= 8 && small_csc_symmetric(s->nV, cs.jc.data(), cs.ir.data(), cs.val.data()));
         M.from_triplet = true; M.n_triplet = nnz; M.symmetric = is_symmetric != 0;
-        int rc = upload_matrix(M, cs, false);
+        int rc = upload_matrix(M, cs, false, s->fits_small);
         if (rc != RSQP_OK) return rc;
         (void)hipStreamSynchronize(s->stream);   // this handle's stream only (the uploads are blocking copies): other handles keep running
         M.structure_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -601,6 +632,12 @@ extern "C" int rsqp_set_H_triplet(rsqp_solver *s, int nnz, const int *irow, cons
     }
     if (!M.from_triplet || nnz != M.n_triplet) return fail(RSQP_ERR_ARG, "rsqp_set_H_triplet: pattern changed");
     if (!M.symmetric) s->h_sym = false;       // (values of a general triplet matrix: not re-examined)
+    if (M.pin) {
+        if (s->cert_pending) { HIPCHK(hipStreamSynchronize(s->stream)); s->cert_pending = false; }
+        double *v = M.val.host;
+        for (int j = 0; j < M.nnz; j++) v[M.h_order[j]] = val[M.h_tmap.empty() ? j : M.h_tmap[j]];
+        return RSQP_OK;
+    }
     HIPCHK(M.tv.upload(val, nnz));
     if (rsqp_launch_scatter(M.nnz, M.order.p, M.tmap.p, M.tv.p, M.val.p, s->stream) != hipSuccess)
         return fail(RSQP_ERR_DEVICE, "value refresh launch failed");
@@ -616,8 +653,10 @@ int set_csc(rsqp_solver *s, DevMatrix &M, int nrow, int ncol, const int *jc, con
     // same pattern (compared entry by entry, not just by count): refresh values
     if (M.initialised && nnz == M.nnz && !M.from_triplet && M.nrow == nrow && M.ncol == ncol &&
         std::equal(jc, jc + ncol + 1, M.h_jc.begin()) && std::equal(ir, ir + nnz, M.h_ir.begin())) {
+        if (M.pin && s->cert_pending) { HIPCHK(hipStreamSynchronize(s->stream)); s->cert_pending = false; }
         HIPCHK(M.val.upload(val, nnz));
-        if (M.have_csr && rsqp_launch_gather(M.nnz, M.perm.p, M.val.p, M.rval.p, s->stream) != hipSuccess)
+        if (M.pin) { if (M.have_csr) for (int k = 0; k < M.nnz; k++) M.rval.host[k] = val[M.h_perm[k]]; }
+        else if (M.have_csr && rsqp_launch_gather(M.nnz, M.perm.p, M.val.p, M.rval.p, s->stream) != hipSuccess)
             return fail(RSQP_ERR_DEVICE, "gather launch failed");
         return RSQP_OK;
     }
@@ -635,7 +674,7 @@ int set_csc(rsqp_solver *s, DevMatrix &M, int nrow, int ncol, const int *jc, con
     // blocks, host mirror) is rebuilt; the dirty flag set above makes optimizeQP re-factorise
     M.from_triplet = false;
     const auto t0 = std::chrono::steady_clock::now();
-    int rc = upload_matrix(M, cs, want_csr);
+    int rc = upload_matrix(M, cs, want_csr, s->fits_small);
     s->desc_ready = false;
     if (rc == RSQP_OK) {
         (void)hipStreamSynchronize(s->stream);   // this handle's stream only (the uploads are blocking copies): other handles keep running
@@ -770,7 +809,7 @@ int solve_large(rsqp_solver *s, int mode, int *nWSR, const double *x0, const dou
 }
 }  // namespace
 
-namespace { void launch_speculative_certificate(rsqp_solver *s, const QPPools &p); }
+namespace { void launch_speculative_certificate(rsqp_solver *s, const QPPools &p); bool spec_cert_enabled(); }
 
 extern "C" int rsqp_solve(rsqp_solver *s, int mode, int *nWSR, const double *x0, const double *y0,
                           const int *guess_b) {
@@ -791,11 +830,16 @@ extern "C" int rsqp_solve(rsqp_solver *s, int mode, int *nWSR, const double *x0,
         if (guess_b) { HIPCHK(s->d_guess.upload(guess_b, s->nV)); p.guess_b = s->d_guess.p; }
     }
     if (s->d_done && spin_enabled()) { p.done_flag = s->d_done; p.done_val = ++s->done_seq; }
+    // the hs071-scale tableau kernel forms the certificate QPhandler::solveQP asks for at the end of the SAME launch
+    const bool fused_cert = p.done_flag && p.tiny_ok && rsqp_tiny_fits(s->nV, s->nC) && spec_cert_enabled() && !s->lp_mode &&
+                            s->A.initialised == (s->nC > 0) && getenv("RSQP_SMALL_ENGINE") == nullptr;
+    if (fused_cert) { p.cert_out = s->d_kkt.p; p.cert_Wb = s->d_Wb.p; p.cert_Wc = s->d_Wc.p; }
     hipError_t e = rsqp_launch_small_qp(p, 1, s->nV, s->nC,
                                         rsqp_mat_lds_bytes(s->nV, s->nC, s->A.initialised ? s->A.nnz : 0, s->H.initialised ? s->H.nnz : 0),
                                         mode, *nWSR, s->stream);
     if (e != hipSuccess) return fail(RSQP_ERR_DEVICE, std::string("QP kernel launch: ") + hipGetErrorString(e));
-    launch_speculative_certificate(s, p);
+    if (fused_cert) { s->spec_cert = true; s->spec_cert_val = p.done_val; s->cert_pending = false; }
+    else launch_speculative_certificate(s, p);
     // the results live in host-mapped memory and the kernel raises a host-mapped flag behind them: spinning on it saves
     // the ~10 us a blocking hipStreamSynchronize takes to wake up (a single hs071-scale solve is ~30 us end to end)
     if (p.done_flag) { if ((rc = wait_done(s, p.done_val)) != RSQP_OK) return rc; }
@@ -1027,7 +1071,7 @@ void launch_speculative_certificate(rsqp_solver *s, const QPPools &p) {
     fill_kkt_args(s, a);
     a.done_flag = s->d_done; a.done_val = ++s->done_seq;
     if (rsqp_launch_small_certificate(p, a, 1, s->d_Ax.p, s->d_ATy.p, s->d_Hx.p, s->stream) != hipSuccess) return;
-    s->spec_cert = true; s->spec_cert_val = a.done_val;
+    s->spec_cert = true; s->spec_cert_val = a.done_val; s->cert_pending = true;
 }
 
 int run_certificate(rsqp_solver *s, rsqp_optimality_status *out, int *W_c, int *W_b, int *invalid) {
@@ -1035,6 +1079,7 @@ int run_certificate(rsqp_solver *s, rsqp_optimality_status *out, int *W_c, int *
     if (s->spec_cert && !s->vec_dirty) {      // launched behind the solve, nothing changed since: only wait for it
         s->spec_cert = false;
         int rcw = wait_done(s, s->spec_cert_val);
+        s->cert_pending = false;
         if (rcw != RSQP_OK) return rcw;
         return collect_certificate(s, out, W_c, W_b, invalid);
     }

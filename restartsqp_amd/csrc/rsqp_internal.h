@@ -49,6 +49,9 @@ struct QPPools {
     int done_val;     //   on it instead of sleeping in hipStreamSynchronize); nullptr for batches
     int k_debug_bail; // test hook (RSQP_K_DEBUG_BAIL=n): the explicit-KKT-inverse kernel bails out of a HOT start before its n-th change; -1 off
     int only_bailed;  // 1: the null-space kernel runs only the members the explicit-KKT-inverse kernel left with ret == RET_BAIL
+    double *cert_out; int *cert_Wb, *cert_Wc;   // single-QP handles on the tableau kernel of qp_tiny.hip: the KKT certificate
+                      //    (6 doubles: primal, dual, compl, stat, KKT_error, invalid) and the mapped working set are formed at
+                      //    the END of the solve kernel -- QPhandler::solveQP always asks for them (src/QPhandler.cpp:470-499); or nullptr
     int tiny_ok;      // 1: every H of the batch is symmetric (or absent): problems of <= 8 variables may take the register-resident
                       //    tableau kernel (qp_tiny.hip), which keeps K symmetric by construction
     int keep_state;   // 1: write the hot-start part of the engine image back to HBM at the end of a solve (what the

@@ -2,12 +2,7 @@
 #pragma once
 #include "rsqp_internal.h"
 
-#define RSQP_K_ABOVE 1
-#define RSQP_K_BELOW (-1)
-#define RSQP_K_BOTH (-99)
-#define RSQP_K_INACTIVE 0
-#define RSQP_K_INVALID 12345
-#define RSQP_K_INFTY 1.0e20
+#include "rsqp_kkt.h"
 
 // arguments of the fused certificate kernel. Either (nV, nC, offV, offC) arrays for a
 // batch, or nV1 / nC1 with null arrays for one problem.

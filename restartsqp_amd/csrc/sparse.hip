@@ -676,32 +676,6 @@ __device__ inline double block_sum_256(double v, double *sh) {
     return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-__device__ inline int map_bound(int ws, double x, double lb, double ub) {
-    // src/qpOASESInterface.cpp:846-868
-    if (ws == 1) return fabs(x - lb) < 1.0e-8 ? RSQP_K_BOTH : RSQP_K_ABOVE;
-    if (ws == -1) return fabs(x - ub) < 1.0e-8 ? RSQP_K_BOTH : RSQP_K_BELOW;
-    return ws == 0 ? RSQP_K_INACTIVE : RSQP_K_INVALID;
-}
-__device__ inline int map_constr(int ws, double Ax, double lbA, double ubA) {
-    // src/qpOASESInterface.cpp:871-892 -- fabs() wraps the comparison there, so the
-    // test is the SIGNED one
-    if (ws == 1) return (Ax - lbA < 1.0e-8) ? RSQP_K_BOTH : RSQP_K_ABOVE;
-    if (ws == -1) return (Ax - ubA < 1.0e-8) ? RSQP_K_BOTH : RSQP_K_BELOW;
-    return ws == 0 ? RSQP_K_INACTIVE : RSQP_K_INVALID;
-}
-
-__device__ inline void kkt_terms(int W, double yv, double val, double lo, double hi, double &dual,
-                                 double &compl_, int &bad) {
-    // dual feasibility :533-578 and complementarity :611-658
-    switch (W) {
-    case RSQP_K_INACTIVE: dual += fabs(yv); compl_ += fabs(yv); break;
-    case RSQP_K_BELOW: dual += -fmin(0.0, yv); compl_ += fabs(yv * (val - lo)); break;
-    case RSQP_K_ABOVE: dual += fmax(0.0, yv); compl_ += fabs(yv * (hi - val)); break;
-    case RSQP_K_BOTH: break;
-    default: bad = 1;
-    }
-}
-
 __device__ __forceinline__ void kkt_body(const RsqpKktArgs &a, double *sh) {
     const int q = blockIdx.x;
     const int nV = a.nV ? a.nV[q] : a.nV1, nC = a.nC ? a.nC[q] : a.nC1;
