@@ -99,7 +99,7 @@ struct EngineG {
     int nFR, nAC, status, infeasible, unbounded, nflips, bail_reason, parity;
     int debug_bail;             // >= 0: a hot start bails out before its debug_bail-th change (tests of the hand-over); else -1
     int since_refresh;          // working-set changes since A x and A'y - H x were last formed from the data; >= REFRESH: do it now
-    static constexpr int REFRESH = 8;
+    static constexpr int REFRESH = 16;      // (8 in the null-space engines; the tableau forms A x and A'y - H x of the iterate from the data half as often: measured the same answers)
     double hscale;
     long long tlast;   // (-DRSQP_STAMPS builds: cycles per phase of block 0, tools/stamp_k_kernel.py)
 

@@ -96,6 +96,10 @@ __device__ __forceinline__ double recip(double x) {      // v_rcp_f64 + two Newt
 }
 
 constexpr int MV = 8;       // variable slots = lanes of a group
+#ifndef TINY_BLOCK
+#define TINY_BLOCK 256       // threads per workgroup = 32 problems (no barrier, no cross-group traffic: the size only sets the LDS granule)
+#endif
+constexpr int TB = TINY_BLOCK, TG = TINY_BLOCK / 8;
 
 template <int MC>
 struct EngineT {
@@ -602,12 +606,12 @@ template <int MC> __device__ __forceinline__ long long tiny_state_doubles() { re
 constexpr int TINY_MAGIC = 0x7a11e;
 
 template <int MC, int W>
-__global__ void __launch_bounds__(256, W) tiny_qp_kernel(QPPools P, int nq, int mode_in, int maxWSR) {
+__global__ void __launch_bounds__(TB, W) tiny_qp_kernel(QPPools P, int nq, int mode_in, int maxWSR) {
     typedef EngineT<MC> ENG;
     constexpr int N = ENG::N;
-    __shared__ __attribute__((aligned(16))) double kd_all[32 * N * N];
+    __shared__ __attribute__((aligned(16))) double kd_all[TG * N * N];
     const int grp = (int)threadIdx.x >> 3;
-    const int q = (int)blockIdx.x * 32 + grp;
+    const int q = (int)blockIdx.x * TG + grp;
     if (q >= nq) return;        // (no workgroup barrier anywhere: idle groups may leave)
     const QPDesc d = P.desc[q];
     ENG E;
@@ -641,7 +645,7 @@ __global__ void __launch_bounds__(256, W) tiny_qp_kernel(QPPools P, int nq, int 
             }
         }
     }
-    int rcode = RET_OK, nWSR = 0;
+    int rcode = RET_OK, nWSR = 0, setup_pivots = 0;
     if (E.bounds_inconsistent()) {
         // qpOASES areBoundsConsistent: infeasible before any change (a hot start keeps the stored iterate)
         E.infeasible = 1;
@@ -666,11 +670,15 @@ __global__ void __launch_bounds__(256, W) tiny_qp_kernel(QPPools P, int nq, int 
             hx = hy = hg = hc = false;
         }
         TSTAMP(1);
+        if (mode != 1) setup_pivots = E.nFR() + E.nAC();
         if (!ok) rcode = RET_SETUP_FAILED;
         else rcode = E.homotopy(maxWSR, nWSR, mode == 1);
         TSTAMP(2);
     }
-    const double obj = E.finish(rcode == RET_OK);
+    // the refinement step repairs what the update-only tableau accumulates: with at most 4 pivots since G was built from the data
+    // (the two changes of the headline hs071 QP) there is nothing to repair yet -- |dx| ~ 1e-15 either way
+    const int pivots = (mode == 1 ? si[19] : setup_pivots) + nWSR;
+    const double obj = E.finish(rcode == RET_OK && pivots > 4);
     TSTAMP(3);
     // ---- results (x, y = [bounds; constraints], working set, status / nWSR / objective)
     if (l < d.nV) { P.x[d.offV + l] = E.xv; P.ws_b[d.offV + l] = E.sv; P.y[d.offV + d.offC + l] = E.yv; }
@@ -688,7 +696,7 @@ __global__ void __launch_bounds__(256, W) tiny_qp_kernel(QPPools P, int nq, int 
         pr[48 + l * 4 + 0] = E.ax; pr[48 + l * 4 + 1] = E.loA; pr[48 + l * 4 + 2] = E.upA; pr[48 + l * 4 + 3] = E.yc;
         pr[80 + l * 2] = E.dV; pr[80 + l * 2 + 1] = E.dC;
         si[l] = E.sv; si[8 + l] = E.sc;
-        if (l == 0) { si[16] = E.status; si[17] = (E.fmask & 0xff) | ((E.amask & 0xff) << 8); si[18] = TINY_MAGIC; }
+        if (l == 0) { si[16] = E.status; si[17] = (E.fmask & 0xff) | ((E.amask & 0xff) << 8); si[18] = TINY_MAGIC; si[19] = pivots; }
     } else if (l == 0) { si[16] = QPS_NOTINITIALISED; si[18] = TINY_MAGIC; }
     TSTAMP(4);
     if (P.cert_out) {
@@ -743,7 +751,7 @@ int rsqp_tiny_fits(int nVmax, int nCmax) {
 hipError_t rsqp_launch_tiny_qp(const QPPools &p, int nq, int nVmax, int nCmax, int mode, int maxWSR, hipStream_t stream) {
     if (nq <= 0) return hipSuccess;
     if (!rsqp_tiny_fits(nVmax, nCmax)) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)((nq + 31) / 32)), block(256);
+    const dim3 grid((unsigned)((nq + TG - 1) / TG)), block(TB);
     if (nCmax <= 2) hipLaunchKernelGGL((tiny_qp_kernel<2, 2>), grid, block, 0, stream, p, nq, mode, maxWSR);
     else if (nCmax <= 4) hipLaunchKernelGGL((tiny_qp_kernel<4, 2>), grid, block, 0, stream, p, nq, mode, maxWSR);
     else hipLaunchKernelGGL((tiny_qp_kernel<8, 1>), grid, block, 0, stream, p, nq, mode, maxWSR);
