@@ -234,16 +234,16 @@ template <bool SKIP0> __device__ __forceinline__ double2 ld_live(const double *p
     if (SKIP0 && wc == 0.0) return make_double2(0.0, 0.0);
     return *reinterpret_cast<const double2 *>(p);
 }
-template <bool VEC, int NTH, bool SKIP0 = false>
-__global__ void __launch_bounds__(NTH) k_gemv_n1(const double *__restrict__ M, long long ld, int nrows, int ncols,
-                                                const double *__restrict__ w, double alpha, double beta,
-                                                const double *__restrict__ base, double *__restrict__ out,
-                                                const int *__restrict__ mSb, double *__restrict__ mdst) {
+template <bool VEC, int NTH, bool SKIP0>
+__device__ __forceinline__ void gemv_n1_body(const int bx, const double *__restrict__ M, long long ld, int nrows, int ncols,
+                                             const double *__restrict__ w, double alpha, double beta,
+                                             const double *__restrict__ base, double *__restrict__ out,
+                                             const int *__restrict__ mSb, double *__restrict__ mdst) {
     constexpr int RPL = VEC ? 2 : 1;
     constexpr int NG = NTH / 8;          // column groups
     __shared__ double sh[NG][8 * RPL + 1];
     const int rl = threadIdx.x & 7, cg = threadIdx.x >> 3;
-    const int r = (blockIdx.x * 8 + rl) * RPL;
+    const int r = (bx * 8 + rl) * RPL;
     double a0 = 0.0, a1 = 0.0;
     if (VEC) {
         if (r + 1 < nrows) {
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(NTH) k_gemv_n1(const double *__restrict__ M, l
     }
     __syncthreads();
     if ((int)threadIdx.x < 8 * RPL) {
-        const int rr = blockIdx.x * 8 * RPL + threadIdx.x;
+        const int rr = bx * 8 * RPL + threadIdx.x;
         if (rr < nrows) {
             double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
 #pragma unroll
@@ -299,10 +299,28 @@ __global__ void __launch_bounds__(NTH) k_gemv_n1(const double *__restrict__ M, l
         }
     }
 }
+template <bool VEC, int NTH, bool SKIP0 = false>
+__global__ void __launch_bounds__(NTH) k_gemv_n1(const double *__restrict__ M, long long ld, int nrows, int ncols,
+                                                const double *__restrict__ w, double alpha, double beta,
+                                                const double *__restrict__ base, double *__restrict__ out,
+                                                const int *__restrict__ mSb, double *__restrict__ mdst) {
+    gemv_n1_body<VEC, NTH, SKIP0>(blockIdx.x, M, ld, nrows, ncols, w, alpha, beta, base, out, mSb, mdst);
+}
+// two independent products out = M w of that form in ONE launch (the first nb0 workgroups take the first): t = Z v and s = Wz v of
+// an incoming constraint's reflection, A dx_FX and H dx_FX of the step direction -- launch-bound sizes, where a launch costs more
+// than the product (same body: the same bits as two launches)
+template <int NTH, bool SKIP0>
+__global__ void __launch_bounds__(NTH) k_gemv_n1_pair(const double *__restrict__ M0, long long ld0, int nrows0, int ncols0,
+                                                     const double *__restrict__ w0, double *__restrict__ out0, int nb0,
+                                                     const double *__restrict__ M1, long long ld1, int nrows1, int ncols1,
+                                                     const double *__restrict__ w1, double *__restrict__ out1) {
+    if ((int)blockIdx.x < nb0) gemv_n1_body<true, NTH, SKIP0>(blockIdx.x, M0, ld0, nrows0, ncols0, w0, 1.0, 0.0, nullptr, out0, nullptr, nullptr);
+    else gemv_n1_body<true, NTH, SKIP0>(blockIdx.x - nb0, M1, ld1, nrows1, ncols1, w1, 1.0, 0.0, nullptr, out1, nullptr, nullptr);
+}
 
 // The rank-1 update M += coef t v' and out = beta * base + alpha * M w of the UPDATED matrix in one pass, in the single-launch
 // form of k_gemv_n1 (a workgroup owns 16 consecutive rows and all columns, 16-byte accesses; leading dimension even, M 16-byte
-// aligned): the deferred reflection of Z riding on the step direction's LAST product when its first one is carried (k_carry_wZ).
+// aligned): the deferred reflection of Z riding on the step direction's LAST product when its first one is carried (k_carry_add).
 template <int NTH>
 __global__ void __launch_bounds__(NTH) k_ger_gemv_n1(double *__restrict__ M, long long ld, int nrows, int ncols,
                                                      const double *__restrict__ ut, const double *__restrict__ uv,
@@ -454,6 +472,51 @@ __global__ void __launch_bounds__(NT) k_ger_gemv_t(double *__restrict__ M, long 
         if (threadIdx.x == 0 && c0 + k < ncols) out[omap ? omap[c0 + k] : c0 + k] = addv ? v + addv[c0 + k] : v;
     }
 }
+// Everything behind the two products of a carried constraint REMOVAL (t = Y v, s' = v'Minv) in ONE launch over max(nV, n) entries
+// (n = nAC before the removal, kk = n - 1): k_keep_removal, the reflection of the last column of Y (it becomes the new column of Z:
+// written to both) and of the last column of Minv (which then fills the slot k of the removed constraint), the carried range-space
+// part -- wY <- (1 - tau)(P wY)[0..kk), omega = (P wY)[kk], xY <- (1 - tau)(xY - omega z_new) -- and the working-set bookkeeping
+// (k_ws_remove_c). Every workgroup forms the dot product v'wY itself (same loop, same tree: the same bits in all of them);
+// workgroup 0 writes the new wY into wYout (the OTHER half of the double buffer: the others may still be reading wY).
+__global__ void __launch_bounds__(NT) k_remove_tail(int n, int nV, int k, double om, const double *__restrict__ v,
+                                                    const double *__restrict__ srow, const double *__restrict__ t,
+                                                    double *__restrict__ keep_v, double *__restrict__ keep_s, double *__restrict__ scal,
+                                                    int from, int to, int sl, double *__restrict__ ylast, double *__restrict__ znew,
+                                                    double *__restrict__ mlast, double *__restrict__ mk, const double *__restrict__ wY,
+                                                    double *__restrict__ wYout, double *__restrict__ xY, int *AC, int *posAC, int *Sc,
+                                                    int r, double *y, int yidx) {
+    __shared__ double sh[4];
+    const int kk = n - 1;
+    double d = 0.0;
+    for (int i = threadIdx.x; i <= kk; i += NT) d += v[i] * wY[i];
+    d = block_sum(d, sh);
+    const double beta = scal[from], c = beta * d, omega = wY[kk] - c * v[kk], coef = -1.0 * beta;
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < kk; i += NT) wYout[i] = om * (wY[i] - c * v[i]);
+        if (threadIdx.x == 0) {
+            scal[sl] = omega;
+            scal[to] = beta;
+            if (k != kk) { const int rl = AC[kk]; AC[k] = rl; posAC[rl] = k; }
+            posAC[r] = -1; Sc[r] = 0;
+            y[yidx] = 0.0;
+        }
+    }
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i < n) {
+        const double vi = v[i];
+        keep_v[i] = vi;
+        keep_s[i] = i == k ? 0.0 : srow[i];
+        const double m = mlast[i] + (coef * vi) * srow[kk];
+        mlast[i] = m;
+        if (mk) mk[i] = m;
+    }
+    if (i < nV) {
+        const double m = ylast[i] + (coef * t[i]) * v[kk];
+        ylast[i] = m;
+        znew[i] = m;
+        xY[i] = om * (xY[i] - omega * m);
+    }
+}
 // what the deferred reflections of Y and Minv behind a removed constraint need later (remove_constraint_tq): v twice (Y's column
 // coefficients = Minv's row coefficients), s = v'Minv with the entry of the column that is refilled zeroed, beta
 __global__ void k_keep_removal(int n, const double *__restrict__ v, const double *__restrict__ srow, int kzero, double *__restrict__ keep_v,
@@ -468,6 +531,22 @@ __global__ void k_keep_reflector(const double *__restrict__ v, int n, double *__
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) keep[i] = v[i];
     if (i == 0) scal[to] = scal[from];
+}
+
+// ... and, in the same launch, the reflection of the ONE column that is needed at once (the last column of Z, which becomes the new
+// column of Y: element expression of k_ger_v) written to both places: k_keep_reflector + k_ger_v on one column + k_copy
+__global__ void k_keep_reflect_lastcol(const double *__restrict__ v, int n, double *__restrict__ keep, double *__restrict__ scal, int from,
+                                       int to, int nrows, const double *__restrict__ t, double *__restrict__ zlast,
+                                       double *__restrict__ ycol) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keep[i] = v[i];
+    if (i == 0) scal[to] = scal[from];
+    if (i < nrows) {
+        const double coef = -1.0 * scal[from];
+        const double m = zlast[i] + (coef * t[i]) * v[n - 1];
+        zlast[i] = m;
+        ycol[i] = m;
+    }
 }
 
 // scal[slot] = sum_i a[i]*b[i]
@@ -487,16 +566,6 @@ __global__ void k_copy(const double *__restrict__ src, double *__restrict__ dst,
 __global__ void k_fill(double *__restrict__ dst, int n, double v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = v;
-}
-// dst[c] = M[c*ld + row]   (row of a column-major matrix)
-__global__ void k_get_row(const double *__restrict__ M, long long ld, int row, int ncols, double *__restrict__ dst) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < ncols) dst[c] = M[c * ld + row];
-}
-__global__ void k_set_row(double *__restrict__ M, long long ld, int row, int ncols, const double *__restrict__ src,
-                          double scale) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < ncols) M[c * ld + row] = src ? scale * src[c] : 0.0;
 }
 
 // Householder vector for mapping w (length n) onto its LAST component:
@@ -711,15 +780,6 @@ __global__ void __launch_bounds__(NT) k_wz_grow(double *__restrict__ Wz, long lo
     Wz[(long long)b * ld + a] = val;
 }
 
-// ---- sparse helpers ---------------------------------------------------------------
-// a[v] = A[row][v] for free v (all: every v), 0 elsewhere
-__global__ void k_row_of_A(const int *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ rv,
-                           int row, const int *__restrict__ Sb, int all, double *__restrict__ a) {
-    for (int k = rp[row] + blockIdx.x * blockDim.x + threadIdx.x; k < rp[row + 1]; k += gridDim.x * blockDim.x) {
-        const int c = ci[k];
-        if (all || Sb[c] == 0) a[c] = rv[k];
-    }
-}
 // out[j] = A[AC[j]][v]   (column v restricted to the active rows; pos = position of a row in AC or -1)
 __global__ void k_col_of_A_active(const int *__restrict__ jc, const int *__restrict__ ir, const double *__restrict__ val,
                                   int v, const int *__restrict__ pos, double *__restrict__ out) {
@@ -745,29 +805,6 @@ __device__ inline double delta_of(double target, double cur) {
     return (fabs(target) >= RSQP_INFTY && fabs(cur) >= RSQP_INFTY) ? 0.0 : target - cur;
 }
 
-// dx on fixed variables, zero elsewhere
-__global__ void k_dx_fixed(int nV, const int *__restrict__ Sb, const double *__restrict__ lb,
-                           const double *__restrict__ ub, const double *__restrict__ lbN, const double *__restrict__ ubN,
-                           double *__restrict__ dx) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v < nV) dx[v] = Sb[v] == -1 ? delta_of(lbN[v], lb[v]) : (Sb[v] == 1 ? delta_of(ubN[v], ub[v]) : 0.0);
-}
-// bA[j] = delta b (AC[j]) - (A dx_FX)[AC[j]]
-__global__ void k_rhs_active(int nAC, const int *__restrict__ AC, const int *__restrict__ Sc,
-                             const double *__restrict__ lbA, const double *__restrict__ ubA,
-                             const double *__restrict__ lbAN, const double *__restrict__ ubAN,
-                             const double *__restrict__ Adx, double *__restrict__ bA) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nAC) return;
-    const int r = AC[j];
-    bA[j] = (Sc[r] == -1 ? delta_of(lbAN[r], lbA[r]) : delta_of(ubAN[r], ubA[r])) - Adx[r];
-}
-// out = a + (gN - g)   (a may be null)
-__global__ void k_add_dg(int nV, const double *__restrict__ a, const double *__restrict__ gN, const double *__restrict__ g,
-                         double *__restrict__ out) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v < nV) out[v] = (a ? a[v] : 0.0) + (gN[v] - g[v]);
-}
 __global__ void k_axpby(int n, double a, const double *__restrict__ x, double b, const double *__restrict__ y,
                         double *__restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -777,12 +814,6 @@ __global__ void k_axpby(int n, double a, const double *__restrict__ x, double b,
 __global__ void k_merge_free(int nV, const int *__restrict__ Sb, const double *__restrict__ xfree, double *__restrict__ dx) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v < nV && Sb[v] == 0) dx[v] = xfree[v];
-}
-// dy on fixed variables: res - A'dy_C, zero on free ones
-__global__ void k_dy_fixed(int nV, const int *__restrict__ Sb, const double *__restrict__ res,
-                           const double *__restrict__ ATdy, double *__restrict__ dy) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v < nV) dy[v] = Sb[v] != 0 ? res[v] - ATdy[v] : 0.0;
 }
 
 // ratio tests: candidate ids as in qp_small.hip; stage 1 per workgroup, stage 2 one workgroup
@@ -885,30 +916,6 @@ __global__ void __launch_bounds__(NT) k_argmin2(int n, const double *__restrict_
     }
 }
 
-// homotopy step; done: data := targets
-__global__ void k_step_v(int nV, double tau, int done, const int *__restrict__ Sb, double *__restrict__ x,
-                         double *__restrict__ g, double *__restrict__ lb, double *__restrict__ ub,
-                         const double *__restrict__ gN, const double *__restrict__ lbN, const double *__restrict__ ubN,
-                         const double *__restrict__ dx) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= nV) return;
-    if (done) {
-        g[v] = gN[v]; lb[v] = lbN[v]; ub[v] = ubN[v];
-        x[v] = Sb[v] == -1 ? lb[v] : (Sb[v] == 1 ? ub[v] : x[v] + tau * dx[v]);
-    } else {
-        x[v] += tau * dx[v];
-        g[v] += tau * (gN[v] - g[v]);
-        lb[v] += tau * delta_of(lbN[v], lb[v]);
-        ub[v] += tau * delta_of(ubN[v], ub[v]);
-    }
-}
-__global__ void k_step_c(int nC, double tau, int done, double *__restrict__ lbA, double *__restrict__ ubA,
-                         const double *__restrict__ lbAN, const double *__restrict__ ubAN) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nC) return;
-    if (done) { lbA[i] = lbAN[i]; ubA[i] = ubAN[i]; }
-    else { lbA[i] += tau * delta_of(lbAN[i], lbA[i]); ubA[i] += tau * delta_of(ubAN[i], ubA[i]); }
-}
 __global__ void k_axpy(int n, double a, const double *__restrict__ x, double *__restrict__ y) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] += a * x[i];
@@ -919,18 +926,7 @@ __global__ void k_fix_x(int nV, const int *__restrict__ Sb, const double *__rest
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v < nV && Sb[v] != 0) x[v] = Sb[v] == -1 ? lb[v] : ub[v];
 }
-__global__ void k_fix_bA(int nC, const int *__restrict__ Sc, const double *__restrict__ Ax, double *__restrict__ lbA,
-                         double *__restrict__ ubA) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nC) { if (Sc[i] == -1) lbA[i] = Ax[i]; else if (Sc[i] == 1) ubA[i] = Ax[i]; }
-}
-__global__ void k_fix_g(int nV, const double *__restrict__ ATy, const double *__restrict__ y, const double *__restrict__ Hx,
-                        double *__restrict__ g) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v < nV) g[v] = ATy[v] + y[v] - Hx[v];
-}
 __global__ void k_set1(double *p, int i, double v) { p[i] = v; }
-__global__ void k_seti(int *p, int i, int v) { p[i] = v; }
 __global__ void k_copy1(double *dst, int di, const double *src, int si) { dst[di] = src[si]; }
 
 // exchange partner search (ensure_LI): xiC over constraints (by index), xiB over variables
@@ -1018,21 +1014,58 @@ __global__ void k_sd_prep(int nAC, const int *__restrict__ AC, const int *__rest
     }
     if (i < nV) tmpg[i] = Hdxfx[i] + (gN[i] - g[i]);
 }
-// The range-space part of the step direction behind an ADDED constraint, carried instead of recomputed: the right-hand sides of
-// the constraints that were active before have (1 - tau) of their way left, the new row of Minv is -xi/eta | 1/eta (minv_append):
-//   wY[0..k) *= (1 - tau);  wY[k] = (bA[k] - xi'bA[0..k)) / eta   (one workgroup; the new entry also into scal[sl])
-__global__ void __launch_bounds__(NT) k_carry_wY(int k, double om, const double *__restrict__ bA, const double *__restrict__ xi,
-                                                 double *__restrict__ wY, double *__restrict__ scal, int se, int sl) {
+// The step direction behind an ADDED constraint, carried instead of recomputed, in ONE launch over max(nV, 1) entries.
+// Range space: the right-hand sides of the constraints that were active before have (1 - tau) of their way left, the new row of
+// Minv is -xi/eta | 1/eta (minv_append):
+//   wY[0..k) *= (1 - tau);  wY[k] = (bA[k] - xi'bA[0..k)) / eta  (also into scal[sl]);  xY = (1 - tau) xY + wY[k] y_k
+// with bA[j] = delta b(AC[j]) - (A dx_FX)[AC[j]] formed on the fly (k_sd_prep's expression; not stored: nothing else reads it on this
+// path) and y_k the column the constraint added to Y. Every workgroup forms the dot product xi'bA itself (same loop, same tree:
+// the same bits in all of them) and then its slice of xY and of tmpg = H dx_FX + (gN - g) (tmpg == nullptr: not needed); workgroup 0
+// writes wY.
+// Null space (l >= 0, by the LAST workgroup): with P = I - beta v v' the reflection of Z, wZ' = P wZ, col = the last column of
+// P Wz P (k_wz_lastcol), kappa = col[0..l) / col[l]:
+//   wZ[0..l) <- (1 - tau) (wZ'[0..l) - kappa wZ'[l]) + wY_k kappa
+// (block elimination of the last null-space column from Z'HZ wZ = -Z'(g~ + H xY), whose right-hand side gained wY_k Z'H y_k).
+__global__ void __launch_bounds__(NT) k_carry_add(int k, double om, const int *__restrict__ AC, const int *__restrict__ Sc,
+                                                  const double *__restrict__ lbA, const double *__restrict__ ubA,
+                                                  const double *__restrict__ lbAN, const double *__restrict__ ubAN,
+                                                  const double *__restrict__ Adx, const double *__restrict__ xi, double *__restrict__ wY,
+                                                  double *__restrict__ scal, int se, int sl, int nV, const double *__restrict__ yk,
+                                                  double *__restrict__ xY, const double *__restrict__ Hdxfx, const double *__restrict__ gN,
+                                                  const double *__restrict__ g, double *__restrict__ tmpg, int l,
+                                                  const double *__restrict__ v, const double *__restrict__ col, double *__restrict__ wZ,
+                                                  int sb) {
     __shared__ double sh[4];
     double s = 0.0;
-    for (int j = threadIdx.x; j < k; j += NT) { s += xi[j] * bA[j]; wY[j] *= om; }
+    for (int j = threadIdx.x; j < k; j += NT) {
+        const int r = AC[j];
+        const double b = (Sc[r] == -1 ? delta_of(lbAN[r], lbA[r]) : delta_of(ubAN[r], ubA[r])) - Adx[r];
+        s += xi[j] * b;
+    }
     s = block_sum(s, sh);
-    if (threadIdx.x == 0) { const double w = (bA[k] - s) / scal[se]; wY[k] = w; scal[sl] = w; }
-}
-//   xY = (1 - tau) xY + wY[k] y_k   (y_k = the column the constraint added to Y)
-__global__ void k_carry_xY(int n, double om, const double *__restrict__ yk, const double *__restrict__ scal, int sl, double *__restrict__ xY) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) xY[i] = om * xY[i] + scal[sl] * yk[i];
+    const int rk = AC[k];
+    const double bk = (Sc[rk] == -1 ? delta_of(lbAN[rk], lbA[rk]) : delta_of(ubAN[rk], ubA[rk])) - Adx[rk];
+    const double w = (bk - s) / scal[se];
+    if (blockIdx.x == 0) {
+        for (int j = threadIdx.x; j < k; j += NT) wY[j] *= om;
+        if (threadIdx.x == 0) { wY[k] = w; scal[sl] = w; }
+    }
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i < nV) {
+        xY[i] = om * xY[i] + w * yk[i];
+        if (tmpg) tmpg[i] = Hdxfx[i] + (gN[i] - g[i]);
+    }
+    if (l >= 0 && blockIdx.x == gridDim.x - 1) {
+        double d = 0.0;
+        for (int j = threadIdx.x; j <= l; j += NT) d += v[j] * wZ[j];
+        d = block_sum(d, sh);
+        const double c = scal[sb] * d, wl = wZ[l] - c * v[l], rc = 1.0 / col[l];
+        __syncthreads();
+        for (int j = threadIdx.x; j < l; j += NT) {
+            const double kap = col[j] * rc;
+            wZ[j] = om * ((wZ[j] - c * v[j]) - kap * wl) + w * kap;
+        }
+    }
 }
 // ... and over a REMOVED constraint (remove_constraint_tq: Y <- Y P, Minv <- P Minv with P = I - beta v v', then the last column of
 // Y moves to Z): wY <- (1 - tau) (P wY)[0..k), xY <- (1 - tau) (xY - omega z_new) with omega = (P wY)[k]  (one workgroup; omega
@@ -1052,24 +1085,6 @@ __global__ void k_carry_remove_xY(int n, double om, const double *__restrict__ z
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) xY[i] = om * (xY[i] - scal[sl] * znew[i]);
 }
-// The NULL-space part behind an added constraint, carried as well: with P = I - beta v v' the reflection of Z, wZ' = P wZ,
-// col = the last column of P Wz P (k_wz_lastcol), kappa = col[0..l) / col[l], wY_k the new entry of wY:
-//   wZ[0..l) <- (1 - tau) (wZ'[0..l) - kappa wZ'[l]) + wY_k kappa
-// (block elimination of the last null-space column from Z'HZ wZ = -Z'(g~ + H xY), whose right-hand side gained wY_k Z'H y_k;
-// DESIGN 4.1). One workgroup.
-__global__ void __launch_bounds__(NT) k_carry_wZ(int l, double om, const double *__restrict__ v, const double *__restrict__ col,
-                                                 double *__restrict__ wZ, const double *__restrict__ scal, int sb, int sl) {
-    __shared__ double sh[4];
-    double d = 0.0;
-    for (int i = threadIdx.x; i <= l; i += NT) d += v[i] * wZ[i];
-    d = block_sum(d, sh);
-    const double c = scal[sb] * d, wl = wZ[l] - c * v[l], wyk = scal[sl], rc = 1.0 / col[l];
-    __syncthreads();
-    for (int i = threadIdx.x; i < l; i += NT) {
-        const double kap = col[i] * rc;
-        wZ[i] = om * ((wZ[i] - c * v[i]) - kap * wl) + wyk * kap;
-    }
-}
 // ... and behind a REMOVED constraint (the null space gained the column z, Wz its border with u = Wz Z'Hz and rho^2, wz_grow): with
 // s = z'(H dx_old + (gN - g)_old) -- the reduced gradient of the previous step along z, (gN - g)_old = (gN - g) / (1 - tau) -- and
 // omega the component xY lost (k_carry_remove_wY):
@@ -1086,19 +1101,6 @@ __global__ void __launch_bounds__(NT) k_carry_wZ_grow(int n, int nV, double om, 
     const double c = d / scal[srho];
     for (int i = threadIdx.x; i < n; i += NT) wZ[i] = om * (wZ[i] + c * u[i]);
     if (threadIdx.x == 0) wZ[n] = om * (scal[somega] - c);
-}
-// what that needs from the border of Minv: the row xi and eta, out of the way of the next products
-__global__ void k_keep_border(int k, const double *__restrict__ row, double *__restrict__ keep, double *__restrict__ scal, int es,
-                              int eta_from_house, int se) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < k) keep[j] = row[j];
-    if (j == 0) scal[se] = eta_from_house ? scal[2] * scal[0] : scal[es];
-}
-// dy on the fixed variables: (H dx + (gN - g)) - A'dy_C, zero on the free ones
-__global__ void k_dy_fixed2(int nV, const int *__restrict__ Sb, const double *__restrict__ Hdx, const double *__restrict__ gN,
-                            const double *__restrict__ g, const double *__restrict__ ATdy, double *__restrict__ dy) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v < nV) dy[v] = Sb[v] != 0 ? (Hdx[v] + (gN[v] - g[v])) - ATdy[v] : 0.0;
 }
 // the whole homotopy step in one launch: variables, constraints, multipliers, and -- fix != 0 -- the blocking
 // bound / constraint put exactly on its new side (fkind 3: constraint fidx, 4: variable fidx)
@@ -1189,38 +1191,6 @@ __global__ void k_dx_fixed_zero_dy(int nV, int nC, const int *__restrict__ Sb, c
     if (i < nV) dx[i] = Sb[i] == -1 ? delta_of(lbN[i], lb[i]) : (Sb[i] == 1 ? delta_of(ubN[i], ub[i]) : 0.0);
     if (i < nV + nC) dy[i] = 0.0;
 }
-// homotopy step of everything indexed by variables / by constraints
-__global__ void k_step_all_v(int nV, double tau, int done, const int *__restrict__ Sb, double *__restrict__ x,
-                             double *__restrict__ g, double *__restrict__ lb, double *__restrict__ ub,
-                             const double *__restrict__ gN, const double *__restrict__ lbN, const double *__restrict__ ubN,
-                             const double *__restrict__ dx, const double *__restrict__ ATdy, double *__restrict__ ATy,
-                             const double *__restrict__ Hdx, double *__restrict__ Hx) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= nV) return;
-    if (done) {
-        g[v] = gN[v]; lb[v] = lbN[v]; ub[v] = ubN[v];
-        x[v] = Sb[v] == -1 ? lb[v] : (Sb[v] == 1 ? ub[v] : x[v] + tau * dx[v]);
-    } else {
-        x[v] += tau * dx[v];
-        g[v] += tau * (gN[v] - g[v]);
-        lb[v] += tau * delta_of(lbN[v], lb[v]);
-        ub[v] += tau * delta_of(ubN[v], ub[v]);
-        ATy[v] += tau * ATdy[v];
-        Hx[v] += tau * Hdx[v];
-    }
-}
-__global__ void k_step_all_c(int nC, double tau, int done, double *__restrict__ lbA, double *__restrict__ ubA,
-                             const double *__restrict__ lbAN, const double *__restrict__ ubAN,
-                             const double *__restrict__ dAx, double *__restrict__ Ax) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nC) return;
-    if (done) { lbA[i] = lbAN[i]; ubA[i] = ubAN[i]; }
-    else {
-        lbA[i] += tau * delta_of(lbAN[i], lbA[i]);
-        ubA[i] += tau * delta_of(ubAN[i], ubA[i]);
-        Ax[i] += tau * dAx[i];
-    }
-}
 // drift correction without a refresh of the products: x on its bounds, active constraint sides on
 // A x, gradient from stationarity -- one launch over max(nV, nC)
 __global__ void k_drift_all(int nV, int nC, const int *__restrict__ Sb, const int *__restrict__ Sc,
@@ -1239,8 +1209,6 @@ __global__ void k_drift_all(int nV, int nC, const int *__restrict__ Sb, const in
     if (i < nC) { if (Sc[i] == -1) lbA[i] = Ax[i]; else if (Sc[i] == 1) ubA[i] = Ax[i]; }
     if (i < nV + nC) dy[i] = 0.0;
 }
-// working-set bookkeeping of an added constraint
-__global__ void k_set_ws(int *AC, int *posAC, int *Sc, int nAC, int r, int side) { AC[nAC] = r; posAC[r] = nAC; Sc[r] = side; }
 // zero a (length nV) and scatter row `row` of A into it: one workgroup
 __global__ void __launch_bounds__(NT) k_row_of_A_fused(const int *__restrict__ rp, const int *__restrict__ ci,
                                                        const double *__restrict__ rv, int row, const int *__restrict__ Sb,
@@ -1342,23 +1310,29 @@ __global__ void k_unit_cols(double *__restrict__ Z, long long ld, const int *__r
 inline dim3 g1(int n) { return dim3((unsigned)((n + NT - 1) / NT)); }
 
 // ---- small single-thread / utility kernels -----------------------------------------------
-// eta_from_house: eta = image sign * alpha of the last Householder vector (scal[2] * scal[0]), else scal[es];
-// thread nAC also records the new working-set entry (constraint r at position nAC, side)
-__global__ void k_minv_border(double *Minv, long long ldm, int nAC, const double *row,
-                                                     const double *scal, int es, int eta_from_house, int *AC, int *posAC,
-                                                     int *Sc, int r, int side) {
+// The border of Minv behind an added constraint. eta_from_house: eta = image sign * alpha of the last Householder vector
+// (scal[2] * scal[0]), else scal[es]; thread nAC also records the new working-set entry (constraint r at position nAC, side).
+// keep != nullptr: what the carried step direction needs from the border is kept on the way (the row xi in keep, eta in
+// scal[se]); yidx >= 0: the multiplier of the incoming constraint is set (y[yidx] = yval) -- three launches in one
+__global__ void k_minv_border_keep(double *Minv, long long ldm, int nAC, const double *row, double *scal, int es, int eta_from_house,
+                                   int *AC, int *posAC, int *Sc, int r, int side, double *keep, int se, double *y, int yidx, double yval) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > nAC) return;
     const double eta = eta_from_house ? scal[2] * scal[0] : scal[es];
-    if (j == nAC) { AC[nAC] = r; posAC[r] = nAC; Sc[r] = side; }
+    if (j == nAC) {
+        AC[nAC] = r; posAC[r] = nAC; Sc[r] = side;
+        if (keep) scal[se] = eta;
+        if (yidx >= 0) y[yidx] = yval;
+    }
     if (j < nAC) {
-        Minv[(long long)j * ldm + nAC] = -row[j] / eta;   // new row nAC
+        const double rj = row[j];
+        if (keep) keep[j] = rj;
+        Minv[(long long)j * ldm + nAC] = -rj / eta;       // new row nAC
         Minv[(long long)nAC * ldm + j] = 0.0;             // new column nAC
     } else {
         Minv[(long long)nAC * ldm + nAC] = 1.0 / eta;
     }
 }
-__global__ void k_eta_from_house(double *scal) { scal[5] = scal[2] * scal[0]; }
 // a1[0..nAC) = qY, a1[nAC] = q*: unit vector. vt = q~ with last += sgn(q*); beta~ = 1/(1+|q*|),
 // gamma = beta~/(1 - beta~ |qY|^2) = beta~/|q*|
 __global__ void k_house_unit(double *a1, int nAC, double *scal, const double *zs, int v) {
@@ -1450,7 +1424,7 @@ struct RsqpLargeEngine::Impl {
     // vectors (nV)
     double *x, *g, *lb, *ub, *gN, *lbN, *ubN, *dx, *w1, *w2, *w3, *w4, *w5, *w6, *wz1, *wz2, *wz3;
     double *pz_t = nullptr, *pz_v = nullptr, *pw_s = nullptr, *pw_col = nullptr;   // operands of a deferred reflection (z_reflect_and_shrink)
-    double *c_wY = nullptr, *c_xY = nullptr, *c_xi = nullptr, *c_wZ = nullptr;
+    double *c_wY = nullptr, *c_wY2 = nullptr, *c_xY = nullptr, *c_xi = nullptr, *c_wZ = nullptr;   // (c_wY2: the other half of c_wY's double buffer, k_remove_tail)
     double *py_t = nullptr, *py_v = nullptr, *pm_s = nullptr;                     // operands of the deferred reflections of Y / Minv (removed constraint)                    // range-space part of the step direction, carried over an added constraint
     // vectors (nC)
     double *Ax, *lbA, *ubA, *lbAN, *ubAN, *dAx, *c1, *c2, *c3, *a1, *a2, *a3, *a4;
@@ -1530,7 +1504,7 @@ struct RsqpLargeEngine::Impl {
 
     ~Impl() {
         double *dv[] = {Z, Y, Minv, Wz, x, g, lb, ub, gN, lbN, ubN, dx, w1, w2, w3, w4, w5, w6, wz1, wz2, wz3, Ax, lbA, ubA,
-                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col, c_wY, c_xY, c_xi, c_wZ, py_t, py_v, pm_s};
+                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col, c_wY, c_wY2, c_xY, c_xi, c_wZ, py_t, py_v, pm_s};
         for (double *p : dv) if (p) (void)hipFree(p);
         if (big) (void)hipFree(big);
         rsqp_dense_work_free(&dw);
@@ -1635,6 +1609,29 @@ struct RsqpLargeEngine::Impl {
             hipLaunchKernelGGL(k_gemv_n_reduce, dim3((nrows + 63) / 64), dim3(NT), 0, st, part, nrows, nch, alpha, beta, base, out);
         pend(0, 8.0 * nrows * (double)ncols + 8.0 * nrows + 8.0 * ncols);
         chk("gemv_n");
+    }
+    // two products out = M w of the single-launch form in ONE launch (k_gemv_n1_pair); false: the pair does not qualify and the
+    // caller launches them one after the other. skip0: columns with a zero weight are not read (live of them are non-zero)
+    bool pair_enabled = getenv("RSQP_LARGE_NO_PAIR") == nullptr;
+    bool tail_fused = getenv("RSQP_LARGE_NO_TAIL") == nullptr;      // (k_remove_tail; off: the separate kernels)
+    bool gemv_n1_pair(const double *M0, long long l0, int r0, int c0, const double *w0, double *o0, const double *M1, long long l1,
+                      int r1, int c1, const double *w1, double *o1, bool skip0 = false, int live = 0) {
+        if (!pair_enabled || r0 <= 0 || r1 <= 0 || c0 <= 0 || c1 <= 0 || r0 > n1_maxrows || r1 > n1_maxrows) return false;
+        if ((l0 & 1) || (l1 & 1) || ((reinterpret_cast<unsigned long long>(M0) | reinterpret_cast<unsigned long long>(M1)) & 15)) return false;
+        const bool t512 = n1_threads == 512 || (n1_threads == 0 && std::max(r0, r1) <= 3072);
+        const int nb0 = (r0 + 15) / 16, nb1 = (r1 + 15) / 16;
+        pbegin();
+        if (skip0) {
+            if (t512) hipLaunchKernelGGL((k_gemv_n1_pair<512, true>), dim3(nb0 + nb1), dim3(512), 0, st, M0, l0, r0, c0, w0, o0, nb0, M1, l1, r1, c1, w1, o1);
+            else hipLaunchKernelGGL((k_gemv_n1_pair<NT, true>), dim3(nb0 + nb1), dim3(NT), 0, st, M0, l0, r0, c0, w0, o0, nb0, M1, l1, r1, c1, w1, o1);
+            pend(0, 8.0 * (r0 + (double)r1) * live + 8.0 * (r0 + r1) + 8.0 * (c0 + c1));
+        } else {
+            if (t512) hipLaunchKernelGGL((k_gemv_n1_pair<512, false>), dim3(nb0 + nb1), dim3(512), 0, st, M0, l0, r0, c0, w0, o0, nb0, M1, l1, r1, c1, w1, o1);
+            else hipLaunchKernelGGL((k_gemv_n1_pair<NT, false>), dim3(nb0 + nb1), dim3(NT), 0, st, M0, l0, r0, c0, w0, o0, nb0, M1, l1, r1, c1, w1, o1);
+            pend(0, 8.0 * r0 * (double)c0 + 8.0 * r1 * (double)c1 + 8.0 * (r0 + r1) + 8.0 * (c0 + c1));
+        }
+        chk("gemv_n1_pair");
+        return true;
     }
     // out = M w for a vector w with `live` non-zeros (the kernel skips the other columns); falls back to gemv_n
     void gemv_n_live(const double *Mx, long long l, int nrows, int ncols, const double *wv, double *out, int live) {
@@ -1760,23 +1757,35 @@ struct RsqpLargeEngine::Impl {
         }
         pend(3, 16.0 * (double)nZo * nZo);
     }
-    void z_reflect_and_shrink(bool defer = false) {
+    // ycol != nullptr: the reflected last column of Z is also copied there (the new column of Y) -- returns true if that was done
+    // (the deferred form does it in the launch that keeps the reflector), false: the caller copies
+    bool z_reflect_and_shrink(bool defer = false, double *ycol = nullptr) {
         flush_pending();
         if (!house_done) hipLaunchKernelGGL(k_house, dim3(1), dim3(NT), 0, st, wz1, nZ, wz2, scal, 0);   // v -> wz2 (else: done by the products' kernel)
         house_done = false;
         const bool dz = defer && can_defer();
-        gemv_n(Z, ld, nV, nZ, wz2, 1.0, 0.0, nullptr, dz ? pz_t : w5);                   // t = Z v
+        double *s_ = dz ? pw_s : wz3, *col_ = dz ? pw_col : w6;
+        // t = Z v and s = Wz v: one launch at launch-bound sizes
+        const bool paired = wz_enabled && gemv_n1_pair(Z, ld, nV, nZ, wz2, dz ? pz_t : w5, Wz, ld, nZ, nZ, wz2, s_);
+        if (!paired) gemv_n(Z, ld, nV, nZ, wz2, 1.0, 0.0, nullptr, dz ? pz_t : w5);     // t = Z v
+        bool copied = false;
         if (dz) {
-            hipLaunchKernelGGL(k_keep_reflector, g1(nZ), dim3(NT), 0, st, wz2, nZ, pz_v, scal, 1, S_KEEP_BETA);
-            ger(Zc(nZ - 1), ld, nV, 1, pz_t, pz_v + (nZ - 1), S_KEEP_BETA, -1.0);       // the column that moves to Y: now
+            if (ycol) {
+                hipLaunchKernelGGL(k_keep_reflect_lastcol, g1(std::max(nZ, nV)), dim3(NT), 0, st, wz2, nZ, pz_v, scal, 1, S_KEEP_BETA, nV, pz_t,
+                                   Zc(nZ - 1), ycol);
+                copied = true;
+            } else {
+                hipLaunchKernelGGL(k_keep_reflector, g1(nZ), dim3(NT), 0, st, wz2, nZ, pz_v, scal, 1, S_KEEP_BETA);
+                ger(Zc(nZ - 1), ld, nV, 1, pz_t, pz_v + (nZ - 1), S_KEEP_BETA, -1.0);   // the column that moves to Y: now
+            }
             pendZ.on = true; pendZ.ncols = nZ - 1;
         } else ger(Z, ld, nV, nZ, w5, wz2, 1, -1.0);                                     // Z -= beta t v'
-        if (!wz_enabled) return;
-        double *s_ = dz ? pw_s : wz3, *col_ = dz ? pw_col : w6;
-        gemv_n(Wz, ld, nZ, nZ, wz2, 1.0, 0.0, nullptr, s_);                              // s = Wz v
+        if (!wz_enabled) return copied;
+        if (!paired) gemv_n(Wz, ld, nZ, nZ, wz2, 1.0, 0.0, nullptr, s_);                 // s = Wz v
         hipLaunchKernelGGL(k_wz_lastcol, g1(nZ), dim3(NT), 0, st, Wz, ld, nZ, s_, wz2, scal, 1, dz ? S_KEEP_THETA : 4, col_);   // theta = v's
         if (dz) { pendW.on = true; pendW.nZold = nZ; }
         else wz_shrink_now(nZ, wz3, wz2, w6, 1, 4);
+        return copied;
     }
     // the step direction's  out = Z'x + addv  and  out = alpha Wz w  with the deferred updates applied on the way
     void gemv_t_Z_pending(const double *xv, const double *addv, double *out) {
@@ -1820,12 +1829,12 @@ struct RsqpLargeEngine::Impl {
 
     // append the Y column `ycol` (already stored at Y[:, nAC]) for constraint r whose products
     // with the old Y are in a1 (wY) and with the new column in scal[eta_slot]
-    // The step direction's wY = Minv bA and xY = Y wY are CARRIED over an incoming constraint (k_carry_wY / k_carry_xY: two
-    // O(n) kernels instead of one pass over Minv and one over Y) and recomputed exactly after any other change, at the first
+    // The step direction's wY = Minv bA and xY = Y wY are CARRIED over an incoming constraint (k_carry_add: one
+    // O(n) kernel instead of one pass over Minv and one over Y) and recomputed exactly after any other change, at the first
     // step, and every CARRY_REFRESH carried steps (RSQP_LARGE_NO_CARRY=1: always exactly).
     static constexpr int S_KEEP_ETA = 43, S_KEEP_WLAST = 42, CARRY_REFRESH = 8;
     bool carry_enabled = getenv("RSQP_LARGE_NO_CARRY") == nullptr;
-    bool carry_null_enabled = getenv("RSQP_LARGE_NO_CARRY_NULL") == nullptr;   // (the null-space part as well, k_carry_wZ)
+    bool carry_null_enabled = getenv("RSQP_LARGE_NO_CARRY_NULL") == nullptr;   // (the null-space part as well)
     bool carry_valid = false;        // c_wY / c_xY are those of the last step direction, nothing but a homotopy step since
     bool carry_pending = false;      // ... and the change behind it was a plain added constraint (border kept in c_xi, S_KEEP_ETA)
     bool carry_ready = false;        // ... or a plain removed constraint: c_wY / c_xY already transformed (remove_constraint_tq)
@@ -1834,21 +1843,20 @@ struct RsqpLargeEngine::Impl {
     long long stat_carried = 0, stat_carried_null = 0;
     bool plain_add = false;          // the change is ONE added constraint (no exchange partner removed first)
     double last_tau = 0.0;
-    void minv_append(int eta_slot, bool eta_from_house, int r, int side, bool keep_for_carry = false) {
+    // (yidx >= 0: y[yidx] = yval set by the same launch -- the multiplier of the incoming constraint)
+    void minv_append(int eta_slot, bool eta_from_house, int r, int side, bool keep_for_carry = false, int yidx = -1, double yval = 0.0) {
         // new row nAC: -(wY' Minv)/eta ; new column nAC: 0 ; corner 1/eta ; working set: constraint r at position nAC
         gemv_t(Minv, ldm, nAC, nAC, a1, a2);  // a2[j] = sum_i wY[i] Minv[i][j]
-        if (keep_for_carry)
-            hipLaunchKernelGGL(k_keep_border, g1(std::max(nAC, 1)), dim3(NT), 0, st, nAC, a2, c_xi, scal, eta_slot, eta_from_house ? 1 : 0, S_KEEP_ETA);
-        hipLaunchKernelGGL(k_minv_border, g1(nAC + 1), dim3(NT), 0, st, Minv, ldm, nAC, a2, scal, eta_slot, eta_from_house ? 1 : 0,
-                           AC, posAC, Sc, r, side);
+        hipLaunchKernelGGL(k_minv_border_keep, g1(nAC + 1), dim3(NT), 0, st, Minv, ldm, nAC, a2, scal, eta_slot, eta_from_house ? 1 : 0,
+                           AC, posAC, Sc, r, side, keep_for_carry ? c_xi : (double *)nullptr, S_KEEP_ETA, y, yidx, yval);
     }
 
-    int add_constraint(int r, int side, bool skipZ, bool defer = false) {
+    // (yidx / yval: see minv_append)
+    int add_constraint(int r, int side, bool skipZ, bool defer = false, int yidx = -1, double yval = 0.0) {
         // a (free part) in w1; wZ in wz1; wY in a1 were computed by the caller (li_test_constraint)
         if (!skipZ) {
-            z_reflect_and_shrink(defer);
             // new Y column = last column of the reflected Z; eta = a'y_new = image sign * alpha
-            copy(Zc(nZ - 1), Yc(nAC), nV);
+            if (!z_reflect_and_shrink(defer, Yc(nAC))) copy(Zc(nZ - 1), Yc(nAC), nV);
         } else {
             // exchange / flip: the row is orthogonal to all null-space columns but the last
             flush_pending();
@@ -1858,7 +1866,7 @@ struct RsqpLargeEngine::Impl {
         }
         nZ--;
         const bool keep = defer && !skipZ && plain_add && carry_enabled && carry_valid && carried < CARRY_REFRESH;
-        minv_append(5, !skipZ, r, side, keep);
+        minv_append(5, !skipZ, r, side, keep, yidx, yval);
         carry_pending = keep;
         hAC[nAC] = r; hSc[r] = side;
         nAC++;
@@ -1931,8 +1939,7 @@ struct RsqpLargeEngine::Impl {
     // TQ part of removing the constraint at position k: Y loses a column, it lands in Z[:, nZ]
     void remove_constraint_tq(int k) {
         const int r = hAC[k];
-        copy(Minv + k * ldm, a1, nAC);                                   // u = Minv[:, k]
-        hipLaunchKernelGGL(k_house, dim3(1), dim3(NT), 0, st, a1, nAC, a2, scal, 0);  // v -> a2
+        hipLaunchKernelGGL(k_house, dim3(1), dim3(NT), 0, st, Minv + k * ldm, nAC, a2, scal, 0);  // u = Minv[:, k]; v -> a2
         // a plain removal whose step direction will be carried (below) does not need Y and Minv before that step direction's LAST
         // two products (Y'r, Minv'(Y'r)): their reflections wait and ride on those (k_ger_gemv_t) -- only the last column of each is
         // reflected now (it moves to Z / into the slot of the removed constraint)
@@ -1941,6 +1948,20 @@ struct RsqpLargeEngine::Impl {
                          (((reinterpret_cast<unsigned long long>(Y) | reinterpret_cast<unsigned long long>(Minv)) & 15) == 0);
         gemv_n(Y, ld, nV, nAC, a2, 1.0, 0.0, nullptr, dfr ? py_t : w5);  // t = Y v
         gemv_t(Minv, ldm, nAC, nAC, a2, a3);                             // s' = v' Minv
+        if (dfr && tail_fused) {
+            // (dfr implies will_carry) everything that follows in one launch
+            hipLaunchKernelGGL(k_remove_tail, g1(std::max(nV, nAC)), dim3(NT), 0, st, nAC, nV, k, 1.0 - last_tau, a2, a3, py_t, py_v, pm_s, scal, 1,
+                               S_KEEP_BETA2, S_KEEP_WLAST, Yc(nAC - 1), Zc(nZ), Minv + (long long)(nAC - 1) * ldm,
+                               k != nAC - 1 ? Minv + k * ldm : (double *)nullptr, c_wY, c_wY2, c_xY, AC, posAC, Sc, r, y, nV + r);
+            std::swap(c_wY, c_wY2);
+            pendY.on = true; pendY.n = nAC - 1;
+            pendM.on = true; pendM.n = nAC - 1;
+            carry_ready = true;
+            if (k != nAC - 1) hAC[k] = hAC[nAC - 1];
+            hSc[r] = 0;
+            nAC--;
+            return;
+        }
         if (dfr) {
             hipLaunchKernelGGL(k_keep_removal, g1(nAC), dim3(NT), 0, st, nAC, a2, a3, k, py_v, pm_s, scal, 1, S_KEEP_BETA2);
             ger(Yc(nAC - 1), ld, nV, 1, py_t, a2 + (nAC - 1), 1, -1.0);
@@ -2114,9 +2135,8 @@ struct RsqpLargeEngine::Impl {
         }
         if (kind == 3) {
             plain_add = li;
-            add_constraint(idx, side, !full, true);      // (the last operation of the change: the step direction follows)
-            plain_add = false;
-            hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, y, nV + idx, ynew);
+            add_constraint(idx, side, !full, true, nV + idx, ynew);      // (the last operation of the change: the step direction follows;
+            plain_add = false;                                           //  sets y[nV + idx] = ynew as well)
         } else {
             add_bound(idx, side, !full);
             hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, y, idx, ynew);
@@ -2128,29 +2148,39 @@ struct RsqpLargeEngine::Impl {
     void step_direction() {
         if (!dx_ready) hipLaunchKernelGGL(k_dx_fixed_zero_dy, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, lb, ub, lbN, ubN, dx, dy);
         dx_ready = false;           // (set by drift_correction, whose kernel then has done this already)
-        // A dx_FX, H dx_FX: dx is zero on the free variables here (mean over the dense 2048 x 4096 cold start: 196 of
-        // 2048 entries live), so the column-major products read the live columns only
-        if (live_skip && M.denseA && M.haveH && M.denseH && M.hreg == 0.0 && 4 * (nV - nFR) < nV) {
-            gemv_n_live(M.denseA, nC, nC, nV, dx, c1, nV - nFR);
-            gemv_n_live(M.denseH, nV, nV, nV, dx, w2, nV - nFR);           // H symmetric
-        } else AH_times(dx, c1, w2);
-        hipLaunchKernelGGL(k_sd_prep, g1(std::max(nAC, nV)), dim3(NT), 0, st, nAC, AC, Sc, lbA, ubA, lbAN, ubAN, c1, a1, nV, w2, gN, g,
-                           w1);                                            // bA -> a1, tmpg -> w1
-        // range space: wY = Minv bA ; xY = Y wY
+        // what of the last step direction is carried over the change (range space: wY = Minv bA, xY = Y wY; null space: wZ)
         bool carry_null = false;      // the null-space part is carried too (needs the deferred reflection's v / col / beta)
         const bool was_ready = carry_ready && carry_valid;
-        if (carry_ready && carry_valid) {
-            carried++; stat_carried++;                                     // (transformed by remove_constraint_tq already)
-        } else if (carry_pending && carry_valid && nAC > 0) {
-            const double om = 1.0 - last_tau;
-            hipLaunchKernelGGL(k_carry_wY, dim3(1), dim3(NT), 0, st, nAC - 1, om, a1, c_xi, c_wY, scal, S_KEEP_ETA, S_KEEP_WLAST);
-            hipLaunchKernelGGL(k_carry_xY, g1(nV), dim3(NT), 0, st, nV, om, Yc(nAC - 1), scal, S_KEEP_WLAST, c_xY);
-            carried++; stat_carried++;
+        const bool carry_add = !was_ready && carry_pending && carry_valid && nAC > 0;
+        if (carry_add)
             carry_null = carry_null_enabled && pendZ.on && pendZ.ncols == nZ && pendW.on && pendW.nZold - 1 == nZ && nZ > 0 && nV <= 16384 &&
                          (((reinterpret_cast<unsigned long long>(pz_t)) & 15) == 0);
+        const bool carry_null_grow = was_ready && carry_null_enabled && nZ > 0 && 1.0 - last_tau > 1e-6;
+        // A dx_FX, H dx_FX: dx is zero on the free variables here (mean over the dense 2048 x 4096 cold start: 196 of
+        // 2048 entries live), so the column-major products read the live columns only. A removed constraint with both parts carried
+        // needs neither product (no right-hand side is formed), an added one with both parts carried only A dx_FX
+        if (carry_null_grow) {
+        } else if (live_skip && M.denseA && M.haveH && M.denseH && M.hreg == 0.0 && 4 * (nV - nFR) < nV) {
+            if (!gemv_n1_pair(M.denseA, nC, nC, nV, dx, c1, M.denseH, nV, nV, nV, dx, w2, true, nV - nFR)) {
+                gemv_n_live(M.denseA, nC, nC, nV, dx, c1, nV - nFR);
+                gemv_n_live(M.denseH, nV, nV, nV, dx, w2, nV - nFR);       // H symmetric
+            }
+        } else if (carry_add && carry_null) A_times(dx, c1);
+        else AH_times(dx, c1, w2);
+        // bA -> a1, tmpg -> w1 (a carried added constraint forms both inside k_carry_add; a carried removed one whose null-space part
+        // is carried as well needs neither)
+        if (!carry_add && !carry_null_grow)
+            hipLaunchKernelGGL(k_sd_prep, g1(std::max(nAC, nV)), dim3(NT), 0, st, nAC, AC, Sc, lbA, ubA, lbAN, ubAN, c1, a1, nV, w2, gN, g, w1);
+        if (was_ready) {
+            carried++; stat_carried++;                                     // (transformed by remove_constraint_tq already)
+        } else if (carry_add) {
+            const double om = 1.0 - last_tau;
+            hipLaunchKernelGGL(k_carry_add, g1(std::max(nV, 1)), dim3(NT), 0, st, nAC - 1, om, AC, Sc, lbA, ubA, lbAN, ubAN, c1, c_xi, c_wY, scal,
+                               S_KEEP_ETA, S_KEEP_WLAST, nV, Yc(nAC - 1), c_xY, w2, gN, g, carry_null ? (double *)nullptr : w1,
+                               carry_null ? nZ : -1, pz_v, pw_col, c_wZ, S_KEEP_BETA);
+            carried++; stat_carried++;
             if (carry_null) {
                 stat_carried_null++;
-                hipLaunchKernelGGL(k_carry_wZ, dim3(1), dim3(NT), 0, st, nZ, om, pz_v, pw_col, c_wZ, scal, S_KEEP_BETA, S_KEEP_WLAST);
                 pendW.on = false;
                 wz_shrink_now(pendW.nZold, pw_s, pz_v, pw_col, S_KEEP_BETA, S_KEEP_THETA);        // (no product with Wz to ride on)
             }
@@ -2165,7 +2195,6 @@ struct RsqpLargeEngine::Impl {
         carry_valid = true;
         double *const w3 = c_xY;                                           // (xY lives in its own buffer: the next step may scale it)
         // null space: wZ = -Wz Z'(tmpg + H xY) ; dx_FR = xY + Z wZ
-        const bool carry_null_grow = was_ready && carry_null_enabled && nZ > 0 && 1.0 - last_tau > 1e-6;
         if (carry_null_grow) {
             // a removed constraint: wZ from the bordered system (the new null-space column is Z[:, nZ - 1], u / rho^2 are wz_grow's)
             stat_carried_null++;
@@ -2173,7 +2202,7 @@ struct RsqpLargeEngine::Impl {
                                S_KEEP_WLAST);
             gemv_n(Z, ld, nV, nZ, c_wZ, 1.0, 1.0, w3, w4, Sb, dx);
         } else if (carry_null) {
-            // wZ carried (k_carry_wZ above): the deferred reflection of Z rides on the product Z wZ instead of on Z'w
+            // wZ carried (k_carry_add above): the deferred reflection of Z rides on the product Z wZ instead of on Z'w
             pendZ.on = false;
             pbegin();
             hipLaunchKernelGGL((k_ger_gemv_n1<NT>), dim3((nV + 15) / 16), dim3(NT), 0, st, Z, ld, nV, nZ, pz_t, pz_v, scal, S_KEEP_BETA, -1.0,
@@ -2516,7 +2545,7 @@ hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
     DA(x, nV); DA(g, nV); DA(lb, nV); DA(ub, nV); DA(gN, nV); DA(lbN, nV); DA(ubN, nV); DA(dx, nV);
     DA(w1, nV); DA(w2, nV); DA(w3, nV); DA(w4, nV); DA(w5, nV); DA(w6, nV); DA(wz1, nV); DA(wz2, nV); DA(wz3, nV);
     DA(pz_t, nV); DA(pz_v, nV); DA(pw_s, nV); DA(pw_col, nV);
-    DA(c_wY, P.nAmax + 2); DA(c_xY, nV); DA(c_xi, P.nAmax + 2); DA(c_wZ, nV);
+    DA(c_wY, P.nAmax + 2); DA(c_wY2, P.nAmax + 2); DA(c_xY, nV); DA(c_xi, P.nAmax + 2); DA(c_wZ, nV);
     DA(py_t, nV); DA(py_v, P.nAmax + 2); DA(pm_s, P.nAmax + 2);
     DA(Ax, nC); DA(lbA, nC); DA(ubA, nC); DA(lbAN, nC); DA(ubAN, nC); DA(dAx, nC); DA(c1, nC); DA(c2, nC); DA(c3, nC);
     DA(a1, P.nAmax + 2); DA(a2, P.nAmax + 2); DA(a3, P.nAmax + 2); DA(a4, P.nAmax + 2);
