@@ -48,6 +48,18 @@ __device__ inline double block_sum(double v, double *sh) {
     return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// sum over i = threadIdx.x, threadIdx.x + NT, ... < n of f(i) for ONE workgroup, four independent accumulators: a single
+// accumulator makes every iteration wait for the previous one's load (40 iterations x ~0.5 us at n = 10 000: the 17 - 24 us of
+// the one-workgroup kernels in profiles/r03_h_kernel_stats_large_sparse.csv); every kernel that forms the same sum uses this
+// routine, so the bits agree between them (house_tail)
+template <class F> __device__ __forceinline__ double lane_sum4(int n, F f) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = threadIdx.x;
+    for (; i + 3 * NT < n; i += 4 * NT) { s0 += f(i); s1 += f(i + NT); s2 += f(i + 2 * NT); s3 += f(i + 3 * NT); }
+    for (; i < n; i += NT) s0 += f(i);
+    return (s0 + s1) + (s2 + s3);
+}
+
 // out[c] = sum_r M[c*ld + r] * x[r]. A workgroup owns GT_COLS consecutive columns: every lane
 // keeps GT_COLS independent 16-byte loads in flight per step and x is read once for all of them.
 // (ld and the column bases are even for every matrix of this engine, so the double2 loads are
@@ -487,8 +499,7 @@ __global__ void __launch_bounds__(NT) k_remove_tail(int n, int nV, int k, double
                                                     int r, double *y, int yidx) {
     __shared__ double sh[4];
     const int kk = n - 1;
-    double d = 0.0;
-    for (int i = threadIdx.x; i <= kk; i += NT) d += v[i] * wY[i];
+    double d = lane_sum4(kk + 1, [&](int i) { return v[i] * wY[i]; });
     d = block_sum(d, sh);
     const double beta = scal[from], c = beta * d, omega = wY[kk] - c * v[kk], coef = -1.0 * beta;
     if (blockIdx.x == 0) {
@@ -553,8 +564,7 @@ __global__ void k_keep_reflect_lastcol(const double *__restrict__ v, int n, doub
 __global__ void __launch_bounds__(NT) k_dot(const double *__restrict__ a, const double *__restrict__ b, int n,
                                             double *__restrict__ scal, int slot) {
     __shared__ double sh[4];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += NT) s += a[i] * b[i];
+    double s = lane_sum4(n, [&](int i) { return a[i] * b[i]; });
     s = block_sum(s, sh);
     if (threadIdx.x == 0) scal[slot] = s;
 }
@@ -575,8 +585,7 @@ __global__ void k_fill(double *__restrict__ dst, int n, double v) {
 __global__ void __launch_bounds__(NT) k_house(const double *__restrict__ w, int n, double *__restrict__ v,
                                               double *__restrict__ scal, int s0) {
     __shared__ double sh[4];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += NT) s += w[i] * w[i];
+    double s = lane_sum4(n, [&](int i) { return w[i] * w[i]; });
     s = block_sum(s, sh);
     const double alpha = sqrt(s), wl = w[n - 1], sg = wl >= 0.0 ? 1.0 : -1.0;
     for (int i = threadIdx.x; i < n; i += NT) v[i] = w[i] + (i == n - 1 ? sg * alpha : 0.0);
@@ -616,8 +625,7 @@ __global__ void __launch_bounds__(NT) k_wz_lastcol(const double *__restrict__ Wz
                              const double *__restrict__ v, double *__restrict__ scal, int sb, int st,
                              double *__restrict__ col) {
     __shared__ double sh[4];
-    double th = 0.0;
-    for (int i = threadIdx.x; i < nZ; i += NT) th += v[i] * s[i];
+    double th = lane_sum4(nZ, [&](int i) { return v[i] * s[i]; });
     th = block_sum(th, sh);
     if (blockIdx.x == 0 && threadIdx.x == 0) scal[st] = th;
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1014,50 +1022,39 @@ __global__ void k_sd_prep(int nAC, const int *__restrict__ AC, const int *__rest
     }
     if (i < nV) tmpg[i] = Hdxfx[i] + (gN[i] - g[i]);
 }
-// The step direction behind an ADDED constraint, carried instead of recomputed, in ONE launch over max(nV, 1) entries.
-// Range space: the right-hand sides of the constraints that were active before have (1 - tau) of their way left, the new row of
-// Minv is -xi/eta | 1/eta (minv_append):
+// The step direction behind an ADDED constraint, carried instead of recomputed, in ONE launch over max(nV, 1) entries
+// (+ one workgroup). Range space: the right-hand sides of the constraints that were active before have (1 - tau) of their way left,
+// the new row of Minv is -xi/eta | 1/eta (minv_append):
 //   wY[0..k) *= (1 - tau);  wY[k] = (bA[k] - xi'bA[0..k)) / eta  (also into scal[sl]);  xY = (1 - tau) xY + wY[k] y_k
-// with bA[j] = delta b(AC[j]) - (A dx_FX)[AC[j]] formed on the fly (k_sd_prep's expression; not stored: nothing else reads it on this
-// path) and y_k the column the constraint added to Y. Every workgroup forms the dot product xi'bA itself (same loop, same tree:
-// the same bits in all of them) and then its slice of xY and of tmpg = H dx_FX + (gN - g) (tmpg == nullptr: not needed); workgroup 0
-// writes wY.
-// Null space (l >= 0, by the LAST workgroup): with P = I - beta v v' the reflection of Z, wZ' = P wZ, col = the last column of
-// P Wz P (k_wz_lastcol), kappa = col[0..l) / col[l]:
+// with bA from k_sd_prep and y_k the column the constraint added to Y. Every workgroup forms the dot product xi'bA itself (same
+// loop, same tree: the same bits in all of them) and then its slice of xY; the LAST workgroup has no slice (the grid is one
+// workgroup larger than the slices need): it writes wY and carries the null-space part.
+// (Forming bA inside this kernel as well -- five gathers through AC per entry, by every workgroup -- measured 13 us at nV = 2048
+//  and 37 us at nV = 10 000 against 4.6 + ~6 us for the two kernels: profiles/r04_b_kernel_stats_large_*.csv.)
+// Null space (l >= 0): with P = I - beta v v' the reflection of Z, wZ' = P wZ, col = the last column of P Wz P (k_wz_lastcol),
+// kappa = col[0..l) / col[l]:
 //   wZ[0..l) <- (1 - tau) (wZ'[0..l) - kappa wZ'[l]) + wY_k kappa
 // (block elimination of the last null-space column from Z'HZ wZ = -Z'(g~ + H xY), whose right-hand side gained wY_k Z'H y_k).
-__global__ void __launch_bounds__(NT) k_carry_add(int k, double om, const int *__restrict__ AC, const int *__restrict__ Sc,
-                                                  const double *__restrict__ lbA, const double *__restrict__ ubA,
-                                                  const double *__restrict__ lbAN, const double *__restrict__ ubAN,
-                                                  const double *__restrict__ Adx, const double *__restrict__ xi, double *__restrict__ wY,
-                                                  double *__restrict__ scal, int se, int sl, int nV, const double *__restrict__ yk,
-                                                  double *__restrict__ xY, const double *__restrict__ Hdxfx, const double *__restrict__ gN,
-                                                  const double *__restrict__ g, double *__restrict__ tmpg, int l,
+__global__ void __launch_bounds__(NT) k_carry_add(int k, double om, const double *__restrict__ bA, const double *__restrict__ xi,
+                                                  double *__restrict__ wY, double *__restrict__ scal, int se, int sl, int nV,
+                                                  const double *__restrict__ yk, double *__restrict__ xY, int l,
                                                   const double *__restrict__ v, const double *__restrict__ col, double *__restrict__ wZ,
                                                   int sb) {
     __shared__ double sh[4];
-    double s = 0.0;
-    for (int j = threadIdx.x; j < k; j += NT) {
-        const int r = AC[j];
-        const double b = (Sc[r] == -1 ? delta_of(lbAN[r], lbA[r]) : delta_of(ubAN[r], ubA[r])) - Adx[r];
-        s += xi[j] * b;
-    }
+    double s = lane_sum4(k, [&](int j) { return xi[j] * bA[j]; });
+    const bool extra = blockIdx.x == gridDim.x - 1;
+    double d = (extra && l >= 0) ? lane_sum4(l + 1, [&](int j) { return v[j] * wZ[j]; }) : 0.0;   // (its loads overlap the first sum's)
     s = block_sum(s, sh);
-    const int rk = AC[k];
-    const double bk = (Sc[rk] == -1 ? delta_of(lbAN[rk], lbA[rk]) : delta_of(ubAN[rk], ubA[rk])) - Adx[rk];
-    const double w = (bk - s) / scal[se];
-    if (blockIdx.x == 0) {
-        for (int j = threadIdx.x; j < k; j += NT) wY[j] *= om;
-        if (threadIdx.x == 0) { wY[k] = w; scal[sl] = w; }
+    const double w = (bA[k] - s) / scal[se];
+    if (!extra) {
+        const int i = blockIdx.x * NT + threadIdx.x;
+        if (i < nV) xY[i] = om * xY[i] + w * yk[i];
+        return;
     }
-    const int i = blockIdx.x * NT + threadIdx.x;
-    if (i < nV) {
-        xY[i] = om * xY[i] + w * yk[i];
-        if (tmpg) tmpg[i] = Hdxfx[i] + (gN[i] - g[i]);
-    }
-    if (l >= 0 && blockIdx.x == gridDim.x - 1) {
-        double d = 0.0;
-        for (int j = threadIdx.x; j <= l; j += NT) d += v[j] * wZ[j];
+    // the extra workgroup (no slice of its own): wY, then wZ
+    for (int j = threadIdx.x; j < k; j += NT) wY[j] *= om;
+    if (threadIdx.x == 0) { wY[k] = w; scal[sl] = w; }
+    if (l >= 0) {
         d = block_sum(d, sh);
         const double c = scal[sb] * d, wl = wZ[l] - c * v[l], rc = 1.0 / col[l];
         __syncthreads();
@@ -1073,8 +1070,7 @@ __global__ void __launch_bounds__(NT) k_carry_add(int k, double om, const int *_
 __global__ void __launch_bounds__(NT) k_carry_remove_wY(int k, double om, const double *__restrict__ v, double *__restrict__ wY,
                                                         double *__restrict__ scal, int sb, int sl) {
     __shared__ double sh[4];
-    double d = 0.0;
-    for (int i = threadIdx.x; i <= k; i += NT) d += v[i] * wY[i];
+    double d = lane_sum4(k + 1, [&](int i) { return v[i] * wY[i]; });
     d = block_sum(d, sh);
     const double c = scal[sb] * d;
     if (threadIdx.x == 0) scal[sl] = wY[k] - c * v[k];
@@ -1095,8 +1091,7 @@ __global__ void __launch_bounds__(NT) k_carry_wZ_grow(int n, int nV, double om, 
                                                       double *__restrict__ wZ, const double *__restrict__ scal, int srho, int somega) {
     __shared__ double sh[4];
     const double iom = 1.0 / om;
-    double d = 0.0;
-    for (int i = threadIdx.x; i < nV; i += NT) d += z[i] * (Hdx[i] + (gN[i] - g[i]) * iom);
+    double d = lane_sum4(nV, [&](int i) { return z[i] * (Hdx[i] + (gN[i] - g[i]) * iom); });
     d = block_sum(d, sh);
     const double c = d / scal[srho];
     for (int i = threadIdx.x; i < n; i += NT) wZ[i] = om * (wZ[i] + c * u[i]);
@@ -1160,8 +1155,7 @@ __global__ void __launch_bounds__(NT) k_bound_products(const double *__restrict_
                                                        double *__restrict__ scal, int s1, int s2, double *__restrict__ ctl, double seqv,
                                                        double *__restrict__ hv) {
     __shared__ double sh[4];
-    double q = 0.0;
-    for (int c = threadIdx.x; c < nZ; c += NT) { const double t = Z[c * ld + v]; wz1[c] = t; q += t * t; }
+    double q = lane_sum4(nZ, [&](int c) { const double t = Z[c * ld + v]; wz1[c] = t; return t * t; });
     for (int c = threadIdx.x; c < nAC; c += NT) a1[c] = Y[c * ld + v];
     q = block_sum(q, sh);
     if (threadIdx.x == 0) { scal[s1] = 1.0; scal[s2] = q; ctl[2] = 1.0; ctl[3] = q; publish(ctl, seqv); }
@@ -1209,6 +1203,13 @@ __global__ void k_drift_all(int nV, int nC, const int *__restrict__ Sb, const in
     if (i < nC) { if (Sc[i] == -1) lbA[i] = Ax[i]; else if (Sc[i] == 1) ubA[i] = Ax[i]; }
     if (i < nV + nC) dy[i] = 0.0;
 }
+// a[v] = A[row][v] on the free variables (all != 0: on every variable), zero elsewhere -- from the dense row-major copy, where
+// row `row` is contiguous: one entry per thread, any number of workgroups
+__global__ void k_row_of_A_dense(const double *__restrict__ AT, int nV, int row, const int *__restrict__ Sb, int all,
+                                 double *__restrict__ a) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nV) a[v] = (all || Sb[v] == 0) ? AT[(long long)row * nV + v] : 0.0;
+}
 // zero a (length nV) and scatter row `row` of A into it: one workgroup
 __global__ void __launch_bounds__(NT) k_row_of_A_fused(const int *__restrict__ rp, const int *__restrict__ ci,
                                                        const double *__restrict__ rv, int row, const int *__restrict__ Sb,
@@ -1225,9 +1226,8 @@ __global__ void __launch_bounds__(NT) k_norms_publish(const double *__restrict__
                                                       int n2, double *__restrict__ scal, int s1, int s2,
                                                       double *__restrict__ ctl, double seqv, double *__restrict__ hv) {
     __shared__ double sh[4];
-    double p = 0.0, q = 0.0;
-    if (a) for (int i = threadIdx.x; i < n1; i += NT) p += a[i] * a[i];
-    for (int i = threadIdx.x; i < n2; i += NT) q += b[i] * b[i];
+    double p = a ? lane_sum4(n1, [&](int i) { return a[i] * a[i]; }) : 0.0;
+    double q = lane_sum4(n2, [&](int i) { return b[i] * b[i]; });
     p = a ? block_sum(p, sh) : 1.0;
     q = block_sum(q, sh);
     if (threadIdx.x == 0) { scal[s1] = p; scal[s2] = q; ctl[2] = p; ctl[3] = q; publish(ctl, seqv); }
@@ -1350,8 +1350,7 @@ __global__ void k_axpy_s(int n, const double *scal, int si, const double *x, dou
 // a1 = c (= Minv a_v) on entry; on exit a1 = vY = -c; nu = sqrt(1+|c|^2); vlast = 1 + nu; beta~ = 1/(nu(nu+1))
 __global__ void k_house_free(double *a1, int nAC, double *scal) {
     __shared__ double sh[4];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < nAC; i += NT) s += a1[i] * a1[i];
+    double s = lane_sum4(nAC, [&](int i) { return a1[i] * a1[i]; });
     s = block_sum(s, sh);
     for (int i = threadIdx.x; i < nAC; i += NT) a1[i] = -a1[i];
     if (threadIdx.x == 0) {
@@ -1370,9 +1369,8 @@ __global__ void k_sm_coef(double *scal) { scal[16] = scal[8] / (1.0 - scal[8] * 
 __global__ void __launch_bounds__(NT) k_rho2(double *scal, double *ctl, const double *__restrict__ z, const double *__restrict__ Hz,
                                              int nV, const double *__restrict__ kv, const double *__restrict__ uv, int nZ, double seqv) {
     __shared__ double sh[4];
-    double p = 0.0, q = 0.0;
-    for (int i = threadIdx.x; i < nV; i += NT) p += z[i] * Hz[i];
-    for (int i = threadIdx.x; i < nZ; i += NT) q += kv[i] * uv[i];
+    double p = lane_sum4(nV, [&](int i) { return z[i] * Hz[i]; });
+    double q = lane_sum4(nZ, [&](int i) { return kv[i] * uv[i]; });
     p = block_sum(p, sh);
     q = block_sum(q, sh);
     if (threadIdx.x != 0) return;
@@ -1669,6 +1667,9 @@ struct RsqpLargeEngine::Impl {
     }
     void AT_times(const double *in, double *out) {  // out[nV] = A' in
         if (nC <= 0) fill(out, nV, 0.0);
+        // (every vector this is called with lives on the ACTIVE constraints, but reading only those rows through the row-major copy
+        //  with k_gemv_n1<.., SKIP0> measured 17.5 us against 8.5 us for the full transposed product at 2048 x 4096: the skipped
+        //  loads leave too few in flight; the matrices of that size sit in the 256 MB memory-side cache anyway)
         else if (M.denseA) gemv_t(M.denseA, nC, nC, nV, in, out);
         else (void)rsqp_launch_spmv(M.blk_c, M.nblk_c, M.Ajc, M.Air, M.Aval, in, out, 1, 0, 0, 0, 0, st);
     }
@@ -1703,7 +1704,8 @@ struct RsqpLargeEngine::Impl {
         return RET_OK;
     }
     void row_of_A(int r, double *a, bool all) {
-        hipLaunchKernelGGL(k_row_of_A_fused, dim3(1), dim3(NT), 0, st, M.Arp, M.Aci, M.Arv, r, Sb, all ? 1 : 0, nV, a);
+        if (M.denseAT) hipLaunchKernelGGL(k_row_of_A_dense, g1(nV), dim3(NT), 0, st, M.denseAT, nV, r, Sb, all ? 1 : 0, a);
+        else hipLaunchKernelGGL(k_row_of_A_fused, dim3(1), dim3(NT), 0, st, M.Arp, M.Aci, M.Arv, r, Sb, all ? 1 : 0, nV, a);
     }
     double *Zc(int c) { return Z + c * ld; }
     double *Yc(int c) { return Y + c * ld; }
@@ -2165,19 +2167,17 @@ struct RsqpLargeEngine::Impl {
                 gemv_n_live(M.denseA, nC, nC, nV, dx, c1, nV - nFR);
                 gemv_n_live(M.denseH, nV, nV, nV, dx, w2, nV - nFR);       // H symmetric
             }
-        } else if (carry_add && carry_null) A_times(dx, c1);
+        } else if (carry_add && carry_null) A_times(dx, c1);    // (tmpg is not read on this path: k_sd_prep forms it from a stale w2)
         else AH_times(dx, c1, w2);
-        // bA -> a1, tmpg -> w1 (a carried added constraint forms both inside k_carry_add; a carried removed one whose null-space part
-        // is carried as well needs neither)
-        if (!carry_add && !carry_null_grow)
+        // bA -> a1, tmpg -> w1 (a carried removed constraint whose null-space part is carried as well needs neither)
+        if (!carry_null_grow)
             hipLaunchKernelGGL(k_sd_prep, g1(std::max(nAC, nV)), dim3(NT), 0, st, nAC, AC, Sc, lbA, ubA, lbAN, ubAN, c1, a1, nV, w2, gN, g, w1);
         if (was_ready) {
             carried++; stat_carried++;                                     // (transformed by remove_constraint_tq already)
         } else if (carry_add) {
             const double om = 1.0 - last_tau;
-            hipLaunchKernelGGL(k_carry_add, g1(std::max(nV, 1)), dim3(NT), 0, st, nAC - 1, om, AC, Sc, lbA, ubA, lbAN, ubAN, c1, c_xi, c_wY, scal,
-                               S_KEEP_ETA, S_KEEP_WLAST, nV, Yc(nAC - 1), c_xY, w2, gN, g, carry_null ? (double *)nullptr : w1,
-                               carry_null ? nZ : -1, pz_v, pw_col, c_wZ, S_KEEP_BETA);
+            hipLaunchKernelGGL(k_carry_add, dim3(g1(std::max(nV, 1)).x + 1), dim3(NT), 0, st, nAC - 1, om, a1, c_xi, c_wY, scal, S_KEEP_ETA,
+                               S_KEEP_WLAST, nV, Yc(nAC - 1), c_xY, carry_null ? nZ : -1, pz_v, pw_col, c_wZ, S_KEEP_BETA);
             carried++; stat_carried++;
             if (carry_null) {
                 stat_carried_null++;
