@@ -409,7 +409,7 @@ def hs_batch_config(capi, problems, parallel, reps=50, cpu_seconds=4.0):
     for tag, idx in (("512_qps", order), ("64_qps_shard_of_8_gpus", shard0)):
         probs = [all_probs[k] for k in idx]
         b = capi.Batch(probs)
-        b.set_keep_state(False)      # cold-start-only batch: the explicit-KKT-inverse kernel + the null-space kernel on what it bails on
+        b.set_keep_state(False)      # cold-start-only batch: the KKT-tableau kernel + the null-space kernel on what it bails on
         b.solve(capi.MODE_COLD, 1000)
         ms = []
         for _ in range(reps):

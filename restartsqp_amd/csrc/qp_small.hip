@@ -1146,7 +1146,7 @@ small_qp_kernel(QPPools P, int nq, int stride, int mode, int maxWSR) {
     } else {
         E.infeasible = E.unbounded = 0;
         if constexpr (ENG::K_IMAGE) {
-            // the state is one the explicit-KKT-inverse kernel wrote (and then bailed out of this hot start): its factors
+            // the state is one the KKT-tableau kernel wrote (and then bailed out of this hot start): its factors
             // are not this engine's -- rebuild them for the stored working set, keep the homotopy data
             if (E.iscal[4] != 0) {     // (1: round 3, M = K^-1; 2: the tableau of qp_small_g.h -- either way not this engine's factors)
                 rcode = E.rebuild_factors();

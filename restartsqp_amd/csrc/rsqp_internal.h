@@ -18,7 +18,7 @@
 enum { QPS_NOTINITIALISED = 0, QPS_PREPARINGAUXILIARYQP = 1, QPS_AUXILIARYQPSOLVED = 2,
        QPS_PERFORMINGHOMOTOPY = 3, QPS_HOMOTOPYQPSOLVED = 4, QPS_SOLVED = 5 };
 enum { RET_OK = 0, RET_MAX_NWSR = 1, RET_INFEASIBLE = 2, RET_UNBOUNDED = 3, RET_SETUP_FAILED = 4,
-       RET_BAIL = 9 };   // internal: the explicit-KKT-inverse kernel hands the problem to the null-space kernel (never reported)
+       RET_BAIL = 9 };   // internal: the KKT-tableau kernel hands the problem to the null-space kernel (never reported)
 
 // one problem of a batch: sizes and offsets into the pooled device arrays
 struct QPDesc {
@@ -47,8 +47,8 @@ struct QPPools {
     int reinit_from_y0;   // warm re-initialisation (mode 3) without guessed constraints: 1 = sides from sign(y0), 0 = from A x0
     int *done_flag;   // single-QP solves: host-mapped word that receives done_val once the results are out (the host spins
     int done_val;     //   on it instead of sleeping in hipStreamSynchronize); nullptr for batches
-    int k_debug_bail; // test hook (RSQP_K_DEBUG_BAIL=n): the explicit-KKT-inverse kernel bails out of a HOT start before its n-th change; -1 off
-    int only_bailed;  // 1: the null-space kernel runs only the members the explicit-KKT-inverse kernel left with ret == RET_BAIL
+    int k_debug_bail; // test hook (RSQP_K_DEBUG_BAIL=n): the KKT-tableau kernel bails out of a HOT start before its n-th change; -1 off
+    int only_bailed;  // 1: the null-space kernel runs only the members the KKT-tableau kernel left with ret == RET_BAIL
     double *cert_out; int *cert_Wb, *cert_Wc;   // single-QP handles on the tableau kernel of qp_tiny.hip: the KKT certificate
                       //    (6 doubles: primal, dual, compl, stat, KKT_error, invalid) and the mapped working set are formed at
                       //    the END of the solve kernel -- QPhandler::solveQP always asks for them (src/QPhandler.cpp:470-499); or nullptr
@@ -74,7 +74,7 @@ __host__ __device__ inline long long rsqp_image_bytes(int nV, int nC) {
 }
 
 // persistent state of one problem in HBM: the image of the null-space engines, followed by the extension of the
-// explicit-KKT-inverse kernel (qp_small_k.h): M = K^-1 with one slot per variable and constraint, (nV + nC)^2 doubles
+// KKT-tableau kernel (qp_small_g.h): G = -SWEEP_S(K) with one slot per variable and constraint, (nV + nC)^2 doubles
 __host__ __device__ inline long long rsqp_state_bytes(int nV, int nC) {
     long long b = rsqp_image_bytes(nV, nC) + 8LL * (long long)(nV + nC) * (nV + nC);
     // hs071-scale problems (qp_tiny.hip): the register-resident tableau engine keeps a fixed-slot state of (8 + MC)^2 + 96

@@ -561,7 +561,7 @@ def test_degenerate_sweep_mismatch_rate_is_bounded(capi, oracle, keep_state):
     last bits of differently ordered sums, and a few answers end in another (equally optimal) working set than the
     oracle's. This sweep (the former tools/random_parity_sweep.py --degenerate) pins the observed rate: at most 1 % of
     1 500 seeded degenerate inputs may differ, and every one of them must still be a certified KKT point whenever the
-    oracle's answer is. keep_state False = the explicit-KKT-inverse kernel + null-space fallback, True = null-space only."""
+    oracle's answer is. keep_state False = the KKT-tableau kernel + null-space fallback, True = null-space only."""
     rng = np.random.default_rng(20260105)
     probs = [problems.degenerate_qp(rng, k % 5) for k in range(1500)]
     b = capi.Batch(probs)

@@ -1,4 +1,5 @@
-"""The explicit-KKT-inverse formulation (restartsqp_amd/csrc/qp_small_k.h; CPU prototype tools/proto_k/proto_k.cpp).
+"""The register-resident KKT-tableau formulation (restartsqp_amd/csrc/qp_small_g.h; CPU prototype tools/proto_k/proto_g.cpp;
+round 3's explicit KKT inverse, tools/proto_k/proto_k.cpp, is kept as a second prototype).
 
 CPU part: the prototype against the oracle -- every QP either identical (status, working sets, nWSR, x / y to 1e-9) or a
 clean bail-out. GPU part: cold-start-only batches (keep_state = 0) of mid-size problems run the kernel; members it bails
@@ -26,7 +27,7 @@ def test_prototype_matches_oracle_or_bails(oracle):
         r = K.compare(q)
         assert not r.startswith("DIFF"), (q.name, q.nV, q.nC, r)
         tally[r] = tally.get(r, 0) + 1
-    assert tally.get("same", 0) >= 150, tally                 # the convex members are carried, the hs071-like ones bail
+    assert tally.get("same", 0) >= 150, tally                 # (the tableau carries the hs071-like members too; bails: rounding-band pivots)
     # degenerate inputs (exact ties): bails are fine, mismatches must stay as rare as for the GPU engines
     rng = np.random.default_rng(32)
     res = [K.compare(problems.degenerate_qp(rng, int(rng.integers(0, 5)))) for _ in range(400)]
@@ -43,7 +44,7 @@ def _same(q, r, qp, n):
 @pytest.mark.gpu
 def test_cold_only_batches_match_oracle(capi, oracle):
     """BASELINE configs[4] (512 mixed hs0xx QPs, largest first) and 300 random convex QPs of 9..69 variables as cold-start-only
-    batches: the explicit-KKT-inverse kernel + the null-space kernel on what it bails on; every member vs the oracle, and
+    batches: the KKT-tableau kernel + the null-space kernel on what it bails on; every member vs the oracle, and
     the batch bit-identical when solved again."""
     allp = problems.hs_batch(512)
     rng = np.random.default_rng(7)
@@ -70,7 +71,7 @@ def test_cold_only_batches_match_oracle(capi, oracle):
 @pytest.mark.gpu
 def test_bailed_members_take_the_null_space_path(capi, oracle):
     """Non-convex and degenerate members (the reference's dumps, singular Hessians, LP-like data) in a cold-start-only batch
-    next to convex ones: what the KKT-inverse kernel cannot carry must come back exactly as the default path solves it."""
+    next to convex ones: what the KKT-tableau kernel cannot carry must come back exactly as the default path solves it."""
     from conftest import dump_paths
     from restartsqp_amd.qpdump import read_qore_dump
     rng = np.random.default_rng(11)
@@ -97,7 +98,7 @@ def test_bailed_members_take_the_null_space_path(capi, oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("bail_after", [None, "0", "1", "3"])
 def test_hot_starts_and_hand_over(bail_after):
-    """Default batches (hot-start state kept): members of 20..60 variables run the explicit-KKT-inverse kernel cold AND hot;
+    """Default batches (hot-start state kept): members of 20..60 variables run the KKT-tableau kernel cold AND hot;
     non-convex members sit in the same batch with null-space states. With the test hook RSQP_K_DEBUG_BAIL=n every hot start
     of the kernel bails out before its n-th change and the null-space kernel continues from the stored state (factors rebuilt
     for the stored working set, homotopy data kept): same nWSR, working sets and point as the oracle's hot start either way

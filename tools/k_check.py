@@ -1,4 +1,4 @@
-"""GPU check of the explicit-KKT-inverse kernel (qp_small_k.h) on the 512-QP hs0xx batch and on random convex QPs:
+"""GPU check of the KKT-tableau kernel (qp_small_g.h) on the 512-QP hs0xx batch and on random convex QPs:
 every member against the oracle (status, working sets, nWSR, x / y to 1e-9), and the batch time with and without it.
 Usage (GPU box): python tools/k_check.py [nrandom]"""
 import os

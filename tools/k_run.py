@@ -1,4 +1,4 @@
-"""Runs the explicit-KKT-inverse kernel on the 69 x 28 members of the hs0xx batch (profiling target of tools/pmc_k.sh)."""
+"""Runs the KKT-tableau kernel on the 69 x 28 members of the hs0xx batch (profiling target of tools/pmc_k.sh)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

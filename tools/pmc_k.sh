@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes (instruction mix, waits, LDS, instruction cache) for the explicit-KKT-inverse kernel (qp_small_g.h) on the 14
+# PMC passes (instruction mix, waits, LDS, instruction cache) for the KKT-tableau kernel (qp_small_g.h) on the 14
 # members of 69 x 28 of the hs0xx batch. Output: $1 (default gpurun_out/pmc_k.json)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python3 __graft_entry__.py > /dev/null || exit 1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 additions to tools/round_profiles.sh (run on the GPU box):  bash tools/round3_profiles.sh r03_a
-#   <tag>_stamps_kkt_inverse_69x28.txt      cycles per phase of the explicit-KKT-inverse kernel (block 0)
+#   <tag>_stamps_kkt_inverse_69x28.txt      cycles per phase of the KKT-tableau kernel (block 0)
 #   <tag>_pmc_kkt_inverse.json              instruction mix / waits / LDS / instruction cache of that kernel
 #   <tag>_pmc_mfma_blocked_setup.json       SQ_VALU_MFMA_BUSY_CYCLES & co. of the blocked QR + Q + R^-1 (a 4096 x 3072 instance:
 #                                           a counter pass serialises every one of the launches; the 10 000 x 7 670 one takes minutes)
