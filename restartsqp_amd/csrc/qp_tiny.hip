@@ -157,8 +157,9 @@ struct EngineT {
     }
 
     // ------------------------------------------------------------------ staging
-    __device__ __forceinline__ void stage(const QPPools &P, const QPDesc &d) {
-        const int *gAjc = P.Ajc + d.offAjc, *gAir = P.Air + d.offAnz, *gHjc = P.Hjc + d.offHjc, *gHir = P.Hir + d.offHnz;
+    // (patA / patH: where the row-index arrays of this problem's PATTERN start -- its own entries, or member 0's in a batch of one pattern)
+    __device__ __forceinline__ void stage(const QPPools &P, const QPDesc &d, int patA, int patH) {
+        const int *gAjc = P.Ajc + d.offAjc, *gAir = P.Air + patA, *gHjc = P.Hjc + d.offHjc, *gHir = P.Hir + patH;
         const double *gAval = P.Aval + d.offAnz, *gHval = P.Hval + d.offHnz;
         // every load that does not depend on another one first: the vectors and the column pointers travel together
         const bool v = vV(), c = vC();
@@ -613,7 +614,15 @@ __global__ void __launch_bounds__(TB, W) tiny_qp_kernel(QPPools P, int nq, int m
     const int grp = (int)threadIdx.x >> 3;
     const int q = (int)blockIdx.x * TG + grp;
     if (q >= nq) return;        // (no workgroup barrier anywhere: idle groups may leave)
-    const QPDesc d = P.desc[q];
+    // a batch of ONE shape and ONE sparsity pattern (QPPools::uni_pat): offsets by arithmetic, pattern arrays of member 0
+    QPDesc d;
+    int patA, patH;
+    if (P.uni_pat) {
+        d.nV = P.uniV; d.nC = P.uniC; d.offV = q * P.uniV; d.offC = q * P.uniC; d.offAjc = 0; d.offHjc = 0; d.offArp = 0;
+        d.offAnz = q * P.uni_annz; d.offHnz = q * P.uni_hnnz; d.haveH = P.uni_haveH; d.annz = P.uni_annz; d.hnnz = P.uni_hnnz;
+        d.hreg = 0.0; d.offState = (long long)q * P.uni_state;
+        patA = patH = 0;
+    } else { d = P.desc[q]; patA = d.offAnz; patH = d.offHnz; }
     ENG E;
     E.l = (int)threadIdx.x & 7; E.nV = d.nV; E.nC = d.nC; E.hreg = d.hreg;
     E.Kd = (ldouble *)kd_all + grp * N * N;
@@ -623,7 +632,7 @@ __global__ void __launch_bounds__(TB, W) tiny_qp_kernel(QPPools P, int nq, int m
     E.tlast = clock64();
     long long &tlast = E.tlast;
 #endif
-    E.stage(P, d);
+    E.stage(P, d, patA, patH);
     TSTAMP(0);
     int mode = mode_in;
     double *sd = P.state + d.offState;

@@ -1167,6 +1167,7 @@ extern "C" int rsqp_H_times(rsqp_solver *s, const double *p, double *result) {
 // =====================================================================================
 struct rsqp_batch {
     int nq = 0, device = 0, nVmax = 0, nCmax = 0, uniV = -1, uniC = -1;
+    bool uni_pat = false; int uni_annz = 0, uni_hnnz = 0; long long uni_state = 0;     // (QPPools::uni_pat)
     long long sumV = 0, sumC = 0, sumAnz = 0, sumHnz = 0, mat_bytes_max = 0;
     bool haveH = false;
     bool h_sym = true;                    // every H symmetric value by value (the tableau kernel of qp_tiny.hip may take the batch)
@@ -1212,6 +1213,8 @@ QPPools pools_of(rsqp_batch *b) {
     p.keep_state = b->keep_state ? 1 : 0;
     p.done_flag = nullptr; p.done_val = 0;
     p.tiny_ok = (b->h_sym || !b->haveH) ? 1 : 0;
+    p.uni_pat = b->uni_pat ? 1 : 0;
+    p.uni_annz = b->uni_annz; p.uni_hnnz = b->uni_hnnz; p.uni_haveH = b->haveH ? 1 : 0; p.uni_state = b->uni_state;
     return p;
 }
 }  // namespace
@@ -1270,6 +1273,20 @@ extern "C" int rsqp_batch_create(int nq, const int *nV, const int *nC, const int
         }
     } else if (b->haveH) b->h_sym = false;
     b->sumV = offV; b->sumC = offC; b->sumAnz = offAnz; b->sumHnz = offHnz;
+    // uniform batch: every member has the sizes and the patterns of member 0 (QPPools::uni_pat)
+    b->uni_pat = b->uniV > 0 && b->uniC >= 0;
+    if (b->uni_pat) {
+        const QPDesc &d0 = b->desc[0];
+        b->uni_annz = d0.annz; b->uni_hnnz = d0.hnnz; b->uni_state = rsqp_state_bytes(d0.nV, d0.nC) / 8;
+        for (int q = 1; q < nq && b->uni_pat; q++) {
+            const QPDesc &d = b->desc[q];
+            b->uni_pat = d.annz == d0.annz && d.hnnz == d0.hnnz &&
+                         std::memcmp(Ajc + d.offAjc, Ajc, sizeof(int) * (d0.nV + 1)) == 0 &&
+                         std::memcmp(Air + d.offAnz, Air, sizeof(int) * d0.annz) == 0 &&
+                         (!b->haveH || (std::memcmp(Hjc + d.offHjc, Hjc, sizeof(int) * (d0.nV + 1)) == 0 &&
+                                        std::memcmp(Hir + d.offHnz, Hir, sizeof(int) * d0.hnnz) == 0));
+        }
+    }
     HIPCHK(hipStreamCreate(&b->stream));
     HIPCHK(hipEventCreate(&b->ev0)); HIPCHK(hipEventCreate(&b->ev1));
     HIPCHK(hipEventCreate(&b->ev2)); HIPCHK(hipEventCreate(&b->ev3));
