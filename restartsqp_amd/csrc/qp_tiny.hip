@@ -620,7 +620,7 @@ __global__ void __launch_bounds__(TB, W) tiny_qp_kernel(QPPools P, int nq, int m
     if (P.uni_pat) {
         d.nV = P.uniV; d.nC = P.uniC; d.offV = q * P.uniV; d.offC = q * P.uniC; d.offAjc = 0; d.offHjc = 0; d.offArp = 0;
         d.offAnz = q * P.uni_annz; d.offHnz = q * P.uni_hnnz; d.haveH = P.uni_haveH; d.annz = P.uni_annz; d.hnnz = P.uni_hnnz;
-        d.hreg = 0.0; d.offState = (long long)q * P.uni_state;
+        d.hreg = P.uni_hreg; d.offState = (long long)q * P.uni_state;
         patA = patH = 0;
     } else { d = P.desc[q]; patA = d.offAnz; patH = d.offHnz; }
     ENG E;

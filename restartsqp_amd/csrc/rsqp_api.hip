@@ -38,17 +38,21 @@ struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
     T *host = nullptr;   // non-null: p is the device view of host-mapped pinned memory owned elsewhere
+    T *stage = nullptr;  // non-null: p is a slice of a device arena owned elsewhere and `stage` the same slice of its pinned staging
+                         // mirror -- uploads are written there, the owner copies the arena to the device in ONE piece (DevMatrix)
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p && !host) (void)hipFree(p);
+        if (p && !host && !stage) (void)hipFree(p);
         p = nullptr;
         host = nullptr;
+        stage = nullptr;
         n = 0;
     }
     void map(T *dev, T *hst, size_t count) { release(); p = dev; host = hst; n = count; }
+    void carve(T *dev, T *stg, size_t count) { release(); p = dev; stage = stg; n = count; }
     hipError_t alloc(size_t count, bool zero = true) {
         release();
         n = count;
@@ -60,6 +64,7 @@ struct DevBuf {
     hipError_t upload(const T *h, size_t count) {
         if (count == 0) return hipSuccess;
         if (host) { std::memcpy(host, h, count * sizeof(T)); return hipSuccess; }
+        if (stage) { std::memcpy(stage, h, count * sizeof(T)); return hipSuccess; }     // (reaches the device with the arena)
         return hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice);
     }
     hipError_t from(const std::vector<T> &h) {
@@ -211,9 +216,44 @@ struct DevMatrix {
     // directly -- a value refresh (SpHbMat::setMatVal through order_) is then a host loop over a few dozen entries, no copy
     // and no launch (a blocking hipMemcpy + a scatter launch cost ~15 us per matrix per SQP iteration of hs071)
     void *pin = nullptr;
+    size_t pin_cap = 0;                    // entries each of the two value arrays in `pin` can hold
     std::vector<int> h_rorder, h_tmap, h_perm;
+    // ... and everything else the structure analysis uploads (pattern, permutations, SpMV plan) is a slice of ONE device arena
+    // with a pinned staging mirror, both allocated by rsqp_create -- where the reference allocates as well
+    // (Algorithm::allocate_memory), outside the first SQP iteration: set_A / set_H of that iteration then cost one asynchronous
+    // copy instead of 17 hipMalloc + 15 blocking hipMemcpy + 2 hipHostMalloc (365 -> ~90 us for the first iteration of hs071)
+    char *arena_dev = nullptr, *arena_stage = nullptr;
+    size_t arena_cap = 0, arena_used = 0;
+    hipError_t reserve(int nrow_, int ncol_) {
+        const size_t cap = (size_t)nrow_ * (size_t)ncol_ + 2 * (size_t)(nrow_ + ncol_) + 8;      // dense + an identity block or two
+        arena_cap = 64 * cap + 64 * (size_t)(nrow_ + ncol_) + 4096;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&arena_dev), arena_cap);
+        if (e != hipSuccess) { arena_dev = nullptr; arena_cap = 0; return e; }
+        e = hipHostMalloc(reinterpret_cast<void **>(&arena_stage), arena_cap, hipHostMallocDefault);
+        if (e != hipSuccess) { arena_stage = nullptr; return e; }
+        std::memset(arena_stage, 0, arena_cap);
+        e = hipHostMalloc(&pin, 2 * (cap + 2) * sizeof(double), hipHostMallocMapped);
+        if (e != hipSuccess) { pin = nullptr; return e; }
+        std::memset(pin, 0, 2 * (cap + 2) * sizeof(double));
+        pin_cap = cap + 2;
+        return hipSuccess;
+    }
+    template <class T> bool take(DevBuf<T> &b, size_t count) {      // next slice of the arena (16-byte aligned, zero-filled)
+        const size_t bytes = (std::max<size_t>(count, 1) * sizeof(T) + 15) & ~(size_t)15;
+        if (!arena_dev || arena_used + bytes > arena_cap) return false;
+        std::memset(arena_stage + arena_used, 0, bytes);
+        b.carve(reinterpret_cast<T *>(arena_dev + arena_used), reinterpret_cast<T *>(arena_stage + arena_used), count);
+        arena_used += bytes;
+        return true;
+    }
+    void drop_slices() {
+        jc.release(); ir.release(); order.release(); tmap.release(); tv.release(); blk_c.release(); blk_r.release();
+        rp.release(); ci.release(); perm.release(); rorder.release();
+    }
     ~DevMatrix() {
         if (pin) { val.release(); rval.release(); (void)hipHostFree(pin); }
+        if (arena_dev) { drop_slices(); (void)hipFree(arena_dev); }
+        if (arena_stage) (void)hipHostFree(arena_stage);
     }
 };
 
@@ -280,15 +320,70 @@ struct rsqp_solver {
 
 namespace {
 
-int upload_matrix(DevMatrix &M, const Compressed &c, bool want_csr, bool zero_copy = false) {
+// arena form of the function below (LDS-scale single-QP handles whose arena holds the matrix): no allocation, one copy
+int upload_matrix_arena(DevMatrix &M, const Compressed &c, bool want_csr, hipStream_t stream) {
+    M.arena_used = 0;
+    M.drop_slices();
+    const size_t n = M.pin_cap;
+    void *dev = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&dev, M.pin, 0));
+    M.val.map(static_cast<double *>(dev), static_cast<double *>(M.pin), n);
+    M.rval.map(static_cast<double *>(dev) + n, static_cast<double *>(M.pin) + n, n);
+    std::memset(M.pin, 0, 2 * n * sizeof(double));
+    HIPCHK(M.val.upload(c.val.data(), c.val.size()));
+    bool ok = M.take(M.jc, c.jc.size()) && M.take(M.ir, (size_t)M.nnz + 2) && M.take(M.order, std::max(M.nnz, 1)) &&
+              M.take(M.tv, std::max(M.nnz, 1));
+    if (ok && !c.tmap.empty()) ok = M.take(M.tmap, c.tmap.size());
+    std::vector<int4> blk = build_blocks(M.ncol, c.jc.data(), rsqp_spmv_chunk());
+    M.nblk_c = (int)blk.size();
+    ok = ok && M.take(M.blk_c, blk.size());
+    if (!ok) return 1;
+    (void)M.jc.upload(c.jc.data(), c.jc.size()); (void)M.ir.upload(c.ir.data(), c.ir.size());
+    (void)M.order.upload(c.order.data(), c.order.size());
+    if (!c.tmap.empty()) (void)M.tmap.upload(c.tmap.data(), c.tmap.size());
+    (void)M.blk_c.upload(blk.data(), blk.size());
+    M.have_csr = want_csr;
+    if (want_csr) {
+        CsrCopy r;
+        csr_from_csc(M.nrow, M.ncol, c.jc.data(), c.ir.data(), r);
+        std::vector<int> inv(std::max(M.nnz, 1), 0), ro(std::max(M.nnz, 1), 0);
+        for (int k = 0; k < M.nnz; k++) inv[r.perm[k]] = k;
+        for (size_t i = 0; i < c.order.size(); i++) ro[i] = inv[c.order[i]];
+        std::vector<int4> blr = build_blocks(M.nrow, r.rp.data(), rsqp_spmv_chunk());
+        M.nblk_r = (int)blr.size();
+        ok = M.take(M.rp, r.rp.size()) && M.take(M.ci, (size_t)M.nnz + 2) && M.take(M.perm, std::max(M.nnz, 1)) &&
+             M.take(M.rorder, ro.size()) && M.take(M.blk_r, blr.size());
+        if (!ok) return 1;
+        (void)M.rp.upload(r.rp.data(), r.rp.size()); (void)M.ci.upload(r.ci.data(), r.ci.size());
+        (void)M.perm.upload(r.perm.data(), r.perm.size()); (void)M.rorder.upload(ro.data(), ro.size());
+        (void)M.blk_r.upload(blr.data(), blr.size());
+        M.h_rorder = ro; M.h_perm = r.perm;
+        for (int k = 0; k < M.nnz; k++) M.rval.host[k] = M.val.host[r.perm[k]];
+    }
+    HIPCHK(hipMemcpyAsync(M.arena_dev, M.arena_stage, M.arena_used, hipMemcpyHostToDevice, stream));
+    M.initialised = true;
+    return RSQP_OK;
+}
+
+int upload_matrix(DevMatrix &M, const Compressed &c, bool want_csr, bool zero_copy = false, hipStream_t stream = nullptr) {
     M.nrow = c.nrow; M.ncol = c.ncol; M.nnz = c.nnz();
     M.h_jc = c.jc; M.h_ir = c.ir; M.h_order = c.order; M.h_tmap = c.tmap;
-    if (M.pin) { M.val.release(); M.rval.release(); (void)hipHostFree(M.pin); M.pin = nullptr; }
+    if (zero_copy && M.arena_dev && M.pin && (size_t)M.nnz + 2 <= M.pin_cap) {
+        (void)hipStreamSynchronize(stream);        // (an earlier copy of the staging mirror may still be on its way)
+        const int rc = upload_matrix_arena(M, c, want_csr, stream);
+        if (rc == RSQP_OK) return rc;
+        if (rc < 0) return rc;
+        // the arena is too small for this matrix (rc == 1): the allocating path below, and the arena is not used again
+        M.drop_slices(); M.val.release(); M.rval.release();
+        (void)hipFree(M.arena_dev); M.arena_dev = nullptr; M.arena_cap = 0;
+    }
+    if (M.pin) { M.val.release(); M.rval.release(); (void)hipHostFree(M.pin); M.pin = nullptr; M.pin_cap = 0; }
     HIPCHK(M.jc.from(c.jc));
     HIPCHK(M.ir.alloc(M.nnz + 2, true)); HIPCHK(M.ir.upload(c.ir.data(), c.ir.size()));
     if (zero_copy) {
         const size_t n = (size_t)M.nnz + 2;
         HIPCHK(hipHostMalloc(&M.pin, 2 * n * sizeof(double), hipHostMallocMapped));
+        M.pin_cap = n;
         std::memset(M.pin, 0, 2 * n * sizeof(double));
         void *dev = nullptr;
         HIPCHK(hipHostGetDevicePointer(&dev, M.pin, 0));
@@ -359,8 +454,8 @@ int ensure_desc(rsqp_solver *s) {
     d.nV = s->nV; d.nC = s->nC; d.haveH = (s->H.initialised && !s->lp_mode) ? 1 : 0;
     d.annz = d.hnnz = -1;
     d.hreg = s->hreg;
-    std::vector<QPDesc> hd(1, d);
-    HIPCHK(s->d_desc.from(hd));
+    if (s->d_desc.p) { HIPCHK(s->d_desc.upload(&d, 1)); }       // (host-mapped for LDS-scale handles: a store, no copy)
+    else { std::vector<QPDesc> hd(1, d); HIPCHK(s->d_desc.from(hd)); }
     s->desc_ready = true;
     return RSQP_OK;
 }
@@ -388,6 +483,10 @@ QPPools pools_of(rsqp_solver *s) {
     p.done_flag = nullptr; p.done_val = 0;
     p.reinit_from_y0 = s->reinit_from_y0 ? 1 : 0;
     p.tiny_ok = (s->h_sym || !s->H.initialised || s->lp_mode) ? 1 : 0;
+    // the batch of one: the hs071-scale kernel computes the (zero) offsets itself instead of loading the descriptor
+    p.uni_pat = 1;
+    p.uni_annz = s->A.initialised ? s->A.nnz : 0; p.uni_hnnz = s->H.initialised ? s->H.nnz : 0;
+    p.uni_haveH = (s->H.initialised && !s->lp_mode) ? 1 : 0; p.uni_state = 0; p.uni_hreg = s->hreg;
     return p;
 }
 
@@ -456,7 +555,8 @@ extern "C" int rsqp_create(int nV, int nC, int device, rsqp_solver **out) {
     if (s->fits_small) {
         const size_t nd = 3 * (size_t)nV + 2 * (size_t)nC + nV + (nV + nC) + 1 + 6;      // doubles
         const size_t ni = 2 * ((size_t)nV + nC) + 4 + 2;                                   // ints (+ the done flag)
-        const size_t bytes = nd * 8 + ni * 4 + 64;
+        const size_t bytes_io = (nd * 8 + ni * 4 + 64 + 15) & ~(size_t)15;
+        const size_t bytes = bytes_io + sizeof(QPDesc) + 16;          // (+ the problem descriptor: rewritten by a store, ensure_desc)
         HIPCHK(hipHostMalloc(&s->io_host, bytes, hipHostMallocMapped));
         std::memset(s->io_host, 0, bytes);
         void *dev = nullptr;
@@ -483,6 +583,10 @@ extern "C" int rsqp_create(int nV, int nC, int device, rsqp_solver **out) {
         s->d_Wb.map(di + q, hi + q, nV); q += nV;
         s->d_Wc.map(di + q, hi + q, nC); q += nC;
         s->d_done = di + q; s->h_done = hi + q; q++;
+        s->d_desc.map(reinterpret_cast<QPDesc *>(static_cast<char *>(dev) + bytes_io),
+                      reinterpret_cast<QPDesc *>(static_cast<char *>(s->io_host) + bytes_io), 1);
+        if (nC > 0) HIPCHK(s->A.reserve(nC, nV));
+        HIPCHK(s->H.reserve(nV, nV));
     } else {
         for (int k = 0; k < 5; k++) HIPCHK(s->d_vec[k].alloc((k <= RSQP_VEC_UB) ? nV : nC));
         HIPCHK(s->d_x.alloc(nV)); HIPCHK(s->d_y.alloc(nV + nC)); HIPCHK(s->d_obj.alloc(1));
@@ -575,9 +679,9 @@ extern "C" int rsqp_set_A_triplet(rsqp_solver *s, int nnz, const int *irow, cons
         Compressed cs;
         csc_from_entries(s->nC, s->nV, r, c, v, cs);
         M.from_triplet = true; M.n_triplet = nnz; M.n_ident_entries = nid;
-        int rc = upload_matrix(M, cs, true, s->fits_small);
+        int rc = upload_matrix(M, cs, true, s->fits_small, s->stream);
         if (rc != RSQP_OK) return rc;
-        (void)hipStreamSynchronize(s->stream);   // this handle's stream only (the uploads are blocking copies): other handles keep running
+        if (!M.arena_dev) (void)hipStreamSynchronize(s->stream);   // this handle's stream only (the uploads are blocking copies): other handles keep running
         M.structure_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         s->desc_ready = false;
         return RSQP_OK;
@@ -623,9 +727,9 @@ extern "C" int rsqp_set_H_triplet(rsqp_solver *s, int nnz, const int *irow, cons
         cs.tmap = tmap;
         s->h_sym = is_symmetric != 0 || (s->nV <= 8 && small_csc_symmetric(s->nV, cs.jc.data(), cs.ir.data(), cs.val.data()));
         M.from_triplet = true; M.n_triplet = nnz; M.symmetric = is_symmetric != 0;
-        int rc = upload_matrix(M, cs, false, s->fits_small);
+        int rc = upload_matrix(M, cs, false, s->fits_small, s->stream);
         if (rc != RSQP_OK) return rc;
-        (void)hipStreamSynchronize(s->stream);   // this handle's stream only (the uploads are blocking copies): other handles keep running
+        if (!M.arena_dev) (void)hipStreamSynchronize(s->stream);   // this handle's stream only (the uploads are blocking copies): other handles keep running
         M.structure_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         s->desc_ready = false;
         return RSQP_OK;
@@ -674,10 +778,10 @@ int set_csc(rsqp_solver *s, DevMatrix &M, int nrow, int ncol, const int *jc, con
     // blocks, host mirror) is rebuilt; the dirty flag set above makes optimizeQP re-factorise
     M.from_triplet = false;
     const auto t0 = std::chrono::steady_clock::now();
-    int rc = upload_matrix(M, cs, want_csr, s->fits_small);
+    int rc = upload_matrix(M, cs, want_csr, s->fits_small, s->stream);
     s->desc_ready = false;
     if (rc == RSQP_OK) {
-        (void)hipStreamSynchronize(s->stream);   // this handle's stream only (the uploads are blocking copies): other handles keep running
+        if (!M.arena_dev) (void)hipStreamSynchronize(s->stream);   // this handle's stream only (the uploads are blocking copies): other handles keep running
         M.structure_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     return rc;
@@ -1528,6 +1632,7 @@ int rsqp_batch_nq_internal(const rsqp_batch *b) { return b ? b->nq : 0; }
 // and of the CSR-copy gather on the values already staged by rsqp_set_A_triplet (no host transfer inside)
 extern "C" int rsqp_time_value_refresh_fused(rsqp_solver *s, int repeats, float *ms) {
     if (!s || repeats <= 0 || !ms || !s->A.initialised || !s->A.from_triplet || !s->A.have_csr) return fail(RSQP_ERR_ARG, "rsqp_time_value_refresh_fused");
+    if (s->A.pin) return fail(RSQP_ERR_ARG, "rsqp_time_value_refresh_fused: this handle refreshes its values on the host (no kernel to time)");
     HIPCHK(hipSetDevice(s->device));
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -1546,6 +1651,7 @@ extern "C" int rsqp_time_value_refresh_fused(rsqp_solver *s, int repeats, float 
 
 extern "C" int rsqp_time_value_refresh(rsqp_solver *s, int repeats, float *ms_scatter, float *ms_gather) {
     if (!s || repeats <= 0 || !s->A.initialised || !s->A.from_triplet) return fail(RSQP_ERR_ARG, "rsqp_time_value_refresh");
+    if (s->A.pin) return fail(RSQP_ERR_ARG, "rsqp_time_value_refresh: this handle refreshes its values on the host (no kernel to time)");
     HIPCHK(hipSetDevice(s->device));
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));

@@ -56,8 +56,9 @@ struct QPPools {
                       //    tableau kernel (qp_tiny.hip), which keeps K symmetric by construction
     int uni_pat;      // 1: every member has the sizes AND the sparsity patterns of member 0 (checked by the host when the batch is
     int uni_annz, uni_hnnz, uni_haveH;   //    created: parameter scans, perturbations of one QP) -- offsets are q * size then, so the kernel
-    long long uni_state;                 //    needs no descriptor load, and it reads the PATTERN arrays of member 0 (cache-resident for the
+    long long uni_state; double uni_hreg; //    needs no descriptor load, and it reads the PATTERN arrays of member 0 (cache-resident for the
                       //    whole launch) instead of its own copy: two dependent HBM round trips less in front of every solve
+                      //    (single-QP handles are the batch of one: set as well; uni_hreg = the LP regularisation, 0 in batches)
     int keep_state;   // 1: write the hot-start part of the engine image back to HBM at the end of a solve (what the
                       //    SQProblem object keeps between calls); 0: cold-start-only batches skip that write --
                       //    the image is marked "not initialised", a later hot start falls back to a cold start

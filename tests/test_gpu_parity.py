@@ -67,6 +67,27 @@ def test_batch_random_convex(capi, oracle):
             assert abs(r["obj"] - qp.objective) <= 1e-9 * max(1.0, abs(qp.objective))
 
 
+def test_one_shape_batches_with_one_and_with_several_patterns(capi, oracle):
+    """Batches of ONE shape (8 x 2 .. 6 x 5: the register-resident kernel): when every member also has the sparsity pattern of
+    member 0 the kernel computes its offsets and reads member 0's pattern arrays (QPPools::uni_pat); one member with another
+    pattern -- same sizes, same entry counts or not -- must switch that off. Cold solve, then a hot start on new vectors."""
+    rng = np.random.default_rng(77)
+    for nV, nC in ((8, 2), (6, 5), (3, 8)):
+        base = problems.random_qp(rng, nV, nC, density=0.6)
+        same = [problems.perturb(rng, base, 0.05) for _ in range(40)]
+        # values differ per member as well (the pattern stays)
+        for q in same:
+            q.A_val = q.A_val * (1.0 + 0.05 * rng.normal(size=q.A_val.shape))
+        other = [problems.random_qp(rng, nV, nC, density=0.6) for _ in range(8)]
+        for probs in (same, same[:20] + other + same[20:], other):
+            b = capi.Batch(probs)
+            b.solve(capi.MODE_COLD, 1000)
+            for q, r in zip(probs, b.results()):
+                qp, rc, n = oracle_cold(oracle, q)
+                assert_same_solution(qp, r, n)
+            b.close()
+
+
 def test_batch_edge_cases(capi, oracle):
     """No constraints, a single variable, infinite bounds, equalities, infeasible, iteration limit."""
     rng = np.random.default_rng(11)
