@@ -262,6 +262,30 @@ def test_assembly_from_triplets(capi, oracle):
         assert np.array_equal(s.get_H_csc()[2], oracle.sphb_set_matval_sym(hr + 1, hc + 1, True, ooo, nv, ov.copy()))
 
 
+def test_structure_upload_of_small_handles_arena_and_fallback(capi, oracle):
+    """LDS-scale handles take their pattern arrays from an arena allocated by rsqp_create (one copy per set_A / set_H). A triplet
+    list with so many DUPLICATE entries that it exceeds the arena must fall back to the allocating path with the same result."""
+    rng = np.random.default_rng(91)
+    n, m = 4, 2
+    for ndup in (1, 30):                                       # 8 entries / 240 entries (the arena holds a dense 2 x 4 + slack)
+        r, c = np.nonzero(np.ones((m, n)))
+        irow = np.tile(r + 1, ndup); jcol = np.tile(c + 1, ndup)
+        val = rng.normal(size=len(irow))
+        s = capi.Solver(n, m)
+        s.set_A_triplet(irow, jcol, val, [])
+        jc, ir, v, order = s.get_A_csc()
+        jo, io, vo, oo = oracle.sphb_set_structure(m, n, irow, jcol, val, [])
+        assert np.array_equal(jc, jo) and np.array_equal(ir, io) and np.array_equal(v, vo) and np.array_equal(order, oo)
+        val2 = rng.normal(size=len(irow))
+        s.set_A_triplet(irow, jcol, val2, [])
+        assert np.array_equal(s.get_A_csc()[2], oracle.sphb_set_matval(oo, val2, vo.copy(), 0))
+        A = np.zeros((m, n))
+        np.add.at(A, (irow - 1, jcol - 1), val2)
+        x = rng.normal(size=n); y = rng.normal(size=m)
+        assert np.abs(s.A_times(x) - A @ x).max() < 1e-12 and np.abs(s.A_transposed_times(y) - A.T @ y).max() < 1e-12
+        s.close()
+
+
 @pytest.mark.parametrize("from_y0", [True, False])
 def test_dispatch_state_machine(capi, oracle, from_y0):
     """optimizeQP's FIXED / VARIED dispatch (qpOASESInterface.cpp:137-224, 817-833) driven by
