@@ -1381,6 +1381,123 @@ __global__ void __launch_bounds__(NT) k_rho2(double *scal, double *ctl, const do
     ctl[4] = scal[13]; ctl[5] = scal[14];
     publish(ctl, seqv);
 }
+// ---- the range-space (dual) path for a DIAGONAL positive Hessian (Impl::dual) ---------------------------------
+// hinv = 1 / (diag(H) + hreg); flag[0] |= 1 when an entry is not positive (the caller then keeps the null-space path)
+__global__ void k_dual_hinv(int nV, const double *__restrict__ Hval, double hreg, double *__restrict__ hinv, int *__restrict__ flag) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nV) return;
+    const double d = Hval[v] + hreg;
+    hinv[v] = d > 0.0 ? 1.0 / d : 0.0;
+    if (!(d > 1e-300)) atomicOr(flag, 1);
+}
+// out = D^-1 a on the free variables, 0 elsewhere (a is zero on the fixed ones already)
+__global__ void k_dual_scale(int nV, const double *__restrict__ hinv, const double *__restrict__ a, double *__restrict__ out) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nV) out[v] = hinv[v] * a[v];
+}
+// the unit vector of variable v on the free variables (a_FR of a bound) and D^-1 of it
+__global__ void k_dual_unit(int nV, int v, const int *__restrict__ Sb, const double *__restrict__ hinv, double *__restrict__ a,
+                            double *__restrict__ da) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nV) return;
+    const double e = (i == v && Sb[i] == 0) ? 1.0 : 0.0;
+    a[i] = e; da[i] = hinv[i] * e;
+}
+// independence of an incoming row a from the active ones, decided on first-order quantities: with c = A_AC,FR D^-1 a_FR,
+// u = Sinv c (the coefficients of a's representation by the active rows in the D^-1 metric) and atu = A_AC' u:
+//   |a_FR|^2, |r|^2 with r = (a - atu) on the free variables (Z'r = Z'a, |Z'a| <= |r| <= cond(D) |Z'a|), and the pivot of the
+//   bordering s = a_FR'D^-1 a_FR - c'u (second order: only its sign and size as a pivot are used). One workgroup; published.
+__global__ void __launch_bounds__(NT) k_dual_li_publish(int nV, const int *__restrict__ Sb, const double *__restrict__ a,
+                                                        const double *__restrict__ da, const double *__restrict__ atu, int k,
+                                                        const double *__restrict__ c, const double *__restrict__ u,
+                                                        double *__restrict__ scal, double *__restrict__ ctl, double seqv) {
+    __shared__ double sh[4];
+    double a2 = lane_sum4(nV, [&](int i) { return a[i] * a[i]; });
+    double r2 = lane_sum4(nV, [&](int i) { const double r = Sb[i] == 0 ? a[i] - atu[i] : 0.0; return r * r; });
+    double ad = lane_sum4(nV, [&](int i) { return a[i] * da[i]; });
+    double cu = lane_sum4(k, [&](int j) { return c[j] * u[j]; });
+    a2 = block_sum(a2, sh); r2 = block_sum(r2, sh); ad = block_sum(ad, sh); cu = block_sum(cu, sh);
+    if (threadIdx.x != 0) return;
+    const double sp = ad - cu;
+    scal[6] = a2; scal[7] = r2; scal[5] = sp; scal[8] = sp != 0.0 ? 1.0 / sp : 0.0;
+    ctl[2] = a2; ctl[3] = r2; ctl[4] = sp;
+    publish(ctl, seqv);
+}
+// the border of Sinv behind an added constraint (after Sinv += u u' / s): row and column nAC = -u / s, corner 1 / s; thread nAC
+// records the working-set entry and the multiplier of the incoming constraint (yidx >= 0)
+__global__ void k_dual_border(double *Sinv, long long ldm, int nAC, const double *__restrict__ u, const double *__restrict__ scal,
+                              int *AC, int *posAC, int *Sc, int r, int side, double *y, int yidx, double yval) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > nAC) return;
+    const double is = scal[8];
+    if (j == nAC) {
+        AC[nAC] = r; posAC[r] = nAC; Sc[r] = side;
+        if (yidx >= 0) y[yidx] = yval;
+        Sinv[(long long)nAC * ldm + nAC] = is;
+    } else {
+        const double b = -u[j] * is;
+        Sinv[(long long)j * ldm + nAC] = b;
+        Sinv[(long long)nAC * ldm + j] = b;
+    }
+}
+// removal of the constraint at position j: v = column j of Sinv, coef = -1 / v_j  (Sinv += coef v v' zeroes row and column j)
+__global__ void k_dual_colcoef(const double *__restrict__ Sinv, long long ldm, int k, int j, double *__restrict__ v, double *__restrict__ scal) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) v[i] = Sinv[(long long)j * ldm + i];
+    if (i == 0) { const double d = Sinv[(long long)j * ldm + j]; scal[9] = d != 0.0 ? -1.0 / d : 0.0; }
+}
+// ... then the last row / column (k - 1) moves into the freed slot j (Sinv symmetric: both from column k - 1), working set follows
+__global__ void k_dual_move_last(double *Sinv, long long ldm, int k, int j, int *AC, int *posAC, int *Sc, int r, double *y, int yidx) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int last = k - 1;
+    if (c == 0) {
+        if (j != last) { const int rl = AC[last]; AC[j] = rl; posAC[rl] = j; }
+        posAC[r] = -1; Sc[r] = 0;
+        y[yidx] = 0.0;
+    }
+    if (j == last || c >= last) return;
+    const double val = c == j ? Sinv[(long long)last * ldm + last] : Sinv[(long long)last * ldm + c];
+    Sinv[(long long)c * ldm + j] = val;
+    Sinv[(long long)j * ldm + c] = val;
+}
+// a variable is freed: S gains a_v a_v' / d_v, Sinv -= w w' / (d_v + a_v'w) with w = Sinv a_v: the coefficient (one workgroup)
+__global__ void __launch_bounds__(NT) k_dual_free_coef(int k, const double *__restrict__ av, const double *__restrict__ w,
+                                                       const double *__restrict__ Hval, double hreg, int v, double *__restrict__ scal) {
+    __shared__ double sh[4];
+    double d = lane_sum4(k, [&](int j) { return av[j] * w[j]; });
+    d = block_sum(d, sh);
+    if (threadIdx.x == 0) scal[9] = -1.0 / (Hval[v] + hreg + d);
+}
+// step direction: the vector whose product with A gives the right-hand side of S dy = db - A dx_FX + A D^-1 dg_FR
+__global__ void k_dual_rhs_vec(int nV, const int *__restrict__ Sb, const double *__restrict__ hinv, const double *__restrict__ gN,
+                               const double *__restrict__ g, const double *__restrict__ dx, double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nV) out[i] = Sb[i] == 0 ? hinv[i] * (gN[i] - g[i]) : -dx[i];
+}
+__global__ void k_dual_rhs(int nAC, const int *__restrict__ AC, const int *__restrict__ Sc, const double *__restrict__ lbA,
+                           const double *__restrict__ ubA, const double *__restrict__ lbAN, const double *__restrict__ ubAN,
+                           const double *__restrict__ Av, double *__restrict__ rhs) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nAC) return;
+    const int r = AC[j];
+    rhs[j] = (Sc[r] == -1 ? delta_of(lbAN[r], lbA[r]) : delta_of(ubAN[r], ubA[r])) + Av[r];
+}
+// dx on the free variables from stationarity, D dx + dg = A'dy_C; H dx of every variable
+__global__ void k_dual_dx(int nV, const int *__restrict__ Sb, const double *__restrict__ hinv, const double *__restrict__ Hval,
+                          double hreg, const double *__restrict__ ATdy, const double *__restrict__ gN, const double *__restrict__ g,
+                          double *__restrict__ dx, double *__restrict__ Hdx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nV) return;
+    double d = dx[i];
+    if (Sb[i] == 0) { d = hinv[i] * (ATdy[i] - (gN[i] - g[i])); dx[i] = d; }
+    Hdx[i] = (Hval[i] + hreg) * d;
+}
+// rows of B (compressed free coordinates, one column per candidate constraint) scaled by sqrt(1 / d): S = B'B
+__global__ void k_dual_scale_rows(int m, const int *__restrict__ freev, const double *__restrict__ hinv, double *__restrict__ B, long long ldb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) B[(long long)blockIdx.y * ldb + i] *= sqrt(hinv[freev[i]]);
+}
+__global__ void k_set_Sb(int *Sb, int v, int side) { Sb[v] = side; }
 __global__ void k_clip_y(int nV, int nC, const int *Sb, const int *Sc, double *y) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nV + nC) return;
@@ -1502,11 +1619,11 @@ struct RsqpLargeEngine::Impl {
 
     ~Impl() {
         double *dv[] = {Z, Y, Minv, Wz, x, g, lb, ub, gN, lbN, ubN, dx, w1, w2, w3, w4, w5, w6, wz1, wz2, wz3, Ax, lbA, ubA,
-                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col, c_wY, c_wY2, c_xY, c_xi, c_wZ, py_t, py_v, pm_s};
+                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col, c_wY, c_wY2, c_xY, c_xi, c_wZ, py_t, py_v, pm_s, hinv};
         for (double *p : dv) if (p) (void)hipFree(p);
         if (big) (void)hipFree(big);
         rsqp_dense_work_free(&dw);
-        int *iv[] = {Sb, Sc, AC, posAC, pid, res_id, d_fpos, d_cand, d_freev};
+        int *iv[] = {Sb, Sc, AC, posAC, pid, res_id, d_fpos, d_cand, d_freev, dflag};
         for (int *p : iv) if (p) (void)hipFree(p);
         if (h_ctl) (void)hipHostFree(h_ctl);
         if (h_pinned) (void)hipHostFree(h_pinned);
@@ -1610,6 +1727,14 @@ struct RsqpLargeEngine::Impl {
     }
     // two products out = M w of the single-launch form in ONE launch (k_gemv_n1_pair); false: the pair does not qualify and the
     // caller launches them one after the other. skip0: columns with a zero weight are not read (live of them are non-zero)
+    // ---- range-space (dual) path: H diagonal and positive. S = A_AC,FR D^-1 A_AC,FR' and its EXPLICIT inverse Sinv
+    // (nAC x nAC, symmetric, in the buffer of Minv) replace Z, Y, Minv, Wz: per working-set change one rank-1 update of Sinv and
+    // one or two products with it -- nAC^2 entries instead of nV nZ + nZ^2 + nAC^2 + nV nAC. Same homotopy, ratio tests, exchange
+    // rule and drift correction; the definiteness guard of a removal never fires (Z'DZ is positive definite for every Z).
+    bool dual_enabled = getenv("RSQP_LARGE_NO_DUAL") == nullptr;
+    bool dual = false;               // the factors of this handle are Sinv (set by setup_aux; a hot start on new vectors keeps it)
+    double *hinv = nullptr;          // 1 / (diag(H) + hreg)
+    int *dflag = nullptr;
     bool pair_enabled = getenv("RSQP_LARGE_NO_PAIR") == nullptr;
     bool tail_fused = getenv("RSQP_LARGE_NO_TAIL") == nullptr;      // (k_remove_tail; off: the separate kernels)
     bool gemv_n1_pair(const double *M0, long long l0, int r0, int c0, const double *w0, double *o0, const double *M1, long long l1,
@@ -2075,10 +2200,12 @@ struct RsqpLargeEngine::Impl {
     // exchange: incoming row in w4 (all variables), its Y-products in a1. Finds the partner,
     // shifts the duals. ret: RET_OK / RET_INFEASIBLE; partner in (pkind, pidx), y_new
     int ensure_LI(int side, double *y_new, int *pkind, int *pidx) {
-        fill(c1, nC, 0.0);
-        gemv_t(Minv, ldm, nAC, nAC, a1, a2);   // hmm: xiC = Minv' wY  -> xi[j] = sum_i Minv[i][j] wY[i]
-        if (nAC > 0) hipLaunchKernelGGL(k_scatter_active, g1(nAC), dim3(NT), 0, st, a2, AC, nAC, c1);
-        AT_times(c1, w2);
+        if (!dual) {      // (the range-space path has xi = Sinv c scattered in c1 and A_AC'xi in w2 already: dual_products_tail)
+            fill(c1, nC, 0.0);
+            gemv_t(Minv, ldm, nAC, nAC, a1, a2);   // xiC = Minv' wY  -> xi[j] = sum_i Minv[i][j] wY[i]
+            if (nAC > 0) hipLaunchKernelGGL(k_scatter_active, g1(nAC), dim3(NT), 0, st, a2, AC, nAC, c1);
+            AT_times(c1, w2);
+        }
         hipLaunchKernelGGL(k_xiB, g1(nV), dim3(NT), 0, st, nV, Sb, w4, w2, w3);
         const double sgn = side == 1 ? -1.0 : 1.0;
         hipLaunchKernelGGL(k_partner1, dim3(nblk_ratio), dim3(NT), 0, st, nV, nC, Sb, Sc, y, c1, w3, sgn, pt, pid);
@@ -2102,7 +2229,34 @@ struct RsqpLargeEngine::Impl {
         return RET_OK;
     }
 
+    int dual_change_active_set(int kind, int idx, int side) {
+        if (kind == 1) { dual_remove_constraint(position_of(idx)); return RET_OK; }
+        if (kind == 2) { dual_remove_bound(idx); return RET_OK; }
+        double ynew = 0.0;
+        bool li = false;
+        if (kind == 3) dual_constraint_products(idx); else dual_bound_products(idx);
+        if (dual_li_decision(&li) != RET_OK) return RET_SETUP_FAILED;
+        if (!li) {
+            int pkind = 0, pidx = -1;
+            if (kind == 3) row_of_A(idx, w4, true);
+            else { fill(w4, nV, 0.0); hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, w4, idx, 1.0); }
+            int rc = ensure_LI(side, &ynew, &pkind, &pidx);
+            if (rc != RET_OK) return rc;
+            if (pkind == 1) dual_remove_constraint(position_of(pidx)); else dual_remove_bound(pidx);
+            if (kind == 3) dual_constraint_products(idx); else dual_bound_products(idx);
+            if (dual_li_decision(&li) != RET_OK) return RET_SETUP_FAILED;
+            if (!li) return RET_SETUP_FAILED;      // (the partner's removal must have made room for the incoming row)
+        }
+        if (kind == 3) dual_add_constraint(idx, side, nV + idx, ynew);
+        else {
+            dual_add_bound(idx, side);
+            hipLaunchKernelGGL(k_set1, dim3(1), dim3(1), 0, st, y, idx, ynew);
+        }
+        return RET_OK;
+    }
+
     int change_active_set(int kind, int idx, int side) {
+        if (dual) return dual_change_active_set(kind, idx, side);
         flush_pending();
         carry_pending = carry_ready = false;       // (set again by a plain added / removed constraint below)
         if (kind == 1) {
@@ -2146,8 +2300,137 @@ struct RsqpLargeEngine::Impl {
         return RET_OK;
     }
 
+    // ---- range-space (dual) path ---------------------------------------------------------
+    // may this solve take it? H stored as exactly one entry per column on the diagonal (host pattern check by the caller:
+    // M.diagH), every d + hreg > 0 (device check here; one host round trip per set-up)
+    int dual_prepare(bool *ok) {
+        *ok = false;
+        if (!dual_enabled || !M.diagH || !M.haveH || nC <= 0) return RET_OK;
+        LCHK(hipMemsetAsync(dflag, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_dual_hinv, g1(nV), dim3(NT), 0, st, nV, M.Hval, M.hreg, hinv, dflag);
+        LCHK(hipMemcpyAsync(h_pinned_i, dflag, sizeof(int), hipMemcpyDeviceToHost, st));
+        LCHK(hipStreamSynchronize(st));
+        *ok = h_pinned_i[0] == 0;
+        return RET_OK;
+    }
+    // products of an incoming row with the working set: a_FR in w1, D^-1 a_FR in w5, c in a1, u = Sinv c in a2 (and scattered by
+    // constraint in c1), A_AC'u in w2; |a_FR|^2, |r|^2, the pivot s published (scal[5..8])
+    void dual_products_tail() {
+        A_times(w5, c3);
+        if (nAC > 0) hipLaunchKernelGGL(k_gather_active, g1(nAC), dim3(NT), 0, st, c3, AC, nAC, a1);
+        gemv_n(Minv, ldm, nAC, nAC, a1, 1.0, 0.0, nullptr, a2);
+        fill(c1, nC, 0.0);
+        if (nAC > 0) hipLaunchKernelGGL(k_scatter_active, g1(nAC), dim3(NT), 0, st, a2, AC, nAC, c1);
+        AT_times(c1, w2);
+        hipLaunchKernelGGL(k_dual_li_publish, dim3(1), dim3(NT), 0, st, nV, Sb, w1, w5, w2, nAC, a1, a2, scal, d_ctl, next_seq());
+    }
+    void dual_constraint_products(int r) {
+        row_of_A(r, w1, false);
+        hipLaunchKernelGGL(k_dual_scale, g1(nV), dim3(NT), 0, st, nV, hinv, w1, w5);
+        dual_products_tail();
+    }
+    void dual_bound_products(int v) {
+        hipLaunchKernelGGL(k_dual_unit, g1(nV), dim3(NT), 0, st, nV, v, Sb, hinv, w1, w5);
+        dual_products_tail();
+    }
+    int dual_li_decision(bool *li) {
+        if (wait_ctl() != RET_OK) return wait_failed();
+        const double a2n = h_ctl[2], r2 = h_ctl[3], sp = h_ctl[4];
+        *li = nFR - nAC > 0 && a2n > 0.0 && std::sqrt(r2) > RSQP_EPS_LI * std::sqrt(a2n) && sp > 0.0;
+        return RET_OK;
+    }
+    // Sinv <- [[Sinv + u u'/s, -u/s], [-u'/s, 1/s]]  (u in a2, 1/s in scal[8])
+    void dual_add_constraint(int r, int side, int yidx = -1, double yval = 0.0) {
+        ger(Minv, ldm, nAC, nAC, a2, a2, 8, 1.0);
+        hipLaunchKernelGGL(k_dual_border, g1(nAC + 1), dim3(NT), 0, st, Minv, ldm, nAC, a2, scal, AC, posAC, Sc, r, side, y, yidx, yval);
+        hAC[nAC] = r; hSc[r] = side;
+        nAC++;
+        nZ = nFR - nAC;
+    }
+    // a variable joins the fixed set: S loses a_v a_v'/d_v, Sinv += u u'/s with the same u and s as a bordering would use
+    void dual_add_bound(int v, int side) {
+        ger(Minv, ldm, nAC, nAC, a2, a2, 8, 1.0);
+        hipLaunchKernelGGL(k_set_Sb, dim3(1), dim3(1), 0, st, Sb, v, side);
+        hSb[v] = side;
+        nFR--;
+        nZ = nFR - nAC;
+    }
+    void dual_remove_constraint(int k) {
+        const int r = hAC[k];
+        hipLaunchKernelGGL(k_dual_colcoef, g1(nAC), dim3(NT), 0, st, Minv, ldm, nAC, k, a3, scal);
+        ger(Minv, ldm, nAC, nAC, a3, a3, 9, 1.0);
+        hipLaunchKernelGGL(k_dual_move_last, g1(std::max(nAC - 1, 1)), dim3(NT), 0, st, Minv, ldm, nAC, k, AC, posAC, Sc, r, y, nV + r);
+        if (k != nAC - 1) hAC[k] = hAC[nAC - 1];
+        hSc[r] = 0;
+        nAC--;
+        nZ = nFR - nAC;
+    }
+    void dual_remove_bound(int v) {
+        hipLaunchKernelGGL(k_free_bound_ws, dim3(1), dim3(1), 0, st, Sb, v, y);   // Sb[v] = 0, y[v] = 0
+        hSb[v] = 0;
+        nFR++;
+        nZ = nFR - nAC;
+        if (nAC == 0) return;
+        fill(a4, nAC, 0.0);
+        hipLaunchKernelGGL(k_col_of_A_active, dim3(4), dim3(NT), 0, st, M.Ajc, M.Air, M.Aval, v, posAC, a4);  // a_v
+        gemv_n(Minv, ldm, nAC, nAC, a4, 1.0, 0.0, nullptr, a3);          // w = Sinv a_v
+        hipLaunchKernelGGL(k_dual_free_coef, dim3(1), dim3(NT), 0, st, nAC, a4, a3, M.Hval, M.hreg, v, scal);
+        ger(Minv, ldm, nAC, nAC, a3, a3, 9, 1.0);
+    }
+    // factors for a guessed working set: S = B'B with B = D^-1/2 A_cand,FR' (GEMM), Cholesky, inverse. RET_FALLBACK: dependent rows
+    // in the guess (or too few candidates): the caller adds them one by one
+    int dual_setup_blocked(const std::vector<int> &gc, const std::vector<int> &freev, const std::vector<int> &cand) {
+        const int m = nFR, n = (int)cand.size();
+        if (ensure_big() != RET_OK) return RET_SETUP_FAILED;
+        std::vector<int> fpos(nV, -1);
+        for (int i = 0; i < m; i++) fpos[freev[i]] = i;
+        LCHK(hipMemcpyAsync(d_fpos, fpos.data(), sizeof(int) * nV, hipMemcpyHostToDevice, st));
+        LCHK(hipMemcpyAsync(d_cand, cand.data(), sizeof(int) * n, hipMemcpyHostToDevice, st));
+        LCHK(hipMemcpyAsync(d_freev, freev.data(), sizeof(int) * m, hipMemcpyHostToDevice, st));
+        const long long lb_ = pad16(m), lg = pad16(n);
+        double *B = Y, *G = big, *Ui = big + (size_t)ld * ld;
+        LCHK(hipMemsetAsync(B, 0, sizeof(double) * (size_t)lb_ * n, st));
+        hipLaunchKernelGGL(k_build_B, dim3(n), dim3(NT), 0, st, M.Arp, M.Aci, M.Arv, d_cand, d_fpos, B, lb_);
+        hipLaunchKernelGGL(k_dual_scale_rows, dim3((m + NT - 1) / NT, n), dim3(NT), 0, st, m, d_freev, hinv, B, lb_);
+        LCHK(rsqp_dgemm(true, false, n, n, m, 1.0, B, lb_, B, lb_, 0.0, G, lg, st));
+        LCHK(hipMemsetAsync(dw.flag, 0, sizeof(int) * 4, st));
+        LCHK(rsqp_dpotrf_upper(n, G, lg, 1e-10, RSQP_EPS_PD_ABS, &dw, st));      // (a pivot below 1e-10 of its diagonal: the Gram matrix cannot decide independence -- one by one then)
+        LCHK(hipMemcpyAsync(h_pinned_i, dw.flag, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+        LCHK(hipStreamSynchronize(st));      // (the host vectors above go out of scope as well)
+        if (h_pinned_i[1] != 0) return RET_FALLBACK;
+        LCHK(rsqp_dtrtri_upper(n, G, lg, Ui, lg, &dw, st));
+        LCHK(rsqp_dgemm(false, true, n, n, n, 1.0, Ui, lg, Ui, lg, 0.0, Minv, ldm, st));
+        std::vector<int> hpos(nC, -1);
+        for (int k = 0; k < n; k++) { hAC[k] = cand[k]; hpos[cand[k]] = k; hSc[cand[k]] = gc[cand[k]]; }
+        LCHK(hipMemcpyAsync(AC, hAC.data(), sizeof(int) * n, hipMemcpyHostToDevice, st));
+        LCHK(hipMemcpyAsync(posAC, hpos.data(), sizeof(int) * nC, hipMemcpyHostToDevice, st));
+        LCHK(hipMemcpyAsync(Sc, hSc.data(), sizeof(int) * nC, hipMemcpyHostToDevice, st));
+        LCHK(hipStreamSynchronize(st));
+        nAC = n;
+        nZ = nFR - nAC;
+        chk("dual_setup_blocked");
+        return RET_OK;
+    }
+    // step direction: S dy = db - A dx_FX + A D^-1 dg_FR (one product with A for the right-hand side), D dx_FR = A'dy - dg
+    void dual_step_direction() {
+        if (!dx_ready) hipLaunchKernelGGL(k_dx_fixed_zero_dy, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, lb, ub, lbN, ubN, dx, dy);
+        dx_ready = false;
+        hipLaunchKernelGGL(k_dual_rhs_vec, g1(nV), dim3(NT), 0, st, nV, Sb, hinv, gN, g, dx, w5);
+        A_times(w5, c3);
+        if (nAC > 0) {
+            hipLaunchKernelGGL(k_dual_rhs, g1(nAC), dim3(NT), 0, st, nAC, AC, Sc, lbA, ubA, lbAN, ubAN, c3, a1);
+            gemv_n(Minv, ldm, nAC, nAC, a1, 1.0, 0.0, nullptr, c_wY);
+            hipLaunchKernelGGL(k_scatter_active, g1(nAC), dim3(NT), 0, st, c_wY, AC, nAC, dy + nV);
+        }
+        AT_times(dy + nV, ATdy);
+        hipLaunchKernelGGL(k_dual_dx, g1(nV), dim3(NT), 0, st, nV, Sb, hinv, M.Hval, M.hreg, ATdy, gN, g, dx, Hdx);
+        A_times(dx, dAx);
+        chk("dual_step_direction");
+    }
+
     // ---- step direction -----------------------------------------------------------------
     void step_direction() {
+        if (dual) { dual_step_direction(); return; }
         if (!dx_ready) hipLaunchKernelGGL(k_dx_fixed_zero_dy, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, lb, ub, lbN, ubN, dx, dy);
         dx_ready = false;           // (set by drift_correction, whose kernel then has done this already)
         // what of the last step direction is carried over the change (range space: wY = Minv bA, xY = Y wY; null space: wZ)
@@ -2437,6 +2720,28 @@ struct RsqpLargeEngine::Impl {
         std::vector<int> freev;
         for (int v = 0; v < nV; v++) if (gb[v] == 0) freev.push_back(v);
         nFR = nZ = (int)freev.size();
+        if (dual) {
+            // range-space path: Sinv for the guessed constraints (blocked: GEMM + Cholesky + inverse; else one bordering each)
+            A_times(x, Ax);
+            std::vector<int> cand;
+            for (int r = 0; r < nC; r++) if (gc[r] != 0) cand.push_back(r);
+            bool done = cand.empty();
+            if (!done && blocked_setup && (int)cand.size() >= BLOCKED_MIN && (int)cand.size() <= nFR) {
+                const int rcb = dual_setup_blocked(gc, freev, cand);
+                if (rcb == RET_OK) done = true;
+                else if (rcb != RET_FALLBACK) return rcb;
+            }
+            if (!done) {
+                for (int r : cand) {
+                    dual_constraint_products(r);
+                    bool li = false;
+                    if (dual_li_decision(&li) != RET_OK) return RET_SETUP_FAILED;
+                    if (li) dual_add_constraint(r, gc[r]);
+                }
+            }
+            nZ = nFR - nAC;
+            if (profile) { (void)hipStreamSynchronize(st); fprintf(stderr, "[rsqp profile] setup_aux (range-space path): nFR %d nAC %d, t=%.3f s\n", nFR, nAC, now_s() - t_setup0); }
+        } else {
         if (nZ > 0) {
             LCHK(hipMemsetAsync(Z, 0, sizeof(double) * (size_t)ld * nZ, st));
             // free-variable index list staged in dy (read as ints; dy is rewritten before its next use)
@@ -2509,6 +2814,7 @@ struct RsqpLargeEngine::Impl {
                 if (!pd) return RET_SETUP_FAILED;
             }
         }
+        }   // (null-space path)
         // multipliers: zero when inactive, clipped to the admissible sign
         hipLaunchKernelGGL(k_clip_y, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, Sc, y);
         AT_times(y + nV, w1);
@@ -2559,6 +2865,7 @@ hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
     DA(Sb, nV); DA(Sc, nC); DA(AC, nC); DA(posAC, nC); DA(pid, P.nblk_ratio); DA(res_id, 2);
     if ((e = hipMemsetAsync(P.res_id, 0, 2 * sizeof(int), stream)) != hipSuccess) return e;      // res_id[0]: ticket counter of k_ratio1
     DA(d_fpos, nV); DA(d_cand, nC); DA(d_freev, nV);
+    DA(hinv, nV); DA(dflag, 4);
 #undef DA
     if ((e = rsqp_dense_work_alloc(&P.dw, nV)) != hipSuccess) return e;
     if ((e = hipHostMalloc(reinterpret_cast<void **>(&P.h_ctl), 64 * sizeof(double), hipHostMallocMapped)) != hipSuccess) return e;
@@ -2654,6 +2961,11 @@ int RsqpLargeEngine::solve(int mode, const double *d_g, const double *d_lb, cons
             }
         }
         P.nflips = 0;
+        {
+            bool ok = false;
+            if (P.dual_prepare(&ok) != RET_OK) return RET_SETUP_FAILED;
+            P.dual = ok;
+        }
         rc = P.setup_aux(gb, gc);
         if (rc != RET_OK && mode != RSQP_LMODE_COLD) {   // fall back to a cold start
             (void)hipMemsetAsync(P.x, 0, 8 * nV, st); (void)hipMemsetAsync(P.y, 0, 8 * (nV + nC), st);

@@ -870,6 +870,10 @@ int solve_large(rsqp_solver *s, int mode, int *nWSR, const double *x0, const dou
     if (s->H.initialised && !s->lp_mode) {
         m.Hjc = s->H.jc.p; m.Hir = s->H.ir.p; m.Hval = s->H.val.p; m.blk_h = s->H.blk_c.p; m.nblk_h = s->H.nblk_c;
         m.haveH = 1;
+        // a diagonal Hessian (one entry per column, on the diagonal): the engine's range-space path
+        bool diag = s->H.nnz == s->nV && (int)s->H.h_jc.size() == s->nV + 1;
+        for (int c = 0; c < s->nV && diag; c++) diag = s->H.h_jc[c] == c && s->H.h_ir[c] == c;
+        m.diagH = diag ? 1 : 0;
     }
     // dense copies when more than a quarter of the entries are stored (refreshed every solve
     // that follows a matrix update: cheap next to the solve)

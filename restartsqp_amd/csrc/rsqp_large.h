@@ -12,6 +12,8 @@ struct RsqpLargeMatrices {
     int haveH = 0;
     int sparse_rows = 0;             // rows of A are sparse enough (fill < 1/8) for gathered row products
     double hreg = 0.0;               // H + hreg*I
+    int diagH = 0;                   // H is stored as exactly one entry per column, on the diagonal (Hval = its diagonal): the
+                                     // engine may take its range-space path (qp_large.hip, Impl::dual)
     // optional dense column-major copies (null when the matrix is sparse)
     const double *denseA = nullptr;   // nC x nV, ld = nC
     const double *denseAT = nullptr;  // the same matrix row-major (= A' column-major, nV x nC, ld = nV): A x as a transposed
