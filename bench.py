@@ -241,7 +241,7 @@ def _cpu_changes_leg(args):
                       "CHEAPEST regime of the CPU path" % (done, chunk)}
 
 
-def large_configs(capi, problems, seq_steps=50, ref_rule_steps=4, cpu_seconds=10.0):
+def large_configs(capi, problems, seq_steps=50, ref_rule_steps=10, cpu_seconds=10.0):
     """BASELINE configs 2 and 3 on the HBM-resident engine (outside the timed region): cold solve of the dense
     2048 x 4096 QP; cold solve + the 50-QP warm-started sequence of the sparse 10 000 x 20 000 QP through
     rsqp_optimize_qp ("wall-clock per SQP iteration, n=10k sparse") under BOTH re-initialisation rules -- the opt-in
@@ -337,7 +337,7 @@ def large_configs(capi, problems, seq_steps=50, ref_rule_steps=4, cpu_seconds=10
     out["sparse_10000x20000_warm_sequence_y0_rule"] = seq
     ref = run_sequence(ref_rule_steps, 20260150, False)
     ref["note"] = (note + "; re-init rule: the REFERENCE's (library default): no guessed constraints, the working set of the constraints is "
-                   "rebuilt one change at a time; %d steps continuing the sequence above (the full 50 would take ~4 min)" % ref_rule_steps)
+                   "rebuilt one change at a time; %d steps continuing the sequence above (the full 50 would take ~1 min)" % ref_rule_steps)
     out["sparse_10000x20000_warm_sequence_reference_rule"] = ref
 
     # ---- the matrix-core path: one more VARIED step right after a VARIED one = hotstart(H, g, A, ..) on the full working set:
@@ -351,7 +351,24 @@ def large_configs(capi, problems, seq_steps=50, ref_rule_steps=4, cpu_seconds=10
         t = time.perf_counter(); nk = s.optimize_qp(); t = time.perf_counter() - t
         okk, stk, _, _ = s.test_optimality()
         sp = s.setup_profile()
-        if sp:
+        if sp and sp["range_space"]:
+            # diagonal Hessian: the engine's range-space path builds (A_AC,FR D^-1 A_AC,FR')^-1 -- Gram matrix by GEMM, blocked Cholesky,
+            # triangular inverse, U^-1 U^-T -- instead of QR + Q + R^-1 + Z'HZ (that set-up is measured below with the path switched off)
+            fl, ms = sp["flops_qr_q_rinv"] + sp["flops_zhz_chol_inv"], sp["ms_qr_q_rinv"] + sp["ms_zhz_chol_inv"]
+            tf = fl / (ms * 1e-3) / 1e12
+            out["roofline_mfma"] = {
+                "kernel": "blocked set-up of hotstart(H, g, A, ..) on the range-space path (diagonal H): Gram matrix B'B by k_dgemm "
+                          "(v_mfma_f64_16x16x4_f64), blocked Cholesky, triangular inverse, U^-1 U^-T, dense_la.hip",
+                "bound": "mfma", "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F64_PEAK_TFLOPS,
+                "traffic": None, "algorithmic_flops": fl, "ms": ms, "sizes": {k: sp[k] for k in ("nFR", "nAC")},
+                "parts": {"gram": {"ms": sp["ms_qr_q_rinv"], "flops": sp["flops_qr_q_rinv"],
+                                   "tflops": sp["flops_qr_q_rinv"] / max(sp["ms_qr_q_rinv"] * 1e-3, 1e-9) / 1e12},
+                          "chol_inv": {"ms": sp["ms_zhz_chol_inv"], "flops": sp["flops_zhz_chol_inv"],
+                                       "tflops": sp["flops_zhz_chol_inv"] / max(sp["ms_zhz_chol_inv"] * 1e-3, 1e-9) / 1e12}},
+                "step": {"mode": capi.Solver.MODE_NAMES.get(s.last_mode(), "?"), "mode_id": s.last_mode(), "wall_ms": 1e3 * t, "nWSR": nk, "certified": bool(okk)},
+                "note": "algorithmic flops, symmetric results counted once: Gram matrix n^2 m (m = nFR, n = nAC; the GEMM as launched "
+                        "computes both triangles: 2 n^2 m), Cholesky + triangular inverse + U^-1 U^-T n^3; time = HIP events on the engine's stream"}
+        elif sp:
             fl, ms = sp["flops_qr_q_rinv"] + sp["flops_zhz_chol_inv"], sp["ms_qr_q_rinv"] + sp["ms_zhz_chol_inv"]
             tf = fl / (ms * 1e-3) / 1e12
             out["roofline_mfma"] = {
@@ -366,6 +383,27 @@ def large_configs(capi, problems, seq_steps=50, ref_rule_steps=4, cpu_seconds=10
                 "note": "algorithmic flops: QR 2n^2(m-n/3) + explicit Q 4(m^2 n - m n^2 + n^3/3) + R^-1 n^3/3 (m = nFR, n = nAC); "
                         "Z'HZ nV nZ^2 + Cholesky, inverse and U^-1 U^-T nZ^3; time = HIP events on the engine's stream; "
                         "MFMA-busy counters: profiles/r03_*_pmc_mfma_blocked_setup.json"}
+    if "roofline_mfma" in out and "gram" in out["roofline_mfma"].get("parts", {}):
+        # the null-space path's set-up (general H) at the same size, stand-alone through rsqp_dense_qr: blocked Householder QR with
+        # Cholesky-QR panels + explicit Q + R^-1 of nFR x nAC (host buffers in and out; the time is HIP events around the device work)
+        try:
+            import ctypes as C
+            m_, n_ = out["roofline_mfma"]["sizes"]["nFR"], out["roofline_mfma"]["sizes"]["nAC"]
+            rng = np.random.default_rng(0)
+            B = np.asfortranarray(rng.normal(size=(m_, n_))); Q = np.zeros((m_, m_), order="F"); Ri = np.zeros((n_, n_), order="F")
+            nd, msq = C.c_int(0), C.c_float(0)
+            dpp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+            if capi.lib().rsqp_dense_qr(m_, n_, dpp(B), dpp(Q), dpp(Ri), 1e-9, C.byref(nd), C.byref(msq)) == 0:
+                m, n = float(m_), float(n_)
+                flq = 2.0 * n * n * (m - n / 3.0) + 4.0 * (m * m * n - m * n * n + n * n * n / 3.0) + n * n * n / 3.0
+                out["roofline_mfma_blocked_qr"] = {
+                    "kernel": "blocked Householder QR (Cholesky-QR panels) + explicit Q + R^-1, the set-up of the null-space path (general H), dense_la.hip",
+                    "bound": "mfma", "achieved": flq / (msq.value * 1e-3) / 1e12, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": flq / (msq.value * 1e-3) / 1e12 / MFMA_F64_PEAK_TFLOPS, "algorithmic_flops": flq, "ms": msq.value,
+                    "sizes": {"m": m_, "n": n_}, "note": "stand-alone (rsqp_dense_qr on a random matrix of the size above); not on the default path of this configuration any more"}
+            del B, Q, Ri
+        except (AttributeError, MemoryError):
+            pass
     # per-kernel rooflines of the HBM-resident engine: two more steps of the sequence (outside every timing above) with the
     # engine's own accounting on -- HIP events around every launch of a kernel class, algorithmic bytes per call
     s.set_reinit_guess(True)

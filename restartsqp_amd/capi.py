@@ -244,7 +244,7 @@ class Solver:
         if lib().rsqp_get_setup_profile(self._h, buf.ctypes.data_as(dp)) != 1:
             return None
         return {"nFR": int(buf[0]), "nAC": int(buf[1]), "nZ": int(buf[2]), "ms_qr_q_rinv": buf[3], "ms_zhz_chol_inv": buf[4],
-                "flops_qr_q_rinv": buf[5], "flops_zhz_chol_inv": buf[6]}
+                "flops_qr_q_rinv": buf[5], "flops_zhz_chol_inv": buf[6], "range_space": bool(buf[7])}
 
     def structure_seconds(self, which=0):
         return lib().rsqp_get_structure_seconds(self._h, which)

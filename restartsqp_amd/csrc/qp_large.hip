@@ -1417,10 +1417,10 @@ __global__ void __launch_bounds__(1024) k_dual_li_publish(int nV, const int *__r
     int i = threadIdx.x;
     for (; i + 1024 < nV; i += 2048) {
         const double x0 = a[i], x1 = a[i + 1024];
-        const double q0 = Sb[i] == 0 ? x0 - atu[i] : 0.0, q1 = Sb[i + 1024] == 0 ? x1 - atu[i + 1024] : 0.0;
+        const double q0 = (atu && Sb[i] == 0) ? x0 - atu[i] : 0.0, q1 = (atu && Sb[i + 1024] == 0) ? x1 - atu[i + 1024] : 0.0;
         a2 += x0 * x0; a2b += x1 * x1; r2 += q0 * q0; r2b += q1 * q1; ad += x0 * da[i]; adb += x1 * da[i + 1024];
     }
-    if (i < nV) { const double x0 = a[i], q0 = Sb[i] == 0 ? x0 - atu[i] : 0.0; a2 += x0 * x0; r2 += q0 * q0; ad += x0 * da[i]; }
+    if (i < nV) { const double x0 = a[i], q0 = (atu && Sb[i] == 0) ? x0 - atu[i] : 0.0; a2 += x0 * x0; r2 += q0 * q0; ad += x0 * da[i]; }
     int j = threadIdx.x;
     for (; j + 1024 < k; j += 2048) { cu += c[j] * u[j]; cub += c[j + 1024] * u[j + 1024]; }
     if (j < k) cu += c[j] * u[j];
@@ -1438,7 +1438,7 @@ __global__ void __launch_bounds__(1024) k_dual_li_publish(int nV, const int *__r
     for (int q = 0; q < 4; q++) { double v = 0.0; for (int w = 0; w < 16; w++) v += sh[q][w]; t[q] = v; }
     const double sp = t[2] - t[3];
     scal[6] = t[0]; scal[7] = t[1]; scal[5] = sp; scal[8] = sp != 0.0 ? 1.0 / sp : 0.0;
-    ctl[2] = t[0]; ctl[3] = t[1]; ctl[4] = sp;
+    ctl[2] = t[0]; ctl[3] = t[1]; ctl[4] = sp; ctl[5] = t[2];
     publish(ctl, seqv);
 }
 // the multiplier step CARRIED over a plain added constraint (the right-hand sides of the rows that were active before have
@@ -1448,14 +1448,16 @@ __global__ void __launch_bounds__(NT) k_dual_carry_add(int k, double om, const d
                                                        double *__restrict__ dyv, const double *__restrict__ scal, int r,
                                                        const int *__restrict__ Sc, const double *__restrict__ lbA,
                                                        const double *__restrict__ ubA, const double *__restrict__ lbAN,
-                                                       const double *__restrict__ ubAN, const double *__restrict__ Av) {
+                                                       const double *__restrict__ ubAN, const double *__restrict__ Av,
+                                                       const int *__restrict__ AC, double *__restrict__ dyC) {
+    // (dyC: the multiplier step by constraint index -- dy + nV, zeroed before -- filled here as well: one launch less)
     __shared__ double sh[4];
     double t = lane_sum4(k, [&](int j) { return c[j] * dyv[j]; });
     t = block_sum(t, sh);
     const double rk = (Sc[r] == -1 ? delta_of(lbAN[r], lbA[r]) : delta_of(ubAN[r], ubA[r])) + Av[r];
     const double lam = (rk - om * t) * scal[8];
-    for (int j = threadIdx.x; j < k; j += NT) dyv[j] = om * dyv[j] - lam * u[j];
-    if (threadIdx.x == 0) dyv[k] = lam;
+    for (int j = threadIdx.x; j < k; j += NT) { const double d = om * dyv[j] - lam * u[j]; dyv[j] = d; dyC[AC[j]] = d; }
+    if (threadIdx.x == 0) { dyv[k] = lam; dyC[r] = lam; }
 }
 // ... and over a plain removed constraint at position j (v = column j of Sinv before the update): om (dy - (dy_j / v_j) v) with
 // entry j dropped and the last one moved into its slot. One workgroup.
@@ -1657,7 +1659,7 @@ struct RsqpLargeEngine::Impl {
     int gemv_wgs = getenv("RSQP_GEMV_WGS") ? atoi(getenv("RSQP_GEMV_WGS")) : 4096;     // workgroups the chunked y = M w aims for
     bool reinit_from_y0 = false;
     // the last blocked set-up (rsqp_get_setup_profile): HIP-event time and algorithmic flops of its two parts
-    struct SetupStat { int valid = 0, m = 0, n = 0, nZ = 0; float ms_tq = 0.f, ms_wz = 0.f; double flops_tq = 0.0, flops_wz = 0.0; };
+    struct SetupStat { int valid = 0, m = 0, n = 0, nZ = 0, dual = 0; float ms_tq = 0.f, ms_wz = 0.f; double flops_tq = 0.0, flops_wz = 0.0; };
     SetupStat setup_stat;
     hipEvent_t se0 = nullptr, se1 = nullptr, se2 = nullptr;
     static constexpr int BLOCKED_MIN = 32;   // fewer active constraints: the sequential construction is as fast
@@ -2375,14 +2377,24 @@ struct RsqpLargeEngine::Impl {
     }
     // products of an incoming row with the working set: a_FR in w1, D^-1 a_FR in w5, c in a1, u = Sinv c in a2 (and scattered by
     // constraint in c1), A_AC'u in w2; |a_FR|^2, |r|^2, the pivot s published (scal[5..8])
+    // Two stages: the pivot s first -- s > 1e-6 a_FR'D^-1 a_FR is independence beyond doubt (|P a| > 1e-3 |a| in the D^-1 metric);
+    // only below that the residual r of the representation by the active rows is formed (A_AC'u: one more product with A) and
+    // published in a second round (dual_residual: also what an exchange needs, c1 = u by constraint and w2 = A_AC'u)
     void dual_products_tail() {
         A_times(w5, c3);
         if (nAC > 0) hipLaunchKernelGGL(k_gather_active, g1(nAC), dim3(NT), 0, st, c3, AC, nAC, a1);
         gemv_n(Minv, ldm, nAC, nAC, a1, 1.0, 0.0, nullptr, a2);
+        hipLaunchKernelGGL(k_dual_li_publish, dim3(1), dim3(1024), 0, st, nV, (const int *)nullptr, w1, w5, (const double *)nullptr, nAC, a1, a2,
+                           scal, d_ctl, next_seq());
+        dual_have_residual = false;
+    }
+    bool dual_have_residual = false;
+    void dual_residual() {
         fill(c1, nC, 0.0);
         if (nAC > 0) hipLaunchKernelGGL(k_scatter_active, g1(nAC), dim3(NT), 0, st, a2, AC, nAC, c1);
         AT_times(c1, w2);
         hipLaunchKernelGGL(k_dual_li_publish, dim3(1), dim3(1024), 0, st, nV, Sb, w1, w5, w2, nAC, a1, a2, scal, d_ctl, next_seq());
+        dual_have_residual = true;
     }
     void dual_constraint_products(int r) {
         row_of_A(r, w1, false);
@@ -2395,7 +2407,13 @@ struct RsqpLargeEngine::Impl {
     }
     int dual_li_decision(bool *li) {
         if (wait_ctl() != RET_OK) return wait_failed();
-        const double a2n = h_ctl[2], r2 = h_ctl[3], sp = h_ctl[4];
+        double a2n = h_ctl[2], sp = h_ctl[4];
+        const double ad = h_ctl[5];
+        if (nFR - nAC > 0 && a2n > 0.0 && sp > 1e-6 * ad) { *li = true; return RET_OK; }
+        dual_residual();
+        if (wait_ctl() != RET_OK) return wait_failed();
+        a2n = h_ctl[2]; sp = h_ctl[4];
+        const double r2 = h_ctl[3];
         *li = nFR - nAC > 0 && a2n > 0.0 && std::sqrt(r2) > RSQP_EPS_LI * std::sqrt(a2n) && sp > 0.0;
         return RET_OK;
     }
@@ -2453,7 +2471,11 @@ struct RsqpLargeEngine::Impl {
         LCHK(hipMemsetAsync(B, 0, sizeof(double) * (size_t)lb_ * n, st));
         hipLaunchKernelGGL(k_build_B, dim3(n), dim3(NT), 0, st, M.Arp, M.Aci, M.Arv, d_cand, d_fpos, B, lb_);
         hipLaunchKernelGGL(k_dual_scale_rows, dim3((m + NT - 1) / NT, n), dim3(NT), 0, st, m, d_freev, hinv, B, lb_);
+        if (!se0) { (void)hipEventCreate(&se0); (void)hipEventCreate(&se1); (void)hipEventCreate(&se2); }
+        setup_stat = SetupStat();
+        (void)hipEventRecord(se0, st);
         LCHK(rsqp_dgemm(true, false, n, n, m, 1.0, B, lb_, B, lb_, 0.0, G, lg, st));
+        (void)hipEventRecord(se1, st);
         LCHK(hipMemsetAsync(dw.flag, 0, sizeof(int) * 4, st));
         LCHK(rsqp_dpotrf_upper(n, G, lg, 1e-10, RSQP_EPS_PD_ABS, &dw, st));      // (a pivot below 1e-10 of its diagonal: the Gram matrix cannot decide independence -- one by one then)
         LCHK(hipMemcpyAsync(h_pinned_i, dw.flag, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
@@ -2461,6 +2483,16 @@ struct RsqpLargeEngine::Impl {
         if (h_pinned_i[1] != 0) return RET_FALLBACK;
         LCHK(rsqp_dtrtri_upper(n, G, lg, Ui, lg, &dw, st));
         LCHK(rsqp_dgemm(false, true, n, n, n, 1.0, Ui, lg, Ui, lg, 0.0, Minv, ldm, st));
+        (void)hipEventRecord(se2, st);
+        {   // what the matrix cores were asked for (algorithmic: the symmetric results counted once): Gram matrix n^2 m, Cholesky
+            // n^3/3, triangular inverse n^3/3, U^-1 U^-T n^3/3
+            (void)hipEventSynchronize(se2);
+            float ms1 = 0.f, ms2 = 0.f;
+            (void)hipEventElapsedTime(&ms1, se0, se1); (void)hipEventElapsedTime(&ms2, se1, se2);
+            const double dn = n, dm = m;
+            setup_stat.valid = 1; setup_stat.dual = 1; setup_stat.m = m; setup_stat.n = n; setup_stat.nZ = m - n;
+            setup_stat.ms_tq = ms1; setup_stat.ms_wz = ms2; setup_stat.flops_tq = dn * dn * dm; setup_stat.flops_wz = dn * dn * dn;
+        }
         std::vector<int> hpos(nC, -1);
         for (int k = 0; k < n; k++) { hAC[k] = cand[k]; hpos[cand[k]] = k; hSc[cand[k]] = gc[cand[k]]; }
         LCHK(hipMemcpyAsync(AC, hAC.data(), sizeof(int) * n, hipMemcpyHostToDevice, st));
@@ -2478,19 +2510,21 @@ struct RsqpLargeEngine::Impl {
         dx_ready = false;
         hipLaunchKernelGGL(k_dual_rhs_vec, g1(nV), dim3(NT), 0, st, nV, Sb, hinv, gN, g, dx, w5);
         A_times(w5, c3);
+        bool scattered = false;
         if (nAC > 0) {
             if (carry_ready && carry_valid) {
                 carried++; stat_carried++;                                    // (transformed by dual_remove_constraint already)
             } else if (carry_pending && carry_valid) {
                 hipLaunchKernelGGL(k_dual_carry_add, dim3(1), dim3(NT), 0, st, nAC - 1, 1.0 - last_tau, a1, a2, c_wY, scal, dual_carry_row, Sc,
-                                   lbA, ubA, lbAN, ubAN, c3);
+                                   lbA, ubA, lbAN, ubAN, c3, AC, dy + nV);
                 carried++; stat_carried++;
+                scattered = true;
             } else {
                 hipLaunchKernelGGL(k_dual_rhs, g1(nAC), dim3(NT), 0, st, nAC, AC, Sc, lbA, ubA, lbAN, ubAN, c3, a1);
                 gemv_n(Minv, ldm, nAC, nAC, a1, 1.0, 0.0, nullptr, c_wY);
                 carried = 0;
             }
-            hipLaunchKernelGGL(k_scatter_active, g1(nAC), dim3(NT), 0, st, c_wY, AC, nAC, dy + nV);
+            if (!scattered) hipLaunchKernelGGL(k_scatter_active, g1(nAC), dim3(NT), 0, st, c_wY, AC, nAC, dy + nV);
         }
         carry_pending = carry_ready = false;
         carry_valid = true;
@@ -3073,7 +3107,7 @@ void RsqpLargeEngine::profile_enable(bool on) { p_->profile = on; }
 int RsqpLargeEngine::setup_profile(double *out8) const {
     const Impl::SetupStat &t = p_->setup_stat;
     if (!t.valid) return 0;
-    out8[0] = t.m; out8[1] = t.n; out8[2] = t.nZ; out8[3] = t.ms_tq; out8[4] = t.ms_wz; out8[5] = t.flops_tq; out8[6] = t.flops_wz; out8[7] = 0.0;
+    out8[0] = t.m; out8[1] = t.n; out8[2] = t.nZ; out8[3] = t.ms_tq; out8[4] = t.ms_wz; out8[5] = t.flops_tq; out8[6] = t.flops_wz; out8[7] = t.dual;
     return 1;
 }
 // tuning aid: device time per call of one product / update kernel class on an nrows x ncols matrix (the engine's Z

@@ -49,7 +49,8 @@ public:
     void set_reinit_from_y0(bool on);   // warm start without guessed constraints: from A x0 (default, the reference) or sides from sign(y0) (opt-in)
     void profile_get(double *out4n) const;
     // the last blocked (matrix-core) set-up of a non-empty working set: {nFR, nAC, nZ, ms QR + Q + R^-1, ms Z'HZ + Cholesky +
-    // inverse, algorithmic flops of the first part, of the second, 0}; returns 0 when no blocked set-up has run
+    // inverse, algorithmic flops of the first part, of the second, 0}; range-space path: {nFR, nAC, nFR - nAC, ms Gram matrix,
+    // ms Cholesky + inverse, their algorithmic flops, 1}; returns 0 when no blocked set-up has run
     int setup_profile(double *out8) const;
     // device ms per call of kernel class `kind` (0 gemv_n, 1 gemv_t, 2 ger) on an nrows x ncols matrix (<= nV each)
     int time_kernel(int kind, int nrows, int ncols, int reps, float *ms);
