@@ -1487,6 +1487,13 @@ __global__ void k_dual_border(double *Sinv, long long ldm, int nAC, const double
         Sinv[(long long)nAC * ldm + j] = b;
     }
 }
+// the rank-1 part of a bordering is DEFERRED (it rides on the next product with Sinv, k_ger_gemv_n1): u and 1 / s out of the way
+// of the next products, zero behind the block it applies to (the kernel then updates rows / columns 0..n) only)
+__global__ void k_dual_keep_u(int n, const double *__restrict__ u, double *__restrict__ keep, double *__restrict__ scal, int to) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) keep[j] = u[j];
+    if (j == n) { keep[n] = 0.0; keep[n + 1] = 0.0; scal[to] = scal[8]; }
+}
 // removal of the constraint at position j: v = column j of Sinv, coef = -1 / v_j  (Sinv += coef v v' zeroes row and column j)
 __global__ void k_dual_colcoef(const double *__restrict__ Sinv, long long ldm, int k, int j, double *__restrict__ v, double *__restrict__ scal) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1631,7 +1638,7 @@ struct RsqpLargeEngine::Impl {
     // next hot start falls back to a full set-up
     int wait_failed() {
         status = QPS_NOTINITIALISED;
-        pendZ.on = pendW.on = pendY.on = pendM.on = false;
+        pendZ.on = pendW.on = pendY.on = pendM.on = pendS.on = false;
         return RET_SETUP_FAILED;
     }
     double *h_pinned = nullptr;  // small pinned read-back buffer
@@ -1666,7 +1673,7 @@ struct RsqpLargeEngine::Impl {
 
     ~Impl() {
         double *dv[] = {Z, Y, Minv, Wz, x, g, lb, ub, gN, lbN, ubN, dx, w1, w2, w3, w4, w5, w6, wz1, wz2, wz3, Ax, lbA, ubA,
-                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col, c_wY, c_wY2, c_xY, c_xi, c_wZ, py_t, py_v, pm_s, hinv};
+                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col, c_wY, c_wY2, c_xY, c_xi, c_wZ, py_t, py_v, pm_s, hinv, ps_u};
         for (double *p : dv) if (p) (void)hipFree(p);
         if (big) (void)hipFree(big);
         rsqp_dense_work_free(&dw);
@@ -1778,6 +1785,29 @@ struct RsqpLargeEngine::Impl {
     // (nAC x nAC, symmetric, in the buffer of Minv) replace Z, Y, Minv, Wz: per working-set change one rank-1 update of Sinv and
     // one or two products with it -- nAC^2 entries instead of nV nZ + nZ^2 + nAC^2 + nV nAC. Same homotopy, ratio tests, exchange
     // rule and drift correction; the definiteness guard of a removal never fires (Z'DZ is positive definite for every Z).
+    struct { bool on = false; int n = 0; } pendS;      // Sinv[0..n) x [0..n) += scal[S_KEEP_S] ps_u ps_u' not applied yet
+    static constexpr int S_KEEP_S = 45;
+    double *ps_u = nullptr;
+    bool dual_defer = getenv("RSQP_LARGE_NO_FUSE") == nullptr;
+    void dual_flush() {
+        if (!pendS.on) return;
+        pendS.on = false;
+        ger(Minv, ldm, pendS.n, pendS.n, ps_u, ps_u, S_KEEP_S, 1.0);
+    }
+    // out = Sinv w, the deferred rank-1 update applied on the way (one read + one write of Sinv instead of read + write + read)
+    void dual_sinv_times(const double *wv, double *out) {
+        if (pendS.on && nAC == pendS.n + 1 && (ldm & 1) == 0 && ((reinterpret_cast<unsigned long long>(Minv) | reinterpret_cast<unsigned long long>(ps_u)) & 15) == 0) {
+            pendS.on = false;
+            pbegin();
+            hipLaunchKernelGGL((k_ger_gemv_n1<NT>), dim3((nAC + 15) / 16), dim3(NT), 0, st, Minv, ldm, nAC, nAC, ps_u, ps_u, scal, S_KEEP_S, 1.0, wv,
+                               1.0, 0.0, (const double *)nullptr, out, (const int *)nullptr, (double *)nullptr);
+            pend(8, 16.0 * nAC * (double)nAC);
+            chk("dual ger_gemv_n1");
+            return;
+        }
+        dual_flush();
+        gemv_n(Minv, ldm, nAC, nAC, wv, 1.0, 0.0, nullptr, out);
+    }
     bool dual_enabled = getenv("RSQP_LARGE_NO_DUAL") == nullptr;
     bool dual = false;               // the factors of this handle are Sinv (set by setup_aux; a hot start on new vectors keeps it)
     double *hinv = nullptr;          // 1 / (diag(H) + hreg)
@@ -2383,7 +2413,7 @@ struct RsqpLargeEngine::Impl {
     void dual_products_tail() {
         A_times(w5, c3);
         if (nAC > 0) hipLaunchKernelGGL(k_gather_active, g1(nAC), dim3(NT), 0, st, c3, AC, nAC, a1);
-        gemv_n(Minv, ldm, nAC, nAC, a1, 1.0, 0.0, nullptr, a2);
+        dual_sinv_times(a1, a2);
         hipLaunchKernelGGL(k_dual_li_publish, dim3(1), dim3(1024), 0, st, nV, (const int *)nullptr, w1, w5, (const double *)nullptr, nAC, a1, a2,
                            scal, d_ctl, next_seq());
         dual_have_residual = false;
@@ -2419,7 +2449,11 @@ struct RsqpLargeEngine::Impl {
     }
     // Sinv <- [[Sinv + u u'/s, -u/s], [-u'/s, 1/s]]  (u in a2, 1/s in scal[8])
     void dual_add_constraint(int r, int side, int yidx = -1, double yval = 0.0) {
-        ger(Minv, ldm, nAC, nAC, a2, a2, 8, 1.0);
+        dual_flush();       // (none is pending here: the products of this row have applied it)
+        if (dual_defer && nAC > 0) {
+            hipLaunchKernelGGL(k_dual_keep_u, g1(nAC + 1), dim3(NT), 0, st, nAC, a2, ps_u, scal, S_KEEP_S);
+            pendS.on = true; pendS.n = nAC;
+        } else ger(Minv, ldm, nAC, nAC, a2, a2, 8, 1.0);
         hipLaunchKernelGGL(k_dual_border, g1(nAC + 1), dim3(NT), 0, st, Minv, ldm, nAC, a2, scal, AC, posAC, Sc, r, side, y, yidx, yval);
         hAC[nAC] = r; hSc[r] = side;
         nAC++;
@@ -2427,6 +2461,7 @@ struct RsqpLargeEngine::Impl {
     }
     // a variable joins the fixed set: S loses a_v a_v'/d_v, Sinv += u u'/s with the same u and s as a bordering would use
     void dual_add_bound(int v, int side) {
+        dual_flush();
         ger(Minv, ldm, nAC, nAC, a2, a2, 8, 1.0);
         hipLaunchKernelGGL(k_set_Sb, dim3(1), dim3(1), 0, st, Sb, v, side);
         hSb[v] = side;
@@ -2435,6 +2470,7 @@ struct RsqpLargeEngine::Impl {
     }
     void dual_remove_constraint(int k, bool carry) {
         const int r = hAC[k];
+        dual_flush();
         hipLaunchKernelGGL(k_dual_colcoef, g1(nAC), dim3(NT), 0, st, Minv, ldm, nAC, k, a3, scal);
         if (carry) hipLaunchKernelGGL(k_dual_carry_remove, dim3(1), dim3(NT), 0, st, nAC, k, 1.0 - last_tau, a3, c_wY);
         ger(Minv, ldm, nAC, nAC, a3, a3, 9, 1.0);
@@ -2452,7 +2488,7 @@ struct RsqpLargeEngine::Impl {
         if (nAC == 0) return;
         fill(a4, nAC, 0.0);
         hipLaunchKernelGGL(k_col_of_A_active, dim3(4), dim3(NT), 0, st, M.Ajc, M.Air, M.Aval, v, posAC, a4);  // a_v
-        gemv_n(Minv, ldm, nAC, nAC, a4, 1.0, 0.0, nullptr, a3);          // w = Sinv a_v
+        dual_sinv_times(a4, a3);                                         // w = Sinv a_v
         hipLaunchKernelGGL(k_dual_free_coef, dim3(1), dim3(NT), 0, st, nAC, a4, a3, M.Hval, M.hreg, v, scal);
         ger(Minv, ldm, nAC, nAC, a3, a3, 9, 1.0);
     }
@@ -2521,7 +2557,7 @@ struct RsqpLargeEngine::Impl {
                 scattered = true;
             } else {
                 hipLaunchKernelGGL(k_dual_rhs, g1(nAC), dim3(NT), 0, st, nAC, AC, Sc, lbA, ubA, lbAN, ubAN, c3, a1);
-                gemv_n(Minv, ldm, nAC, nAC, a1, 1.0, 0.0, nullptr, c_wY);
+                dual_sinv_times(a1, c_wY);
                 carried = 0;
             }
             if (!scattered) hipLaunchKernelGGL(k_scatter_active, g1(nAC), dim3(NT), 0, st, c_wY, AC, nAC, dy + nV);
@@ -2668,7 +2704,7 @@ struct RsqpLargeEngine::Impl {
         double sum_nFR = 0.0, sum_nAC = 0.0, sum_nZ = 0.0;      // reported by RSQP_PROFILE: the sizes the products run on
         status = QPS_PERFORMINGHOMOTOPY;
         dx_ready = false;
-        pendZ.on = pendW.on = pendY.on = pendM.on = false;      // (nothing is deferred across solves; a solve that failed half-way leaves nothing behind)
+        pendZ.on = pendW.on = pendY.on = pendM.on = pendS.on = false;      // (nothing is deferred across solves; a solve that failed half-way leaves nothing behind)
         carry_valid = carry_pending = carry_ready = false;
         carried = 0;
         refresh_products();
@@ -2716,6 +2752,7 @@ struct RsqpLargeEngine::Impl {
             fprintf(stderr, "[rsqp profile] changes by kind: constraint out %lld, bound out %lld, constraint in %lld, bound in %lld; step directions with the range-space part carried %lld, null-space part too %lld\n",
                     kind_count[1], kind_count[2], kind_count[3], kind_count[4], stat_carried, stat_carried_null);
         flush_pending();
+        dual_flush();
         *nWSR = iter;
         return rcode;
     }
@@ -2844,6 +2881,7 @@ struct RsqpLargeEngine::Impl {
                     if (dual_li_decision(&li) != RET_OK) return RET_SETUP_FAILED;
                     if (li) dual_add_constraint(r, gc[r]);
                 }
+                dual_flush();
             }
             nZ = nFR - nAC;
             if (profile) { (void)hipStreamSynchronize(st); fprintf(stderr, "[rsqp profile] setup_aux (range-space path): nFR %d nAC %d, t=%.3f s\n", nFR, nAC, now_s() - t_setup0); }
@@ -2971,7 +3009,7 @@ hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
     DA(Sb, nV); DA(Sc, nC); DA(AC, nC); DA(posAC, nC); DA(pid, P.nblk_ratio); DA(res_id, 2);
     if ((e = hipMemsetAsync(P.res_id, 0, 2 * sizeof(int), stream)) != hipSuccess) return e;      // res_id[0]: ticket counter of k_ratio1
     DA(d_fpos, nV); DA(d_cand, nC); DA(d_freev, nV);
-    DA(hinv, nV); DA(dflag, 4);
+    DA(hinv, nV); DA(dflag, 4); DA(ps_u, P.nAmax + 4);
 #undef DA
     if ((e = rsqp_dense_work_alloc(&P.dw, nV)) != hipSuccess) return e;
     if ((e = hipHostMalloc(reinterpret_cast<void **>(&P.h_ctl), 64 * sizeof(double), hipHostMallocMapped)) != hipSuccess) return e;
