@@ -156,6 +156,74 @@ def test_deferred_reflection_kernels_match_oracle(capi, oracle, monkeypatch):
         monkeypatch.delenv(knob)
 
 
+def _diag_h_qp(rng, nV, nC, density, hmin=0.5):
+    """random_qp with a DIAGONAL Hessian stored as one entry per column (what the engine's range-space path is for)."""
+    q = problems.random_qp(rng, nV, nC, density)
+    h = hmin + np.abs(rng.normal(size=nV))
+    return QPData(nV, nC, np.arange(nV + 1, dtype=np.int32), np.arange(nV, dtype=np.int32), h, q.A_jc, q.A_ir, q.A_val, q.g, q.lb, q.ub,
+                  q.lbA, q.ubA, name="diagH_%dx%d" % (nV, nC))
+
+
+@pytest.mark.parametrize("knob", [None, "RSQP_LARGE_NO_DUAL", "RSQP_LARGE_NO_CARRY", "RSQP_LARGE_NO_FUSE", "RSQP_NO_BLOCKED_SETUP"])
+def test_range_space_path_all_call_shapes(capi, oracle, monkeypatch, knob):
+    """Diagonal positive Hessian: the HBM-resident engine keeps the explicit inverse of A_AC,FR D^-1 A_AC,FR' instead of the null-space
+    factors (qp_large.hip, Impl::dual). Every call shape against the oracle -- cold, hot start on new vectors, hot start with new
+    matrices (blocked Gram + Cholesky set-up from 32 active constraints on), warm re-initialisation under both rules -- with the
+    path's knobs in turn: switched off (null-space path: the same answers), multiplier step exact at every change, rank-1 updates
+    not deferred, sequential set-up."""
+    if knob:
+        monkeypatch.setenv(knob, "1")
+    rng = np.random.default_rng(8800)
+    for trial, (nV, nC, dens) in enumerate(((60, 90, 0.4), (150, 260, 0.25), (96, 40, 0.6))):
+        q = _diag_h_qp(rng, nV, nC, dens)
+        s = load(capi, q)
+        n = s.solve(capi.MODE_COLD, 20000)
+        qp, rc, n_or = oracle_cold(oracle, q, 20000)
+        same_as_oracle(s, n, qp, n_or)
+        q2 = problems.perturb(rng, q, 0.05)
+        for w, v in zip(range(5), (q2.g, q2.lb, q2.ub, q2.lbA, q2.ubA)):
+            s.set_vector(w, v)
+        n = s.solve(capi.MODE_HOT_VECTORS, 20000)
+        rc, n_or = qp.hotstart(q2.g, q2.lb, q2.ub, q2.lbA, q2.ubA, 20000)
+        same_as_oracle(s, n, qp, n_or)
+        A2 = q2.A_val * (1.0 + 0.01 * rng.normal(size=q2.A_val.shape))
+        s.set_A_csc(q2.A_jc, q2.A_ir, A2); s.set_H_csc(q2.H_jc, q2.H_ir, q2.H_val * 1.05)
+        n = s.solve(capi.MODE_HOT_MATRICES, 20000)
+        qp.set_A_csc(q2.A_jc, q2.A_ir, A2); qp.set_H_csc(q2.H_jc, q2.H_ir, q2.H_val * 1.05)
+        rc, n_or = qp.hotstart_matrices(q2.g, q2.lb, q2.ub, q2.lbA, q2.ubA, 20000)
+        same_as_oracle(s, n, qp, n_or)
+        if knob is None and trial == 1:
+            # guard against a refactoring that silently switches the path off: the blocked set-up of this hot start was the
+            # range-space one (Gram matrix + Cholesky), not QR + Q + R^-1
+            sp = s.setup_profile()
+            assert sp is not None and sp["range_space"], sp
+        x0, y0, gb = s.x, s.y, s.working_set_raw()[0]
+        q3 = problems.perturb(rng, q2, 0.05)
+        for w, v in zip(range(5), (q3.g, q3.lb, q3.ub, q3.lbA, q3.ubA)):
+            s.set_vector(w, v)
+        rule = bool(trial & 1)
+        s.set_reinit_guess(rule); qp.set_guess_constraints_from_y0(rule)
+        n = s.solve(capi.MODE_WARM_REINIT, 20000, x0, y0, gb)
+        rc, n_or = qp.init(q3.g, q3.lb, q3.ub, q3.lbA, q3.ubA, 20000, x0=x0, y0=y0, guess_b=gb)
+        same_as_oracle(s, n, qp, n_or)
+        s.close()
+
+
+def test_range_space_path_needs_a_positive_diagonal(capi, oracle):
+    """A diagonal Hessian with a zero or negative entry is not the range-space path's (D^-1 does not exist / the reduced Hessian can be
+    indefinite): the engine keeps the null-space path with its definiteness guard, and the answer is the oracle's."""
+    rng = np.random.default_rng(8801)
+    q = _diag_h_qp(rng, 40, 30, 0.5)
+    for bad in (0.0, -0.3):
+        h = q.H_val.copy(); h[7] = bad
+        qb = QPData(q.nV, q.nC, q.H_jc, q.H_ir, h, q.A_jc, q.A_ir, q.A_val, q.g, q.lb, q.ub, q.lbA, q.ubA)
+        s = load(capi, qb)
+        n = s.solve(capi.MODE_COLD, 20000)
+        qp, rc, n_or = oracle_cold(oracle, qb, 20000)
+        same_as_oracle(s, n, qp, n_or, check_nwsr=False)
+        s.close()
+
+
 def test_deferred_and_carried_paths_are_taken(capi):
     """Guard against a refactoring that silently switches the round-3 paths off: with the engine's own accounting on, a cold
     start of a mid-size problem (even leading dimension) must show launches of both fused kernels of the deferred reflections."""
