@@ -96,7 +96,7 @@ __device__ __forceinline__ void store_tile(const double (&r)[GK * T / NTHR], dou
 template <int TM, int TN, int NW, int MINW, int GK>
 __global__ void __launch_bounds__(NW * 64, MINW)
 k_dgemm(int ta, int tb, int m, int n, int kfull, int kc, double alpha, const double *__restrict__ A, long long lda,
-        const double *__restrict__ B, long long ldb, double beta, double *__restrict__ C, long long ldc) {
+        const double *__restrict__ B, long long ldb, double beta, double *__restrict__ C, long long ldc, int upper) {
     extern __shared__ __attribute__((aligned(16))) double gemm_lds[];
     // RSQP_GEMM_DB=1 (tuning build, tools/gemm_pad_variants.sh): two LDS buffers, the tiles of step i + 1 stored while step i is
     // still being multiplied, one barrier per K step instead of two -- measured SLOWER (51.3 vs 53.1 TFLOP/s on 4096^3, QR
@@ -109,6 +109,9 @@ k_dgemm(int ta, int tb, int m, int n, int kfull, int kc, double alpha, const dou
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int i0 = blockIdx.x * TM, j0 = blockIdx.y * TN;
+    // upper != 0: a SYMMETRIC result of which only the upper triangle is wanted (Gram matrix, U^-1 U^-T, the trailing update of the
+    // Cholesky factorisation): tiles strictly below the diagonal are not computed (half the work; what they hold is not defined)
+    if (upper && i0 >= j0 + TN) return;
     const bool akc = ta != 0, bkc = tb == 0;   // k-contiguous operands
     // split K: slice blockIdx.z of the inner dimension, partial result into its own m x n slab
     const int kbeg = blockIdx.z * kc, k = min(kfull, kbeg + kc);
@@ -205,7 +208,7 @@ __global__ void k_splitk_reduce(int m, int n, int splits, const double *__restri
 
 static hipError_t dgemm_ws(bool transA, bool transB, int m, int n, int k, double alpha, const double *A, long long lda,
                            const double *B, long long ldb, double beta, double *C, long long ldc, double *ws,
-                           long long ws_cap, hipStream_t st) {
+                           long long ws_cap, hipStream_t st, int upper = 0) {
     if (m <= 0 || n <= 0) return hipSuccess;
     const int ta = transA ? 1 : 0, tb = transB ? 1 : 0;
     // large tiles when they still give every CU work, small ones otherwise
@@ -242,7 +245,7 @@ static hipError_t dgemm_ws(bool transA, bool transB, int m, int n, int k, double
         static std::atomic<unsigned long long> set_{0};                                                            \
         rsqp_allow_full_lds(reinterpret_cast<const void *>(&k_dgemm<a, b, nw, mw, gk>), set_, (int)lds_);          \
         hipLaunchKernelGGL((k_dgemm<a, b, nw, mw, gk>), grid, dim3(nw * 64), lds_, st, ta, tb, m, n, k, kc, al, A, \
-                           lda, B, ldb, be, Cout, ldo);                                                            \
+                           lda, B, ldb, be, Cout, ldo, upper);                                                     \
     } while (0)
     if (TM == 128 && TN == 128) {
         // measured on 4096^3: 8 waves (4 resident per SIMD, 122 VGPRs) 53.5 TFLOP/s; 4 waves x 2 resident
@@ -264,6 +267,33 @@ static hipError_t dgemm_ws(bool transA, bool transB, int m, int n, int k, double
 hipError_t rsqp_dgemm(bool transA, bool transB, int m, int n, int k, double alpha, const double *A, long long lda,
                       const double *B, long long ldb, double beta, double *C, long long ldc, hipStream_t st) {
     return dgemm_ws(transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, 0, st);
+}
+// the same for a symmetric n x n result of which only the UPPER triangle is wanted (tiles strictly below the diagonal are skipped)
+hipError_t rsqp_dgemm_upper(bool transA, bool transB, int n, int k, double alpha, const double *A, long long lda,
+                            const double *B, long long ldb, double beta, double *C, long long ldc, hipStream_t st) {
+    return dgemm_ws(transA, transB, n, n, k, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, 0, st, 1);
+}
+namespace {
+// lower triangle := transpose of the upper one (32 x 32 tiles through LDS)
+__global__ void k_mirror_upper(int n, double *__restrict__ M, long long ld) {
+    __shared__ double tile[32][33];
+    const int bi = blockIdx.x, bj = blockIdx.y;      // tile (rows bi, cols bj) of the UPPER part, bi <= bj
+    if (bi > bj) return;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int i = bi * 32 + threadIdx.x, j = bj * 32 + r;
+        tile[r][threadIdx.x] = (i < n && j < n) ? M[i + (long long)j * ld] : 0.0;      // tile[jj][ii] = M(i, j)
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int i2 = bj * 32 + threadIdx.x, j2 = bi * 32 + r;                         // M(i2, j2) = M(j2, i2), i2 >= j2
+        if (i2 < n && j2 < n && i2 > j2) M[i2 + (long long)j2 * ld] = tile[threadIdx.x][r];
+    }
+}
+}  // namespace
+hipError_t rsqp_mirror_upper(int n, double *M, long long ld, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mirror_upper, dim3((n + 31) / 32, (n + 31) / 32), dim3(32, 8), 0, st, n, M, ld);
+    return hipGetLastError();
 }
 
 // =====================================================================================
@@ -1040,8 +1070,8 @@ hipError_t rsqp_dpotrf_upper(int n, double *G, long long ldg, double pd_rel, dou
             // U12 = Ujj^-T G12  (jb x nt): via W, then copied back
             DCHK(rsqp_dgemm(true, false, jb, nt, jb, 1.0, Uinv, NB, G12, ldg, 0.0, w->W, NB, st));
             DCHK(hipMemcpy2DAsync(G12, sizeof(double) * ldg, w->W, sizeof(double) * NB, sizeof(double) * jb, nt, hipMemcpyDeviceToDevice, st));
-            // G22 -= U12' U12 (both triangles: the lower one is scratch and zeroed below)
-            DCHK(rsqp_dgemm(true, false, nt, nt, jb, -1.0, w->W, NB, w->W, NB, 1.0, G + (k0 + jb) + (long long)(k0 + jb) * ldg, ldg, st));
+            // G22 -= U12' U12 (the upper triangle's tiles only: the lower one is scratch and zeroed below)
+            DCHK(rsqp_dgemm_upper(true, false, nt, jb, -1.0, w->W, NB, w->W, NB, 1.0, G + (k0 + jb) + (long long)(k0 + jb) * ldg, ldg, st));
         }
     }
     hipLaunchKernelGGL(k_zero_lower, dim3((n + 255) / 256, n), dim3(256), 0, st, n, G, ldg);

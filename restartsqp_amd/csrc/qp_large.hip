@@ -2510,7 +2510,7 @@ struct RsqpLargeEngine::Impl {
         if (!se0) { (void)hipEventCreate(&se0); (void)hipEventCreate(&se1); (void)hipEventCreate(&se2); }
         setup_stat = SetupStat();
         (void)hipEventRecord(se0, st);
-        LCHK(rsqp_dgemm(true, false, n, n, m, 1.0, B, lb_, B, lb_, 0.0, G, lg, st));
+        LCHK(rsqp_dgemm_upper(true, false, n, m, 1.0, B, lb_, B, lb_, 0.0, G, lg, st));      // (the Cholesky factorisation reads the upper triangle)
         (void)hipEventRecord(se1, st);
         LCHK(hipMemsetAsync(dw.flag, 0, sizeof(int) * 4, st));
         LCHK(rsqp_dpotrf_upper(n, G, lg, 1e-10, RSQP_EPS_PD_ABS, &dw, st));      // (a pivot below 1e-10 of its diagonal: the Gram matrix cannot decide independence -- one by one then)
@@ -2518,7 +2518,8 @@ struct RsqpLargeEngine::Impl {
         LCHK(hipStreamSynchronize(st));      // (the host vectors above go out of scope as well)
         if (h_pinned_i[1] != 0) return RET_FALLBACK;
         LCHK(rsqp_dtrtri_upper(n, G, lg, Ui, lg, &dw, st));
-        LCHK(rsqp_dgemm(false, true, n, n, n, 1.0, Ui, lg, Ui, lg, 0.0, Minv, ldm, st));
+        LCHK(rsqp_dgemm_upper(false, true, n, n, 1.0, Ui, lg, Ui, lg, 0.0, Minv, ldm, st));
+        LCHK(rsqp_mirror_upper(n, Minv, ldm, st));
         (void)hipEventRecord(se2, st);
         {   // what the matrix cores were asked for (algorithmic: the symmetric results counted once): Gram matrix n^2 m, Cholesky
             // n^3/3, triangular inverse n^3/3, U^-1 U^-T n^3/3

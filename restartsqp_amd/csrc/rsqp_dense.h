@@ -42,6 +42,11 @@ hipError_t rsqp_dgeqrf(int m, int n, double *B, long long ldb, double eps_li, Rs
 // Q (m x m, ldq) = H_1 H_2 ... H_n from the output of rsqp_dgeqrf
 hipError_t rsqp_dorgqr(int m, int n, const double *B, long long ldb, double *Q, long long ldq, RsqpDenseWork *w,
                        hipStream_t st);
+// C (n x n, symmetric result) = alpha op(A) op(B) + beta C, upper triangle only (tiles strictly below the diagonal are skipped and
+// undefined); rsqp_mirror_upper copies the upper triangle into the lower one
+hipError_t rsqp_dgemm_upper(bool transA, bool transB, int n, int k, double alpha, const double *A, long long lda,
+                            const double *B, long long ldb, double beta, double *C, long long ldc, hipStream_t st);
+hipError_t rsqp_mirror_upper(int n, double *M, long long ld, hipStream_t st);
 // X (n x n, ldx) = R^-1 for the upper triangular R (n x n, ldr); X is upper triangular, its strict
 // lower part is zeroed
 hipError_t rsqp_dtrtri_upper(int n, const double *R, long long ldr, double *X, long long ldx, RsqpDenseWork *w,
