@@ -340,6 +340,32 @@ def large_configs(capi, problems, seq_steps=50, ref_rule_steps=10, cpu_seconds=1
                    "rebuilt one change at a time; %d steps continuing the sequence above (the full 50 would take ~1 min)" % ref_rule_steps)
     out["sparse_10000x20000_warm_sequence_reference_rule"] = ref
 
+    # ---- the same configuration on the engine's GENERAL path: the synthetic Hessian of this configuration is diagonal, which the
+    #      engine's range-space path exploits; a Hessian with off-diagonal entries -- or the zero curvature the
+    #      QPhandler formulation gives its slack variables -- takes the null-space path. Its numbers, same inputs, path forced by
+    #      RSQP_LARGE_NO_DUAL (read when the engine of a handle is created): cold start + one FIXED + one VARIED step
+    os.environ["RSQP_LARGE_NO_DUAL"] = "1"
+    try:
+        s2 = load(q)
+        t = time.perf_counter(); n2 = s2.optimize_qp(); t_cold2 = time.perf_counter() - t
+        steps2 = []
+        for qk, changed in problems.sparse_sequence(q, nsteps=2, seed=20260150):
+            t = time.perf_counter()
+            for w, v in zip(range(5), (qk.g, qk.lb, qk.ub, qk.lbA, qk.ubA)):
+                s2.set_vector(w, v)
+            if changed:
+                s2.set_A_csc(qk.A_jc, qk.A_ir, qk.A_val)
+            nk = s2.optimize_qp()
+            okk, _, _, _ = s2.test_optimality()
+            steps2.append({"matrices_changed": bool(changed), "seconds": time.perf_counter() - t, "nWSR": nk, "certified": bool(okk)})
+        s2.close()
+        out["sparse_10000x20000_null_space_path"] = {
+            "cold_seconds": t_cold2, "cold_nWSR": n2, "steps_reference_rule": steps2,
+            "note": "RSQP_LARGE_NO_DUAL=1: what this configuration costs when its Hessian is not diagonal and positive (the same "
+                    "working-set sequences: the two paths differ in how the KKT systems are solved, not in the decisions)"}
+    finally:
+        del os.environ["RSQP_LARGE_NO_DUAL"]
+
     # ---- the matrix-core path: one more VARIED step right after a VARIED one = hotstart(H, g, A, ..) on the full working set:
     #      blocked Householder QR of A_AC,FR', explicit Q = [Y Z], R^-1, Z'HZ, its Cholesky factor and inverse (dense_la.hip)
     for qk, changed in problems.sparse_sequence(q, nsteps=2, seed=20260160):
