@@ -1494,6 +1494,97 @@ __global__ void k_dual_keep_u(int n, const double *__restrict__ u, double *__res
     if (j < n) keep[j] = u[j];
     if (j == n) { keep[n] = 0.0; keep[n + 1] = 0.0; scal[to] = scal[8]; }
 }
+// ---- Sinv is symmetric: stored in its UPPER triangle only (entry (i, j), i <= j, at M[j ld + i]), so that a rank-1 update and a
+// product touch half the bytes. One workgroup per 64 x 64 tile (I <= J) of the triangle: optional update M += coef u u', optional
+// contributions to y = M w -- the tile's rows against w_J (into P1[J][.]) and, transposed, its columns against w_I (into
+// P2[I][.]; a diagonal tile holds i <= j only and gives its diagonal to the row part). k_sym_reduce adds the partials in tile
+// order (deterministic). The tile passes through LDS once: coalesced column loads / stores, both products from there.
+constexpr int SYT = 64;
+__device__ __forceinline__ void sym_tile_of(int t, int &I, int &J) {
+    J = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while (J * (J + 1) / 2 > t) J--;
+    while ((J + 1) * (J + 2) / 2 <= t) J++;
+    I = t - J * (J + 1) / 2;
+}
+template <bool UPD, bool MV>
+__global__ void __launch_bounds__(256) k_sym_tile(double *__restrict__ M, long long ld, int n, const double *__restrict__ u,
+                                                  const double *__restrict__ scal, int ci, double cs, const double *__restrict__ w,
+                                                  double *__restrict__ P1, double *__restrict__ P2) {
+    __shared__ double S[SYT][SYT + 1];
+    __shared__ double wI[SYT], wJ[SYT], rp[2][SYT], cp[2][SYT];
+    int I, J;
+    sym_tile_of((int)blockIdx.x, I, J);
+    const bool diag = I == J;
+    const int ii = threadIdx.x & 63, wv = threadIdx.x >> 6, i = I * SYT + ii;
+    const double ui = (UPD && i < n) ? cs * scal[ci] * u[i] : 0.0;
+    if (MV && threadIdx.x < SYT) { wI[threadIdx.x] = i < n ? w[i] : 0.0; const int j = J * SYT + (int)threadIdx.x; wJ[threadIdx.x] = j < n ? w[j] : 0.0; }
+#pragma unroll 4
+    for (int c = 0; c < 16; c++) {
+        const int jj = wv * 16 + c, j = J * SYT + jj;
+        double m = 0.0;
+        if (i < n && j < n && (!diag || ii <= jj)) {
+            double *p = M + (long long)j * ld + i;
+            m = *p;
+            if (UPD) { m += ui * u[j]; *p = m; }
+        }
+        if (MV) S[jj][ii] = m;
+    }
+    if (!MV) return;
+    __syncthreads();
+    const int h = (threadIdx.x >> 6) & 1, e = threadIdx.x & 63;
+    double a = 0.0;
+    if (threadIdx.x < 128) {
+#pragma unroll 8
+        for (int q = 0; q < 32; q++) { const int jj = 32 * h + q; a += S[jj][e] * wJ[jj]; }       // row e of the tile against w_J
+        rp[h][e] = a;
+    } else {
+#pragma unroll 8
+        for (int q = 0; q < 32; q++) { const int r = 32 * h + q; a += (diag && r == e) ? 0.0 : S[e][r] * wI[r]; }   // column e against w_I
+        cp[h][e] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < SYT) { if (i < n) P1[(long long)J * n + i] = rp[0][threadIdx.x] + rp[1][threadIdx.x]; }
+    else if (threadIdx.x < 2 * SYT) { const int j = J * SYT + e; if (j < n) P2[(long long)I * n + j] = cp[0][e] + cp[1][e]; }
+}
+__global__ void k_sym_reduce(int n, int nt, const double *__restrict__ P1, const double *__restrict__ P2, double *__restrict__ y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int Ti = i / SYT;
+    double s0 = 0.0, s1 = 0.0;
+    for (int J = Ti; J < nt; J++) s0 += P1[(long long)J * n + i];
+    for (int I = 0; I <= Ti; I++) s1 += P2[(long long)I * n + i];
+    y[i] = s0 + s1;
+}
+// (upper-triangle storage) column j of the symmetric matrix and the coefficient of its removal
+__global__ void k_dual_colcoef_sym(const double *__restrict__ Sinv, long long ldm, int k, int j, double *__restrict__ v, double *__restrict__ scal) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) v[i] = i <= j ? Sinv[(long long)j * ldm + i] : Sinv[(long long)i * ldm + j];
+    if (i == 0) { const double d = Sinv[(long long)j * ldm + j]; scal[9] = d != 0.0 ? -1.0 / d : 0.0; }
+}
+__global__ void k_dual_border_sym(double *Sinv, long long ldm, int nAC, const double *__restrict__ u, const double *__restrict__ scal,
+                                  int *AC, int *posAC, int *Sc, int r, int side, double *y, int yidx, double yval) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > nAC) return;
+    const double is = scal[8];
+    if (j == nAC) {
+        AC[nAC] = r; posAC[r] = nAC; Sc[r] = side;
+        if (yidx >= 0) y[yidx] = yval;
+        Sinv[(long long)nAC * ldm + nAC] = is;
+    } else Sinv[(long long)nAC * ldm + j] = -u[j] * is;
+}
+__global__ void k_dual_move_last_sym(double *Sinv, long long ldm, int k, int j, int *AC, int *posAC, int *Sc, int r, double *y, int yidx) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int last = k - 1;
+    if (c == 0) {
+        if (j != last) { const int rl = AC[last]; AC[j] = rl; posAC[rl] = j; }
+        posAC[r] = -1; Sc[r] = 0;
+        y[yidx] = 0.0;
+    }
+    if (j == last || c >= last) return;
+    const double val = c == j ? Sinv[(long long)last * ldm + last] : Sinv[(long long)last * ldm + c];
+    const int lo_ = c < j ? c : j, hi_ = c < j ? j : c;
+    Sinv[(long long)hi_ * ldm + lo_] = val;
+}
 // removal of the constraint at position j: v = column j of Sinv, coef = -1 / v_j  (Sinv += coef v v' zeroes row and column j)
 __global__ void k_dual_colcoef(const double *__restrict__ Sinv, long long ldm, int k, int j, double *__restrict__ v, double *__restrict__ scal) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1673,7 +1764,7 @@ struct RsqpLargeEngine::Impl {
 
     ~Impl() {
         double *dv[] = {Z, Y, Minv, Wz, x, g, lb, ub, gN, lbN, ubN, dx, w1, w2, w3, w4, w5, w6, wz1, wz2, wz3, Ax, lbA, ubA,
-                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col, c_wY, c_wY2, c_xY, c_xi, c_wZ, py_t, py_v, pm_s, hinv, ps_u};
+                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col, c_wY, c_wY2, c_xY, c_xi, c_wZ, py_t, py_v, pm_s, hinv, ps_u, sym_part};
         for (double *p : dv) if (p) (void)hipFree(p);
         if (big) (void)hipFree(big);
         rsqp_dense_work_free(&dw);
@@ -1789,13 +1880,45 @@ struct RsqpLargeEngine::Impl {
     static constexpr int S_KEEP_S = 45;
     double *ps_u = nullptr;
     bool dual_defer = getenv("RSQP_LARGE_NO_FUSE") == nullptr;
+    // Sinv symmetric: upper triangle only (k_sym_tile); RSQP_LARGE_NO_SYM=1: full storage with the GEMV / GER kernels of the null-space path
+    bool dual_sym = getenv("RSQP_LARGE_NO_SYM") == nullptr;
+    double *sym_part = nullptr;      // partial sums of the tiled symmetric product: [2][tiles per side][nAmax]
+    static int sym_tiles(int n) { const int nt = (n + SYT - 1) / SYT; return nt * (nt + 1) / 2; }
+    // Sinv[0..n)^2 += (cs scal[slot]) v v'
+    void dual_rank1(int n, const double *v, int slot, double cs) {
+        if (n <= 0) return;
+        if (!dual_sym) { ger(Minv, ldm, n, n, v, v, slot, cs); return; }
+        pbegin();
+        hipLaunchKernelGGL((k_sym_tile<true, false>), dim3(sym_tiles(n)), dim3(256), 0, st, Minv, ldm, n, v, scal, slot, cs, (const double *)nullptr,
+                           (double *)nullptr, (double *)nullptr);
+        pend(2, 8.0 * n * (double)n);
+    }
     void dual_flush() {
         if (!pendS.on) return;
         pendS.on = false;
-        ger(Minv, ldm, pendS.n, pendS.n, ps_u, ps_u, S_KEEP_S, 1.0);
+        dual_rank1(pendS.n, ps_u, S_KEEP_S, 1.0);
     }
     // out = Sinv w, the deferred rank-1 update applied on the way (one read + one write of Sinv instead of read + write + read)
     void dual_sinv_times(const double *wv, double *out) {
+        if (dual_sym) {
+            if (nAC <= 0) return;
+            const int nt = (nAC + SYT - 1) / SYT;
+            double *P1 = sym_part, *P2 = sym_part + (size_t)nt * nAC;
+            pbegin();
+            if (pendS.on && nAC == pendS.n + 1) {     // (ps_u is zero behind pendS.n: the update leaves the new border alone)
+                pendS.on = false;
+                hipLaunchKernelGGL((k_sym_tile<true, true>), dim3(sym_tiles(nAC)), dim3(256), 0, st, Minv, ldm, nAC, ps_u, scal, S_KEEP_S, 1.0, wv, P1, P2);
+                pend(8, 8.0 * nAC * (double)nAC);
+            } else {
+                dual_flush();
+                hipLaunchKernelGGL((k_sym_tile<false, true>), dim3(sym_tiles(nAC)), dim3(256), 0, st, Minv, ldm, nAC, (const double *)nullptr, scal, 0, 0.0,
+                                   wv, P1, P2);
+                pend(0, 4.0 * nAC * (double)nAC);
+            }
+            hipLaunchKernelGGL(k_sym_reduce, g1(nAC), dim3(NT), 0, st, nAC, nt, P1, P2, out);
+            chk("dual sym product");
+            return;
+        }
         if (pendS.on && nAC == pendS.n + 1 && (ldm & 1) == 0 && ((reinterpret_cast<unsigned long long>(Minv) | reinterpret_cast<unsigned long long>(ps_u)) & 15) == 0) {
             pendS.on = false;
             pbegin();
@@ -2453,8 +2576,9 @@ struct RsqpLargeEngine::Impl {
         if (dual_defer && nAC > 0) {
             hipLaunchKernelGGL(k_dual_keep_u, g1(nAC + 1), dim3(NT), 0, st, nAC, a2, ps_u, scal, S_KEEP_S);
             pendS.on = true; pendS.n = nAC;
-        } else ger(Minv, ldm, nAC, nAC, a2, a2, 8, 1.0);
-        hipLaunchKernelGGL(k_dual_border, g1(nAC + 1), dim3(NT), 0, st, Minv, ldm, nAC, a2, scal, AC, posAC, Sc, r, side, y, yidx, yval);
+        } else dual_rank1(nAC, a2, 8, 1.0);
+        if (dual_sym) hipLaunchKernelGGL(k_dual_border_sym, g1(nAC + 1), dim3(NT), 0, st, Minv, ldm, nAC, a2, scal, AC, posAC, Sc, r, side, y, yidx, yval);
+        else hipLaunchKernelGGL(k_dual_border, g1(nAC + 1), dim3(NT), 0, st, Minv, ldm, nAC, a2, scal, AC, posAC, Sc, r, side, y, yidx, yval);
         hAC[nAC] = r; hSc[r] = side;
         nAC++;
         nZ = nFR - nAC;
@@ -2462,7 +2586,7 @@ struct RsqpLargeEngine::Impl {
     // a variable joins the fixed set: S loses a_v a_v'/d_v, Sinv += u u'/s with the same u and s as a bordering would use
     void dual_add_bound(int v, int side) {
         dual_flush();
-        ger(Minv, ldm, nAC, nAC, a2, a2, 8, 1.0);
+        dual_rank1(nAC, a2, 8, 1.0);
         hipLaunchKernelGGL(k_set_Sb, dim3(1), dim3(1), 0, st, Sb, v, side);
         hSb[v] = side;
         nFR--;
@@ -2471,10 +2595,12 @@ struct RsqpLargeEngine::Impl {
     void dual_remove_constraint(int k, bool carry) {
         const int r = hAC[k];
         dual_flush();
-        hipLaunchKernelGGL(k_dual_colcoef, g1(nAC), dim3(NT), 0, st, Minv, ldm, nAC, k, a3, scal);
+        if (dual_sym) hipLaunchKernelGGL(k_dual_colcoef_sym, g1(nAC), dim3(NT), 0, st, Minv, ldm, nAC, k, a3, scal);
+        else hipLaunchKernelGGL(k_dual_colcoef, g1(nAC), dim3(NT), 0, st, Minv, ldm, nAC, k, a3, scal);
         if (carry) hipLaunchKernelGGL(k_dual_carry_remove, dim3(1), dim3(NT), 0, st, nAC, k, 1.0 - last_tau, a3, c_wY);
-        ger(Minv, ldm, nAC, nAC, a3, a3, 9, 1.0);
-        hipLaunchKernelGGL(k_dual_move_last, g1(std::max(nAC - 1, 1)), dim3(NT), 0, st, Minv, ldm, nAC, k, AC, posAC, Sc, r, y, nV + r);
+        dual_rank1(nAC, a3, 9, 1.0);
+        if (dual_sym) hipLaunchKernelGGL(k_dual_move_last_sym, g1(std::max(nAC - 1, 1)), dim3(NT), 0, st, Minv, ldm, nAC, k, AC, posAC, Sc, r, y, nV + r);
+        else hipLaunchKernelGGL(k_dual_move_last, g1(std::max(nAC - 1, 1)), dim3(NT), 0, st, Minv, ldm, nAC, k, AC, posAC, Sc, r, y, nV + r);
         if (k != nAC - 1) hAC[k] = hAC[nAC - 1];
         hSc[r] = 0;
         nAC--;
@@ -2490,7 +2616,7 @@ struct RsqpLargeEngine::Impl {
         hipLaunchKernelGGL(k_col_of_A_active, dim3(4), dim3(NT), 0, st, M.Ajc, M.Air, M.Aval, v, posAC, a4);  // a_v
         dual_sinv_times(a4, a3);                                         // w = Sinv a_v
         hipLaunchKernelGGL(k_dual_free_coef, dim3(1), dim3(NT), 0, st, nAC, a4, a3, M.Hval, M.hreg, v, scal);
-        ger(Minv, ldm, nAC, nAC, a3, a3, 9, 1.0);
+        dual_rank1(nAC, a3, 9, 1.0);
     }
     // factors for a guessed working set: S = B'B with B = D^-1/2 A_cand,FR' (GEMM), Cholesky, inverse. RET_FALLBACK: dependent rows
     // in the guess (or too few candidates): the caller adds them one by one
@@ -2519,7 +2645,7 @@ struct RsqpLargeEngine::Impl {
         if (h_pinned_i[1] != 0) return RET_FALLBACK;
         LCHK(rsqp_dtrtri_upper(n, G, lg, Ui, lg, &dw, st));
         LCHK(rsqp_dgemm_upper(false, true, n, n, 1.0, Ui, lg, Ui, lg, 0.0, Minv, ldm, st));
-        LCHK(rsqp_mirror_upper(n, Minv, ldm, st));
+        if (!dual_sym) LCHK(rsqp_mirror_upper(n, Minv, ldm, st));
         (void)hipEventRecord(se2, st);
         {   // what the matrix cores were asked for (algorithmic: the symmetric results counted once): Gram matrix n^2 m, Cholesky
             // n^3/3, triangular inverse n^3/3, U^-1 U^-T n^3/3
@@ -3011,6 +3137,7 @@ hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
     if ((e = hipMemsetAsync(P.res_id, 0, 2 * sizeof(int), stream)) != hipSuccess) return e;      // res_id[0]: ticket counter of k_ratio1
     DA(d_fpos, nV); DA(d_cand, nC); DA(d_freev, nV);
     DA(hinv, nV); DA(dflag, 4); DA(ps_u, P.nAmax + 4);
+    DA(sym_part, 2 * (size_t)((P.nAmax + SYT - 1) / SYT + 1) * (size_t)std::max(P.nAmax, 1));
 #undef DA
     if ((e = rsqp_dense_work_alloc(&P.dw, nV)) != hipSuccess) return e;
     if ((e = hipHostMalloc(reinterpret_cast<void **>(&P.h_ctl), 64 * sizeof(double), hipHostMallocMapped)) != hipSuccess) return e;
