@@ -1550,10 +1550,19 @@ __global__ void k_sym_reduce(int n, int nt, const double *__restrict__ P1, const
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int Ti = i / SYT;
-    double s0 = 0.0, s1 = 0.0;
-    for (int J = Ti; J < nt; J++) s0 += P1[(long long)J * n + i];
-    for (int I = 0; I <= Ti; I++) s1 += P2[(long long)I * n + i];
-    y[i] = s0 + s1;
+    // (four independent accumulators per sum: up to 2 x 120 partials per entry, one dependent load chain each measured 22 us)
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+    int J = Ti;
+    for (; J + 3 < nt; J += 4) {
+        a0 += P1[(long long)J * n + i]; a1 += P1[(long long)(J + 1) * n + i]; a2 += P1[(long long)(J + 2) * n + i]; a3 += P1[(long long)(J + 3) * n + i];
+    }
+    for (; J < nt; J++) a0 += P1[(long long)J * n + i];
+    int I = 0;
+    for (; I + 3 <= Ti; I += 4) {
+        b0 += P2[(long long)I * n + i]; b1 += P2[(long long)(I + 1) * n + i]; b2 += P2[(long long)(I + 2) * n + i]; b3 += P2[(long long)(I + 3) * n + i];
+    }
+    for (; I <= Ti; I++) b0 += P2[(long long)I * n + i];
+    y[i] = ((a0 + a1) + (a2 + a3)) + ((b0 + b1) + (b2 + b3));
 }
 // (upper-triangle storage) column j of the symmetric matrix and the coefficient of its removal
 __global__ void k_dual_colcoef_sym(const double *__restrict__ Sinv, long long ldm, int k, int j, double *__restrict__ v, double *__restrict__ scal) {
