@@ -1192,13 +1192,18 @@ __global__ void k_drift_all(int nV, int nC, const int *__restrict__ Sb, const in
                             const double *__restrict__ Ax, double *__restrict__ lbA, double *__restrict__ ubA,
                             const double *__restrict__ ATy, const double *__restrict__ y, const double *__restrict__ Hx,
                             double *__restrict__ g, const double *__restrict__ lbN, const double *__restrict__ ubN,
-                            double *__restrict__ dx, double *__restrict__ dy) {
+                            double *__restrict__ dx, double *__restrict__ dy, const double *__restrict__ hinv = nullptr,
+                            const double *__restrict__ gN = nullptr, double *__restrict__ rv = nullptr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nV) {
         if (Sb[i] != 0) x[i] = Sb[i] == -1 ? lb[i] : ub[i];
-        g[i] = ATy[i] + y[i] - Hx[i];
+        const double gi = ATy[i] + y[i] - Hx[i];
+        g[i] = gi;
         // first kernel of the next step direction (k_dx_fixed_zero_dy) rides along: it reads nothing this one writes
-        dx[i] = Sb[i] == -1 ? delta_of(lbN[i], lb[i]) : (Sb[i] == 1 ? delta_of(ubN[i], ub[i]) : 0.0);
+        const double dxi = Sb[i] == -1 ? delta_of(lbN[i], lb[i]) : (Sb[i] == 1 ? delta_of(ubN[i], ub[i]) : 0.0);
+        dx[i] = dxi;
+        // (range-space path: so does k_dual_rhs_vec -- the vector whose product with A gives the right-hand side of the multiplier step)
+        if (rv) rv[i] = Sb[i] == 0 ? hinv[i] * (gN[i] - gi) : -dxi;
     }
     if (i < nC) { if (Sc[i] == -1) lbA[i] = Ax[i]; else if (Sc[i] == 1) ubA[i] = Ax[i]; }
     if (i < nV + nC) dy[i] = 0.0;
@@ -1211,14 +1216,16 @@ __global__ void k_row_of_A_dense(const double *__restrict__ AT, int nV, int row,
     if (v < nV) a[v] = (all || Sb[v] == 0) ? AT[(long long)row * nV + v] : 0.0;
 }
 // zero a (length nV) and scatter row `row` of A into it: one workgroup
+// (sc / as: optionally the row scaled entry by entry, as[c] = sc[c] a[c] -- D^-1 a_FR of the range-space path -- in the same launch)
 __global__ void __launch_bounds__(NT) k_row_of_A_fused(const int *__restrict__ rp, const int *__restrict__ ci,
                                                        const double *__restrict__ rv, int row, const int *__restrict__ Sb,
-                                                       int all, int nV, double *__restrict__ a) {
-    for (int v = threadIdx.x; v < nV; v += NT) a[v] = 0.0;
+                                                       int all, int nV, double *__restrict__ a, const double *__restrict__ sc = nullptr,
+                                                       double *__restrict__ as = nullptr) {
+    for (int v = threadIdx.x; v < nV; v += NT) { a[v] = 0.0; if (as) as[v] = 0.0; }
     __syncthreads();
     for (int k = rp[row] + threadIdx.x; k < rp[row + 1]; k += NT) {
         const int c = ci[k];
-        if (all || Sb[c] == 0) a[c] = rv[k];
+        if (all || Sb[c] == 0) { a[c] = rv[k]; if (as) as[c] = sc[c] * rv[k]; }
     }
 }
 // scal[s1] = |a|^2 (n1 entries; 1.0 if a is null), scal[s2] = |b|^2 (n2 entries); both published to ctl
@@ -1570,8 +1577,10 @@ __global__ void k_dual_colcoef_sym(const double *__restrict__ Sinv, long long ld
     if (i < k) v[i] = i <= j ? Sinv[(long long)j * ldm + i] : Sinv[(long long)i * ldm + j];
     if (i == 0) { const double d = Sinv[(long long)j * ldm + j]; scal[9] = d != 0.0 ? -1.0 / d : 0.0; }
 }
-__global__ void k_dual_border_sym(double *Sinv, long long ldm, int nAC, const double *__restrict__ u, const double *__restrict__ scal,
-                                  int *AC, int *posAC, int *Sc, int r, int side, double *y, int yidx, double yval) {
+// (keep != nullptr: k_dual_keep_u in the same launch -- u and 1 / s kept for the deferred rank-1 part, zero behind the block)
+__global__ void k_dual_border_sym(double *Sinv, long long ldm, int nAC, const double *__restrict__ u, double *__restrict__ scal,
+                                  int *AC, int *posAC, int *Sc, int r, int side, double *y, int yidx, double yval,
+                                  double *__restrict__ keep, int to) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > nAC) return;
     const double is = scal[8];
@@ -1579,7 +1588,12 @@ __global__ void k_dual_border_sym(double *Sinv, long long ldm, int nAC, const do
         AC[nAC] = r; posAC[r] = nAC; Sc[r] = side;
         if (yidx >= 0) y[yidx] = yval;
         Sinv[(long long)nAC * ldm + nAC] = is;
-    } else Sinv[(long long)nAC * ldm + j] = -u[j] * is;
+        if (keep) { keep[nAC] = 0.0; keep[nAC + 1] = 0.0; scal[to] = is; }
+    } else {
+        const double uj = u[j];
+        Sinv[(long long)nAC * ldm + j] = -uj * is;
+        if (keep) keep[j] = uj;
+    }
 }
 __global__ void k_dual_move_last_sym(double *Sinv, long long ldm, int k, int j, int *AC, int *posAC, int *Sc, int r, double *y, int yidx) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2559,8 +2573,11 @@ struct RsqpLargeEngine::Impl {
         dual_have_residual = true;
     }
     void dual_constraint_products(int r) {
-        row_of_A(r, w1, false);
-        hipLaunchKernelGGL(k_dual_scale, g1(nV), dim3(NT), 0, st, nV, hinv, w1, w5);
+        if (!M.denseAT) hipLaunchKernelGGL(k_row_of_A_fused, dim3(1), dim3(NT), 0, st, M.Arp, M.Aci, M.Arv, r, Sb, 0, nV, w1, hinv, w5);
+        else {
+            row_of_A(r, w1, false);
+            hipLaunchKernelGGL(k_dual_scale, g1(nV), dim3(NT), 0, st, nV, hinv, w1, w5);
+        }
         dual_products_tail();
     }
     void dual_bound_products(int v) {
@@ -2582,11 +2599,13 @@ struct RsqpLargeEngine::Impl {
     // Sinv <- [[Sinv + u u'/s, -u/s], [-u'/s, 1/s]]  (u in a2, 1/s in scal[8])
     void dual_add_constraint(int r, int side, int yidx = -1, double yval = 0.0) {
         dual_flush();       // (none is pending here: the products of this row have applied it)
-        if (dual_defer && nAC > 0) {
-            hipLaunchKernelGGL(k_dual_keep_u, g1(nAC + 1), dim3(NT), 0, st, nAC, a2, ps_u, scal, S_KEEP_S);
+        const bool defer = dual_defer && nAC > 0;
+        if (defer) {
+            if (!dual_sym) hipLaunchKernelGGL(k_dual_keep_u, g1(nAC + 1), dim3(NT), 0, st, nAC, a2, ps_u, scal, S_KEEP_S);
             pendS.on = true; pendS.n = nAC;
         } else dual_rank1(nAC, a2, 8, 1.0);
-        if (dual_sym) hipLaunchKernelGGL(k_dual_border_sym, g1(nAC + 1), dim3(NT), 0, st, Minv, ldm, nAC, a2, scal, AC, posAC, Sc, r, side, y, yidx, yval);
+        if (dual_sym) hipLaunchKernelGGL(k_dual_border_sym, g1(nAC + 1), dim3(NT), 0, st, Minv, ldm, nAC, a2, scal, AC, posAC, Sc, r, side, y, yidx, yval,
+                                         defer ? ps_u : (double *)nullptr, S_KEEP_S);
         else hipLaunchKernelGGL(k_dual_border, g1(nAC + 1), dim3(NT), 0, st, Minv, ldm, nAC, a2, scal, AC, posAC, Sc, r, side, y, yidx, yval);
         hAC[nAC] = r; hSc[r] = side;
         nAC++;
@@ -2678,9 +2697,11 @@ struct RsqpLargeEngine::Impl {
     }
     // step direction: S dy = db - A dx_FX + A D^-1 dg_FR (one product with A for the right-hand side), D dx_FR = A'dy - dg
     void dual_step_direction() {
-        if (!dx_ready) hipLaunchKernelGGL(k_dx_fixed_zero_dy, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, lb, ub, lbN, ubN, dx, dy);
+        if (!dx_ready) {
+            hipLaunchKernelGGL(k_dx_fixed_zero_dy, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, lb, ub, lbN, ubN, dx, dy);
+            hipLaunchKernelGGL(k_dual_rhs_vec, g1(nV), dim3(NT), 0, st, nV, Sb, hinv, gN, g, dx, w5);
+        }       // (else: k_drift_all has formed dx on the fixed variables and the right-hand-side vector w5 already)
         dx_ready = false;
-        hipLaunchKernelGGL(k_dual_rhs_vec, g1(nV), dim3(NT), 0, st, nV, Sb, hinv, gN, g, dx, w5);
         A_times(w5, c3);
         bool scattered = false;
         if (nAC > 0) {
@@ -2828,7 +2849,7 @@ struct RsqpLargeEngine::Impl {
             refresh_products();
         }
         hipLaunchKernelGGL(k_drift_all, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, Sc, lb, ub, x, Ax, lbA, ubA, ATy,
-                           y, Hx, g, lbN, ubN, dx, dy);
+                           y, Hx, g, lbN, ubN, dx, dy, dual ? hinv : (const double *)nullptr, gN, dual ? w5 : (double *)nullptr);
         dx_ready = true;
         chk("drift");
     }
