@@ -1,6 +1,7 @@
-"""HBM-resident engine (qp_large.hip: Householder / explicit-inverse null-space updates) against the
-oracle -- same bar as the LDS-resident kernel: working sets, status and nWSR bit-exact, x / y to
-1e-9 relative -- and BASELINE configs 3 and 4 at full size through the reference's KKT certificate."""
+"""HBM-resident engine (qp_large.hip: Householder / explicit-inverse null-space updates; for diagonal positive
+Hessians -- every sparse configuration below -- the range-space path with the explicit inverse of the Schur
+complement) against the oracle -- same bar as the LDS-resident kernel: working sets, status and nWSR bit-exact,
+x / y to 1e-9 relative -- and BASELINE configs 3 and 4 at full size through the reference's KKT certificate."""
 import json
 import os
 
