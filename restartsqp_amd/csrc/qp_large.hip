@@ -2479,7 +2479,9 @@ struct RsqpLargeEngine::Impl {
             if (pkind == 1) dual_remove_constraint(position_of(pidx), false); else dual_remove_bound(pidx);
             if (kind == 3) dual_constraint_products(idx); else dual_bound_products(idx);
             if (dual_li_decision(&li) != RET_OK) return RET_SETUP_FAILED;
-            if (!li) return RET_SETUP_FAILED;      // (the partner's removal must have made room for the incoming row)
+            // (the partner's removal has made room for the incoming row by construction of the exchange: a residual that stays
+            //  in the rounding band does not veto it as long as the pivot of the bordering is positive)
+            if (!li && !(h_ctl[4] > 1e-14 * h_ctl[5])) return RET_SETUP_FAILED;
         }
         if (kind == 3) {
             dual_add_constraint(idx, side, nV + idx, ynew);

@@ -210,6 +210,39 @@ def test_range_space_path_all_call_shapes(capi, oracle, monkeypatch, knob):
         s.close()
 
 
+def test_range_space_path_degenerate_inputs(capi, oracle):
+    """Degenerate inputs (duplicate constraint, zero row, constraint parallel to a bound, integer data) with a diagonal Hessian on the
+    range-space path: exchanges and the two-stage independence test decide as the oracle does -- status, nWSR, working sets identical;
+    where an exact tie is broken by the last bits (at most 2 of the 60), the answer must still be a certified KKT point with the
+    oracle's objective (the policy of test_degenerate_sweep_mismatch_rate_is_bounded)."""
+    rng = np.random.default_rng(8802)
+    other = 0
+    for t in range(60):
+        q0 = problems.degenerate_qp(rng, t % 4)
+        h = 0.5 + np.abs(rng.normal(size=q0.nV))
+        if t % 4 == 3:
+            h = np.round(h) + 1.0                                   # integer data all the way
+        q = QPData(q0.nV, q0.nC, np.arange(q0.nV + 1, dtype=np.int32), np.arange(q0.nV, dtype=np.int32), h, q0.A_jc, q0.A_ir, q0.A_val,
+                   q0.g, q0.lb, q0.ub, q0.lbA, q0.ubA, name=q0.name)
+        s = load(capi, q)
+        n = s.solve(capi.MODE_COLD, 2000)
+        qp, rc, n_or = oracle_cold(oracle, q, 2000)
+        wb, wc = s.working_set_raw()
+        same = (s.status == qp.exitflag() and n == n_or and np.array_equal(wb, qp.ws_bounds) and np.array_equal(wc, qp.ws_constraints))
+        if same:
+            assert np.abs(s.x - qp.x).max() <= 1e-9 * max(1.0, np.abs(qp.x).max())
+        else:
+            other += 1
+            assert s.status == qp.exitflag(), (t, s.status, qp.exitflag())
+            if s.status == 20:
+                ok, st, _, _ = s.test_optimality()
+                assert ok and st.KKT_error < 1e-8, (t, st.KKT_error)
+                obj = 0.5 * float(s.x @ (h * s.x)) + float(q.g @ s.x)
+                assert abs(obj - qp.objective) <= 1e-8 * max(1.0, abs(qp.objective)), (t, obj, qp.objective)
+        s.close()
+    assert other <= 2, other
+
+
 def test_range_space_path_needs_a_positive_diagonal(capi, oracle):
     """A diagonal Hessian with a zero or negative entry is not the range-space path's (D^-1 does not exist / the reduced Hessian can be
     indefinite): the engine keeps the null-space path with its definiteness guard, and the answer is the oracle's."""
