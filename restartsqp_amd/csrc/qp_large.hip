@@ -1571,6 +1571,81 @@ __global__ void k_sym_reduce(int n, int nt, const double *__restrict__ P1, const
     for (; I <= Ti; I++) b0 += P2[(long long)I * n + i];
     y[i] = ((a0 + a1) + (a2 + a3)) + ((b0 + b1) + (b2 + b3));
 }
+// The same tile scheme for Wz = (Z'HZ)^-1 of the NULL-space path (symmetric as well; upper triangle from wz_sym_min variables on).
+// UPD 2: the elimination step behind a reflected null space (k_wz_shrink's expression) on the leading l x l block; UPD 3: the
+// rank-1 part of a bordering, u u' / rho^2, under the kernel's own definiteness guard (scal[i0] > scal[i0 + 1]: k_wz_grow's);
+// UPD 0: product only. alpha scales the product in k_sym_reduce_a.
+struct SymW { const double *u, *s, *v, *col, *scal; int i0, i1, l; };
+template <int UPD, bool MV>
+__global__ void __launch_bounds__(256) k_symw_tile(double *__restrict__ M, long long ld, int n, SymW q, const double *__restrict__ w,
+                                                   double *__restrict__ P1, double *__restrict__ P2) {
+    __shared__ double S[SYT][SYT + 1];
+    __shared__ double wI[SYT], wJ[SYT], rp[2][SYT], cp[2][SYT];
+    int I, J;
+    sym_tile_of((int)blockIdx.x, I, J);
+    const bool diag = I == J;
+    const int ii = threadIdx.x & 63, wv = threadIdx.x >> 6, i = I * SYT + ii;
+    double beta = 0.0, theta = 0.0, iw22 = 0.0, ir2 = 0.0;
+    bool upd = UPD != 0;
+    if (UPD == 2) { beta = q.scal[q.i0]; theta = q.scal[q.i1]; iw22 = 1.0 / q.col[q.l]; }
+    if (UPD == 3) { const double r2 = q.scal[q.i0]; upd = r2 > q.scal[q.i0 + 1]; ir2 = 1.0 / r2; }
+    const double si = (UPD == 2 && i < n) ? q.s[i] : 0.0, vi = (UPD == 2 && i < n) ? q.v[i] : 0.0, ci = (UPD == 2 && i < n) ? q.col[i] : 0.0;
+    const double ui = (UPD == 3 && i < n) ? q.u[i] : 0.0;
+    if (MV && threadIdx.x < SYT) { wI[threadIdx.x] = i < n ? w[i] : 0.0; const int j = J * SYT + (int)threadIdx.x; wJ[threadIdx.x] = j < n ? w[j] : 0.0; }
+#pragma unroll 4
+    for (int c = 0; c < 16; c++) {
+        const int jj = wv * 16 + c, j = J * SYT + jj;
+        double m = 0.0;
+        if (i < n && j < n && (!diag || ii <= jj)) {
+            double *p = M + (long long)j * ld + i;
+            m = *p;
+            if (UPD == 2) { const double vj = q.v[j]; m += -beta * si * vj - beta * vi * q.s[j] + beta * beta * theta * vi * vj - ci * q.col[j] * iw22; *p = m; }
+            if (UPD == 3 && upd) { m += ui * q.u[j] * ir2; *p = m; }
+        }
+        if (MV) S[jj][ii] = m;
+    }
+    if (!MV) return;
+    __syncthreads();
+    const int h = (threadIdx.x >> 6) & 1, e = threadIdx.x & 63;
+    double a = 0.0;
+    if (threadIdx.x < 128) {
+#pragma unroll 8
+        for (int t = 0; t < 32; t++) { const int jj = 32 * h + t; a += S[jj][e] * wJ[jj]; }
+        rp[h][e] = a;
+    } else {
+#pragma unroll 8
+        for (int t = 0; t < 32; t++) { const int r = 32 * h + t; a += (diag && r == e) ? 0.0 : S[e][r] * wI[r]; }
+        cp[h][e] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < SYT) { if (i < n) P1[(long long)J * n + i] = rp[0][threadIdx.x] + rp[1][threadIdx.x]; }
+    else if (threadIdx.x < 2 * SYT) { const int j = J * SYT + e; if (j < n) P2[(long long)I * n + j] = cp[0][e] + cp[1][e]; }
+}
+__global__ void k_sym_reduce_a(int n, int nt, const double *__restrict__ P1, const double *__restrict__ P2, double alpha, double *__restrict__ y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int Ti = i / SYT;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+    int J = Ti;
+    for (; J + 3 < nt; J += 4) {
+        a0 += P1[(long long)J * n + i]; a1 += P1[(long long)(J + 1) * n + i]; a2 += P1[(long long)(J + 2) * n + i]; a3 += P1[(long long)(J + 3) * n + i];
+    }
+    for (; J < nt; J++) a0 += P1[(long long)J * n + i];
+    int I = 0;
+    for (; I + 3 <= Ti; I += 4) {
+        b0 += P2[(long long)I * n + i]; b1 += P2[(long long)(I + 1) * n + i]; b2 += P2[(long long)(I + 2) * n + i]; b3 += P2[(long long)(I + 3) * n + i];
+    }
+    for (; I <= Ti; I++) b0 += P2[(long long)I * n + i];
+    y[i] = alpha * (((a0 + a1) + (a2 + a3)) + ((b0 + b1) + (b2 + b3)));
+}
+// the border of a grown Wz in upper storage: column nZ = -u / rho^2, corner 1 / rho^2 (same guard as the rank-1 part)
+__global__ void k_wz_grow_col_sym(double *__restrict__ Wz, long long ld, int nZ, const double *__restrict__ u, const double *__restrict__ scal, int sr) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a > nZ) return;
+    const double r2 = scal[sr];
+    if (!(r2 > scal[sr + 1])) return;
+    Wz[(long long)nZ * ld + a] = a == nZ ? 1.0 / r2 : -u[a] / r2;
+}
 // (upper-triangle storage) column j of the symmetric matrix and the coefficient of its removal
 __global__ void k_dual_colcoef_sym(const double *__restrict__ Sinv, long long ldm, int k, int j, double *__restrict__ v, double *__restrict__ scal) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1787,7 +1862,7 @@ struct RsqpLargeEngine::Impl {
 
     ~Impl() {
         double *dv[] = {Z, Y, Minv, Wz, x, g, lb, ub, gN, lbN, ubN, dx, w1, w2, w3, w4, w5, w6, wz1, wz2, wz3, Ax, lbA, ubA,
-                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col, c_wY, c_wY2, c_xY, c_xi, c_wZ, py_t, py_v, pm_s, hinv, ps_u, sym_part};
+                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col, c_wY, c_wY2, c_xY, c_xi, c_wZ, py_t, py_v, pm_s, hinv, ps_u, sym_part, wz_part};
         for (double *p : dv) if (p) (void)hipFree(p);
         if (big) (void)hipFree(big);
         rsqp_dense_work_free(&dw);
@@ -2082,6 +2157,28 @@ struct RsqpLargeEngine::Impl {
     bool fuse_passes = getenv("RSQP_LARGE_NO_FUSE") == nullptr;
     int fuse_wz_min = getenv("RSQP_LARGE_FUSE_WZ_MIN") ? atoi(getenv("RSQP_LARGE_FUSE_WZ_MIN")) : 3072;   // (tests force 0: both fused kernels on small problems)
     static constexpr int S_KEEP_BETA = 40, S_KEEP_THETA = 41;
+    // Wz symmetric: upper triangle only from wz_sym_min variables on (k_symw_tile: half the bytes of every update and product; below
+    // that size the matrices are cache-resident and the single-launch kernels win). Decided per set-up (setup_aux), kept by hot starts.
+    bool wz_sym_enabled = getenv("RSQP_LARGE_NO_WZ_SYM") == nullptr;
+    int wz_sym_min = getenv("RSQP_LARGE_WZ_SYM_MIN") ? atoi(getenv("RSQP_LARGE_WZ_SYM_MIN")) : 4096;   // (tests force 0)
+    bool wz_sym = false;
+    double *wz_part = nullptr;
+    // out = alpha Wz[0..n)^2 w, upper storage; upd: 0 plain, 2 the deferred shrinking applied on the way (q), n = the block it leaves
+    void wz_sym_times(int n, const double *wv, double alpha, double *out, int upd, const SymW &q) {
+        if (n <= 0) return;
+        const int nt = (n + SYT - 1) / SYT;
+        double *P1 = wz_part, *P2 = wz_part + (size_t)nt * n;
+        pbegin();
+        if (upd == 2) hipLaunchKernelGGL((k_symw_tile<2, true>), dim3(sym_tiles(n)), dim3(256), 0, st, Wz, ld, n, q, wv, P1, P2);
+        else hipLaunchKernelGGL((k_symw_tile<0, true>), dim3(sym_tiles(n)), dim3(256), 0, st, Wz, ld, n, q, wv, P1, P2);
+        hipLaunchKernelGGL(k_sym_reduce_a, g1(n), dim3(NT), 0, st, n, nt, P1, P2, alpha, out);
+        pend(upd == 2 ? 7 : 0, (upd == 2 ? 8.0 : 4.0) * n * (double)n);
+        chk("wz_sym_times");
+    }
+    void wz_times(const double *wv, double alpha, double *out) {      // out = alpha Wz w (nZ x nZ), either storage
+        if (wz_sym) { SymW q{}; wz_sym_times(nZ, wv, alpha, out, 0, q); }
+        else gemv_n(Wz, ld, nZ, nZ, wv, alpha, 0.0, nullptr, out);
+    }
     bool can_defer() const {
         return fuse_passes && wz_enabled && (ld & 1) == 0 && nZ > 1 && pz_t &&
                (((reinterpret_cast<unsigned long long>(Z) | reinterpret_cast<unsigned long long>(Wz)) & 15) == 0);
@@ -2096,6 +2193,16 @@ struct RsqpLargeEngine::Impl {
         if (pendM.on) { pendM.on = false; ger(Minv, ldm, pendM.n, pendM.n, py_v, pm_s, S_KEEP_BETA2, -1.0); }
     }
     void wz_shrink_now(int nZo, const double *s_, const double *v_, const double *col_, int sb, int stheta) {
+        if (wz_sym) {
+            if (nZo > 1) {
+                SymW q{nullptr, s_, v_, col_, scal, sb, stheta, nZo - 1};
+                pbegin();
+                hipLaunchKernelGGL((k_symw_tile<2, false>), dim3(sym_tiles(nZo - 1)), dim3(256), 0, st, Wz, ld, nZo - 1, q, (const double *)nullptr,
+                                   (double *)nullptr, (double *)nullptr);
+                pend(3, 8.0 * (double)nZo * nZo);
+            }
+            return;
+        }
         pbegin();
         if (nZo > 1) {
             if ((ld & 1) == 0)
@@ -2116,7 +2223,7 @@ struct RsqpLargeEngine::Impl {
         const bool dz = defer && can_defer();
         double *s_ = dz ? pw_s : wz3, *col_ = dz ? pw_col : w6;
         // t = Z v and s = Wz v: one launch at launch-bound sizes
-        const bool paired = wz_enabled && gemv_n1_pair(Z, ld, nV, nZ, wz2, dz ? pz_t : w5, Wz, ld, nZ, nZ, wz2, s_);
+        const bool paired = wz_enabled && !wz_sym && gemv_n1_pair(Z, ld, nV, nZ, wz2, dz ? pz_t : w5, Wz, ld, nZ, nZ, wz2, s_);
         if (!paired) gemv_n(Z, ld, nV, nZ, wz2, 1.0, 0.0, nullptr, dz ? pz_t : w5);     // t = Z v
         bool copied = false;
         if (dz) {
@@ -2131,7 +2238,7 @@ struct RsqpLargeEngine::Impl {
             pendZ.on = true; pendZ.ncols = nZ - 1;
         } else ger(Z, ld, nV, nZ, w5, wz2, 1, -1.0);                                     // Z -= beta t v'
         if (!wz_enabled) return copied;
-        if (!paired) gemv_n(Wz, ld, nZ, nZ, wz2, 1.0, 0.0, nullptr, s_);                 // s = Wz v
+        if (!paired) wz_times(wz2, 1.0, s_);                                             // s = Wz v
         hipLaunchKernelGGL(k_wz_lastcol, g1(nZ), dim3(NT), 0, st, Wz, ld, nZ, s_, wz2, scal, 1, dz ? S_KEEP_THETA : 4, col_);   // theta = v's
         if (dz) { pendW.on = true; pendW.nZold = nZ; }
         else wz_shrink_now(nZ, wz3, wz2, w6, 1, 4);
@@ -2158,9 +2265,15 @@ struct RsqpLargeEngine::Impl {
     void gemv_n_Wz_pending(const double *wv, double alpha, double *out) {
         // (below ~3000 columns the fused pass is launch-bound -- partial sums + reduction, 35 us at nZ = 2300 -- and the separate
         //  kernels, 19 + 9 us, are faster)
-        if (!(pendW.on && pendW.nZold - 1 == nZ && nZ >= fuse_wz_min && nZ > 0)) {
+        if (wz_sym && pendW.on && pendW.nZold - 1 == nZ && nZ > 0) {      // (upper storage: the fused pass at every size)
+            pendW.on = false;
+            SymW q{nullptr, pw_s, pz_v, pw_col, scal, S_KEEP_BETA, S_KEEP_THETA, nZ};
+            wz_sym_times(nZ, wv, alpha, out, 2, q);
+            return;
+        }
+        if (!(pendW.on && pendW.nZold - 1 == nZ && nZ >= fuse_wz_min && nZ > 0) || wz_sym) {
             if (pendW.on) { pendW.on = false; wz_shrink_now(pendW.nZold, pw_s, pz_v, pw_col, S_KEEP_BETA, S_KEEP_THETA); }
-            gemv_n(Wz, ld, nZ, nZ, wv, alpha, 0.0, nullptr, out);
+            wz_times(wv, alpha, out);
             return;
         }
         pendW.on = false;
@@ -2269,12 +2382,17 @@ struct RsqpLargeEngine::Impl {
         double *z = Zc(nZ);
         H_times(z, w2);
         gemv_t(Z, ld, nV, nZ, w2, wz1);           // k = Z'Hz
-        gemv_n(Wz, ld, nZ, nZ, wz1, 1.0, 0.0, nullptr, wz2);  // u = Wz k
+        wz_times(wz1, 1.0, wz2);                              // u = Wz k
         // kappa = z'Hz, ku = k'u, scal[13] = rho2, scal[14] = threshold
         hipLaunchKernelGGL(k_rho2, dim3(1), dim3(NT), 0, st, scal, d_ctl, z, w2, nV, wz1, wz2, nZ, next_seq());
         // the growth is launched before the host has the verdict: the kernel tests rho2 > threshold itself (scal[13], [14])
         pbegin();
-        if ((ld & 1) == 0)
+        if (wz_sym) {
+            SymW q{wz2, nullptr, nullptr, nullptr, scal, 13, 0, 0};
+            if (nZ > 0) hipLaunchKernelGGL((k_symw_tile<3, false>), dim3(sym_tiles(nZ)), dim3(256), 0, st, Wz, ld, nZ, q, (const double *)nullptr,
+                                           (double *)nullptr, (double *)nullptr);
+            hipLaunchKernelGGL(k_wz_grow_col_sym, g1(nZ + 1), dim3(NT), 0, st, Wz, ld, nZ, wz2, scal, 13);
+        } else if ((ld & 1) == 0)
             hipLaunchKernelGGL(k_wz_grow_v, dim3((nZ + 1 + 2 * NT - 1) / (2 * NT), (nZ + 1 + WZ_COLS - 1) / WZ_COLS), dim3(NT), 0, st, Wz, ld,
                                nZ, wz2, scal, 13);
         else
@@ -3045,6 +3163,7 @@ struct RsqpLargeEngine::Impl {
             nZ = nFR - nAC;
             if (profile) { (void)hipStreamSynchronize(st); fprintf(stderr, "[rsqp profile] setup_aux (range-space path): nFR %d nAC %d, t=%.3f s\n", nFR, nAC, now_s() - t_setup0); }
         } else {
+        wz_sym = wz_sym_enabled && nV >= wz_sym_min;
         if (nZ > 0) {
             LCHK(hipMemsetAsync(Z, 0, sizeof(double) * (size_t)ld * nZ, st));
             // free-variable index list staged in dy (read as ints; dy is rewritten before its next use)
@@ -3170,6 +3289,7 @@ hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
     DA(d_fpos, nV); DA(d_cand, nC); DA(d_freev, nV);
     DA(hinv, nV); DA(dflag, 4); DA(ps_u, P.nAmax + 4);
     DA(sym_part, 2 * (size_t)((P.nAmax + SYT - 1) / SYT + 1) * (size_t)std::max(P.nAmax, 1));
+    DA(wz_part, 2 * (size_t)((nV + SYT - 1) / SYT + 1) * (size_t)nV);
 #undef DA
     if ((e = rsqp_dense_work_alloc(&P.dw, nV)) != hipSuccess) return e;
     if ((e = hipHostMalloc(reinterpret_cast<void **>(&P.h_ctl), 64 * sizeof(double), hipHostMallocMapped)) != hipSuccess) return e;

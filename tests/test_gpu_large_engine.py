@@ -139,8 +139,9 @@ def test_deferred_reflection_kernels_match_oracle(capi, oracle, monkeypatch):
     added constraint (k_carry_wY / k_carry_xY, the default)."""
     rng = np.random.default_rng(4711)
     cases = [problems.random_qp(rng, 64, 40, 0.5), problems.random_qp(rng, 150, 120, 0.3), problems.random_qp(rng, 96, 200, 0.4)]
+    # (RSQP_LARGE_WZ_SYM_MIN=0: Wz in its upper triangle only, the storage of problems from 4 096 variables on, forced for every size)
     for knob, val in (("RSQP_LARGE_FUSE_WZ_MIN", "0"), ("RSQP_LARGE_NO_FUSE", "1"), ("RSQP_LARGE_NO_CARRY", "1"),
-                      ("RSQP_LARGE_NO_CARRY_NULL", "1")):
+                      ("RSQP_LARGE_NO_CARRY_NULL", "1"), ("RSQP_LARGE_WZ_SYM_MIN", "0")):
         monkeypatch.setenv(knob, val)
         for q in cases:
             s = load(capi, q)
