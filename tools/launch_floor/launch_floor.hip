@@ -2,7 +2,7 @@
 // the host spinning on it (the protocol of rsqp_solve for LDS-scale handles).  hipcc --offload-arch=gfx950 -O3 launch_floor.hip
 //   empty      : the kernel only writes the word
 //   mapped_in  : + 5 dependent-free loads from host-mapped memory (the vectors of the QP) and a 200-B result written back
-//   chain<k>   : + k dependent f64 FMA chains of 1000 steps by one wave (what a latency-bound solve looks like to the clock governor)
+//   chain<k>   : + a loop of k dependent f64 FMAs by one wave (a loop trip -- compare, branch, FMA -- measured 15 ns: not a statement about clocks)
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
