@@ -101,11 +101,21 @@ constexpr int MV = 8;       // variable slots = lanes of a group
 #endif
 constexpr int TB = TINY_BLOCK, TG = TINY_BLOCK / 8;
 
-template <int MC>
+// GL = false: the tableau in registers (lane l holds rows l of both parts: 2 N doubles). GL = true: the tableau in LDS (row major,
+// beside the dense K), every lane reads / updates its own two rows there and reads any other row directly -- no permutes for the
+// pivot rows, no select chains for "entry q of my rows", and ~80 VGPRs less: a third wave per SIMD. A wave of this kernel takes
+// its ~45 k cycles whatever runs beside it (the same count for 1 QP and for 65 536), so throughput is resident waves / that latency.
+template <int MC, bool GL = false>
 struct EngineT {
     static constexpr int N = MV + MC, REFRESH = 8;
-    // ---- registers: my two rows of the tableau
-    double GV[N], GC[N];
+    static constexpr int NS = N;          // row stride of the LDS tableau
+    // ---- registers: my two rows of the tableau (GL: unused)
+    double GV[GL ? 1 : N], GC[GL ? 1 : N];
+    ldouble *Gl;                          // GL: the tableau of my problem in LDS
+    __device__ __forceinline__ double gv(int k) const { if constexpr (GL) return Gl[l * NS + k]; else return GV[k]; }
+    __device__ __forceinline__ double gc(int k) const { if constexpr (GL) return l < MC ? Gl[(MV + l) * NS + k] : 0.0; else return GC[k]; }
+    __device__ __forceinline__ void set_gv(int k, double v) { if constexpr (GL) Gl[l * NS + k] = v; else GV[k] = v; }
+    __device__ __forceinline__ void set_gc(int k, double v) { if constexpr (GL) { if (l < MC) Gl[(MV + l) * NS + k] = v; } else GC[k] = v; }
     // ---- state of my variable row and (l < nC) my constraint row
     double xv, lo, up, loN, upN, yv, g, gN, gy, inV;
     double ax, loA, upA, cloN, cupN, yc, inC;
@@ -132,6 +142,7 @@ struct EngineT {
     // entry q (uniform over the group, not a compile-time constant) of my two rows = G_lq, G_{8+l,q}: by symmetry the entries of
     // ROW q that belong to my slots. A chain of selects on wave masks (k == q): no register-array indexing, no extra registers
     __device__ __forceinline__ void my_entries(int q, double &ev, double &ec) const {
+        if constexpr (GL) { ev = Gl[l * NS + q]; ec = l < MC ? Gl[(MV + l) * NS + q] : 0.0; return; }
         ev = 0.0; ec = 0.0;
 #pragma unroll
         for (int k = 0; k < N; k++) { const bool h = k == q; ev = h ? GV[k] : ev; ec = h ? GC[k] : ec; }
@@ -153,7 +164,10 @@ struct EngineT {
     // row `src` of the variable (isc = false) or constraint part of G into every lane (= column of that slot: G is symmetric)
     __device__ __forceinline__ void fetch_row(bool isc, int src, double (&u)[N]) const {
 #pragma unroll
-        for (int k = 0; k < N; k++) u[k] = fetch8(isc ? GC[k] : GV[k], src);
+        for (int k = 0; k < N; k++) {
+            if constexpr (GL) u[k] = Gl[((isc ? MV : 0) + src) * NS + k];        // (every lane of the group reads the same row)
+            else u[k] = fetch8(isc ? GC[k] : GV[k], src);
+        }
     }
 
     // ------------------------------------------------------------------ staging
@@ -194,8 +208,9 @@ struct EngineT {
     }
     __device__ __forceinline__ void g_from_K() {     // S empty: G = -K
 #pragma unroll
-        for (int k = 0; k < N; k++) { GV[k] = -Kd[l * N + k]; GC[k] = l < MC ? -Kd[(MV + (l < MC ? l : 0)) * N + k] : 0.0; }
+        for (int k = 0; k < N; k++) { set_gv(k, -Kd[l * N + k]); set_gc(k, l < MC ? -Kd[(MV + (l < MC ? l : 0)) * N + k] : 0.0); }
         dV = -Kd[l * N + l]; dC = 0.0;
+        if constexpr (GL) TSYNC();
     }
     __device__ __forceinline__ bool bounds_inconsistent() const {
         return or8(((vV() && loN > upN + RSQP_EPS) || (vC() && cloN > cupN + RSQP_EPS)) ? 1 : 0) != 0;
@@ -228,10 +243,11 @@ struct EngineT {
         for (int k = 0; k < N; k++) {
             const bool h = k == q;
             const double ut = h ? sgn : u[k];
-            GV[k] = fma(tv, ut, GV[k] * (h ? 0.0 : kv));
-            GC[k] = fma(tc, ut, GC[k] * (h ? 0.0 : kc));
+            set_gv(k, fma(tv, ut, gv(k) * (h ? 0.0 : kv)));
+            set_gc(k, fma(tc, ut, gc(k) * (h ? 0.0 : kc)));
         }
         dV = fma(tv, uv, dV * kv); dC = fma(tc, uc, dC * kc);
+        if constexpr (GL) TSYNC();
     }
     // 2 x 2 block pivot on (p, q) with W = [G_pp G_pq; G_pq G_qq]^-1: G <- G00 - U~ W U~', U~ = [u_p u_q], rows p, q = diag(sp, sq)
     __device__ __forceinline__ void pivot2(const double (&up_)[N], const double (&uq)[N], int p, double sp, int q, double sq,
@@ -247,9 +263,10 @@ struct EngineT {
             const bool hp = k == p, hq = k == q;
             const double a = hp ? sp : (hq ? 0.0 : up_[k]), b = hq ? sq : (hp ? 0.0 : uq[k]), kk = (hp || hq) ? 0.0 : 1.0;
             const double cp = fma(w11, a, w12 * b), cq = fma(w12, a, w22 * b);
-            GV[k] = fma(-av, cp, fma(-bv, cq, GV[k] * (kk * kv)));
-            GC[k] = fma(-ac, cp, fma(-bc, cq, GC[k] * (kk * kc)));
+            set_gv(k, fma(-av, cp, fma(-bv, cq, gv(k) * (kk * kv))));
+            set_gc(k, fma(-ac, cp, fma(-bc, cq, gc(k) * (kk * kc))));
         }
+        if constexpr (GL) TSYNC();
         dV = fma(-av, fma(w11, av, w12 * bv), fma(-bv, fma(w12, av, w22 * bv), dV * kv));
         dC = fma(-ac, fma(w11, ac, w12 * bc), fma(-bc, fma(w12, ac, w22 * bc), dC * kc));
     }
@@ -501,7 +518,7 @@ struct EngineT {
                 gather(inV, inC, all);
                 double ov = 0.0, oc = 0.0;
 #pragma unroll
-                for (int k = 0; k < N; k++) { ov = fma(GV[k], all[k], ov); oc = fma(GC[k], all[k], oc); }
+                for (int k = 0; k < N; k++) { ov = fma(gv(k), all[k], ov); oc = fma(gc(k), all[k], oc); }
                 const double dg = gN - g;
                 dxv = sv == 0 ? ov : inV; dyv = sv == 0 ? 0.0 : dg - ov; hd = sv == 0 ? -dg : -ov;
                 dax = sc != 0 ? inC : -oc; dyc = sc != 0 ? -oc : 0.0;
@@ -590,7 +607,7 @@ struct EngineT {
             gather(inV, inC, all);
             double ov = 0.0, oc = 0.0;
 #pragma unroll
-            for (int k = 0; k < N; k++) { ov = fma(GV[k], all[k], ov); oc = fma(GC[k], all[k], oc); }
+            for (int k = 0; k < N; k++) { ov = fma(gv(k), all[k], ov); oc = fma(gc(k), all[k], oc); }
             if (vV() && sv == 0) xv += ov;
             if (sc != 0) yc -= oc;
         }
@@ -606,11 +623,12 @@ struct EngineT {
 template <int MC> __device__ __forceinline__ long long tiny_state_doubles() { return (long long)(MV + MC) * (MV + MC) + 8LL * 6 + 8LL * 4 + 8LL * 2; }
 constexpr int TINY_MAGIC = 0x7a11e;
 
-template <int MC, int W>
+template <int MC, int W, bool GL = false>
 __global__ void __launch_bounds__(TB, W) tiny_qp_kernel(QPPools P, int nq, int mode_in, int maxWSR) {
-    typedef EngineT<MC> ENG;
+    typedef EngineT<MC, GL> ENG;
     constexpr int N = ENG::N;
     __shared__ __attribute__((aligned(16))) double kd_all[TG * N * N];
+    __shared__ __attribute__((aligned(16))) double gl_all[GL ? TG * N * ENG::NS : 1];
     const int grp = (int)threadIdx.x >> 3;
     const int q = (int)blockIdx.x * TG + grp;
     if (q >= nq) return;        // (no workgroup barrier anywhere: idle groups may leave)
@@ -626,6 +644,7 @@ __global__ void __launch_bounds__(TB, W) tiny_qp_kernel(QPPools P, int nq, int m
     ENG E;
     E.l = (int)threadIdx.x & 7; E.nV = d.nV; E.nC = d.nC; E.hreg = d.hreg;
     E.Kd = (ldouble *)kd_all + grp * N * N;
+    E.Gl = (ldouble *)gl_all + (GL ? grp * N * ENG::NS : 0);
     E.nflips = 0; E.infeasible = E.unbounded = 0; E.status = QPS_NOTINITIALISED; E.fmask = E.amask = 0; E.since_refresh = 0;
     const int l = E.l;
 #ifdef RSQP_STAMPS
@@ -646,7 +665,8 @@ __global__ void __launch_bounds__(TB, W) tiny_qp_kernel(QPPools P, int nq, int m
             px = pr[l * 6 + 0]; pyv = pr[l * 6 + 5]; pyc = pr[48 + l * 4 + 3]; psv = si[l]; psc = si[8 + l];
             if (mode == 1) {
 #pragma unroll
-                for (int k = 0; k < N; k++) { E.GV[k] = sd[l * N + k]; E.GC[k] = l < MC ? sd[(MV + (l < MC ? l : 0)) * N + k] : 0.0; }
+                for (int k = 0; k < N; k++) { E.set_gv(k, sd[l * N + k]); E.set_gc(k, l < MC ? sd[(MV + (l < MC ? l : 0)) * N + k] : 0.0); }
+                if constexpr (GL) TSYNC();
                 E.xv = px; E.g = pr[l * 6 + 1]; E.lo = pr[l * 6 + 2]; E.up = pr[l * 6 + 3]; E.gy = pr[l * 6 + 4]; E.yv = pyv;
                 E.ax = pr[48 + l * 4 + 0]; E.loA = pr[48 + l * 4 + 1]; E.upA = pr[48 + l * 4 + 2]; E.yc = pyc;
                 E.sv = psv; E.sc = psc; E.status = si[16]; E.fmask = si[17] & 0xff; E.amask = (si[17] >> 8) & 0xff;
@@ -699,7 +719,7 @@ __global__ void __launch_bounds__(TB, W) tiny_qp_kernel(QPPools P, int nq, int m
     }
     if (P.keep_state) {
 #pragma unroll
-        for (int k = 0; k < N; k++) { sd[l * N + k] = E.GV[k]; if (l < MC) sd[(MV + l) * N + k] = E.GC[k]; }
+        for (int k = 0; k < N; k++) { sd[l * N + k] = E.gv(k); if (l < MC) sd[(MV + l) * N + k] = E.gc(k); }
         double *pr = sd + N * N;
         pr[l * 6 + 0] = E.xv; pr[l * 6 + 1] = E.g; pr[l * 6 + 2] = E.lo; pr[l * 6 + 3] = E.up; pr[l * 6 + 4] = E.gy; pr[l * 6 + 5] = E.yv;
         pr[48 + l * 4 + 0] = E.ax; pr[48 + l * 4 + 1] = E.loA; pr[48 + l * 4 + 2] = E.upA; pr[48 + l * 4 + 3] = E.yc;
@@ -761,7 +781,10 @@ hipError_t rsqp_launch_tiny_qp(const QPPools &p, int nq, int nVmax, int nCmax, i
     if (nq <= 0) return hipSuccess;
     if (!rsqp_tiny_fits(nVmax, nCmax)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((nq + TG - 1) / TG)), block(TB);
-    if (nCmax <= 2) hipLaunchKernelGGL((tiny_qp_kernel<2, 2>), grid, block, 0, stream, p, nq, mode, maxWSR);
+    // RSQP_TINY_LDS=1: the tableau in LDS, three waves per SIMD (tuning: default decided by measurement)
+    static const int glds = getenv("RSQP_TINY_LDS") ? atoi(getenv("RSQP_TINY_LDS")) : 0;
+    if (nCmax <= 2 && glds) hipLaunchKernelGGL((tiny_qp_kernel<2, 3, true>), grid, block, 0, stream, p, nq, mode, maxWSR);
+    else if (nCmax <= 2) hipLaunchKernelGGL((tiny_qp_kernel<2, 2>), grid, block, 0, stream, p, nq, mode, maxWSR);
     else if (nCmax <= 4) hipLaunchKernelGGL((tiny_qp_kernel<4, 2>), grid, block, 0, stream, p, nq, mode, maxWSR);
     else hipLaunchKernelGGL((tiny_qp_kernel<8, 1>), grid, block, 0, stream, p, nq, mode, maxWSR);
     return hipGetLastError();
