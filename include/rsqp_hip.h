@@ -102,6 +102,11 @@ double rsqp_get_structure_seconds(const rsqp_solver *s, int which);
 /* RSQP_MODE_* the dispatch of the last rsqp_optimize_qp / _lp (or the caller of rsqp_solve) used: which of the four call
  * shapes of qpOASESInterface.cpp:155,180-206 ran; -1 before the first solve */
 int rsqp_get_last_mode(const rsqp_solver *s);
+/* which formulation of the HBM-resident engine holds the factors of this handle (the stand-in for qpOASES' TQ / Cholesky factors
+ * behind SQProblem::init / hotstart, call sites qpOASESInterface.cpp:155,180-206): 0 = null-space (any Hessian), 1 = range-space,
+ * diagonal positive Hessian, 2 = general range-space with a banded H^-1 operator, 3 = the same with the dense inverse;
+ * -1: the handle has no HBM-resident engine (or has not solved yet) */
+int rsqp_get_large_path(const rsqp_solver *s);
 int rsqp_get_nV(const rsqp_solver *s);
 int rsqp_get_nC(const rsqp_solver *s);
 /* engine selection: 0 = automatic (the LDS-resident kernel when the problem image fits the

@@ -40,6 +40,7 @@ SYMBOLS = {
     "rsqp_set_options": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rsqp_set_reinit_guess": (C.c_int, [C.c_void_p, C.c_int]),
     "rsqp_get_last_mode": (C.c_int, [C.c_void_p]),
+    "rsqp_get_large_path": (C.c_int, [C.c_void_p]),
     "rsqp_get_nV": (C.c_int, [C.c_void_p]),
     "rsqp_get_nC": (C.c_int, [C.c_void_p]),
     "rsqp_write_qp_dump": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, ip, ip, dp, ip, ip, dp]),
@@ -279,6 +280,13 @@ class Solver:
     def last_mode(self):
         """RSQP_MODE_* the dispatch of the last optimize_qp / optimize_lp chose"""
         return lib().rsqp_get_last_mode(self._h)
+
+    LARGE_PATHS = {-1: "none", 0: "null-space", 1: "range-space (diagonal H)", 2: "general range-space (banded H^-1)",
+                   3: "general range-space (dense H^-1)"}
+
+    def large_path(self):
+        """which formulation of the HBM-resident engine holds this handle's factors (rsqp_get_large_path)"""
+        return lib().rsqp_get_large_path(self._h)
 
     def set_options(self, qp_maxiter=1000, lp_maxiter=100):
         check(lib().rsqp_set_options(self._h, qp_maxiter, lp_maxiter))

@@ -1749,6 +1749,7 @@ __global__ void k_clip_y(int nV, int nC, const int *Sb, const int *Sc, double *y
     if (s == 0 || (s == -1 && yi < 0.0) || (s == 1 && yi > 0.0)) y[i] = 0.0;
 }
 
+#include "qp_rs_kernels.h"
 
 }  // namespace
 
@@ -1787,6 +1788,8 @@ struct RsqpLargeEngine::Impl {
     // vectors (nC)
     double *Ax, *lbA, *ubA, *lbAN, *ubAN, *dAx, *c1, *c2, *c3, *a1, *a2, *a3, *a4;
     double *y, *dy, *part, *scal, *pt, *res_t;
+    int *Sall = nullptr;        // working-set status of [variables; constraints] in ONE array (Sb = Sall, Sc = Sall + nV): the general
+                                // range-space path addresses both kinds of row by one id
     int *Sb, *Sc, *AC, *posAC, *pid, *res_id;
     // host mirrors
     std::vector<int> hSb, hSc, hAC;
@@ -1827,7 +1830,7 @@ struct RsqpLargeEngine::Impl {
     // next hot start falls back to a full set-up
     int wait_failed() {
         status = QPS_NOTINITIALISED;
-        pendZ.on = pendW.on = pendY.on = pendM.on = pendS.on = false;
+        pendZ.on = pendW.on = pendY.on = pendM.on = pendS.on = pendR.on = false;
         return RET_SETUP_FAILED;
     }
     double *h_pinned = nullptr;  // small pinned read-back buffer
@@ -1862,11 +1865,12 @@ struct RsqpLargeEngine::Impl {
 
     ~Impl() {
         double *dv[] = {Z, Y, Minv, Wz, x, g, lb, ub, gN, lbN, ubN, dx, w1, w2, w3, w4, w5, w6, wz1, wz2, wz3, Ax, lbA, ubA,
-                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col, c_wY, c_wY2, c_xY, c_xi, c_wZ, py_t, py_v, pm_s, hinv, ps_u, sym_part, wz_part};
+                        lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col, c_wY, c_wY2, c_xY, c_xi, c_wZ, py_t, py_v, pm_s, hinv, ps_u, sym_part, wz_part,
+                        rs_p, rs_Ap, ra1, ra2, ra3, ra4, rs_dl, rs_ps_u, rs_G, band_buf};
         for (double *p : dv) if (p) (void)hipFree(p);
         if (big) (void)hipFree(big);
         rsqp_dense_work_free(&dw);
-        int *iv[] = {Sb, Sc, AC, posAC, pid, res_id, d_fpos, d_cand, d_freev, dflag};
+        int *iv[] = {Sall, AC, posAC, pid, res_id, d_fpos, d_cand, d_freev, dflag, R, posR};
         for (int *p : iv) if (p) (void)hipFree(p);
         if (h_ctl) (void)hipHostFree(h_ctl);
         if (h_pinned) (void)hipHostFree(h_pinned);
@@ -2541,7 +2545,7 @@ struct RsqpLargeEngine::Impl {
     // exchange: incoming row in w4 (all variables), its Y-products in a1. Finds the partner,
     // shifts the duals. ret: RET_OK / RET_INFEASIBLE; partner in (pkind, pidx), y_new
     int ensure_LI(int side, double *y_new, int *pkind, int *pidx) {
-        if (!dual) {      // (the range-space path has xi = Sinv c scattered in c1 and A_AC'xi in w2 already: dual_products_tail)
+        if (!dual && !rsh) {      // (the range-space paths have xi = Sinv c scattered in c1 and A_AC'xi in w2 already: dual_residual / rs_residual)
             fill(c1, nC, 0.0);
             gemv_t(Minv, ldm, nAC, nAC, a1, a2);   // xiC = Minv' wY  -> xi[j] = sum_i Minv[i][j] wY[i]
             if (nAC > 0) hipLaunchKernelGGL(k_scatter_active, g1(nAC), dim3(NT), 0, st, a2, AC, nAC, c1);
@@ -2614,6 +2618,7 @@ struct RsqpLargeEngine::Impl {
     }
 
     int change_active_set(int kind, int idx, int side) {
+        if (rsh) return rs_change_active_set(kind, idx, side);
         if (dual) return dual_change_active_set(kind, idx, side);
         flush_pending();
         carry_pending = carry_ready = false;       // (set again by a plain added / removed constraint below)
@@ -2849,6 +2854,7 @@ struct RsqpLargeEngine::Impl {
 
     // ---- step direction -----------------------------------------------------------------
     void step_direction() {
+        if (rsh) { rs_step_direction(); return; }
         if (dual) { dual_step_direction(); return; }
         if (!dx_ready) hipLaunchKernelGGL(k_dx_fixed_zero_dy, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, lb, ub, lbN, ubN, dx, dy);
         dx_ready = false;           // (set by drift_correction, whose kernel then has done this already)
@@ -2964,12 +2970,15 @@ struct RsqpLargeEngine::Impl {
         since_refresh = 0;
     }
     void drift_correction() {
+        bool refreshed = false;
         if (dirty_products || ++since_refresh >= REFRESH) {
             hipLaunchKernelGGL(k_fix_x, g1(nV), dim3(NT), 0, st, nV, Sb, lb, ub, x);
             refresh_products();
+            refreshed = true;
         }
         hipLaunchKernelGGL(k_drift_all, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, Sc, lb, ub, x, Ax, lbA, ubA, ATy,
                            y, Hx, g, lbN, ubN, dx, dy, dual ? hinv : (const double *)nullptr, gN, dual ? w5 : (double *)nullptr);
+        if (rsh && refreshed) rs_refresh_p();      // p = H^-1 (gN - g), A p: exact again (in between they shrink with the step, k_rs_scale_p)
         dx_ready = true;
         chk("drift");
     }
@@ -2987,6 +2996,7 @@ struct RsqpLargeEngine::Impl {
         refresh_products();
         hipLaunchKernelGGL(k_rerelax, g1(nV), dim3(NT), 0, st, nV, Sb, x, lbN, ubN, lb, ub);
         if (nC > 0) hipLaunchKernelGGL(k_rerelax, g1(nC), dim3(NT), 0, st, nC, Sc, Ax, lbAN, ubAN, lbA, ubA);
+        if (rsh) { pendR.on = false; rs_refresh_p(); }
         for (;;) {
             step_direction();
             hipLaunchKernelGGL(k_ratio1, dim3(nblk_ratio), dim3(NT), 0, st, nV, nC, Sb, Sc, x, y, dx, dy, Ax, dAx, lb, ub,
@@ -2994,6 +3004,7 @@ struct RsqpLargeEngine::Impl {
             // the homotopy step decodes the winner on the device and runs while the host waits for its own copy
             hipLaunchKernelGGL(k_step_all, g1(nV + nC), dim3(NT), 0, st, nV, nC, scal + 30, iter < maxit ? 1 : 0, Sb, x, g, lb, ub, gN, lbN,
                                ubN, dx, ATdy, ATy, Hdx, Hx, lbA, ubA, lbAN, ubAN, dAx, Ax, dy, y);
+            if (rsh) hipLaunchKernelGGL(k_rs_scale_p, g1(std::max(nV, nC)), dim3(NT), 0, st, nV, nC, scal + 30, rs_p, rs_Ap);
             if (wait_ctl() != RET_OK) return wait_failed();
             double tau = h_ctl[0];
             const int bid = (int)h_ctl[1];
@@ -3030,9 +3041,45 @@ struct RsqpLargeEngine::Impl {
                     kind_count[1], kind_count[2], kind_count[3], kind_count[4], stat_carried, stat_carried_null);
         flush_pending();
         dual_flush();
+        rs_flush();
         *nWSR = iter;
         return rcode;
     }
+
+
+    // ---- GENERAL range-space path (rsh; DESIGN 4.5, kernels in qp_rs_kernels.h, bodies in qp_rs_path.h) ----------------------------
+    // any symmetric positive definite H: active bounds AND constraints are rows of C, Sinv = (C H^-1 C')^-1 (upper triangle, in the
+    // buffer of Wz, leading dimension ld), H^-1 an operator built once per Hessian (banded LDL' / explicit dense inverse in Z)
+    bool rsh_enabled = getenv("RSQP_LARGE_NO_RSH") == nullptr;
+    bool rs_force_dense = getenv("RSQP_LARGE_RSH_DENSE") != nullptr;      // (tests: the dense operator on a banded Hessian)
+    bool rsh = false;
+    int rs_kind = 0;                 // 1: banded factor (k_band_apply), 2: explicit dense inverse in Z
+    int nR = 0;                      // active rows: (nV - nFR) + nAC
+    int *R = nullptr, *posR = nullptr;
+    std::vector<int> hR, hposR;
+    double *rs_p = nullptr, *rs_Ap = nullptr, *ra1 = nullptr, *ra2 = nullptr, *ra3 = nullptr, *ra4 = nullptr, *rs_dl = nullptr, *rs_ps_u = nullptr;
+    double *rs_G = nullptr;          // ld x ld scratch of the blocked set-up (allocated on first use)
+    double *band_buf = nullptr;      // the nine arrays of the banded operator
+    BandOp band{};
+    struct { bool on = false; int n = 0; } pendR;
+    int rs_prepare(bool *ok);
+    int rs_build_band(const std::vector<double> &hv, bool *ok);
+    int rs_build_dense(bool *ok);
+    void rs_hinv_apply(const double *in, const double *sub, double *out, bool fix_dx);
+    void rs_rank1(int n, const double *v, int slot, double cs);
+    void rs_flush();
+    void rs_sinv_times(const double *wv, double *out);
+    void rs_products(int id);
+    void rs_residual();
+    int rs_li_decision(bool *li);
+    void rs_add_row(int id, int side, int yidx, double yval);
+    void rs_remove_row(int k);
+    int rs_change_active_set(int kind, int idx, int side);
+    void rs_step_direction();
+    void rs_refresh_p();
+    int rs_setup_rows(const std::vector<int> &rows, const std::vector<int> &gb, const std::vector<int> &gc);
+    int rs_setup(const std::vector<int> &gb, const std::vector<int> &gc);
+    void rs_count(int id, int delta);
 
     // ---- blocked set-up (dense_la.hip) --------------------------------------------------------------
     static constexpr int RET_FALLBACK = -77;
@@ -3140,7 +3187,11 @@ struct RsqpLargeEngine::Impl {
         std::vector<int> freev;
         for (int v = 0; v < nV; v++) if (gb[v] == 0) freev.push_back(v);
         nFR = nZ = (int)freev.size();
-        if (dual) {
+        if (rsh) {
+            const int rcs = rs_setup(gb, gc);
+            if (rcs != RET_OK) return rcs;
+            if (profile) { (void)hipStreamSynchronize(st); fprintf(stderr, "[rsqp profile] setup_aux (general range-space path, %s H^-1): nFR %d nAC %d, t=%.3f s\n", rs_kind == 1 ? "banded" : "dense", nFR, nAC, now_s() - t_setup0); }
+        } else if (dual) {
             // range-space path: Sinv for the guessed constraints (blocked: GEMM + Cholesky + inverse; else one bordering each)
             A_times(x, Ax);
             std::vector<int> cand;
@@ -3249,6 +3300,8 @@ struct RsqpLargeEngine::Impl {
     }
 };
 
+#include "qp_rs_path.h"
+
 // =====================================================================================
 // public wrapper
 // =====================================================================================
@@ -3284,11 +3337,14 @@ hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
     DA(scal, 64);
     P.nblk_ratio = std::min(1024, std::max(1, (nV + nC + NT - 1) / NT));
     DA(pt, P.nblk_ratio); DA(res_t, 2);
-    DA(Sb, nV); DA(Sc, nC); DA(AC, nC); DA(posAC, nC); DA(pid, P.nblk_ratio); DA(res_id, 2);
+    DA(Sall, nV + std::max(nC, 1)); P.Sb = P.Sall; P.Sc = P.Sall + nV;
+    DA(AC, nC); DA(posAC, nC); DA(pid, P.nblk_ratio); DA(res_id, 2);
+    DA(R, nV + 1); DA(posR, nV + nC + 1);
     if ((e = hipMemsetAsync(P.res_id, 0, 2 * sizeof(int), stream)) != hipSuccess) return e;      // res_id[0]: ticket counter of k_ratio1
     DA(d_fpos, nV); DA(d_cand, nC); DA(d_freev, nV);
     DA(hinv, nV); DA(dflag, 4); DA(ps_u, P.nAmax + 4);
     DA(sym_part, 2 * (size_t)((P.nAmax + SYT - 1) / SYT + 1) * (size_t)std::max(P.nAmax, 1));
+    DA(rs_p, nV); DA(rs_Ap, std::max(nC, 1)); DA(ra1, nV + 4); DA(ra2, nV + 4); DA(ra3, nV + 4); DA(ra4, nV + 4); DA(rs_dl, nV + 4); DA(rs_ps_u, nV + 4);
     DA(wz_part, 2 * (size_t)((nV + SYT - 1) / SYT + 1) * (size_t)nV);
 #undef DA
     if ((e = rsqp_dense_work_alloc(&P.dw, nV)) != hipSuccess) return e;
@@ -3297,6 +3353,7 @@ hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
     if ((e = hipHostMalloc(reinterpret_cast<void **>(&P.h_pinned), 64 * sizeof(double))) != hipSuccess) return e;
     if ((e = hipHostMalloc(reinterpret_cast<void **>(&P.h_pinned_i), 64 * sizeof(int))) != hipSuccess) return e;
     P.hSb.assign(nV, 0); P.hSc.assign(nC, 0); P.hAC.assign(std::max(nC, 1), 0);
+    P.hR.assign(nV + 1, 0); P.hposR.assign(nV + nC + 1, -1);
     return hipSuccess;
 }
 
@@ -3389,6 +3446,12 @@ int RsqpLargeEngine::solve(int mode, const double *d_g, const double *d_lb, cons
             bool ok = false;
             if (P.dual_prepare(&ok) != RET_OK) return RET_SETUP_FAILED;
             P.dual = ok;
+            P.rsh = false;
+            if (!ok) {
+                bool ok2 = false;
+                if (P.rs_prepare(&ok2) != RET_OK) return RET_SETUP_FAILED;
+                P.rsh = ok2;
+            }
         }
         rc = P.setup_aux(gb, gc);
         if (rc != RET_OK && mode != RSQP_LMODE_COLD) {   // fall back to a cold start
@@ -3416,6 +3479,7 @@ int RsqpLargeEngine::status_word() const {
     return p_->infeasible ? 100 + p_->status : (p_->unbounded ? 200 + p_->status : p_->status);
 }
 int RsqpLargeEngine::nflips() const { return p_->nflips; }
+int RsqpLargeEngine::path() const { return p_->rsh ? 1 + p_->rs_kind : (p_->dual ? 1 : 0); }
 hipError_t RsqpLargeEngine::last_error() const { return p_->err_; }
 const char *RsqpLargeEngine::profile_name(int k) {
     static const char *nm[PROFILE_CLASSES] = {"gemv_n", "gemv_t", "ger", "wz_shrink", "wz_grow", "spmv", "ger_gemv_t", "shrink_gemv", "ger_gemv_n", ""};

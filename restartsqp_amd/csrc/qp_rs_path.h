@@ -1,0 +1,386 @@
+// qp_rs_path.h -- host side of the GENERAL range-space path of the HBM-resident engine (RsqpLargeEngine::Impl::rsh). Included by
+// qp_large.hip behind the definition of Impl; formulation and kernels: qp_rs_kernels.h, DESIGN 4.5.
+//
+// Which solves take it: H present, symmetric and positive definite, not the diagonal special case of DESIGN 4.4 (that one keeps
+// its own, cheaper treatment of bounds), and an H^-1 operator can be built -- banded (half bandwidth <= 2, nV <= 16 384) or
+// dense (nV <= 16 384). Everything around the factors -- homotopy, ratio tests, tie breaks, drift correction, exchange rule, host
+// protocol -- is the code of qp_large.hip, so the working-set sequences are those of the null-space path.
+#pragma once
+
+using Impl = RsqpLargeEngine::Impl;
+
+// ---- the H^-1 operator -------------------------------------------------------------------------------------------------------------
+// banded: LDL' on the host (O(n) work, the values come over once per set-up), homogeneous solutions per chunk, nine arrays up
+int Impl::rs_build_band(const std::vector<double> &hv, bool *ok) {
+    *ok = false;
+    const int n = nV;
+    std::vector<double> d0(n, 0.0), e1(n, 0.0), e2(n, 0.0);      // H[i][i], H[i][i-1], H[i][i-2]
+    for (int c = 0; c < n; c++)
+        for (int k = M.h_Hjc[c]; k < M.h_Hjc[c + 1]; k++) {
+            const int r = M.h_Hir[k];
+            if (r == c) d0[c] += hv[k];
+            else if (r == c + 1) e1[r] += hv[k];
+            else if (r == c + 2) e2[r] += hv[k];
+        }
+    for (int i = 0; i < n; i++) d0[i] += M.hreg;
+    std::vector<double> d(n), l1(n, 0.0), l2(n, 0.0);
+    for (int i = 0; i < n; i++) {
+        if (i >= 2) l2[i] = e2[i] / d[i - 2];
+        if (i >= 1) l1[i] = (e1[i] - (i >= 2 ? l2[i] * d[i - 2] * l1[i - 1] : 0.0)) / d[i - 1];
+        double di = d0[i];
+        if (i >= 1) di -= l1[i] * l1[i] * d[i - 1];
+        if (i >= 2) di -= l2[i] * l2[i] * d[i - 2];
+        if (!(di > 1e-12 * std::fabs(d0[i])) || !(di > 0.0)) return RET_OK;      // not positive definite (enough): not this path
+        d[i] = di;
+    }
+    const int T = BAND_T, c = (n + T - 1) / T;
+    std::vector<double> buf((size_t)4 * T * c + 5 * (size_t)n, 0.0);
+    double *l1i = buf.data(), *l2i = l1i + (size_t)T * c, *u1i = l2i + (size_t)T * c, *u2i = u1i + (size_t)T * c;
+    double *ga = u2i + (size_t)T * c, *gb = ga + n, *ha = gb + n, *hb = ha + n, *dinv = hb + n;
+    double growth = 0.0;
+    for (int t = 0; t < T; t++) {
+        const int s0 = t * c, e = std::min(s0 + c, n);
+        double a1 = 1.0, a2 = 0.0, b1 = 0.0, b2 = 1.0;        // (g[i-1], g[i-2]) of the two homogeneous solutions
+        for (int i = s0; i < e; i++) {
+            const int k = i - s0;
+            l1i[(size_t)k * T + t] = l1[i]; l2i[(size_t)k * T + t] = l2[i];
+            const double u1 = i + 1 < n ? l1[i + 1] : 0.0, u2 = i + 2 < n ? l2[i + 2] : 0.0;
+            u1i[(size_t)k * T + t] = u1; u2i[(size_t)k * T + t] = u2;
+            const double na = -l1[i] * a1 - l2[i] * a2, nb = -l1[i] * b1 - l2[i] * b2;
+            ga[i] = na; gb[i] = nb; a2 = a1; a1 = na; b2 = b1; b1 = nb;
+            growth = std::max(growth, std::max(std::fabs(na), std::fabs(nb)));
+            dinv[i] = 1.0 / d[i];
+        }
+        a1 = 1.0; a2 = 0.0; b1 = 0.0; b2 = 1.0;              // (h[i+1], h[i+2])
+        for (int i = e - 1; i >= s0; i--) {
+            const double u1 = i + 1 < n ? l1[i + 1] : 0.0, u2 = i + 2 < n ? l2[i + 2] : 0.0;
+            const double na = -u1 * a1 - u2 * a2, nb = -u1 * b1 - u2 * b2;
+            ha[i] = na; hb[i] = nb; a2 = a1; a1 = na; b2 = b1; b1 = nb;
+            growth = std::max(growth, std::max(std::fabs(na), std::fabs(nb)));
+        }
+    }
+    // (a factor whose homogeneous solutions grow along a chunk -- H far from diagonal dominance -- would lose digits in the
+    //  chunked recurrences: such a Hessian takes the dense operator)
+    if (!(growth <= 1e3)) return RET_OK;
+    if (!band_buf) LCHK(hipMalloc(reinterpret_cast<void **>(&band_buf), sizeof(double) * buf.size()));
+    LCHK(hipMemcpy(band_buf, buf.data(), sizeof(double) * buf.size(), hipMemcpyHostToDevice));
+    band.n = n; band.T = T; band.c = c;
+    band.l1i = band_buf; band.l2i = band.l1i + (size_t)T * c; band.u1i = band.l2i + (size_t)T * c; band.u2i = band.u1i + (size_t)T * c;
+    band.ga = band.u2i + (size_t)T * c; band.gb = band.ga + n; band.ha = band.gb + n; band.hb = band.ha + n; band.dinv = band.hb + n;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_apply), hipFuncAttributeMaxDynamicSharedMemorySize, BAND_MAX_N * 8));
+        attr_set = true;
+    }
+    *ok = true;
+    return RET_OK;
+}
+// dense: Cholesky, triangular inverse, U^-1 U^-T on the matrix cores (dense_la.hip), both triangles kept (columns are gathered)
+int Impl::rs_build_dense(bool *ok) {
+    *ok = false;
+    if (ensure_big() != RET_OK) return RET_SETUP_FAILED;
+    double *G = big, *Ui = big + (size_t)ld * ld;
+    LCHK(hipMemsetAsync(G, 0, sizeof(double) * (size_t)ld * nV, st));
+    hipLaunchKernelGGL(k_rs_sinv_from_H, dim3(nV), dim3(64), 0, st, nV, M.Hjc, M.Hir, M.Hval, M.hreg, G, ld);
+    LCHK(hipMemsetAsync(dw.flag, 0, sizeof(int) * 4, st));
+    LCHK(rsqp_dpotrf_upper(nV, G, ld, 1e-12, 0.0, &dw, st));
+    LCHK(hipMemcpyAsync(h_pinned_i, dw.flag, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+    LCHK(hipStreamSynchronize(st));
+    if (h_pinned_i[1] != 0) return RET_OK;
+    LCHK(rsqp_dtrtri_upper(nV, G, ld, Ui, ld, &dw, st));
+    LCHK(rsqp_dgemm_upper(false, true, nV, nV, 1.0, Ui, ld, Ui, ld, 0.0, Z, ld, st));
+    LCHK(rsqp_mirror_upper(nV, Z, ld, st));
+    *ok = true;
+    return RET_OK;
+}
+int Impl::rs_prepare(bool *ok) {
+    *ok = false;
+    if (!rsh_enabled || !M.haveH || !M.h_Hjc || !M.h_Hir || M.Hnnz <= 0 || nV > BAND_MAX_N) return RET_OK;
+    // symmetry (pattern and values) and band width from the host mirror of the pattern + one copy of the values
+    std::vector<double> hv(M.Hnnz);
+    LCHK(hipMemcpyAsync(hv.data(), M.Hval, sizeof(double) * M.Hnnz, hipMemcpyDeviceToHost, st));
+    LCHK(hipStreamSynchronize(st));
+    int hb = 0;
+    double amax = 0.0;
+    for (int c = 0; c < nV; c++)
+        for (int k = M.h_Hjc[c]; k < M.h_Hjc[c + 1]; k++) { hb = std::max(hb, std::abs(M.h_Hir[k] - c)); amax = std::max(amax, std::fabs(hv[k])); }
+    {   // H(r, c) == H(c, r): every stored entry must find its mirror image (binary search in the sorted column)
+        for (int c = 0; c < nV; c++)
+            for (int k = M.h_Hjc[c]; k < M.h_Hjc[c + 1]; k++) {
+                const int r = M.h_Hir[k];
+                if (r == c) continue;
+                const int *b = M.h_Hir + M.h_Hjc[r], *e = M.h_Hir + M.h_Hjc[r + 1];
+                const int *f = std::lower_bound(b, e, c);
+                if (f == e || *f != c) return RET_OK;
+                if (std::fabs(hv[f - M.h_Hir] - hv[k]) > 1e-12 * amax) return RET_OK;
+            }
+    }
+    bool built = false;
+    if (hb <= 2 && !rs_force_dense) { if (rs_build_band(hv, &built) != RET_OK) return RET_SETUP_FAILED; if (built) rs_kind = 1; }
+    if (!built) { if (rs_build_dense(&built) != RET_OK) return RET_SETUP_FAILED; if (built) rs_kind = 2; }
+    *ok = built;
+    return RET_OK;
+}
+// out = H^-1 (in - sub); fix_dx: the step direction's epilogue (dx on the fixed variables = the move of their bounds, kept in w6)
+void Impl::rs_hinv_apply(const double *in, const double *sub, double *out, bool fix_dx) {
+    pbegin();
+    if (rs_kind == 1) {
+        hipLaunchKernelGGL(k_band_apply, dim3(1), dim3(1024), sizeof(double) * nV, st, band, in, sub, out, 0LL, fix_dx ? Sb : (const int *)nullptr,
+                           fix_dx ? w6 : (const double *)nullptr);
+        pend(5, 72.0 * nV);
+    } else {
+        const double *src = in;
+        if (sub) { hipLaunchKernelGGL(k_rs_diff, g1(nV), dim3(NT), 0, st, nV, in, sub, wz3); src = wz3; }
+        gemv_n(Z, ld, nV, nV, src, 1.0, 0.0, nullptr, out);
+        if (fix_dx) hipLaunchKernelGGL(k_rs_fix_dx, g1(nV), dim3(NT), 0, st, nV, Sb, w6, out);
+    }
+    chk("rs_hinv_apply");
+}
+
+// ---- Sinv ------------------------------------------------------------------------------------------------------------------------
+void Impl::rs_rank1(int n, const double *v, int slot, double cs) {
+    if (n <= 0) return;
+    pbegin();
+    hipLaunchKernelGGL((k_sym_tile<true, false>), dim3(sym_tiles(n)), dim3(256), 0, st, Wz, ld, n, v, scal, slot, cs, (const double *)nullptr,
+                       (double *)nullptr, (double *)nullptr);
+    pend(2, 8.0 * n * (double)n);
+}
+void Impl::rs_flush() {
+    if (!pendR.on) return;
+    pendR.on = false;
+    rs_rank1(pendR.n, rs_ps_u, S_KEEP_S, 1.0);
+}
+// out = Sinv w, the deferred rank-1 part of the last bordering applied on the way
+void Impl::rs_sinv_times(const double *wv, double *out) {
+    if (nR <= 0) return;
+    const int nt = (nR + SYT - 1) / SYT;
+    double *P1 = wz_part, *P2 = wz_part + (size_t)nt * nR;
+    pbegin();
+    if (pendR.on && nR == pendR.n + 1) {
+        pendR.on = false;
+        hipLaunchKernelGGL((k_sym_tile<true, true>), dim3(sym_tiles(nR)), dim3(256), 0, st, Wz, ld, nR, rs_ps_u, scal, S_KEEP_S, 1.0, wv, P1, P2);
+        pend(8, 8.0 * nR * (double)nR);
+    } else {
+        rs_flush();
+        hipLaunchKernelGGL((k_sym_tile<false, true>), dim3(sym_tiles(nR)), dim3(256), 0, st, Wz, ld, nR, (const double *)nullptr, scal, 0, 0.0, wv, P1, P2);
+        pend(0, 4.0 * nR * (double)nR);
+    }
+    hipLaunchKernelGGL(k_sym_reduce, g1(nR), dim3(NT), 0, st, nR, nt, P1, P2, out);
+    chk("rs sym product");
+}
+void Impl::rs_count(int id, int delta) {       // delta +1: the row joined, -1: it left
+    if (id < nV) nFR -= delta; else nAC += delta;
+    nZ = nFR - nAC;
+}
+
+// ---- a row joins / leaves ---------------------------------------------------------------------------------------------------------
+// products of the incoming row with the working set: c in w1 (all variables), w = H^-1 c' in w5, cv = C w in ra1, u = Sinv cv in
+// ra2; |c_FR|^2, the pivot s and c w published (stage 1 of the independence test)
+void Impl::rs_products(int id) {
+    hipLaunchKernelGGL(k_rs_row, dim3(1), dim3(NT), 0, st, nV, id, M.Arp, M.Aci, M.Arv, M.denseAT, w1);
+    if (rs_kind == 2 && !M.denseAT) hipLaunchKernelGGL(k_rs_hinv_row, g1(nV), dim3(NT), 0, st, nV, id, M.Arp, M.Aci, M.Arv, Z, ld, w5);
+    else rs_hinv_apply(w1, nullptr, w5, false);
+    A_times(w5, c3);
+    if (nR > 0) hipLaunchKernelGGL(k_rs_gather, g1(nR), dim3(NT), 0, st, nR, R, nV, w5, c3, ra1);
+    rs_sinv_times(ra1, ra2);
+    hipLaunchKernelGGL(k_rs_li_publish, dim3(1), dim3(1024), 0, st, nV, Sb, w1, w5, (const double *)nullptr, nR, ra1, ra2, scal, d_ctl, next_seq());
+}
+// stage 2: the first-order residual (also what an exchange needs: c1 = u by constraint, w2 = A_AC'u_C)
+void Impl::rs_residual() {
+    fill(c1, std::max(nC, 1), 0.0);
+    if (nR > 0) hipLaunchKernelGGL(k_rs_scatter_c, g1(nR), dim3(NT), 0, st, nR, R, nV, ra2, c1);
+    AT_times(c1, w2);
+    hipLaunchKernelGGL(k_rs_li_publish, dim3(1), dim3(1024), 0, st, nV, Sb, w1, w5, w2, nR, ra1, ra2, scal, d_ctl, next_seq());
+}
+int Impl::rs_li_decision(bool *li) {
+    if (wait_ctl() != RET_OK) return wait_failed();
+    double a2n = h_ctl[2], sp = h_ctl[4];
+    const double ad = h_ctl[5];
+    if (nR < nV && a2n > 0.0 && sp > 1e-6 * ad) { *li = true; return RET_OK; }
+    rs_residual();
+    if (wait_ctl() != RET_OK) return wait_failed();
+    a2n = h_ctl[2]; sp = h_ctl[4];
+    const double r2 = h_ctl[3];
+    *li = nR < nV && a2n > 0.0 && std::sqrt(r2) > RSQP_EPS_LI * std::sqrt(a2n) && sp > 0.0;
+    return RET_OK;
+}
+// Sinv <- [[Sinv + u u'/s, -u/s], [-u'/s, 1/s]]  (u in ra2, 1/s in scal[8]); the rank-1 part rides on the next product
+void Impl::rs_add_row(int id, int side, int yidx, double yval) {
+    rs_flush();
+    const bool defer = nR > 0;
+    if (defer) { pendR.on = true; pendR.n = nR; }
+    hipLaunchKernelGGL(k_dual_border_sym, g1(nR + 1), dim3(NT), 0, st, Wz, ld, nR, ra2, scal, R, posR, Sall, id, side, y, yidx, yval,
+                       defer ? rs_ps_u : (double *)nullptr, S_KEEP_S);
+    hR[nR] = id; hposR[id] = nR;
+    if (id < nV) hSb[id] = side; else hSc[id - nV] = side;
+    nR++;
+    rs_count(id, +1);
+}
+void Impl::rs_remove_row(int k) {
+    const int id = hR[k];
+    rs_flush();
+    hipLaunchKernelGGL(k_dual_colcoef_sym, g1(nR), dim3(NT), 0, st, Wz, ld, nR, k, ra3, scal);
+    rs_rank1(nR, ra3, 9, 1.0);
+    hipLaunchKernelGGL(k_dual_move_last_sym, g1(std::max(nR - 1, 1)), dim3(NT), 0, st, Wz, ld, nR, k, R, posR, Sall, id, y, id);
+    if (k != nR - 1) { hR[k] = hR[nR - 1]; hposR[hR[k]] = k; }
+    hposR[id] = -1;
+    if (id < nV) hSb[id] = 0; else hSc[id - nV] = 0;
+    nR--;
+    rs_count(id, -1);
+}
+int Impl::rs_change_active_set(int kind, int idx, int side) {
+    carry_pending = carry_ready = false;
+    const int id = (kind == 1 || kind == 3) ? nV + idx : idx;
+    if (kind == 1 || kind == 2) { rs_remove_row(hposR[id]); return RET_OK; }
+    double ynew = 0.0;
+    bool li = false;
+    rs_products(id);
+    if (rs_li_decision(&li) != RET_OK) return RET_SETUP_FAILED;
+    if (!li) {
+        int pkind = 0, pidx = -1;
+        hipLaunchKernelGGL(k_rs_row, dim3(1), dim3(NT), 0, st, nV, id, M.Arp, M.Aci, M.Arv, M.denseAT, w4);
+        const int rc = ensure_LI(side, &ynew, &pkind, &pidx);
+        if (rc != RET_OK) return rc;
+        const int pid_ = pkind == 1 ? nV + pidx : pidx;
+        rs_remove_row(hposR[pid_]);
+        rs_products(id);
+        if (rs_li_decision(&li) != RET_OK) return RET_SETUP_FAILED;
+        if (!li && !(h_ctl[4] > 1e-14 * h_ctl[5])) return RET_SETUP_FAILED;
+    }
+    rs_add_row(id, side, id, ynew);
+    return RET_OK;
+}
+
+// ---- step direction ----------------------------------------------------------------------------------------------------------------
+void Impl::rs_refresh_p() {
+    rs_hinv_apply(gN, g, rs_p, false);
+    A_times(rs_p, rs_Ap);
+}
+void Impl::rs_step_direction() {
+    if (!dx_ready) hipLaunchKernelGGL(k_dx_fixed_zero_dy, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, lb, ub, lbN, ubN, dx, dy);
+    dx_ready = false;
+    if (nR > 0) {
+        hipLaunchKernelGGL(k_rs_rhs, g1(nR), dim3(NT), 0, st, nR, R, nV, Sall, lb, ub, lbN, ubN, lbA, ubA, lbAN, ubAN, rs_p, rs_Ap, ra4);
+        rs_sinv_times(ra4, rs_dl);
+        hipLaunchKernelGGL(k_rs_scatter, g1(nR), dim3(NT), 0, st, nR, R, rs_dl, dy);
+    }
+    AT_times(dy + nV, ATdy);
+    hipLaunchKernelGGL(k_rs_q, g1(nV), dim3(NT), 0, st, nV, Sb, ATdy, dy, gN, g, Hdx, dx, w6);
+    rs_hinv_apply(Hdx, nullptr, dx, true);
+    A_times(dx, dAx);
+    carry_pending = carry_ready = false;
+    carry_valid = false;
+    chk("rs_step_direction");
+}
+
+// ---- set-up -------------------------------------------------------------------------------------------------------------------------
+// Sinv for a given list of rows by GEMM + Cholesky + inverse: Cd = C' dense, T = H^-1 Cd, S = Cd'T (upper tiles), U'U = S,
+// Sinv = U^-1 U^-T. RET_FALLBACK: S is not positive definite to working precision (dependent rows in the guess)
+int Impl::rs_setup_rows(const std::vector<int> &rows, const std::vector<int> &gb, const std::vector<int> &gc) {
+    const int n = (int)rows.size();
+    if (ensure_big() != RET_OK) return RET_SETUP_FAILED;
+    if (!rs_G) LCHK(hipMalloc(reinterpret_cast<void **>(&rs_G), sizeof(double) * (size_t)ld * ld));
+    double *Cd = big, *T = big + (size_t)ld * ld;
+    LCHK(hipMemcpyAsync(R, rows.data(), sizeof(int) * n, hipMemcpyHostToDevice, st));
+    LCHK(hipMemsetAsync(Cd, 0, sizeof(double) * (size_t)ld * n, st));
+    hipLaunchKernelGGL(k_rs_build_C, dim3(n), dim3(64), 0, st, nV, R, M.Arp, M.Aci, M.Arv, Cd, ld);
+    if (!se0) { (void)hipEventCreate(&se0); (void)hipEventCreate(&se1); (void)hipEventCreate(&se2); }
+    setup_stat = SetupStat();
+    (void)hipEventRecord(se0, st);
+    if (rs_kind == 1) hipLaunchKernelGGL(k_band_apply, dim3(n), dim3(1024), sizeof(double) * nV, st, band, Cd, (const double *)nullptr, T, ld, (const int *)nullptr, (const double *)nullptr);
+    else LCHK(rsqp_dgemm(false, false, nV, n, nV, 1.0, Z, ld, Cd, ld, 0.0, T, ld, st));
+    LCHK(rsqp_dgemm_upper(true, false, n, nV, 1.0, Cd, ld, T, ld, 0.0, rs_G, ld, st));
+    (void)hipEventRecord(se1, st);
+    LCHK(hipMemsetAsync(dw.flag, 0, sizeof(int) * 4, st));
+    LCHK(rsqp_dpotrf_upper(n, rs_G, ld, 1e-10, RSQP_EPS_PD_ABS, &dw, st));
+    LCHK(hipMemcpyAsync(h_pinned_i, dw.flag, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+    LCHK(hipStreamSynchronize(st));
+    if (h_pinned_i[1] != 0) return RET_FALLBACK;
+    double *Ui = big;
+    LCHK(rsqp_dtrtri_upper(n, rs_G, ld, Ui, ld, &dw, st));
+    LCHK(rsqp_dgemm_upper(false, true, n, n, 1.0, Ui, ld, Ui, ld, 0.0, Wz, ld, st));
+    (void)hipEventRecord(se2, st);
+    {
+        (void)hipEventSynchronize(se2);
+        float ms1 = 0.f, ms2 = 0.f;
+        (void)hipEventElapsedTime(&ms1, se0, se1); (void)hipEventElapsedTime(&ms2, se1, se2);
+        const double dn = n, dm = nV;
+        setup_stat.valid = 1; setup_stat.dual = 2; setup_stat.m = nV; setup_stat.n = n; setup_stat.nZ = nV - n;
+        setup_stat.ms_tq = ms1; setup_stat.ms_wz = ms2;
+        setup_stat.flops_tq = dn * dn * dm + (rs_kind == 2 ? 2.0 * dm * dm * dn : 0.0); setup_stat.flops_wz = dn * dn * dn;
+    }
+    std::fill(hposR.begin(), hposR.end(), -1);
+    std::fill(hSb.begin(), hSb.end(), 0); std::fill(hSc.begin(), hSc.end(), 0);
+    nFR = nV; nAC = 0;
+    for (int k = 0; k < n; k++) {
+        const int id = rows[k];
+        hR[k] = id; hposR[id] = k;
+        if (id < nV) { hSb[id] = gb[id]; nFR--; } else { hSc[id - nV] = gc[id - nV]; nAC++; }
+    }
+    nR = n; nZ = nFR - nAC;
+    LCHK(hipMemcpyAsync(posR, hposR.data(), sizeof(int) * (nV + nC), hipMemcpyHostToDevice, st));
+    LCHK(hipMemcpyAsync(Sb, hSb.data(), sizeof(int) * nV, hipMemcpyHostToDevice, st));
+    if (nC > 0) LCHK(hipMemcpyAsync(Sc, hSc.data(), sizeof(int) * nC, hipMemcpyHostToDevice, st));
+    LCHK(hipStreamSynchronize(st));
+    chk("rs_setup_rows");
+    return RET_OK;
+}
+// the factors of a guessed working set (gb: bounds, gc: constraints; Sb already holds gb, Sc is zero, x is set)
+int Impl::rs_setup(const std::vector<int> &gb, const std::vector<int> &gc) {
+    pendR.on = false;
+    A_times(x, Ax);
+    std::vector<int> rows, cons;
+    for (int v = 0; v < nV; v++) if (gb[v] != 0) rows.push_back(v);
+    for (int r = 0; r < nC; r++) if (gc[r] != 0) cons.push_back(nV + r);
+    const int nFX = (int)rows.size();
+    nFR = nV - nFX; nAC = 0; nR = 0; nZ = nFR;
+    std::fill(hposR.begin(), hposR.end(), -1);
+    LCHK(hipMemsetAsync(posR, 0xff, sizeof(int) * (nV + nC), st));
+    bool rows_done = false;
+    if (nFX == nV) {
+        // every variable fixed: S = H^-1, Sinv = H itself -- no factorisation (the cold start of a box-constrained QP)
+        LCHK(hipMemsetAsync(Wz, 0, sizeof(double) * (size_t)ld * nV, st));
+        hipLaunchKernelGGL(k_rs_sinv_from_H, dim3(nV), dim3(64), 0, st, nV, M.Hjc, M.Hir, M.Hval, M.hreg, Wz, ld);
+        hipLaunchKernelGGL(k_rs_iota, g1(nV), dim3(NT), 0, st, nV, R, posR);
+        for (int v = 0; v < nV; v++) { hR[v] = v; hposR[v] = v; }
+        nR = nV;
+        rows_done = true;
+        // (no constraint can join while no variable is free: the guessed ones, if any, are dropped like dependent rows)
+        cons.clear();
+    }
+    if (!rows_done && blocked_setup && nFX + (int)cons.size() >= BLOCKED_MIN && nFX + (int)cons.size() <= nV) {
+        std::vector<int> all(rows);
+        all.insert(all.end(), cons.begin(), cons.end());
+        int rcb = rs_setup_rows(all, gb, gc);
+        if (rcb == RET_OK) { rows_done = true; cons.clear(); }
+        else if (rcb != RET_FALLBACK) return rcb;
+        else if (nFX >= BLOCKED_MIN) {          // dependent constraints in the guess: the bounds blocked (H^-1_FX,FX is definite), the rest one by one
+            rcb = rs_setup_rows(rows, gb, gc);
+            if (rcb == RET_OK) rows_done = true;
+            else if (rcb != RET_FALLBACK) return rcb;
+        }
+    }
+    if (!rows_done) {
+        // one bordering per row; Sb is cleared first so that the independence test sees the variables it has not fixed yet as free
+        LCHK(hipMemsetAsync(Sb, 0, sizeof(int) * nV, st));
+        std::fill(hSb.begin(), hSb.end(), 0);
+        nFR = nV; nZ = nFR;
+        for (int id : rows) {
+            rs_products(id);
+            bool li = false;
+            if (rs_li_decision(&li) != RET_OK) return RET_SETUP_FAILED;
+            if (!li) return RET_SETUP_FAILED;      // (a bound is never dependent on other bounds)
+            rs_add_row(id, gb[id], -1, 0.0);
+        }
+    }
+    // (yidx = -1: the multipliers of the guess, uploaded by solve(), are left alone)
+    for (int id : cons) {
+        rs_products(id);
+        bool li = false;
+        if (rs_li_decision(&li) != RET_OK) return RET_SETUP_FAILED;
+        if (li) rs_add_row(id, gc[id - nV], -1, 0.0);
+    }
+    rs_flush();
+    nZ = nFR - nAC;
+    return RET_OK;
+}

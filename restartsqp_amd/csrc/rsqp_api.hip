@@ -641,6 +641,7 @@ extern "C" double rsqp_get_structure_seconds(const rsqp_solver *s, int which) {
     return M.initialised ? M.structure_seconds : -1.0;
 }
 extern "C" int rsqp_get_last_mode(const rsqp_solver *s) { return s ? s->last_mode : -1; }
+extern "C" int rsqp_get_large_path(const rsqp_solver *s) { return (s && s->large && s->large_ready) ? s->large->path() : -1; }
 extern "C" int rsqp_get_nV(const rsqp_solver *s) { return s ? s->nV : -1; }
 extern "C" int rsqp_get_nC(const rsqp_solver *s) { return s ? s->nC : -1; }
 
@@ -870,6 +871,7 @@ int solve_large(rsqp_solver *s, int mode, int *nWSR, const double *x0, const dou
     if (s->H.initialised && !s->lp_mode) {
         m.Hjc = s->H.jc.p; m.Hir = s->H.ir.p; m.Hval = s->H.val.p; m.blk_h = s->H.blk_c.p; m.nblk_h = s->H.nblk_c;
         m.haveH = 1;
+        if ((int)s->H.h_jc.size() == s->nV + 1 && (int)s->H.h_ir.size() == s->H.nnz) { m.h_Hjc = s->H.h_jc.data(); m.h_Hir = s->H.h_ir.data(); m.Hnnz = s->H.nnz; }
         // a diagonal Hessian (one entry per column, on the diagonal): the engine's range-space path
         bool diag = s->H.nnz == s->nV && (int)s->H.h_jc.size() == s->nV + 1;
         for (int c = 0; c < s->nV && diag; c++) diag = s->H.h_jc[c] == c && s->H.h_ir[c] == c;

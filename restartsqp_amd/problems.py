@@ -213,7 +213,10 @@ def sparse_pattern(n=10000, m=20000, nnz=200000, seed=20260102):
     return np.cumsum(jc).astype(np.int32), rows.astype(np.int32), rng
 
 
-def sparse_qp(n=10000, m=20000, nnz=200000, seed=20260102, box=1.0):
+def sparse_qp(n=10000, m=20000, nnz=200000, seed=20260102, box=1.0, band=0):
+    """BASELINE configs[3]: H = diag(1 + |N(0,1)|); band=5: "+ optional 5-band SPD" -- two off-diagonals on
+    each side, 0.25 N(0,1), the diagonal raised by the absolute row sums so that H stays strictly diagonally dominant (SPD).
+    Jacobian, gradient and limits are those of the diagonal configuration (the band's numbers are drawn after everything else)."""
     jc, ir, rng = sparse_pattern(n, m, nnz, seed)
     val = rng.normal(size=nnz)
     h = 1.0 + np.abs(rng.normal(size=n))
@@ -224,8 +227,25 @@ def sparse_qp(n=10000, m=20000, nnz=200000, seed=20260102, box=1.0):
     cols = np.repeat(np.arange(n), np.diff(jc))
     np.add.at(Ax, ir, val * xh[cols])
     lbA = Ax - np.abs(rng.normal(size=m)); ubA = Ax + np.abs(rng.normal(size=m))
-    return QPData(n, m, H_jc, H_ir, h, jc, ir, val, g, -box * np.ones(n), box * np.ones(n), lbA, ubA,
-                  name="sparse_%dx%d" % (n, m))
+    name = "sparse_%dx%d" % (n, m)
+    if band:
+        assert band == 5, "band: 0 (diagonal) or 5"
+        o1 = 0.25 * rng.normal(size=n - 1); o2 = 0.25 * rng.normal(size=n - 2)
+        rs = np.zeros(n)
+        rs[:-1] += np.abs(o1); rs[1:] += np.abs(o1); rs[:-2] += np.abs(o2); rs[2:] += np.abs(o2)
+        d = h + rs
+        rows, colsH, vals = [], [], []
+        for off, o in ((0, d), (1, o1), (2, o2)):
+            i = np.arange(n - off)
+            rows.append(i + off); colsH.append(i); vals.append(o)
+            if off:
+                rows.append(i); colsH.append(i + off); vals.append(o)
+        rows, colsH, vals = np.concatenate(rows), np.concatenate(colsH), np.concatenate(vals)
+        order = np.lexsort((rows, colsH))
+        H_ir = rows[order].astype(np.int32); h = vals[order]
+        H_jc = np.concatenate(([0], np.cumsum(np.bincount(colsH, minlength=n)))).astype(np.int32)
+        name += "_band5"
+    return QPData(n, m, H_jc, H_ir, h, jc, ir, val, g, -box * np.ones(n), box * np.ones(n), lbA, ubA, name=name)
 
 
 def sparse_sequence(q, nsteps=50, seed=20260102):

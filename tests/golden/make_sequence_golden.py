@@ -3,7 +3,9 @@ configuration at n = 2 500, m = 5 000 (50 000 non-zeros) driven through the rest
 (oracle.OracleInterface) under the REFERENCE's re-initialisation rule (qpOASESInterface.cpp:199-207: init(.., x_qp,
 y_qp, &bounds), no guessed constraints): the cold start, then 4 steps of problems.sparse_sequence (FIXED, VARIED =
 flip, FIXED, VARIED = flip). Comparison data for the HIP engine -- not outputs of the reference (qpOASES is not
-available: "parity unpinned"). Minutes of CPU; the tests only read the JSON."""
+available: "parity unpinned"). Minutes of CPU; the tests only read the JSON.
+`python make_sequence_golden.py 2500 4 5` writes the same for the 5-band Hessian of problems.sparse_qp(band=5)
+(oracle_sparse_band5_sequence_2500_reference_rule.json)."""
 import json
 import os
 import sys
@@ -15,8 +17,8 @@ import oracle as O  # noqa: E402
 from restartsqp_amd import problems  # noqa: E402
 
 
-def main(n=2500, nsteps=4):
-    q = problems.sparse_qp(n, 2 * n, 20 * n)
+def main(n=2500, nsteps=4, band=0):
+    q = problems.sparse_qp(n, 2 * n, 20 * n, band=band)
     oi = O.OracleInterface(q.nV, q.nC, qp_maxiter=400000, from_y0=False)
     oi.set_A_csc(q.A_jc, q.A_ir, q.A_val); oi.qp.set_H_csc(q.H_jc, q.H_ir, q.H_val)
     steps = []
@@ -32,9 +34,9 @@ def main(n=2500, nsteps=4):
         if changed:
             oi.set_A_csc(qk.A_jc, qk.A_ir, qk.A_val)
         t = time.time(); used = oi.optimize_qp(qk.g, qk.lb, qk.ub, qk.lbA, qk.ubA); record(used, time.time() - t)
-    path = os.path.join(ROOT, "tests/golden/oracle_sparse_sequence_%d_reference_rule.json" % n)
+    path = os.path.join(ROOT, "tests/golden/oracle_sparse%s_sequence_%d_reference_rule.json" % ("_band5" if band else "", n))
     with open(path, "w") as f:
-        json.dump(dict(n=n, rule="reference (constraints from A x0 only)", steps=steps), f)
+        json.dump(dict(n=n, band=band, rule="reference (constraints from A x0 only)", steps=steps), f)
     print("wrote", path)
 
 
