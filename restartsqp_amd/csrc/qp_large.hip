@@ -1108,7 +1108,7 @@ __global__ void k_step_all(int nV, int nC, const double *__restrict__ res, int a
                            const double *__restrict__ Hdx, double *__restrict__ Hx, double *__restrict__ lbA,
                            double *__restrict__ ubA, const double *__restrict__ lbAN, const double *__restrict__ ubAN,
                            const double *__restrict__ dAx, double *__restrict__ Ax, const double *__restrict__ dy,
-                           double *__restrict__ y) {
+                           double *__restrict__ y, double *__restrict__ rsp = nullptr, double *__restrict__ rsAp = nullptr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     double tau = res[0];
     const int bid = (int)res[1];
@@ -1136,6 +1136,7 @@ __global__ void k_step_all(int nV, int nC, const double *__restrict__ res, int a
             ATy[v] += tau * ATdy[v];
             Hx[v] += tau * Hdx[v];
             if (fix && fkind == 4 && v == fidx) { if (fside == -1) lb[v] = x[v]; else ub[v] = x[v]; }
+            if (rsp) rsp[v] *= 1.0 - tau;      // (general range-space path: p = H^-1 (gN - g) shrinks like gN - g itself)
         }
     }
     if (i < nC) {
@@ -1145,6 +1146,7 @@ __global__ void k_step_all(int nV, int nC, const double *__restrict__ res, int a
             ubA[i] += tau * delta_of(ubAN[i], ubA[i]);
             Ax[i] += tau * dAx[i];
             if (fix && fkind == 3 && i == fidx) { if (fside == -1) lbA[i] = Ax[i]; else ubA[i] = Ax[i]; }
+            if (rsAp) rsAp[i] *= 1.0 - tau;
         }
     }
     if (i < nV + nC) y[i] += tau * dy[i];
@@ -1553,7 +1555,9 @@ __global__ void __launch_bounds__(256) k_sym_tile(double *__restrict__ M, long l
     if (threadIdx.x < SYT) { if (i < n) P1[(long long)J * n + i] = rp[0][threadIdx.x] + rp[1][threadIdx.x]; }
     else if (threadIdx.x < 2 * SYT) { const int j = J * SYT + e; if (j < n) P2[(long long)I * n + j] = cp[0][e] + cp[1][e]; }
 }
-__global__ void k_sym_reduce(int n, int nt, const double *__restrict__ P1, const double *__restrict__ P2, double *__restrict__ y) {
+// (R / full: the result scattered by row id as well -- the multiplier step of the general range-space path)
+__global__ void k_sym_reduce(int n, int nt, const double *__restrict__ P1, const double *__restrict__ P2, double *__restrict__ y,
+                             const int *__restrict__ R = nullptr, double *__restrict__ full = nullptr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int Ti = i / SYT;
@@ -1569,7 +1573,9 @@ __global__ void k_sym_reduce(int n, int nt, const double *__restrict__ P1, const
         b0 += P2[(long long)I * n + i]; b1 += P2[(long long)(I + 1) * n + i]; b2 += P2[(long long)(I + 2) * n + i]; b3 += P2[(long long)(I + 3) * n + i];
     }
     for (; I <= Ti; I++) b0 += P2[(long long)I * n + i];
-    y[i] = ((a0 + a1) + (a2 + a3)) + ((b0 + b1) + (b2 + b3));
+    const double val = ((a0 + a1) + (a2 + a3)) + ((b0 + b1) + (b2 + b3));
+    y[i] = val;
+    if (R) full[R[i]] = val;
 }
 // The same tile scheme for Wz = (Z'HZ)^-1 of the NULL-space path (symmetric as well; upper triangle from wz_sym_min variables on).
 // UPD 2: the elimination step behind a reflected null space (k_wz_shrink's expression) on the leading l x l block; UPD 3: the
@@ -2978,7 +2984,7 @@ struct RsqpLargeEngine::Impl {
         }
         hipLaunchKernelGGL(k_drift_all, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, Sc, lb, ub, x, Ax, lbA, ubA, ATy,
                            y, Hx, g, lbN, ubN, dx, dy, dual ? hinv : (const double *)nullptr, gN, dual ? w5 : (double *)nullptr);
-        if (rsh && refreshed) rs_refresh_p();      // p = H^-1 (gN - g), A p: exact again (in between they shrink with the step, k_rs_scale_p)
+        if (rsh && refreshed) rs_refresh_p();      // p = H^-1 (gN - g), A p: exact again (in between they shrink with the step, k_step_all)
         dx_ready = true;
         chk("drift");
     }
@@ -3003,8 +3009,8 @@ struct RsqpLargeEngine::Impl {
                                lbA, ubA, lbN, ubN, lbAN, ubAN, pt, pid, d_ctl, next_seq(), scal + 30, res_id, Hdx, gN, g, ATdy, dy);
             // the homotopy step decodes the winner on the device and runs while the host waits for its own copy
             hipLaunchKernelGGL(k_step_all, g1(nV + nC), dim3(NT), 0, st, nV, nC, scal + 30, iter < maxit ? 1 : 0, Sb, x, g, lb, ub, gN, lbN,
-                               ubN, dx, ATdy, ATy, Hdx, Hx, lbA, ubA, lbAN, ubAN, dAx, Ax, dy, y);
-            if (rsh) hipLaunchKernelGGL(k_rs_scale_p, g1(std::max(nV, nC)), dim3(NT), 0, st, nV, nC, scal + 30, rs_p, rs_Ap);
+                               ubN, dx, ATdy, ATy, Hdx, Hx, lbA, ubA, lbAN, ubAN, dAx, Ax, dy, y, rsh ? rs_p : (double *)nullptr,
+                               rsh ? rs_Ap : (double *)nullptr);
             if (wait_ctl() != RET_OK) return wait_failed();
             double tau = h_ctl[0];
             const int bid = (int)h_ctl[1];
@@ -3066,14 +3072,17 @@ struct RsqpLargeEngine::Impl {
     int rs_build_band(const std::vector<double> &hv, bool *ok);
     int rs_build_dense(bool *ok);
     void rs_hinv_apply(const double *in, const double *sub, double *out, bool fix_dx);
+    void band_launch(int ncols, const double *in, const double *sub, double *out, long long ldc, bool qmode);
     void rs_rank1(int n, const double *v, int slot, double cs);
     void rs_flush();
-    void rs_sinv_times(const double *wv, double *out);
+    void rs_sinv_times(const double *wv, double *out, bool scatter_dy = false);
+    bool rs_carry_enabled = getenv("RSQP_LARGE_NO_CARRY") == nullptr;
+    int rs_carry_id = -1;
     void rs_products(int id);
     void rs_residual();
     int rs_li_decision(bool *li);
     void rs_add_row(int id, int side, int yidx, double yval);
-    void rs_remove_row(int k);
+    void rs_remove_row(int k, bool carry = false);
     int rs_change_active_set(int kind, int idx, int side);
     void rs_step_direction();
     void rs_refresh_p();

@@ -19,100 +19,130 @@
 #pragma once
 
 // ---- banded H^-1 (half bandwidth <= 2): x = L^-T D^-1 L^-1 b, L unit lower with sub-diagonals l1 (i, i - 1) and l2 (i, i - 2) ------
-// The two triangular solves are linear recurrences of depth 2. Rows are cut into T chunks of c rows; thread t < T solves chunk t
-// with zero incoming state (sequential over c rows, the vector in LDS, the factor read in a chunk-interleaved layout so that the
-// T threads load consecutive addresses), one thread then chains the T outgoing states through the precomputed homogeneous
-// solutions, and all lanes add `state x homogeneous solution` to their rows. ~2 (c + T) dependent steps instead of 2 n.
+// The two triangular solves are linear recurrences of depth 2, i.e. compositions of affine maps of the state (z[i-1], z[i-2]).
+// ONE workgroup of 1024 threads; thread t owns the c = ceil(n / 1024) consecutive rows of chunk t with their factor entries in
+// REGISTERS (loaded once, up front, from a chunk-interleaved layout: consecutive threads read consecutive addresses):
+//   1. the chunk's map "incoming state -> outgoing state" (a particular and two homogeneous runs over the c rows),
+//   2. an inclusive scan of the 1024 maps: 6 shuffle steps inside a wave, the 16 wave totals through LDS,
+//   3. the chunk again with its true incoming state.
+// Forward, scale by 1/d, the same backward (reversed order). ~4 c + 12 dependent steps per sweep instead of 2 n; the first version
+// (one thread chaining 128 chunk states, factor entries fetched from memory inside the dependent loop) took 62 us per product at
+// n = 10 000 (profiles/r05_c_first_rs_kernel_stats_large_band5.csv).
 struct BandOp {
-    int n, T, c;                  // rows, chunks, rows per chunk (T * c >= n)
-    const double *l1i, *l2i;      // forward factor entries, interleaved: l1i[k * T + t] = l1[t * c + k] (0 beyond n)
-    const double *u1i, *u2i;      // backward: u1[i] = l1[i + 1], u2[i] = l2[i + 2], interleaved the same way
-    const double *ga, *gb;        // forward homogeneous solutions per row (state (1, 0) / (0, 1) ahead of the row's chunk)
-    const double *ha, *hb;        // backward homogeneous solutions per row (state behind the row's chunk)
-    const double *dinv;           // 1 / d
+    int n, c;                     // rows, rows per chunk (1024 c >= n)
+    const double *l1i, *l2i;      // l1i[k * 1024 + t] = l1[t c + k], k = 0..c;  l2i likewise, k = 0..c + 1  (0 beyond n)
+    const double *dinv;           // 1 / d, plain
 };
-constexpr int BAND_MAX_N = 16384;         // the vector lives in LDS (128 KB)
-constexpr int BAND_T = 128;
-__device__ __forceinline__ void band_apply_body(const BandOp &op, const double *__restrict__ in, const double *__restrict__ sub,
-                                                double *__restrict__ out, double *v, double (*st)[2], double (*PE)[6]) {
-    const int n = op.n, T = op.T, c = op.c, tid = threadIdx.x, nth = blockDim.x;
-    for (int i = tid; i < n; i += nth) v[i] = sub ? in[i] - sub[i] : in[i];
-    __syncthreads();
-    // forward, chunk by chunk with zero incoming state; then the chunk's affine map "incoming state -> outgoing state"
-    // (z[e-1], z[e-2]) = E + P (z[s-1], z[s-2]) goes to LDS so that the chaining thread reads no global memory
-    if (tid < T) {
-        const int s0 = tid * c, e = min(s0 + c, n);
-        double z1 = 0.0, z2 = 0.0;
-        for (int i = s0; i < e; i++) {
-            const int k = i - s0;
-            const double z = v[i] - op.l1i[k * T + tid] * z1 - op.l2i[k * T + tid] * z2;
-            v[i] = z; z2 = z1; z1 = z;
-        }
-        double *q = PE[tid];
-        if (e <= s0) { q[0] = 0.0; q[1] = 1.0; q[2] = 0.0; q[3] = 0.0; q[4] = 0.0; q[5] = 1.0; }
-        else {
-            q[0] = z1; q[1] = op.ga[e - 1]; q[2] = op.gb[e - 1];
-            if (e - 2 >= s0) { q[3] = z2; q[4] = op.ga[e - 2]; q[5] = op.gb[e - 2]; }
-            else { q[3] = 0.0; q[4] = 1.0; q[5] = 0.0; }
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double a = 0.0, b = 0.0;          // state entering chunk t: (z[s - 1], z[s - 2])
-        for (int t = 0; t < T; t++) {
-            st[t][0] = a; st[t][1] = b;
-            const double *q = PE[t];
-            const double na = q[0] + q[1] * a + q[2] * b, nb = q[3] + q[4] * a + q[5] * b;
-            a = na; b = nb;
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += nth) { const int t = i / c; v[i] = (v[i] + op.ga[i] * st[t][0] + op.gb[i] * st[t][1]) * op.dinv[i]; }
-    __syncthreads();
-    // backward: x[i] = y[i] - u1[i] x[i+1] - u2[i] x[i+2]; a chunk's map (x[s], x[s+1]) = E + P (x[e], x[e+1])
-    if (tid < T) {
-        const int s0 = tid * c, e = min(s0 + c, n);
-        double x1 = 0.0, x2 = 0.0;
-        for (int i = e - 1; i >= s0; i--) {
-            const int k = i - s0;
-            const double x = v[i] - op.u1i[k * T + tid] * x1 - op.u2i[k * T + tid] * x2;
-            v[i] = x; x2 = x1; x1 = x;
-        }
-        double *q = PE[tid];
-        if (e <= s0) { q[0] = 0.0; q[1] = 1.0; q[2] = 0.0; q[3] = 0.0; q[4] = 0.0; q[5] = 1.0; }
-        else {
-            q[0] = x1; q[1] = op.ha[s0]; q[2] = op.hb[s0];
-            if (s0 + 1 < e) { q[3] = x2; q[4] = op.ha[s0 + 1]; q[5] = op.hb[s0 + 1]; }
-            else { q[3] = 0.0; q[4] = 1.0; q[5] = 0.0; }
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double a = 0.0, b = 0.0;          // state entering chunk t from behind: (x[e], x[e + 1])
-        for (int t = T - 1; t >= 0; t--) {
-            st[t][0] = a; st[t][1] = b;
-            const double *q = PE[t];
-            const double na = q[0] + q[1] * a + q[2] * b, nb = q[3] + q[4] * a + q[5] * b;
-            a = na; b = nb;
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += nth) { const int t = i / c; out[i] = v[i] + op.ha[i] * st[t][0] + op.hb[i] * st[t][1]; }
+constexpr int BAND_MAX_N = 16384;         // the vector passes through LDS (128 KB)
+constexpr int BAND_TH = 1024;
+struct AMap { double p00, p01, p10, p11, e0, e1; };       // s_out = P s_in + e
+__device__ __forceinline__ AMap amap_then(const AMap &a, const AMap &b) {      // first a, then b
+    AMap r;
+    r.p00 = b.p00 * a.p00 + b.p01 * a.p10; r.p01 = b.p00 * a.p01 + b.p01 * a.p11;
+    r.p10 = b.p10 * a.p00 + b.p11 * a.p10; r.p11 = b.p10 * a.p01 + b.p11 * a.p11;
+    r.e0 = b.p00 * a.e0 + b.p01 * a.e1 + b.e0; r.e1 = b.p10 * a.e0 + b.p11 * a.e1 + b.e1;
+    return r;
 }
-// out = H^-1 (in - sub)   (sub may be null; in == out allowed). One workgroup; column blockIdx.x of a matrix when ld != 0.
-// mSb / mfix: optional epilogue of the step direction -- out[v] = mfix[v] where mSb[v] != 0 (dx exactly on its bound's move)
-__global__ void __launch_bounds__(1024) k_band_apply(BandOp op, const double *__restrict__ in, const double *__restrict__ sub,
-                                                     double *__restrict__ out, long long ld, const int *__restrict__ mSb,
-                                                     const double *__restrict__ mfix) {
-    extern __shared__ double band_lds[];
-    double *v = band_lds;
-    __shared__ double st[BAND_T][2], PE[BAND_T][6];
-    const long long off = (long long)blockIdx.x * ld;
-    band_apply_body(op, in + off, sub, out + off, v, st, PE);
-    if (mSb) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < op.n; i += blockDim.x) if (mSb[i] != 0) out[i] = mfix[i];
+__device__ __forceinline__ AMap amap_shfl(const AMap &m, int src) {
+    AMap r;
+    r.p00 = __shfl(m.p00, src); r.p01 = __shfl(m.p01, src); r.p10 = __shfl(m.p10, src); r.p11 = __shfl(m.p11, src);
+    r.e0 = __shfl(m.e0, src); r.e1 = __shfl(m.e1, src);
+    return r;
+}
+// state entering this thread's chunk, given every chunk's map m (rev: chunks are chained from the last one down)
+__device__ __forceinline__ void band_scan(AMap m, bool rev, AMap *wm, double &s0, double &s1) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int src = rev ? lane + d : lane - d;
+        const AMap o = amap_shfl(m, src & 63);
+        if (rev ? (lane + d < 64) : (lane >= d)) m = amap_then(o, m);
     }
+    __syncthreads();                                   // (wm may still be read by the previous sweep)
+    if (lane == (rev ? 0 : 63)) wm[wave] = m;
+    __syncthreads();
+    double a = 0.0, b = 0.0;                           // state entering this wave
+    if (!rev) { for (int w = 0; w < wave; w++) { const AMap q = wm[w]; const double na = q.p00 * a + q.p01 * b + q.e0, nb = q.p10 * a + q.p11 * b + q.e1; a = na; b = nb; } }
+    else { for (int w = BAND_TH / 64 - 1; w > wave; w--) { const AMap q = wm[w]; const double na = q.p00 * a + q.p01 * b + q.e0, nb = q.p10 * a + q.p11 * b + q.e1; a = na; b = nb; } }
+    const AMap pv = amap_shfl(m, (rev ? lane + 1 : lane - 1) & 63);     // the map up to the chunk before this one, inside the wave
+    if (rev ? (lane == 63) : (lane == 0)) { s0 = a; s1 = b; }
+    else { s0 = pv.p00 * a + pv.p01 * b + pv.e0; s1 = pv.p10 * a + pv.p11 * b + pv.e1; }
+}
+// the step direction's product in one launch: in = q - (gN - g) with q = A'dl_C + dl_B formed on the way (and stored: it IS H dx),
+// out = dx on the FREE variables only (the fixed ones keep the move of their bound, which dx holds on entry)
+struct BandQ { const int *Sb; const double *ATdy, *dy, *gN, *g; double *Hdx; };
+// out = H^-1 (in - sub)   (sub may be null; in == out allowed). One workgroup; column blockIdx.x of a matrix when ld != 0.
+template <int C>
+__global__ void __launch_bounds__(BAND_TH) k_band_apply(BandOp op, const double *__restrict__ in, const double *__restrict__ sub,
+                                                        double *__restrict__ out, long long ld, BandQ q) {
+    extern __shared__ double band_lds[];
+    __shared__ AMap wm[BAND_TH / 64];
+    double *v = band_lds;
+    const int n = op.n, c = op.c, tid = threadIdx.x;
+    const long long off = (long long)blockIdx.x * ld;
+    in += off; out += off;
+    // factor entries of this chunk (and the one / two rows behind it, which the backward sweep multiplies with)
+    double L1[C + 1], L2[C + 2];
+#pragma unroll
+    for (int k = 0; k < C + 1; k++) L1[k] = k <= c ? op.l1i[k * BAND_TH + tid] : 0.0;
+#pragma unroll
+    for (int k = 0; k < C + 2; k++) L2[k] = k <= c + 1 ? op.l2i[k * BAND_TH + tid] : 0.0;
+    if (q.Sb) {
+        for (int i = tid; i < n; i += BAND_TH) {
+            const double h = (q.ATdy[i] + (q.Sb[i] != 0 ? q.dy[i] : 0.0)) - (q.gN[i] - q.g[i]);
+            q.Hdx[i] = h; v[i] = h;
+        }
+    } else {
+        for (int i = tid; i < n; i += BAND_TH) v[i] = sub ? in[i] - sub[i] : in[i];
+    }
+    __syncthreads();
+    const int s0i = tid * c, cnt = max(0, min(c, n - s0i));
+    double b[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) b[k] = k < cnt ? v[s0i + k] : 0.0;
+    // ---- forward: z[i] = b[i] - l1[i] z[i-1] - l2[i] z[i-2]
+    AMap m;
+    {
+        double z1 = 0.0, z2 = 0.0, a1 = 1.0, a2 = 0.0, b1 = 0.0, b2 = 1.0;
+#pragma unroll
+        for (int k = 0; k < C; k++)
+            if (k < cnt) {
+                const double z = b[k] - L1[k] * z1 - L2[k] * z2, na = -L1[k] * a1 - L2[k] * a2, nb = -L1[k] * b1 - L2[k] * b2;
+                z2 = z1; z1 = z; a2 = a1; a1 = na; b2 = b1; b1 = nb;
+            }
+        m.p00 = a1; m.p10 = a2; m.p01 = b1; m.p11 = b2; m.e0 = z1; m.e1 = z2;
+    }
+    double t1, t2;
+    band_scan(m, false, wm, t1, t2);
+#pragma unroll
+    for (int k = 0; k < C; k++)
+        if (k < cnt) {
+            const double z = b[k] - L1[k] * t1 - L2[k] * t2;
+            t2 = t1; t1 = z;
+            b[k] = z * op.dinv[s0i + k];
+        }
+    // ---- backward: x[i] = y[i] - l1[i+1] x[i+1] - l2[i+2] x[i+2]
+    {
+        double z1 = 0.0, z2 = 0.0, a1 = 1.0, a2 = 0.0, b1 = 0.0, b2 = 1.0;
+#pragma unroll
+        for (int k = C - 1; k >= 0; k--)
+            if (k < cnt) {
+                const double z = b[k] - L1[k + 1] * z1 - L2[k + 2] * z2, na = -L1[k + 1] * a1 - L2[k + 2] * a2, nb = -L1[k + 1] * b1 - L2[k + 2] * b2;
+                z2 = z1; z1 = z; a2 = a1; a1 = na; b2 = b1; b1 = nb;
+            }
+        m.p00 = a1; m.p10 = a2; m.p01 = b1; m.p11 = b2; m.e0 = z1; m.e1 = z2;
+    }
+    band_scan(m, true, wm, t1, t2);
+#pragma unroll
+    for (int k = C - 1; k >= 0; k--)
+        if (k < cnt) {
+            const double z = b[k] - L1[k + 1] * t1 - L2[k + 2] * t2;
+            t2 = t1; t1 = z;
+            v[s0i + k] = z;
+        }
+    __syncthreads();
+    if (q.Sb) { for (int i = tid; i < n; i += BAND_TH) if (q.Sb[i] == 0) out[i] = v[i]; }
+    else for (int i = tid; i < n; i += BAND_TH) out[i] = v[i];
 }
 
 // ---- rows of C ----------------------------------------------------------------------------------------------------------------
@@ -207,28 +237,33 @@ __global__ void k_rs_rhs(int nR, const int *__restrict__ R, int nV, const int *_
     else { const int r = id - nV; rhs[j] = (Sall[id] == -1 ? delta_of(lbAN[r], lbA[r]) : delta_of(ubAN[r], ubA[r])) + Ap[r]; }
 }
 // q = A'dl_C + dl_B;  H dx = q - (gN - g)   (dx = H^-1 of it follows)
-// (dfix: the moves of the fixed variables, which dx holds on entry, are kept for the epilogue of the H^-1 product)
+// (dense operator: the banded one forms this inside k_band_apply)
 __global__ void k_rs_q(int nV, const int *__restrict__ Sb, const double *__restrict__ ATdy, const double *__restrict__ dy,
-                       const double *__restrict__ gN, const double *__restrict__ g, double *__restrict__ Hdx,
-                       const double *__restrict__ dx, double *__restrict__ dfix) {
+                       const double *__restrict__ gN, const double *__restrict__ g, double *__restrict__ Hdx) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nV) return;
     Hdx[i] = (ATdy[i] + (Sb[i] != 0 ? dy[i] : 0.0)) - (gN[i] - g[i]);
-    dfix[i] = dx[i];
 }
-// dx on the fixed variables exactly on their bound's move (the H^-1 product gives it up to rounding)
-__global__ void k_rs_fix_dx(int nV, const int *__restrict__ Sb, const double *__restrict__ dfix, double *__restrict__ dx) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nV && Sb[i] != 0) dx[i] = dfix[i];
-}
-// p = H^-1 (gN - g) and A p shrink with the homotopy step like gN - g itself (tau from the device copy of the ratio test)
-__global__ void k_rs_scale_p(int nV, int nC, const double *__restrict__ res, double *__restrict__ p, double *__restrict__ Ap) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int bid = (int)res[1];
-    if (bid == 0x7fffffff) return;
-    const double om = 1.0 - res[0];
-    if (i < nV) p[i] *= om;
-    if (i < nC) Ap[i] *= om;
+// the multiplier step CARRIED over a row that joined at position k (the right-hand sides of the rows that were active before
+// have (1 - tau) of their way left): Sinv_new rhs_new = [om dl - lam u; lam], lam = (rhs_k - om cv'dl) / s -- O(nR) instead of a
+// pass over Sinv. One workgroup; dy (by row id, zeroed before) is filled as well.
+__global__ void __launch_bounds__(NT) k_rs_carry_add(int k, double om, const double *__restrict__ cv, const double *__restrict__ u,
+                                                     double *__restrict__ dl, const double *__restrict__ scal, int id, int nV,
+                                                     const int *__restrict__ Sall, const double *__restrict__ lb,
+                                                     const double *__restrict__ ub, const double *__restrict__ lbN,
+                                                     const double *__restrict__ ubN, const double *__restrict__ lbA,
+                                                     const double *__restrict__ ubA, const double *__restrict__ lbAN,
+                                                     const double *__restrict__ ubAN, const double *__restrict__ p,
+                                                     const double *__restrict__ Ap, const int *__restrict__ R, double *__restrict__ dy) {
+    __shared__ double sh[4];
+    double t = lane_sum4(k, [&](int j) { return cv[j] * dl[j]; });
+    t = block_sum(t, sh);
+    double rk;
+    if (id < nV) rk = (Sall[id] == -1 ? delta_of(lbN[id], lb[id]) : delta_of(ubN[id], ub[id])) + p[id];
+    else { const int r = id - nV; rk = (Sall[id] == -1 ? delta_of(lbAN[r], lbA[r]) : delta_of(ubAN[r], ubA[r])) + Ap[r]; }
+    const double lam = (rk - om * t) * scal[8];
+    for (int j = threadIdx.x; j < k; j += NT) { const double d = om * dl[j] - lam * u[j]; dl[j] = d; dy[R[j]] = d; }
+    if (threadIdx.x == 0) { dl[k] = lam; dy[id] = lam; }
 }
 __global__ void k_rs_diff(int n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -33,43 +33,41 @@ int Impl::rs_build_band(const std::vector<double> &hv, bool *ok) {
         if (!(di > 1e-12 * std::fabs(d0[i])) || !(di > 0.0)) return RET_OK;      // not positive definite (enough): not this path
         d[i] = di;
     }
-    const int T = BAND_T, c = (n + T - 1) / T;
-    std::vector<double> buf((size_t)4 * T * c + 5 * (size_t)n, 0.0);
-    double *l1i = buf.data(), *l2i = l1i + (size_t)T * c, *u1i = l2i + (size_t)T * c, *u2i = u1i + (size_t)T * c;
-    double *ga = u2i + (size_t)T * c, *gb = ga + n, *ha = gb + n, *hb = ha + n, *dinv = hb + n;
-    double growth = 0.0;
-    for (int t = 0; t < T; t++) {
-        const int s0 = t * c, e = std::min(s0 + c, n);
-        double a1 = 1.0, a2 = 0.0, b1 = 0.0, b2 = 1.0;        // (g[i-1], g[i-2]) of the two homogeneous solutions
-        for (int i = s0; i < e; i++) {
-            const int k = i - s0;
-            l1i[(size_t)k * T + t] = l1[i]; l2i[(size_t)k * T + t] = l2[i];
-            const double u1 = i + 1 < n ? l1[i + 1] : 0.0, u2 = i + 2 < n ? l2[i + 2] : 0.0;
-            u1i[(size_t)k * T + t] = u1; u2i[(size_t)k * T + t] = u2;
-            const double na = -l1[i] * a1 - l2[i] * a2, nb = -l1[i] * b1 - l2[i] * b2;
-            ga[i] = na; gb[i] = nb; a2 = a1; a1 = na; b2 = b1; b1 = nb;
-            growth = std::max(growth, std::max(std::fabs(na), std::fabs(nb)));
-            dinv[i] = 1.0 / d[i];
+    // (a factor whose homogeneous solutions grow along the rows -- H far from diagonal dominance -- would lose digits in the scan
+    //  of chunk maps: such a Hessian takes the dense operator). Growth of the two homogeneous solutions over windows of 64 rows:
+    {
+        double growth = 0.0;
+        for (int s0 = 0; s0 < n; s0 += 64) {
+            double a1 = 1.0, a2 = 0.0, b1 = 0.0, b2 = 1.0;
+            for (int i = s0; i < std::min(s0 + 64, n); i++) {
+                const double na = -l1[i] * a1 - l2[i] * a2, nb = -l1[i] * b1 - l2[i] * b2;
+                a2 = a1; a1 = na; b2 = b1; b1 = nb;
+                growth = std::max(growth, std::max(std::fabs(na), std::fabs(nb)));
+            }
         }
-        a1 = 1.0; a2 = 0.0; b1 = 0.0; b2 = 1.0;              // (h[i+1], h[i+2])
-        for (int i = e - 1; i >= s0; i--) {
-            const double u1 = i + 1 < n ? l1[i + 1] : 0.0, u2 = i + 2 < n ? l2[i + 2] : 0.0;
-            const double na = -u1 * a1 - u2 * a2, nb = -u1 * b1 - u2 * b2;
-            ha[i] = na; hb[i] = nb; a2 = a1; a1 = na; b2 = b1; b1 = nb;
-            growth = std::max(growth, std::max(std::fabs(na), std::fabs(nb)));
+        if (!(growth <= 1e3)) return RET_OK;
+    }
+    const int T = BAND_TH, c = (n + T - 1) / T;
+    std::vector<double> buf((size_t)T * (2 * c + 3) + (size_t)n, 0.0);
+    double *l1i = buf.data(), *l2i = l1i + (size_t)T * (c + 1), *dinv = l2i + (size_t)T * (c + 2);
+    for (int t = 0; t < T; t++) {
+        for (int k = 0; k <= c + 1; k++) {
+            const int i = t * c + k;
+            if (k <= c) l1i[(size_t)k * T + t] = i < n ? l1[i] : 0.0;
+            l2i[(size_t)k * T + t] = i < n ? l2[i] : 0.0;
         }
     }
-    // (a factor whose homogeneous solutions grow along a chunk -- H far from diagonal dominance -- would lose digits in the
-    //  chunked recurrences: such a Hessian takes the dense operator)
-    if (!(growth <= 1e3)) return RET_OK;
+    for (int i = 0; i < n; i++) dinv[i] = 1.0 / d[i];
     if (!band_buf) LCHK(hipMalloc(reinterpret_cast<void **>(&band_buf), sizeof(double) * buf.size()));
     LCHK(hipMemcpy(band_buf, buf.data(), sizeof(double) * buf.size(), hipMemcpyHostToDevice));
-    band.n = n; band.T = T; band.c = c;
-    band.l1i = band_buf; band.l2i = band.l1i + (size_t)T * c; band.u1i = band.l2i + (size_t)T * c; band.u2i = band.u1i + (size_t)T * c;
-    band.ga = band.u2i + (size_t)T * c; band.gb = band.ga + n; band.ha = band.gb + n; band.hb = band.ha + n; band.dinv = band.hb + n;
+    band.n = n; band.c = c;
+    band.l1i = band_buf; band.l2i = band.l1i + (size_t)T * (c + 1); band.dinv = band.l2i + (size_t)T * (c + 2);
     static bool attr_set = false;
     if (!attr_set) {
-        LCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_apply), hipFuncAttributeMaxDynamicSharedMemorySize, BAND_MAX_N * 8));
+        LCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_apply<4>), hipFuncAttributeMaxDynamicSharedMemorySize, BAND_MAX_N * 8));
+        LCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_apply<8>), hipFuncAttributeMaxDynamicSharedMemorySize, BAND_MAX_N * 8));
+        LCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_apply<12>), hipFuncAttributeMaxDynamicSharedMemorySize, BAND_MAX_N * 8));
+        LCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_apply<16>), hipFuncAttributeMaxDynamicSharedMemorySize, BAND_MAX_N * 8));
         attr_set = true;
     }
     *ok = true;
@@ -121,18 +119,30 @@ int Impl::rs_prepare(bool *ok) {
     *ok = built;
     return RET_OK;
 }
-// out = H^-1 (in - sub); fix_dx: the step direction's epilogue (dx on the fixed variables = the move of their bounds, kept in w6)
+void Impl::band_launch(int ncols, const double *in, const double *sub, double *out, long long ldc, bool qmode) {
+    BandQ q{};
+    if (qmode) { q.Sb = Sb; q.ATdy = ATdy; q.dy = dy; q.gN = gN; q.g = g; q.Hdx = Hdx; }
+    const size_t lds = sizeof(double) * (size_t)nV;
+    const int c = band.c;
+    if (c <= 4) hipLaunchKernelGGL(k_band_apply<4>, dim3(ncols), dim3(BAND_TH), lds, st, band, in, sub, out, ldc, q);
+    else if (c <= 8) hipLaunchKernelGGL(k_band_apply<8>, dim3(ncols), dim3(BAND_TH), lds, st, band, in, sub, out, ldc, q);
+    else if (c <= 12) hipLaunchKernelGGL(k_band_apply<12>, dim3(ncols), dim3(BAND_TH), lds, st, band, in, sub, out, ldc, q);
+    else hipLaunchKernelGGL(k_band_apply<16>, dim3(ncols), dim3(BAND_TH), lds, st, band, in, sub, out, ldc, q);
+}
+// out = H^-1 (in - sub); fix_dx: the step direction's product -- in = q - (gN - g) formed on the way (into Hdx), out = dx written on
+// the free variables only (in / sub are ignored)
 void Impl::rs_hinv_apply(const double *in, const double *sub, double *out, bool fix_dx) {
     pbegin();
     if (rs_kind == 1) {
-        hipLaunchKernelGGL(k_band_apply, dim3(1), dim3(1024), sizeof(double) * nV, st, band, in, sub, out, 0LL, fix_dx ? Sb : (const int *)nullptr,
-                           fix_dx ? w6 : (const double *)nullptr);
-        pend(5, 72.0 * nV);
+        band_launch(1, in, sub, out, 0LL, fix_dx);
+        pend(5, 40.0 * nV);
+    } else if (fix_dx) {
+        hipLaunchKernelGGL(k_rs_q, g1(nV), dim3(NT), 0, st, nV, Sb, ATdy, dy, gN, g, Hdx);
+        gemv_n(Z, ld, nV, nV, Hdx, 1.0, 0.0, nullptr, w4, Sb, out);       // (merge epilogue: out = the product on the free variables only)
     } else {
         const double *src = in;
         if (sub) { hipLaunchKernelGGL(k_rs_diff, g1(nV), dim3(NT), 0, st, nV, in, sub, wz3); src = wz3; }
         gemv_n(Z, ld, nV, nV, src, 1.0, 0.0, nullptr, out);
-        if (fix_dx) hipLaunchKernelGGL(k_rs_fix_dx, g1(nV), dim3(NT), 0, st, nV, Sb, w6, out);
     }
     chk("rs_hinv_apply");
 }
@@ -151,7 +161,7 @@ void Impl::rs_flush() {
     rs_rank1(pendR.n, rs_ps_u, S_KEEP_S, 1.0);
 }
 // out = Sinv w, the deferred rank-1 part of the last bordering applied on the way
-void Impl::rs_sinv_times(const double *wv, double *out) {
+void Impl::rs_sinv_times(const double *wv, double *out, bool scatter_dy) {
     if (nR <= 0) return;
     const int nt = (nR + SYT - 1) / SYT;
     double *P1 = wz_part, *P2 = wz_part + (size_t)nt * nR;
@@ -165,7 +175,7 @@ void Impl::rs_sinv_times(const double *wv, double *out) {
         hipLaunchKernelGGL((k_sym_tile<false, true>), dim3(sym_tiles(nR)), dim3(256), 0, st, Wz, ld, nR, (const double *)nullptr, scal, 0, 0.0, wv, P1, P2);
         pend(0, 4.0 * nR * (double)nR);
     }
-    hipLaunchKernelGGL(k_sym_reduce, g1(nR), dim3(NT), 0, st, nR, nt, P1, P2, out);
+    hipLaunchKernelGGL(k_sym_reduce, g1(nR), dim3(NT), 0, st, nR, nt, P1, P2, out, scatter_dy ? R : (const int *)nullptr, scatter_dy ? dy : (double *)nullptr);
     chk("rs sym product");
 }
 void Impl::rs_count(int id, int delta) {       // delta +1: the row joined, -1: it left
@@ -216,10 +226,11 @@ void Impl::rs_add_row(int id, int side, int yidx, double yval) {
     nR++;
     rs_count(id, +1);
 }
-void Impl::rs_remove_row(int k) {
+void Impl::rs_remove_row(int k, bool carry) {
     const int id = hR[k];
     rs_flush();
     hipLaunchKernelGGL(k_dual_colcoef_sym, g1(nR), dim3(NT), 0, st, Wz, ld, nR, k, ra3, scal);
+    if (carry) hipLaunchKernelGGL(k_dual_carry_remove, dim3(1), dim3(NT), 0, st, nR, k, 1.0 - last_tau, ra3, rs_dl);
     rs_rank1(nR, ra3, 9, 1.0);
     hipLaunchKernelGGL(k_dual_move_last_sym, g1(std::max(nR - 1, 1)), dim3(NT), 0, st, Wz, ld, nR, k, R, posR, Sall, id, y, id);
     if (k != nR - 1) { hR[k] = hR[nR - 1]; hposR[hR[k]] = k; }
@@ -231,13 +242,20 @@ void Impl::rs_remove_row(int k) {
 int Impl::rs_change_active_set(int kind, int idx, int side) {
     carry_pending = carry_ready = false;
     const int id = (kind == 1 || kind == 3) ? nV + idx : idx;
-    if (kind == 1 || kind == 2) { rs_remove_row(hposR[id]); return RET_OK; }
+    if (kind == 1 || kind == 2) {
+        // a row leaves: the multiplier step is carried (rs_dl transformed here, with the column of Sinv as it is before the update)
+        const bool will_carry = rs_carry_enabled && carry_valid && carried < CARRY_REFRESH && nR > 1;
+        rs_remove_row(hposR[id], will_carry);
+        carry_ready = will_carry;
+        return RET_OK;
+    }
     double ynew = 0.0;
-    bool li = false;
+    bool li = false, exchanged = false;
     rs_products(id);
     if (rs_li_decision(&li) != RET_OK) return RET_SETUP_FAILED;
     if (!li) {
         int pkind = 0, pidx = -1;
+        exchanged = true;
         hipLaunchKernelGGL(k_rs_row, dim3(1), dim3(NT), 0, st, nV, id, M.Arp, M.Aci, M.Arv, M.denseAT, w4);
         const int rc = ensure_LI(side, &ynew, &pkind, &pidx);
         if (rc != RET_OK) return rc;
@@ -248,6 +266,9 @@ int Impl::rs_change_active_set(int kind, int idx, int side) {
         if (!li && !(h_ctl[4] > 1e-14 * h_ctl[5])) return RET_SETUP_FAILED;
     }
     rs_add_row(id, side, id, ynew);
+    // a plain addition (no exchange before it: cv in ra1, u in ra2, 1 / s in scal[8] are those of the bordering)
+    carry_pending = rs_carry_enabled && ynew == 0.0 && li && carry_valid && carried < CARRY_REFRESH && !exchanged;
+    rs_carry_id = id;
     return RET_OK;
 }
 
@@ -260,16 +281,24 @@ void Impl::rs_step_direction() {
     if (!dx_ready) hipLaunchKernelGGL(k_dx_fixed_zero_dy, g1(nV + nC), dim3(NT), 0, st, nV, nC, Sb, lb, ub, lbN, ubN, dx, dy);
     dx_ready = false;
     if (nR > 0) {
-        hipLaunchKernelGGL(k_rs_rhs, g1(nR), dim3(NT), 0, st, nR, R, nV, Sall, lb, ub, lbN, ubN, lbA, ubA, lbAN, ubAN, rs_p, rs_Ap, ra4);
-        rs_sinv_times(ra4, rs_dl);
-        hipLaunchKernelGGL(k_rs_scatter, g1(nR), dim3(NT), 0, st, nR, R, rs_dl, dy);
+        if (carry_ready && carry_valid) {                     // (transformed by rs_remove_row already)
+            hipLaunchKernelGGL(k_rs_scatter, g1(nR), dim3(NT), 0, st, nR, R, rs_dl, dy);
+            carried++; stat_carried++;
+        } else if (carry_pending && carry_valid) {
+            hipLaunchKernelGGL(k_rs_carry_add, dim3(1), dim3(NT), 0, st, nR - 1, 1.0 - last_tau, ra1, ra2, rs_dl, scal, rs_carry_id, nV, Sall, lb, ub,
+                               lbN, ubN, lbA, ubA, lbAN, ubAN, rs_p, rs_Ap, R, dy);
+            carried++; stat_carried++;
+        } else {
+            hipLaunchKernelGGL(k_rs_rhs, g1(nR), dim3(NT), 0, st, nR, R, nV, Sall, lb, ub, lbN, ubN, lbA, ubA, lbAN, ubAN, rs_p, rs_Ap, ra4);
+            rs_sinv_times(ra4, rs_dl, true);
+            carried = 0;
+        }
     }
     AT_times(dy + nV, ATdy);
-    hipLaunchKernelGGL(k_rs_q, g1(nV), dim3(NT), 0, st, nV, Sb, ATdy, dy, gN, g, Hdx, dx, w6);
-    rs_hinv_apply(Hdx, nullptr, dx, true);
+    rs_hinv_apply(nullptr, nullptr, dx, true);
     A_times(dx, dAx);
     carry_pending = carry_ready = false;
-    carry_valid = false;
+    carry_valid = nR > 0;
     chk("rs_step_direction");
 }
 
@@ -287,7 +316,7 @@ int Impl::rs_setup_rows(const std::vector<int> &rows, const std::vector<int> &gb
     if (!se0) { (void)hipEventCreate(&se0); (void)hipEventCreate(&se1); (void)hipEventCreate(&se2); }
     setup_stat = SetupStat();
     (void)hipEventRecord(se0, st);
-    if (rs_kind == 1) hipLaunchKernelGGL(k_band_apply, dim3(n), dim3(1024), sizeof(double) * nV, st, band, Cd, (const double *)nullptr, T, ld, (const int *)nullptr, (const double *)nullptr);
+    if (rs_kind == 1) band_launch(n, Cd, nullptr, T, ld, false);
     else LCHK(rsqp_dgemm(false, false, nV, n, nV, 1.0, Z, ld, Cd, ld, 0.0, T, ld, st));
     LCHK(rsqp_dgemm_upper(true, false, n, nV, 1.0, Cd, ld, T, ld, 0.0, rs_G, ld, st));
     (void)hipEventRecord(se1, st);
