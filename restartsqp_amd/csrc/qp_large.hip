@@ -3067,6 +3067,8 @@ struct RsqpLargeEngine::Impl {
     double *rs_G = nullptr;          // ld x ld scratch of the blocked set-up (allocated on first use)
     double *band_buf = nullptr;      // the nine arrays of the banded operator
     BandOp band{};
+    double band_seq = 0.0;           // tag of the last multi-workgroup product (k_band_apply_mw)
+    bool band_mw = getenv("RSQP_LARGE_BAND_1WG") == nullptr;      // (tests / tuning: the one-workgroup kernel for single vectors as well)
     struct { bool on = false; int n = 0; } pendR;
     int rs_prepare(bool *ok);
     int rs_build_band(const std::vector<double> &hv, bool *ok);
@@ -3477,6 +3479,10 @@ int RsqpLargeEngine::solve(int mode, const double *d_g, const double *d_lb, cons
     rc = P.homotopy(maxit, &n);
     *nWSR = n;
     (void)hipStreamSynchronize(st);
+    if (P.rsh && P.rs_kind == 1) {       // a spin of the multi-workgroup banded product that ran out (never seen): nothing of this solve can be trusted
+        int e = 0;
+        if (hipMemcpy(&e, P.dflag + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess || e != 0) { P.status = QPS_NOTINITIALISED; return RET_SETUP_FAILED; }
+    }
     return rc;
 }
 

@@ -18,23 +18,34 @@
 // Reference: the arithmetic stands in for qpOASES' SQProblem::hotstart / init behind src/qpOASESInterface.cpp:155-206.
 #pragma once
 
-// ---- banded H^-1 (half bandwidth <= 2): x = L^-T D^-1 L^-1 b, L unit lower with sub-diagonals l1 (i, i - 1) and l2 (i, i - 2) ------
-// The two triangular solves are linear recurrences of depth 2, i.e. compositions of affine maps of the state (z[i-1], z[i-2]).
-// ONE workgroup of 1024 threads; thread t owns the c = ceil(n / 1024) consecutive rows of chunk t with their factor entries in
-// REGISTERS (loaded once, up front, from a chunk-interleaved layout: consecutive threads read consecutive addresses):
+// ---- banded H^-1 (half bandwidth <= 2) ----------------------------------------------------------------------------------------------
+// H = L D L' (L unit lower, sub-diagonals l1, l2), S = D^1/2, M = S^-1 L S (unit lower as well):  H^-1 = S^-1 M^-T M^-1 S^-1. The
+// diagonal scalings ride on the coalesced load / store of the vector; the two triangular solves are linear recurrences of depth 2,
+// i.e. compositions of affine maps of the state (z[i-1], z[i-2]). 1024 threads; thread t owns the c = ceil(n / 1024) consecutive
+// rows of chunk t with their factor entries in REGISTERS (loaded once, up front, from a chunk-interleaved layout: consecutive
+// threads read consecutive addresses):
 //   1. the chunk's map "incoming state -> outgoing state" (a particular and two homogeneous runs over the c rows),
-//   2. an inclusive scan of the 1024 maps: 6 shuffle steps inside a wave, the 16 wave totals through LDS,
+//   2. an inclusive scan of the 1024 maps,
 //   3. the chunk again with its true incoming state.
-// Forward, scale by 1/d, the same backward (reversed order). ~4 c + 12 dependent steps per sweep instead of 2 n; the first version
-// (one thread chaining 128 chunk states, factor entries fetched from memory inside the dependent loop) took 62 us per product at
-// n = 10 000 (profiles/r05_c_first_rs_kernel_stats_large_band5.csv).
+// Forward, then the same backward (reversed order): ~4 c + 12 dependent steps per sweep instead of 2 n.
+//   k_band_apply<C>     ONE workgroup of 1024 threads (scan: 6 shuffle steps per wave, the 16 wave totals through LDS); a grid of
+//                       them for the columns of a matrix (blocked set-up).
+//   k_band_apply_mw<C>  ONE vector on 16 single-wave workgroups: a workgroup moves 1/16 of the bytes (a single compute unit
+//                       streams ~60-100 GB/s: the one-workgroup kernel took 23 us for the ~0.7 MB of a product at n = 10 000,
+//                       profiles/r05_e_kernel_stats_large_band5.csv) and hands its total map to the others through
+//                       device-scope words tagged with the call's sequence number (forward: to the workgroups above it,
+//                       backward: below). All 16 are resident at once, every spin is bounded.
+// History: the first version (one thread chaining 128 chunk states, factor entries fetched inside the dependent loop) took 62 us.
 struct BandOp {
     int n, c;                     // rows, rows per chunk (1024 c >= n)
-    const double *l1i, *l2i;      // l1i[k * 1024 + t] = l1[t c + k], k = 0..c;  l2i likewise, k = 0..c + 1  (0 beyond n)
-    const double *dinv;           // 1 / d, plain
+    const double *m1i, *m2i;      // m1i[k * 1024 + t] = M[i][i-1] for i = t c + k, k = 0..c;  m2i: M[i][i-2], k = 0..c + 1  (0 beyond n)
+    const double *sinv;           // 1 / sqrt(d), plain
+    double *agg;                  // [2][16][8] totals of the multi-workgroup form: 6 doubles of the map + the tag
+    int *err;                     // set when a spin ran out (never seen; the engine then reports a set-up failure)
 };
 constexpr int BAND_MAX_N = 16384;         // the vector passes through LDS (128 KB)
 constexpr int BAND_TH = 1024;
+constexpr int BAND_MW = 16;               // workgroups of the multi-workgroup form (one wave each)
 struct AMap { double p00, p01, p10, p11, e0, e1; };       // s_out = P s_in + e
 __device__ __forceinline__ AMap amap_then(const AMap &a, const AMap &b) {      // first a, then b
     AMap r;
@@ -49,28 +60,57 @@ __device__ __forceinline__ AMap amap_shfl(const AMap &m, int src) {
     r.e0 = __shfl(m.e0, src); r.e1 = __shfl(m.e1, src);
     return r;
 }
-// state entering this thread's chunk, given every chunk's map m (rev: chunks are chained from the last one down)
-__device__ __forceinline__ void band_scan(AMap m, bool rev, AMap *wm, double &s0, double &s1) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void amap_apply(const AMap &q, double &a, double &b) {
+    const double na = q.p00 * a + q.p01 * b + q.e0, nb = q.p10 * a + q.p11 * b + q.e1;
+    a = na; b = nb;
+}
+// inclusive scan of the maps of one wave in processing order (rev: from lane 63 down)
+__device__ __forceinline__ AMap band_wave_scan(AMap m, bool rev) {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const int src = rev ? lane + d : lane - d;
         const AMap o = amap_shfl(m, src & 63);
         if (rev ? (lane + d < 64) : (lane >= d)) m = amap_then(o, m);
     }
-    __syncthreads();                                   // (wm may still be read by the previous sweep)
-    if (lane == (rev ? 0 : 63)) wm[wave] = m;
-    __syncthreads();
-    double a = 0.0, b = 0.0;                           // state entering this wave
-    if (!rev) { for (int w = 0; w < wave; w++) { const AMap q = wm[w]; const double na = q.p00 * a + q.p01 * b + q.e0, nb = q.p10 * a + q.p11 * b + q.e1; a = na; b = nb; } }
-    else { for (int w = BAND_TH / 64 - 1; w > wave; w--) { const AMap q = wm[w]; const double na = q.p00 * a + q.p01 * b + q.e0, nb = q.p10 * a + q.p11 * b + q.e1; a = na; b = nb; } }
-    const AMap pv = amap_shfl(m, (rev ? lane + 1 : lane - 1) & 63);     // the map up to the chunk before this one, inside the wave
-    if (rev ? (lane == 63) : (lane == 0)) { s0 = a; s1 = b; }
-    else { s0 = pv.p00 * a + pv.p01 * b + pv.e0; s1 = pv.p10 * a + pv.p11 * b + pv.e1; }
+    return m;
+}
+// the chunk's map (forward: rows 0..cnt-1 with M[i][i-1], M[i][i-2]; backward: rows cnt-1..0 with M[i+1][i], M[i+2][i])
+template <int C, bool REV>
+__device__ __forceinline__ AMap band_chunk_map(const double (&b)[C], const double (&L1)[C + 1], const double (&L2)[C + 2], int cnt) {
+    double z1 = 0.0, z2 = 0.0, a1 = 1.0, a2 = 0.0, b1 = 0.0, b2 = 1.0;
+#pragma unroll
+    for (int kk = 0; kk < C; kk++) {
+        const int k = REV ? C - 1 - kk : kk;
+        if (k < cnt) {
+            const double f1 = REV ? L1[k + 1] : L1[k], f2 = REV ? L2[k + 2] : L2[k];
+            const double z = b[k] - f1 * z1 - f2 * z2, na = -f1 * a1 - f2 * a2, nb = -f1 * b1 - f2 * b2;
+            z2 = z1; z1 = z; a2 = a1; a1 = na; b2 = b1; b1 = nb;
+        }
+    }
+    AMap m;
+    m.p00 = a1; m.p10 = a2; m.p01 = b1; m.p11 = b2; m.e0 = z1; m.e1 = z2;
+    return m;
+}
+template <int C, bool REV>
+__device__ __forceinline__ void band_chunk_run(double (&b)[C], const double (&L1)[C + 1], const double (&L2)[C + 2], int cnt, double t1, double t2) {
+#pragma unroll
+    for (int kk = 0; kk < C; kk++) {
+        const int k = REV ? C - 1 - kk : kk;
+        if (k < cnt) {
+            const double f1 = REV ? L1[k + 1] : L1[k], f2 = REV ? L2[k + 2] : L2[k];
+            const double z = b[k] - f1 * t1 - f2 * t2;
+            t2 = t1; t1 = z; b[k] = z;
+        }
+    }
 }
 // the step direction's product in one launch: in = q - (gN - g) with q = A'dl_C + dl_B formed on the way (and stored: it IS H dx),
 // out = dx on the FREE variables only (the fixed ones keep the move of their bound, which dx holds on entry)
 struct BandQ { const int *Sb; const double *ATdy, *dy, *gN, *g; double *Hdx; };
+__device__ __forceinline__ double band_input(const BandQ &q, const double *__restrict__ in, const double *__restrict__ sub, int i) {
+    if (q.Sb) { const double h = (q.ATdy[i] + (q.Sb[i] != 0 ? q.dy[i] : 0.0)) - (q.gN[i] - q.g[i]); q.Hdx[i] = h; return h; }
+    return sub ? in[i] - sub[i] : in[i];
+}
 // out = H^-1 (in - sub)   (sub may be null; in == out allowed). One workgroup; column blockIdx.x of a matrix when ld != 0.
 template <int C>
 __global__ void __launch_bounds__(BAND_TH) k_band_apply(BandOp op, const double *__restrict__ in, const double *__restrict__ sub,
@@ -78,71 +118,99 @@ __global__ void __launch_bounds__(BAND_TH) k_band_apply(BandOp op, const double 
     extern __shared__ double band_lds[];
     __shared__ AMap wm[BAND_TH / 64];
     double *v = band_lds;
-    const int n = op.n, c = op.c, tid = threadIdx.x;
+    const int n = op.n, c = op.c, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long off = (long long)blockIdx.x * ld;
     in += off; out += off;
-    // factor entries of this chunk (and the one / two rows behind it, which the backward sweep multiplies with)
     double L1[C + 1], L2[C + 2];
 #pragma unroll
-    for (int k = 0; k < C + 1; k++) L1[k] = k <= c ? op.l1i[k * BAND_TH + tid] : 0.0;
+    for (int k = 0; k < C + 1; k++) L1[k] = k <= c ? op.m1i[k * BAND_TH + tid] : 0.0;
 #pragma unroll
-    for (int k = 0; k < C + 2; k++) L2[k] = k <= c + 1 ? op.l2i[k * BAND_TH + tid] : 0.0;
-    if (q.Sb) {
-        for (int i = tid; i < n; i += BAND_TH) {
-            const double h = (q.ATdy[i] + (q.Sb[i] != 0 ? q.dy[i] : 0.0)) - (q.gN[i] - q.g[i]);
-            q.Hdx[i] = h; v[i] = h;
-        }
-    } else {
-        for (int i = tid; i < n; i += BAND_TH) v[i] = sub ? in[i] - sub[i] : in[i];
-    }
+    for (int k = 0; k < C + 2; k++) L2[k] = k <= c + 1 ? op.m2i[k * BAND_TH + tid] : 0.0;
+    for (int i = tid; i < n; i += BAND_TH) v[i] = band_input(q, in, sub, i) * op.sinv[i];
     __syncthreads();
     const int s0i = tid * c, cnt = max(0, min(c, n - s0i));
     double b[C];
 #pragma unroll
     for (int k = 0; k < C; k++) b[k] = k < cnt ? v[s0i + k] : 0.0;
-    // ---- forward: z[i] = b[i] - l1[i] z[i-1] - l2[i] z[i-2]
-    AMap m;
-    {
-        double z1 = 0.0, z2 = 0.0, a1 = 1.0, a2 = 0.0, b1 = 0.0, b2 = 1.0;
 #pragma unroll
-        for (int k = 0; k < C; k++)
-            if (k < cnt) {
-                const double z = b[k] - L1[k] * z1 - L2[k] * z2, na = -L1[k] * a1 - L2[k] * a2, nb = -L1[k] * b1 - L2[k] * b2;
-                z2 = z1; z1 = z; a2 = a1; a1 = na; b2 = b1; b1 = nb;
-            }
-        m.p00 = a1; m.p10 = a2; m.p01 = b1; m.p11 = b2; m.e0 = z1; m.e1 = z2;
+    for (int sweep = 0; sweep < 2; sweep++) {
+        const bool rev = sweep == 1;
+        AMap m = rev ? band_chunk_map<C, true>(b, L1, L2, cnt) : band_chunk_map<C, false>(b, L1, L2, cnt);
+        m = band_wave_scan(m, rev);
+        __syncthreads();                                   // (wm may still be read by the previous sweep)
+        if (lane == (rev ? 0 : 63)) wm[wave] = m;
+        __syncthreads();
+        double a = 0.0, bb = 0.0;                          // state entering this wave
+        if (!rev) { for (int w = 0; w < wave; w++) amap_apply(wm[w], a, bb); }
+        else { for (int w = BAND_TH / 64 - 1; w > wave; w--) amap_apply(wm[w], a, bb); }
+        const AMap pv = amap_shfl(m, (rev ? lane + 1 : lane - 1) & 63);     // the map up to the chunk before this one, inside the wave
+        if (!(rev ? (lane == 63) : (lane == 0))) amap_apply(pv, a, bb);
+        if (rev) band_chunk_run<C, true>(b, L1, L2, cnt, a, bb); else band_chunk_run<C, false>(b, L1, L2, cnt, a, bb);
     }
-    double t1, t2;
-    band_scan(m, false, wm, t1, t2);
 #pragma unroll
-    for (int k = 0; k < C; k++)
-        if (k < cnt) {
-            const double z = b[k] - L1[k] * t1 - L2[k] * t2;
-            t2 = t1; t1 = z;
-            b[k] = z * op.dinv[s0i + k];
-        }
-    // ---- backward: x[i] = y[i] - l1[i+1] x[i+1] - l2[i+2] x[i+2]
-    {
-        double z1 = 0.0, z2 = 0.0, a1 = 1.0, a2 = 0.0, b1 = 0.0, b2 = 1.0;
-#pragma unroll
-        for (int k = C - 1; k >= 0; k--)
-            if (k < cnt) {
-                const double z = b[k] - L1[k + 1] * z1 - L2[k + 2] * z2, na = -L1[k + 1] * a1 - L2[k + 2] * a2, nb = -L1[k + 1] * b1 - L2[k + 2] * b2;
-                z2 = z1; z1 = z; a2 = a1; a1 = na; b2 = b1; b1 = nb;
-            }
-        m.p00 = a1; m.p10 = a2; m.p01 = b1; m.p11 = b2; m.e0 = z1; m.e1 = z2;
-    }
-    band_scan(m, true, wm, t1, t2);
-#pragma unroll
-    for (int k = C - 1; k >= 0; k--)
-        if (k < cnt) {
-            const double z = b[k] - L1[k + 1] * t1 - L2[k + 2] * t2;
-            t2 = t1; t1 = z;
-            v[s0i + k] = z;
-        }
+    for (int k = 0; k < C; k++) if (k < cnt) v[s0i + k] = b[k];
     __syncthreads();
-    if (q.Sb) { for (int i = tid; i < n; i += BAND_TH) if (q.Sb[i] == 0) out[i] = v[i]; }
-    else for (int i = tid; i < n; i += BAND_TH) out[i] = v[i];
+    if (q.Sb) { for (int i = tid; i < n; i += BAND_TH) if (q.Sb[i] == 0) out[i] = v[i] * op.sinv[i]; }
+    else for (int i = tid; i < n; i += BAND_TH) out[i] = v[i] * op.sinv[i];
+}
+// the same product of ONE vector on BAND_MW single-wave workgroups (see above); seq: this call's tag (> 0, increasing)
+template <int C>
+__global__ void __launch_bounds__(64) k_band_apply_mw(BandOp op, const double *__restrict__ in, const double *__restrict__ sub,
+                                                      double *__restrict__ out, BandQ q, double seq) {
+    __shared__ double v[64 * C];
+    __shared__ double wa[BAND_MW][6];
+    const int n = op.n, c = op.c, lane = threadIdx.x, blk = blockIdx.x, tid = blk * 64 + lane;
+    double L1[C + 1], L2[C + 2];
+#pragma unroll
+    for (int k = 0; k < C + 1; k++) L1[k] = k <= c ? op.m1i[k * BAND_TH + tid] : 0.0;
+#pragma unroll
+    for (int k = 0; k < C + 2; k++) L2[k] = k <= c + 1 ? op.m2i[k * BAND_TH + tid] : 0.0;
+    const int r0 = blk * 64 * c, r1 = min(r0 + 64 * c, n);          // the rows of this workgroup
+    for (int i = r0 + lane; i < r1; i += 64) v[i - r0] = band_input(q, in, sub, i) * op.sinv[i];
+    __syncthreads();
+    const int s0i = tid * c, cnt = max(0, min(c, n - s0i));
+    double b[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) b[k] = k < cnt ? v[s0i - r0 + k] : 0.0;
+#pragma unroll
+    for (int sweep = 0; sweep < 2; sweep++) {
+        const bool rev = sweep == 1;
+        AMap m = rev ? band_chunk_map<C, true>(b, L1, L2, cnt) : band_chunk_map<C, false>(b, L1, L2, cnt);
+        m = band_wave_scan(m, rev);
+        double *mine = op.agg + ((size_t)sweep * BAND_MW + blk) * 8;
+        if (lane == (rev ? 0 : 63)) {                      // this workgroup's total: six words, then the tag behind a device-scope fence
+            __hip_atomic_store(mine + 0, m.p00, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(mine + 1, m.p01, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mine + 2, m.p10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(mine + 3, m.p11, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mine + 4, m.e0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(mine + 5, m.e1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+            __hip_atomic_store(mine + 6, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // lane w fetches the total of workgroup w if that one is processed before this one
+        const bool need = lane < BAND_MW && (rev ? lane > blk : lane < blk);
+        if (need) {
+            const double *src = op.agg + ((size_t)sweep * BAND_MW + lane) * 8;
+            int spins = 0;
+            while (__hip_atomic_load(src + 6, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22)) { atomicExch(op.err, 1); break; }
+            }
+            __threadfence();
+#pragma unroll
+            for (int e = 0; e < 6; e++) wa[lane][e] = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        double a = 0.0, bb = 0.0;                          // state entering this workgroup
+        if (!rev) { for (int w = 0; w < blk; w++) { AMap t; t.p00 = wa[w][0]; t.p01 = wa[w][1]; t.p10 = wa[w][2]; t.p11 = wa[w][3]; t.e0 = wa[w][4]; t.e1 = wa[w][5]; amap_apply(t, a, bb); } }
+        else { for (int w = BAND_MW - 1; w > blk; w--) { AMap t; t.p00 = wa[w][0]; t.p01 = wa[w][1]; t.p10 = wa[w][2]; t.p11 = wa[w][3]; t.e0 = wa[w][4]; t.e1 = wa[w][5]; amap_apply(t, a, bb); } }
+        const AMap pv = amap_shfl(m, (rev ? lane + 1 : lane - 1) & 63);
+        if (!(rev ? (lane == 63) : (lane == 0))) amap_apply(pv, a, bb);
+        if (rev) band_chunk_run<C, true>(b, L1, L2, cnt, a, bb); else band_chunk_run<C, false>(b, L1, L2, cnt, a, bb);
+        __syncthreads();                                   // (wa is rewritten by the next sweep)
+    }
+#pragma unroll
+    for (int k = 0; k < C; k++) if (k < cnt) v[s0i - r0 + k] = b[k];
+    __syncthreads();
+    for (int i = r0 + lane; i < r1; i += 64) if (!q.Sb || q.Sb[i] == 0) out[i] = v[i - r0] * op.sinv[i];
 }
 
 // ---- rows of C ----------------------------------------------------------------------------------------------------------------

@@ -48,24 +48,31 @@ int Impl::rs_build_band(const std::vector<double> &hv, bool *ok) {
         if (!(growth <= 1e3)) return RET_OK;
     }
     const int T = BAND_TH, c = (n + T - 1) / T;
-    std::vector<double> buf((size_t)T * (2 * c + 3) + (size_t)n, 0.0);
-    double *l1i = buf.data(), *l2i = l1i + (size_t)T * (c + 1), *dinv = l2i + (size_t)T * (c + 2);
+    const size_t nagg = 2 * BAND_MW * 8;
+    std::vector<double> buf((size_t)T * (2 * c + 3) + (size_t)n + nagg, 0.0);
+    double *m1i = buf.data(), *m2i = m1i + (size_t)T * (c + 1), *sinv = m2i + (size_t)T * (c + 2);
+    std::vector<double> sq(n);
+    for (int i = 0; i < n; i++) { sq[i] = std::sqrt(d[i]); sinv[i] = 1.0 / sq[i]; }
     for (int t = 0; t < T; t++) {
         for (int k = 0; k <= c + 1; k++) {
             const int i = t * c + k;
-            if (k <= c) l1i[(size_t)k * T + t] = i < n ? l1[i] : 0.0;
-            l2i[(size_t)k * T + t] = i < n ? l2[i] : 0.0;
+            if (k <= c) m1i[(size_t)k * T + t] = (i < n && i >= 1) ? l1[i] * sq[i - 1] / sq[i] : 0.0;
+            m2i[(size_t)k * T + t] = (i < n && i >= 2) ? l2[i] * sq[i - 2] / sq[i] : 0.0;
         }
     }
-    for (int i = 0; i < n; i++) dinv[i] = 1.0 / d[i];
     if (!band_buf) LCHK(hipMalloc(reinterpret_cast<void **>(&band_buf), sizeof(double) * buf.size()));
     LCHK(hipMemcpy(band_buf, buf.data(), sizeof(double) * buf.size(), hipMemcpyHostToDevice));
     band.n = n; band.c = c;
-    band.l1i = band_buf; band.l2i = band.l1i + (size_t)T * (c + 1); band.dinv = band.l2i + (size_t)T * (c + 2);
+    band.m1i = band_buf; band.m2i = band.m1i + (size_t)T * (c + 1); band.sinv = band.m2i + (size_t)T * (c + 2);
+    band.agg = band_buf + (size_t)T * (2 * c + 3) + (size_t)n;
+    band.err = dflag + 1;
+    band_seq = 0.0;
+    LCHK(hipMemsetAsync(dflag + 1, 0, sizeof(int), st));
     static bool attr_set = false;
     if (!attr_set) {
         LCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_apply<4>), hipFuncAttributeMaxDynamicSharedMemorySize, BAND_MAX_N * 8));
         LCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_apply<8>), hipFuncAttributeMaxDynamicSharedMemorySize, BAND_MAX_N * 8));
+        LCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_apply<10>), hipFuncAttributeMaxDynamicSharedMemorySize, BAND_MAX_N * 8));
         LCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_apply<12>), hipFuncAttributeMaxDynamicSharedMemorySize, BAND_MAX_N * 8));
         LCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_apply<16>), hipFuncAttributeMaxDynamicSharedMemorySize, BAND_MAX_N * 8));
         attr_set = true;
@@ -122,12 +129,18 @@ int Impl::rs_prepare(bool *ok) {
 void Impl::band_launch(int ncols, const double *in, const double *sub, double *out, long long ldc, bool qmode) {
     BandQ q{};
     if (qmode) { q.Sb = Sb; q.ATdy = ATdy; q.dy = dy; q.gN = gN; q.g = g; q.Hdx = Hdx; }
-    const size_t lds = sizeof(double) * (size_t)nV;
     const int c = band.c;
-    if (c <= 4) hipLaunchKernelGGL(k_band_apply<4>, dim3(ncols), dim3(BAND_TH), lds, st, band, in, sub, out, ldc, q);
-    else if (c <= 8) hipLaunchKernelGGL(k_band_apply<8>, dim3(ncols), dim3(BAND_TH), lds, st, band, in, sub, out, ldc, q);
-    else if (c <= 12) hipLaunchKernelGGL(k_band_apply<12>, dim3(ncols), dim3(BAND_TH), lds, st, band, in, sub, out, ldc, q);
-    else hipLaunchKernelGGL(k_band_apply<16>, dim3(ncols), dim3(BAND_TH), lds, st, band, in, sub, out, ldc, q);
+    if (ncols == 1 && band_mw) {       // one vector: 16 single-wave workgroups
+        const double seq = (band_seq += 1.0);
+#define RS_MW(CC) hipLaunchKernelGGL(k_band_apply_mw<CC>, dim3(BAND_MW), dim3(64), 0, st, band, in, sub, out, q, seq)
+        if (c <= 4) RS_MW(4); else if (c <= 8) RS_MW(8); else if (c <= 10) RS_MW(10); else if (c <= 12) RS_MW(12); else RS_MW(16);
+#undef RS_MW
+        return;
+    }
+    const size_t lds = sizeof(double) * (size_t)nV;
+#define RS_1W(CC) hipLaunchKernelGGL(k_band_apply<CC>, dim3(ncols), dim3(BAND_TH), lds, st, band, in, sub, out, ldc, q)
+    if (c <= 4) RS_1W(4); else if (c <= 8) RS_1W(8); else if (c <= 10) RS_1W(10); else if (c <= 12) RS_1W(12); else RS_1W(16);
+#undef RS_1W
 }
 // out = H^-1 (in - sub); fix_dx: the step direction's product -- in = q - (gN - g) formed on the way (into Hdx), out = dx written on
 // the free variables only (in / sub are ignored)

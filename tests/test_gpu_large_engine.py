@@ -15,6 +15,16 @@ from restartsqp_amd.qpdump import QPData, dense_to_csc, read_qore_dump
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["default_path", "null_space_path"])
+def engine_path(request, monkeypatch):
+    """Every test of this file runs twice: with the engine's own choice of formulation (a positive definite Hessian takes the
+    general range-space path of DESIGN 4.5 since round 5) and with that path switched off (RSQP_LARGE_NO_RSH=1: the null-space
+    path -- or, for a diagonal Hessian, the range-space path of DESIGN 4.4 -- as in rounds 1-4)."""
+    if request.param == "null_space_path":
+        monkeypatch.setenv("RSQP_LARGE_NO_RSH", "1")
+    return request.param
+
+
 def load(capi, q, engine=2, nWSR=100000):
     s = capi.Solver(q.nV, q.nC)
     s.set_engine(engine)
@@ -259,9 +269,11 @@ def test_range_space_path_needs_a_positive_diagonal(capi, oracle):
         s.close()
 
 
-def test_deferred_and_carried_paths_are_taken(capi):
+def test_deferred_and_carried_paths_are_taken(capi, engine_path):
     """Guard against a refactoring that silently switches the round-3 paths off: with the engine's own accounting on, a cold
     start of a mid-size problem (even leading dimension) must show launches of both fused kernels of the deferred reflections."""
+    if engine_path != "null_space_path":
+        pytest.skip("kernels of the null-space path")
     q = problems.random_qp(np.random.default_rng(4712), 150, 120, 0.3)
     s = load(capi, q)
     s.set_engine_profiling(True)

@@ -66,7 +66,7 @@ def all_call_shapes(capi, oracle, rng, q, want_path):
     assert ok and st.KKT_error < 1e-9
 
 
-@pytest.mark.parametrize("knob", [None, "RSQP_LARGE_RSH_DENSE", "RSQP_NO_BLOCKED_SETUP"])
+@pytest.mark.parametrize("knob", [None, "RSQP_LARGE_RSH_DENSE", "RSQP_NO_BLOCKED_SETUP", "RSQP_LARGE_BAND_1WG", "RSQP_LARGE_NO_CARRY"])
 def test_banded_hessian_all_call_shapes(capi, oracle, monkeypatch, knob):
     if knob:
         monkeypatch.setenv(knob, "1")
