@@ -365,6 +365,7 @@ def large_configs(capi, problems, seq_steps=50, ref_rule_steps=10, cpu_seconds=1
     t = time.perf_counter(); n = s.solve(capi.MODE_COLD, 200000); t = time.perf_counter() - t
     ok, st, _, _ = s.test_optimality()
     out["dense_2048x4096_cold"] = {"seconds": t, "nWSR": n, "ms_per_working_set_change": 1e3 * t / max(n, 1),
+                                   "path": capi.Solver.LARGE_PATHS.get(s.large_path(), "?"),
                                    "KKT_error": st.KKT_error, "certified": bool(ok), "cpu_baseline": cpu,
                                    "gpu_same_first_changes": first,
                                    "gpu_over_cpu_per_change": (cpu["value"] / first["ms_per_change"]) if "value" in cpu else None}
@@ -389,6 +390,7 @@ def large_configs(capi, problems, seq_steps=50, ref_rule_steps=10, cpu_seconds=1
     t = time.perf_counter(); n = s.optimize_qp(); t = time.perf_counter() - t
     ok, st, _, _ = s.test_optimality()
     out["sparse_10000x20000_cold"] = {"seconds": t, "nWSR": n, "ms_per_working_set_change": 1e3 * t / max(n, 1),
+                                      "path": capi.Solver.LARGE_PATHS.get(s.large_path(), "?"),
                                       "KKT_error": st.KKT_error, "certified": bool(ok), "entry": "rsqp_optimize_qp",
                                       "cpu_baseline": cpu, "gpu_same_first_changes": first,
                                       "gpu_over_cpu_per_change": (cpu["value"] / first["ms_per_change"]) if "value" in cpu else None}
@@ -449,6 +451,31 @@ def large_configs(capi, problems, seq_steps=50, ref_rule_steps=10, cpu_seconds=1
                     "working-set sequences: the two paths differ in how the KKT systems are solved, not in the decisions)"}
     finally:
         del os.environ["RSQP_LARGE_NO_DUAL"]
+
+    # ---- SURVEY 8(d)'s other Hessian for this configuration: "+ optional 5-band SPD" (problems.sparse_qp(band=5)): not diagonal,
+    #      so DESIGN 4.4's path does not apply; it takes the GENERAL range-space path (bounds and constraints as rows of C,
+    #      explicit inverse of C H^-1 C', H^-1 as a banded LDL' operator). Cold start + one FIXED + one VARIED step (reference rule)
+    qb = problems.sparse_qp(band=5)
+    s3 = load(qb)
+    t = time.perf_counter(); n3 = s3.optimize_qp(); t_cold3 = time.perf_counter() - t
+    ok3, st3, _, _ = s3.test_optimality()
+    b5 = {"cold_seconds": t_cold3, "cold_nWSR": n3, "cold_ms_per_working_set_change": 1e3 * t_cold3 / max(n3, 1), "cold_certified": bool(ok3),
+          "path": capi.Solver.LARGE_PATHS.get(s3.large_path(), "?"), "steps_reference_rule": []}
+    for qk, changed in problems.sparse_sequence(qb, nsteps=2, seed=20260150):
+        t = time.perf_counter()
+        for w, v in zip(range(5), (qk.g, qk.lb, qk.ub, qk.lbA, qk.ubA)):
+            s3.set_vector(w, v)
+        if changed:
+            s3.set_A_csc(qk.A_jc, qk.A_ir, qk.A_val)
+        nk = s3.optimize_qp()
+        okk, _, _, _ = s3.test_optimality()
+        dt = time.perf_counter() - t
+        b5["steps_reference_rule"].append({"matrices_changed": bool(changed), "seconds": dt, "nWSR": nk, "certified": bool(okk)})
+        b5["varied_seconds" if changed else "fixed_seconds"] = dt
+    s3.close()
+    b5["note"] = ("H = diag + two off-diagonals on each side (strictly diagonally dominant); same Jacobian, gradient and limits as the diagonal "
+                  "configuration; round 4 (null-space path, any non-diagonal H): cold 13.1 s, VARIED 5.08 s")
+    out["sparse_10000x20000_band5"] = b5
 
     # ---- the matrix-core path: one more VARIED step right after a VARIED one = hotstart(H, g, A, ..) on the full working set:
     #      blocked Householder QR of A_AC,FR', explicit Q = [Y Z], R^-1, Z'HZ, its Cholesky factor and inverse (dense_la.hip)

@@ -997,6 +997,10 @@ extern "C" int rsqp_optimize_qp(rsqp_solver *s, int *nWSR_used) {
             // the reference leaves firstQPsolved_ false here even when the retry succeeds
             rc = handle_error(s, &total);
             if (rc != RSQP_OK) return rc;
+            // still unsolved: the reference THROWS QP_NOT_OPTIMAL inside handle_error (:754-756) -- nothing behind the call runs: no
+            // reset_flags, no second handle_error, and the first init's nWSR never reaches Stats::qp_iter (:211-212 are skipped), only
+            // the retry's (:751-752). The adapter raises the exception from !rsqp_is_solved()
+            if (!solved(s)) { if (nWSR_used) *nWSR_used = total; return RSQP_OK; }
         }
     } else {
         // get_Matrix_change_status (:817-833)
@@ -1072,7 +1076,12 @@ extern "C" int rsqp_optimize_lp(rsqp_solver *s, int *nWSR_used) {
         rc = rsqp_solve(s, RSQP_MODE_COLD, &nWSR, nullptr, nullptr, nullptr);
         if (rc != RSQP_OK) return rc;
         if (solved(s)) s->firstQPsolved = true;
-        else { set_reg_for_init(); if ((rc = handle_error_lp(s, &total)) != RSQP_OK) return rc; }
+        else {
+            set_reg_for_init();
+            if ((rc = handle_error_lp(s, &total)) != RSQP_OK) return rc;
+            // (LP_NOT_OPTIMAL thrown inside handle_error, :714-716: the count behind the call, :278-279, is never added)
+            if (!solved(s)) { if (nWSR_used) *nWSR_used = total; return RSQP_OK; }
+        }
     } else {
         const int cur = (s->upd_A || s->upd_H) ? 2 : 1;
         if (s->old_status == 0) s->old_status = cur;
@@ -1094,7 +1103,11 @@ extern "C" int rsqp_optimize_lp(rsqp_solver *s, int *nWSR_used) {
         }
         if (rc != RSQP_OK) return rc;
         s->upd_A = s->upd_H = s->upd_bounds = s->upd_g = false;
-        if (!solved(s)) { set_reg_for_init(); if ((rc = handle_error_lp(s, &total)) != RSQP_OK) return rc; }
+        if (!solved(s)) {
+            set_reg_for_init();
+            if ((rc = handle_error_lp(s, &total)) != RSQP_OK) return rc;
+            if (!solved(s)) { if (nWSR_used) *nWSR_used = total; return RSQP_OK; }
+        }
     }
     total += nWSR;
     if (solved(s)) {

@@ -8,8 +8,29 @@
 // text in rsqp_last_error() when the library or a call fails -- nothing falls back to a host path.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// a build host without the RCCL headers (single-GPU installs): the handful of types and prototypes this file binds by name,
+// as <rccl/rccl.h> declares them -- the library still loads, and the entries fail with RSQP_ERR_DEVICE where librccl is missing
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclChar = 0, ncclDouble = 8 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId *);
+ncclResult_t ncclCommInitRank(ncclComm_t *, int, ncclUniqueId, int);
+ncclResult_t ncclCommDestroy(ncclComm_t);
+ncclResult_t ncclCommUserRank(const ncclComm_t, int *);
+ncclResult_t ncclCommCount(const ncclComm_t, int *);
+ncclResult_t ncclAllGather(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+ncclResult_t ncclBroadcast(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+const char *ncclGetErrorString(ncclResult_t);
+}
+#endif
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -38,12 +59,20 @@ Rccl g_rccl;
 std::once_flag g_once;
 
 void load_rccl() {
+    // RSQP_RCCL_LIBRARY names the one file to load instead of the usual candidates (a non-standard install; the CPU test of the
+    // "library missing" path points it at a file that does not exist)
+    const char *forced = getenv("RSQP_RCCL_LIBRARY");
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::string why;
     for (const char *n : names) {
+        if (forced) n = forced;
         g_rccl.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (g_rccl.h) break;
+        const char *e = dlerror();       // (ONE call: it returns the message and clears it -- ADVICE r4)
+        why = e ? e : "?";
+        if (forced) break;
     }
-    if (!g_rccl.h) { g_rccl.err = std::string("librccl.so not loadable: ") + (dlerror() ? dlerror() : "?"); return; }
+    if (!g_rccl.h) { g_rccl.err = std::string("librccl.so not loadable: ") + why; return; }
 #define RSQP_SYM(f)                                                                        \
     g_rccl.f = reinterpret_cast<decltype(g_rccl.f)>(dlsym(g_rccl.h, "nccl" #f));            \
     if (!g_rccl.f) { g_rccl.err = "librccl.so lacks nccl" #f; return; }

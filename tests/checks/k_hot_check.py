@@ -1,4 +1,4 @@
-"""Hot starts on the explicit-KKT-inverse kernel (qp_small_k.h) against the CPU oracle: batches whose members have 20..60
+"""Hot starts on the KKT-tableau kernel (restartsqp_amd/csrc/qp_small_g.h) against the CPU oracle: batches whose members have 20..60
 variables, cold start, then three hot starts on perturbed vectors; every member every step: nWSR, working sets, x / y.
 With RSQP_K_DEBUG_BAIL=n in the environment every hot start of that kernel bails out before its n-th change and the
 null-space kernel takes the member over from the stored state (factors rebuilt for the stored working set, homotopy data
@@ -16,7 +16,7 @@ rng = np.random.default_rng(21)
 probs = []
 for k in range(36):
     q = problems.random_qp(rng, int(rng.integers(20, 60)), int(rng.integers(5, 30)))
-    if k % 3 == 2:      # an indefinite Hessian: flipping bounds, the KKT-inverse kernel bails out of the cold start
+    if k % 3 == 2:      # an indefinite Hessian: flipping bounds, the tableau kernel bails out of the cold start
         H = q.dense_H(); H[0, 0] = -abs(H[0, 0]); H[1, 1] = 0.0; H[1, :] = 0.0; H[:, 1] = 0.0
         q = QPData(q.nV, q.nC, *dense_to_csc(H), q.A_jc, q.A_ir, q.A_val, q.g, q.lb, q.ub, q.lbA, q.ubA, name="indefinite")
     probs.append(q)

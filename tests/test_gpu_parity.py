@@ -424,6 +424,31 @@ def test_handle_error_iteration_limit_then_cold_reinit(capi, oracle, engine):
     assert s.optimize_qp() == 40 and not s.is_solved() and s.status == 28
 
 
+@pytest.mark.parametrize("engine", [1, 2])
+def test_first_solve_and_its_rescue_both_fail(capi, oracle, engine):
+    """optimizeQP when the FIRST init runs out of iterations and handle_error's re-init does too: the reference throws
+    QP_NOT_OPTIMAL inside handle_error (src/qpOASESInterface.cpp:161-163, 754-756), so the rest of optimizeQP never runs -- one
+    rescue, not two, and Stats::qp_iter receives the rescue's count only (:751-752; :211-212 are skipped). Then the same handle,
+    larger budget: firstQPsolved_ is still false -> a cold init that succeeds."""
+    rng = np.random.default_rng(7024)
+    nV, nC = int(rng.integers(8, 20)), int(rng.integers(6, 20))
+    qa = problems.random_qp(rng, nV, nC)
+    qp, rc, na = oracle_cold(oracle, qa)
+    assert na == 31
+    s = capi.Solver(nV, nC)
+    s.set_engine(engine)
+    s.set_options(qp_maxiter=20)
+    s.set_A_csc(qa.A_jc, qa.A_ir, qa.A_val); s.set_H_csc(qa.H_jc, qa.H_ir, qa.H_val)
+    for w, v in zip(range(5), (qa.g, qa.lb, qa.ub, qa.lbA, qa.ubA)):
+        s.set_vector(w, v)
+    assert s.optimize_qp() == 20 and not s.is_solved() and s.status == 28
+    s.set_options(qp_maxiter=100)
+    assert s.optimize_qp() == na and s.is_solved() and s.status == 20
+    assert s.last_mode() == capi.MODE_COLD
+    wb, wc = s.working_set_raw()
+    assert np.array_equal(wb, qp.ws_bounds) and np.array_equal(wc, qp.ws_constraints)
+
+
 def test_spmv_batched_parity_and_properties(capi, oracle):
     """Stream SpMV: small case against the oracle's entry-order loops; BASELINE-size case
     (n=10k, m=20k, 200k non-zeros) through size-independent properties: linearity,

@@ -135,3 +135,22 @@ def test_c_abi_sharding_matches_the_python_partitions():
             assert L.rsqp_balanced_shard(512, nV.ctypes.data_as(ip), nC.ctypes.data_as(ip), rank, world, idx.ctypes.data_as(ip), C.byref(cnt)) == 0
             assert idx[:cnt.value].tolist() == shards[rank].tolist()
     assert L.rsqp_shard_range(10, 3, 3, C.byref(lo), C.byref(hi)) != 0
+
+
+def test_rccl_entries_fail_loudly_when_the_library_is_missing():
+    """on a host without librccl every rsqp_rccl_* entry must return RSQP_ERR_DEVICE with the loader's message (the
+    first version called dlerror() twice and built a std::string from NULL). RSQP_RCCL_LIBRARY points the loader at a file that
+    does not exist; a child process, because the library is bound once per process."""
+    import subprocess, sys
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r)\n"
+            "from restartsqp_amd import capi\n"
+            "L = capi.lib(); buf = C.create_string_buffer(128)\n"
+            "rc = L.rsqp_rccl_unique_id(buf)\n"
+            "msg = L.rsqp_last_error().decode()\n"
+            "assert rc == capi.ERR_DEVICE, rc\n"
+            "assert 'not loadable' in msg and 'no_such_rccl' in msg, msg\n"
+            "assert L.rsqp_rccl_comm_create(buf, 0, 1, 0, C.byref(C.c_void_p())) == capi.ERR_DEVICE\n"
+            "print('ok')\n" % ROOT)
+    env = dict(os.environ, RSQP_RCCL_LIBRARY="/nonexistent/no_such_rccl.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr + out.stdout

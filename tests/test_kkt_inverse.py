@@ -1,5 +1,4 @@
-"""The register-resident KKT-tableau formulation (restartsqp_amd/csrc/qp_small_g.h; CPU prototype tools/proto_k/proto_g.cpp;
-round 3's explicit KKT inverse, tools/proto_k/proto_k.cpp, is kept as a second prototype).
+"""The register-resident KKT-tableau formulation (restartsqp_amd/csrc/qp_small_g.h; CPU prototype tools/proto_k/proto_g.cpp).
 
 CPU part: the prototype against the oracle -- every QP either identical (status, working sets, nWSR, x / y to 1e-9) or a
 clean bail-out. GPU part: cold-start-only batches (keep_state = 0) of mid-size problems run the kernel; members it bails

@@ -1,5 +1,5 @@
-"""Validation of the explicit-KKT-inverse formulation (tools/proto_k/proto_k.cpp, the CPU prototype of EngineK) against
-the oracle: status, working sets, nWSR identical, x / y to 1e-9 -- or a clean BAIL. Usage: python tools/proto_k/check.py [what]"""
+"""Validation of the KKT-tableau formulation (tools/proto_k/proto_g.cpp, the CPU prototype of restartsqp_amd/csrc/qp_small_g.h)
+against the oracle: status, working sets, nWSR identical, x / y to 1e-9 -- or a clean BAIL. Usage: python tools/proto_k/check.py [what]"""
 import ctypes as C
 import os
 import subprocess
@@ -13,7 +13,7 @@ import oracle as O  # noqa: E402
 from restartsqp_amd import problems  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-WHICH = os.environ.get("PROTO", "g")      # g: the tableau formulation of round 4 (proto_g.cpp); k: the explicit KKT inverse of round 3
+WHICH = "g"      # the tableau formulation (proto_g.cpp; round 3's explicit-KKT-inverse prototype went with its kernel)
 subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", os.path.join(HERE, "libproto%s.so" % WHICH), os.path.join(HERE, "proto_%s.cpp" % WHICH)])
 L = C.CDLL(os.path.join(HERE, "libproto%s.so" % WHICH))
 dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
