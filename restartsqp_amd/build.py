@@ -66,7 +66,7 @@ def _includes(path, seen=None):
     return seen
 
 
-def _tu_hash(f, hdr_hash=None):
+def _tu_hash(f):
     """content hash of one translation unit: the source, every header it includes (transitively), the flags"""
     src = os.path.join(CSRC, f)
     return _sha([src] + sorted(_includes(src)), " ".join(FLAGS))
@@ -103,12 +103,11 @@ def build_lib(force=False, verbose=False):
         return LIB
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    hdr_hash = _sha(_headers())
     srcs = _sources()
 
     def stale(f):
         hp = _obj(f)[:-2] + ".hash"
-        return force or not os.path.exists(_obj(f)) or not os.path.exists(hp) or open(hp).read().strip() != _tu_hash(f, hdr_hash)
+        return force or not os.path.exists(_obj(f)) or not os.path.exists(hp) or open(hp).read().strip() != _tu_hash(f)
 
     todo = [f for f in srcs if stale(f)]
 
@@ -118,7 +117,7 @@ def build_lib(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         with open(_obj(f)[:-2] + ".hash", "w") as fh:
-            fh.write(_tu_hash(f, hdr_hash))
+            fh.write(_tu_hash(f))
 
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(todo)))) as ex:
         list(ex.map(compile_one, todo))

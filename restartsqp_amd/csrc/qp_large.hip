@@ -3048,6 +3048,7 @@ struct RsqpLargeEngine::Impl {
         flush_pending();
         dual_flush();
         rs_flush();
+        if (rsh && rs_refine_enabled && status == QPS_SOLVED && rcode == RET_OK && iter > 0) rs_refine();      // (no change, nothing accumulated: a hot start on unchanged data returns the same bits)
         *nWSR = iter;
         return rcode;
     }
@@ -3088,6 +3089,8 @@ struct RsqpLargeEngine::Impl {
     int rs_change_active_set(int kind, int idx, int side);
     void rs_step_direction();
     void rs_refresh_p();
+    void rs_refine();
+    bool rs_refine_enabled = getenv("RSQP_LARGE_NO_REFINE") == nullptr;
     int rs_setup_rows(const std::vector<int> &rows, const std::vector<int> &gb, const std::vector<int> &gc);
     int rs_setup(const std::vector<int> &gb, const std::vector<int> &gc);
     void rs_count(int id, int delta);

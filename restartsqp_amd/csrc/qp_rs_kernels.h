@@ -338,6 +338,43 @@ __global__ void k_rs_diff(int n, const double *__restrict__ a, const double *__r
     if (i < n) out[i] = a[i] - b[i];
 }
 
+// ---- one step of iterative refinement on the final KKT system (rs_refine) --------------------------------------------------------
+// rg = H x + g - A'y_C on the free variables (the stationarity residual there; on a fixed variable it DEFINES the bound's multiplier)
+__global__ void k_rs_refine_rg(int nV, const int *__restrict__ Sb, const double *__restrict__ Hx, const double *__restrict__ g,
+                               const double *__restrict__ ATy, double *__restrict__ rg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nV) rg[i] = Sb[i] == 0 ? (Hx[i] + g[i]) - ATy[i] : 0.0;
+}
+// right-hand side over the active rows: what the row lacks + (C H^-1 rg)   (x sits exactly on its active bounds: nothing lacks there)
+__global__ void k_rs_refine_rhs(int nR, const int *__restrict__ R, int nV, const int *__restrict__ Sall, const double *__restrict__ lbA,
+                                const double *__restrict__ ubA, const double *__restrict__ Ax, const double *__restrict__ t,
+                                const double *__restrict__ At, double *__restrict__ rhs) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nR) return;
+    const int id = R[j];
+    if (id < nV) rhs[j] = t[id];
+    else { const int r = id - nV; rhs[j] = ((Sall[id] == -1 ? lbA[r] : ubA[r]) - Ax[r]) + At[r]; }
+}
+// q = A'dl_C + dl_B - rg  (the product with H^-1 gives the correction of x)
+__global__ void k_rs_refine_q(int nV, const int *__restrict__ Sb, const double *__restrict__ ATdy, const double *__restrict__ dy,
+                              const double *__restrict__ rg, double *__restrict__ q) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nV) q[i] = (ATdy[i] + (Sb[i] != 0 ? dy[i] : 0.0)) - rg[i];
+}
+// x += dx on the free variables, y_C += dl_C
+__global__ void k_rs_refine_apply(int nV, int nC, const int *__restrict__ Sb, const int *__restrict__ Sc, const double *__restrict__ dx,
+                                  const double *__restrict__ dy, double *__restrict__ x, double *__restrict__ y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nV && Sb[i] == 0) x[i] += dx[i];
+    if (i < nC && Sc[i] != 0) y[nV + i] += dy[nV + i];
+}
+// the multipliers of the fixed variables from stationarity with the corrected x and y_C
+__global__ void k_rs_refine_yb(int nV, const int *__restrict__ Sb, const double *__restrict__ Hx, const double *__restrict__ g,
+                               const double *__restrict__ ATy, double *__restrict__ y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nV && Sb[i] != 0) y[i] = (Hx[i] + g[i]) - ATy[i];
+}
+
 // ---- set-up ---------------------------------------------------------------------------------------------------------------------
 // Cd[:, j] = row R[j] of C as a dense column (columns zero-filled beforehand)
 __global__ void k_rs_build_C(int nV, const int *__restrict__ R, const int *__restrict__ rp, const int *__restrict__ ci,

@@ -315,6 +315,33 @@ void Impl::rs_step_direction() {
     chk("rs_step_direction");
 }
 
+// One step of iterative refinement on the KKT system of the FINAL working set, residuals formed from the data: the explicit inverse
+// of C H^-1 C' squares the conditioning of the active rows and is kept current by rank-1 formulas, so a long homotopy on a vertex
+// solution leaves x / y with ~1e-9 relative error (tests/checks/fuzz_large_vs_oracle.py, 64 x 212: 3e-9) where the orthogonal
+// factors of the null-space path give 1e-13; one correction through the same Sinv brings it back to working precision. The tableau
+// engines end a solve the same way. Leaves Ax, ATy, Hx exact for the corrected point.
+void Impl::rs_refine() {
+    rs_flush();
+    hipLaunchKernelGGL(k_fix_x, g1(nV), dim3(NT), 0, st, nV, Sb, lb, ub, x);
+    refresh_products();                                             // Ax, A'y_C, H x of the point the homotopy ended in
+    hipLaunchKernelGGL(k_rs_refine_rg, g1(nV), dim3(NT), 0, st, nV, Sb, Hx, g, ATy, w1);
+    rs_hinv_apply(w1, nullptr, w5, false);                          // t = H^-1 rg
+    A_times(w5, c3);
+    fill(dy, nV + nC, 0.0);
+    if (nR > 0) {
+        hipLaunchKernelGGL(k_rs_refine_rhs, g1(nR), dim3(NT), 0, st, nR, R, nV, Sall, lbA, ubA, Ax, w5, c3, ra4);
+        rs_sinv_times(ra4, ra3, true);                              // (scatters into dy)
+    }
+    AT_times(dy + nV, ATdy);
+    hipLaunchKernelGGL(k_rs_refine_q, g1(nV), dim3(NT), 0, st, nV, Sb, ATdy, dy, w1, w2);
+    rs_hinv_apply(w2, nullptr, w4, false);
+    hipLaunchKernelGGL(k_rs_refine_apply, g1(std::max(nV, nC)), dim3(NT), 0, st, nV, nC, Sb, Sc, w4, dy, x, y);
+    refresh_products();
+    hipLaunchKernelGGL(k_rs_refine_yb, g1(nV), dim3(NT), 0, st, nV, Sb, Hx, g, ATy, y);
+    carry_valid = false;
+    chk("rs_refine");
+}
+
 // ---- set-up -------------------------------------------------------------------------------------------------------------------------
 // Sinv for a given list of rows by GEMM + Cholesky + inverse: Cd = C' dense, T = H^-1 Cd, S = Cd'T (upper tiles), U'U = S,
 // Sinv = U^-1 U^-T. RET_FALLBACK: S is not positive definite to working precision (dependent rows in the guess)

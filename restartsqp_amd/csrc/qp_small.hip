@@ -1202,6 +1202,10 @@ static int env_int(const char *name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
+int rsqp_small_launch_is_tiny(const QPPools &p, int nVmax, int nCmax) {
+    static const int forcedE = env_int("RSQP_SMALL_ENGINE", -1);
+    return (forcedE < 0 && p.tiny_ok && rsqp_tiny_fits(nVmax, nCmax)) ? 1 : 0;
+}
 hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCmax, long long mat_bytes_max, int mode,
                                 int maxWSR, hipStream_t stream) {
     QPPools p = p_in;
@@ -1216,7 +1220,7 @@ hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCma
     // 23x6 1.26 / 1.01, 37x14 2.57 / 1.51, 69x28 10.8 / 4.1 -- the chains of the TQ form grow with nZ.
     static const int forcedE = env_int("RSQP_SMALL_ENGINE", -1);
     // hs071-scale problems: the register-resident tableau kernel (qp_tiny.hip) serves every call shape
-    if (forcedE < 0 && p.tiny_ok && rsqp_tiny_fits(nVmax, nCmax)) return rsqp_launch_tiny_qp(p, nq, nVmax, nCmax, mode, maxWSR, stream);
+    if (rsqp_small_launch_is_tiny(p, nVmax, nCmax)) return rsqp_launch_tiny_qp(p, nq, nVmax, nCmax, mode, maxWSR, stream);
     const int eng = forcedE == 0 || forcedE == 1 ? forcedE : (nVmax > 8 ? 1 : 0);
     if (eng == 1 && mat_bytes_max >= 0) mat_bytes_max = 8LL * ((long long)nVmax * nVmax + (long long)nCmax * nVmax);
     // uniform hs071-scale batches (8 x 2 through the QPhandler formulation; parameter scans of one NLP iterate) run

@@ -238,6 +238,12 @@ struct DevMatrix {
         pin_cap = cap + 2;
         return hipSuccess;
     }
+    void release_arena() {     // undo a partial reserve(): without an arena every array is allocated on its own
+        if (pin) { (void)hipHostFree(pin); pin = nullptr; pin_cap = 0; }
+        if (arena_dev) { (void)hipFree(arena_dev); arena_dev = nullptr; }
+        if (arena_stage) { (void)hipHostFree(arena_stage); arena_stage = nullptr; }
+        arena_cap = arena_used = 0;
+    }
     template <class T> bool take(DevBuf<T> &b, size_t count) {      // next slice of the arena (16-byte aligned, zero-filled)
         const size_t bytes = (std::max<size_t>(count, 1) * sizeof(T) + 15) & ~(size_t)15;
         if (!arena_dev || arena_used + bytes > arena_cap) return false;
@@ -302,6 +308,8 @@ struct rsqp_solver {
     bool fits_small = true;
     RsqpLargeEngine *large = nullptr;
     bool large_ready = false, profile_large = false;
+    int state_engine = -1;        // which kernel family wrote the hot-start state of this handle: 1 the register-resident tableau kernel, 0 the
+                                  // LDS-resident ones (different layouts in the same block), -1 none yet
     bool h_sym = true;            // H symmetric value by value (or absent): the tableau kernel of qp_tiny.hip may take the handle
     int last_mode = -1;           // RSQP_MODE_* of the last rsqp_solve (what the dispatch of optimizeQP / optimizeLP chose): rsqp_get_last_mode
     bool reinit_from_y0 = false;  // rsqp_set_reinit_guess: default = the reference rule (qpOASESInterface.cpp:199-207); 1 = opt-in shortcut
@@ -585,8 +593,9 @@ extern "C" int rsqp_create(int nV, int nC, int device, rsqp_solver **out) {
         s->d_done = di + q; s->h_done = hi + q; q++;
         s->d_desc.map(reinterpret_cast<QPDesc *>(static_cast<char *>(dev) + bytes_io),
                       reinterpret_cast<QPDesc *>(static_cast<char *>(s->io_host) + bytes_io), 1);
-        if (nC > 0) HIPCHK(s->A.reserve(nC, nV));
-        HIPCHK(s->H.reserve(nV, nV));
+        // (a failed reservation is "no arena": set_A / set_H then allocate per array as the HBM-scale handles do -- ADVICE r4)
+        if (nC > 0 && s->A.reserve(nC, nV) != hipSuccess) { s->A.release_arena(); (void)hipGetLastError(); }
+        if (s->H.reserve(nV, nV) != hipSuccess) { s->H.release_arena(); (void)hipGetLastError(); }
     } else {
         for (int k = 0; k < 5; k++) HIPCHK(s->d_vec[k].alloc((k <= RSQP_VEC_UB) ? nV : nC));
         HIPCHK(s->d_x.alloc(nV)); HIPCHK(s->d_y.alloc(nV + nC)); HIPCHK(s->d_obj.alloc(1));
@@ -736,11 +745,12 @@ extern "C" int rsqp_set_H_triplet(rsqp_solver *s, int nnz, const int *irow, cons
         return RSQP_OK;
     }
     if (!M.from_triplet || nnz != M.n_triplet) return fail(RSQP_ERR_ARG, "rsqp_set_H_triplet: pattern changed");
-    if (!M.symmetric) s->h_sym = false;       // (values of a general triplet matrix: not re-examined)
+    if (!M.symmetric) s->h_sym = false;       // (values of a general triplet matrix: re-examined below where they are at hand)
     if (M.pin) {
         if (s->cert_pending) { HIPCHK(hipStreamSynchronize(s->stream)); s->cert_pending = false; }
         double *v = M.val.host;
         for (int j = 0; j < M.nnz; j++) v[M.h_order[j]] = val[M.h_tmap.empty() ? j : M.h_tmap[j]];
+        if (!M.symmetric) s->h_sym = s->nV <= 8 && small_csc_symmetric(s->nV, M.h_jc.data(), M.h_ir.data(), v);
         return RSQP_OK;
     }
     HIPCHK(M.tv.upload(val, nnz));
@@ -944,6 +954,12 @@ extern "C" int rsqp_solve(rsqp_solver *s, int mode, int *nWSR, const double *x0,
     const bool fused_cert = p.done_flag && p.tiny_ok && rsqp_tiny_fits(s->nV, s->nC) && spec_cert_enabled() && !s->lp_mode &&
                             s->A.initialised == (s->nC > 0) && getenv("RSQP_SMALL_ENGINE") == nullptr;
     if (fused_cert) { p.cert_out = s->d_kkt.p; p.cert_Wb = s->d_Wb.p; p.cert_Wc = s->d_Wc.p; }
+    {   // the tableau kernel and the LDS-resident kernels keep different layouts in the same state block: a solve that changes
+        // the family (H lost or regained its symmetry between two solves) starts cold instead of restoring the other's bytes
+        const int fam = rsqp_small_launch_is_tiny(p, s->nV, s->nC);
+        if ((mode == RSQP_MODE_HOT_VECTORS || mode == RSQP_MODE_HOT_MATRICES) && s->state_engine != fam) { mode = RSQP_MODE_COLD; s->last_mode = mode; }
+        s->state_engine = fam;
+    }
     hipError_t e = rsqp_launch_small_qp(p, 1, s->nV, s->nC,
                                         rsqp_mat_lds_bytes(s->nV, s->nC, s->A.initialised ? s->A.nnz : 0, s->H.initialised ? s->H.nnz : 0),
                                         mode, *nWSR, s->stream);
@@ -1293,6 +1309,7 @@ struct rsqp_batch {
     bool uni_pat = false; int uni_annz = 0, uni_hnnz = 0; long long uni_state = 0;     // (QPPools::uni_pat)
     long long sumV = 0, sumC = 0, sumAnz = 0, sumHnz = 0, mat_bytes_max = 0;
     bool haveH = false;
+    int state_engine = -1;                // kernel family that wrote the members' hot-start states (see rsqp_solver::state_engine)
     bool h_sym = true;                    // every H symmetric value by value (the tableau kernel of qp_tiny.hip may take the batch)
     std::vector<int> h_Hjc, h_Hir;        // host copy of the H patterns (re-examined when the values change), small batches only
     std::vector<QPDesc> desc;
@@ -1477,6 +1494,11 @@ extern "C" int rsqp_batch_solve(rsqp_batch *b, int mode, int max_nWSR) {
     HIPCHK(hipSetDevice(b->device));
     QPPools p = pools_of(b);
     if (!b->timing) HIPCHK(hipEventRecord(b->ev0, b->stream));
+    {
+        const int fam = rsqp_small_launch_is_tiny(p, b->nVmax, b->nCmax);
+        if ((mode == RSQP_MODE_HOT_VECTORS || mode == RSQP_MODE_HOT_MATRICES) && b->state_engine != fam) mode = RSQP_MODE_COLD;
+        b->state_engine = fam;
+    }
     hipError_t e = rsqp_launch_small_qp(p, b->nq, b->nVmax, b->nCmax, b->mat_bytes_max, mode, max_nWSR, b->stream);
     if (e != hipSuccess) return fail(RSQP_ERR_DEVICE, std::string("QP kernel launch: ") + hipGetErrorString(e));
     if (!b->timing) HIPCHK(hipEventRecord(b->ev1, b->stream));

@@ -107,4 +107,8 @@ long long rsqp_mat_lds_bytes(int nV, int nC, int annz, int hnnz);
 int rsqp_small_qp_fits(int nVmax, int nCmax);
 // qp_tiny.hip: the register-resident tableau kernel for problems of at most 8 variables and 8 constraints
 int rsqp_tiny_fits(int nVmax, int nCmax);
+// 1 when rsqp_launch_small_qp hands this launch to the register-resident tableau kernel (qp_tiny.hip), whose hot-start state has
+// another layout than the LDS-resident kernels': the caller forces a cold start when the answer changes between two solves of a
+// handle or batch
+int rsqp_small_launch_is_tiny(const QPPools &p, int nVmax, int nCmax);
 hipError_t rsqp_launch_tiny_qp(const QPPools &p, int nq, int nVmax, int nCmax, int mode, int maxWSR, hipStream_t stream);

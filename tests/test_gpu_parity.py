@@ -82,8 +82,28 @@ def test_one_shape_batches_with_one_and_with_several_patterns(capi, oracle):
         for probs in (same, same[:20] + other + same[20:], other):
             b = capi.Batch(probs)
             b.solve(capi.MODE_COLD, 1000)
+            orcs = []
             for q, r in zip(probs, b.results()):
                 qp, rc, n = oracle_cold(oracle, q)
+                assert_same_solution(qp, r, n)
+                orcs.append(qp)
+            # hot start on new vectors (state I/O of every member: offState = q * uni_state on the one-pattern path) ...
+            p2 = [problems.perturb(rng, q, 0.05) for q in probs]
+            b.set_vectors_from(p2)
+            b.solve(capi.MODE_HOT_VECTORS, 1000)
+            for q, qp, r in zip(p2, orcs, b.results()):
+                rc, n = qp.hotstart(q.g, q.lb, q.ub, q.lbA, q.ubA, 1000)
+                assert_same_solution(qp, r, n)
+            # ... and on new matrix values as well (member 0's pattern arrays are read in this mode too)
+            p3 = [problems.perturb(rng, q, 0.05) for q in p2]
+            for q in p3:
+                q.A_val = q.A_val * (1.0 + 0.02 * rng.normal(size=q.A_val.shape))
+            b.set_vectors_from(p3)
+            b.set_matrix_values(np.concatenate([q.A_val for q in p3]), np.concatenate([q.H_val for q in p3]))
+            b.solve(capi.MODE_HOT_MATRICES, 1000)
+            for q, qp, r in zip(p3, orcs, b.results()):
+                qp.set_A_csc(q.A_jc, q.A_ir, q.A_val); qp.set_H_csc(q.H_jc, q.H_ir, q.H_val)
+                rc, n = qp.hotstart_matrices(q.g, q.lb, q.ub, q.lbA, q.ubA, 1000)
                 assert_same_solution(qp, r, n)
             b.close()
 
@@ -422,6 +442,37 @@ def test_handle_error_iteration_limit_then_cold_reinit(capi, oracle, engine):
     for w, v in zip(range(5), (qa.g, qa.lb, qa.ub, qa.lbA, qa.ubA)):
         s.set_vector(w, v)
     assert s.optimize_qp() == 40 and not s.is_solved() and s.status == 28
+
+
+def test_hot_start_after_the_hessian_lost_its_symmetry(capi, oracle):
+    """an 8 x 2 handle solves on the register-resident tableau kernel while H is symmetric; a value refresh that makes H
+    non-symmetric sends the next solve to the LDS-resident kernel, whose state layout differs -- the hot start must not restore
+    the other kernel's bytes (it starts cold), and with symmetric values again the tableau kernel must not either."""
+    rng = np.random.default_rng(99)
+    q = problems.hs071_first_qp()
+    H = q.dense_H() + np.eye(q.nV)                # (convex, so that the non-symmetric solve is well defined too)
+    irow, jcol = np.nonzero(np.ones_like(H))
+    vals = H[irow, jcol]
+    s = capi.Solver(q.nV, q.nC)
+    s.set_A_csc(q.A_jc, q.A_ir, q.A_val)
+    s.set_H_triplet(irow + 1, jcol + 1, vals, is_symmetric=0)          # a general triplet matrix whose values happen to be symmetric
+    for w, v in zip(range(5), (q.g, q.lb, q.ub, q.lbA, q.ubA)):
+        s.set_vector(w, v)
+    s.solve(capi.MODE_COLD, 1000)
+    assert s.status == 20
+    for trial, bump in enumerate((0.05, 0.0, 0.05)):                   # non-symmetric, symmetric again, non-symmetric
+        H2 = H.copy(); H2[0, 1] += bump
+        s.set_H_triplet(irow + 1, jcol + 1, H2[irow, jcol], is_symmetric=0)
+        q2 = problems.perturb(rng, q, 0.02)
+        for w, v in zip(range(5), (q2.g, q2.lb, q2.ub, q2.lbA, q2.ubA)):
+            s.set_vector(w, v)
+        s.solve(capi.MODE_HOT_MATRICES, 1000)
+        from restartsqp_amd.qpdump import QPData, dense_to_csc
+        qq = QPData(q.nV, q.nC, *dense_to_csc(H2), q.A_jc, q.A_ir, q.A_val, q2.g, q2.lb, q2.ub, q2.lbA, q2.ubA)
+        qp, rc, n_or = oracle_cold(oracle, qq)
+        assert s.status == qp.exitflag() == 20, trial
+        ok, st, _, _ = s.test_optimality()
+        assert ok and np.abs(s.x - qp.x).max() <= 1e-9 * max(1.0, np.abs(qp.x).max()), trial
 
 
 @pytest.mark.parametrize("engine", [1, 2])
