@@ -1780,7 +1780,7 @@ struct RsqpLargeEngine::Impl {
     long long ld = 0, ldm = 0;
     // (sizes below 256 keep their own leading dimension: alignment buys nothing there, and the even-ld kernel variants sum in
     //  another order -- on the reference's non-convex dump hs107 that changed which side a flip takes and the run cycled)
-    static long long pad16(long long n) { static const bool off = getenv("RSQP_LARGE_NO_PAD") != nullptr; return (off || n < 256) ? n : ((n + 15) & ~15LL); }
+    static long long pad16(long long n) { const bool off = getenv("RSQP_LARGE_NO_PAD") != nullptr; return (off || n < 256) ? n : ((n + 15) & ~15LL); }      // (read where a handle is created: init / bytes_needed)
     hipStream_t st = nullptr;
     hipError_t err_ = hipSuccess;
     RsqpLargeMatrices M;

@@ -317,7 +317,7 @@ void Impl::rs_step_direction() {
 
 // One step of iterative refinement on the KKT system of the FINAL working set, residuals formed from the data: the explicit inverse
 // of C H^-1 C' squares the conditioning of the active rows and is kept current by rank-1 formulas, so a long homotopy on a vertex
-// solution leaves x / y with ~1e-9 relative error (tests/checks/fuzz_large_vs_oracle.py, 64 x 212: 3e-9) where the orthogonal
+// solution leaves x / y with ~1e-9 relative error (the randomised large-engine check under tests/checks, a 64 x 212 member: 3e-9) where the orthogonal
 // factors of the null-space path give 1e-13; one correction through the same Sinv brings it back to working precision. The tableau
 // engines end a solve the same way. Leaves Ax, ATy, Hx exact for the corrected point.
 void Impl::rs_refine() {

@@ -1202,31 +1202,38 @@ static int env_int(const char *name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-int rsqp_small_launch_is_tiny(const QPPools &p, int nVmax, int nCmax) {
-    static const int forcedE = env_int("RSQP_SMALL_ENGINE", -1);
-    return (forcedE < 0 && p.tiny_ok && rsqp_tiny_fits(nVmax, nCmax)) ? 1 : 0;
+SmallKnobs rsqp_small_knobs_from_env() {
+    SmallKnobs k;
+    k.engine = env_int("RSQP_SMALL_ENGINE", -1); k.k_debug_bail = env_int("RSQP_K_DEBUG_BAIL", -1); k.noshape = env_int("RSQP_SMALL_NOSHAPE", 0);
+    k.lanes = env_int("RSQP_SMALL_LANES", -1); k.waves = env_int("RSQP_SMALL_WAVES", -1); k.wide = env_int("RSQP_SMALL_WIDE", -1);
+    k.wide_lanes = env_int("RSQP_SMALL_WIDE_LANES", 256) == 512 ? 512 : 256; k.nospread = env_int("RSQP_SMALL_NOSPREAD", 0);
+    k.no_kkt = env_int("RSQP_SMALL_NO_KKT", 0); k.kkt_only = env_int("RSQP_SMALL_KKT_ONLY", 0); k.no_tiny = env_int("RSQP_SMALL_NO_TINY", 0);
+    k.tiny_lds = env_int("RSQP_TINY_LDS", 0); k.exp_matglobal = env_int("RSQP_EXP_MATGLOBAL", 0);
+    k.no_spin = getenv("RSQP_NO_SPIN") != nullptr; k.no_spec_cert = getenv("RSQP_NO_SPEC_CERT") != nullptr;
+    return k;
 }
-hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCmax, long long mat_bytes_max, int mode,
+int rsqp_small_launch_is_tiny(const SmallKnobs &kn, const QPPools &p, int nVmax, int nCmax) {
+    return (kn.engine < 0 && p.tiny_ok && rsqp_tiny_fits(kn, nVmax, nCmax)) ? 1 : 0;
+}
+hipError_t rsqp_launch_small_qp(const SmallKnobs &kn, const QPPools &p_in, int nq, int nVmax, int nCmax, long long mat_bytes_max, int mode,
                                 int maxWSR, hipStream_t stream) {
     QPPools p = p_in;
     p.only_bailed = 0;
-    static const int kdbg = env_int("RSQP_K_DEBUG_BAIL", -1);
-    p.k_debug_bail = kdbg;
+    p.k_debug_bail = kn.k_debug_bail;
     if (nq <= 0) return hipSuccess;
     if (align16(rsqp_image_bytes(nVmax, nCmax)) > kMaxLds) return hipErrorInvalidValue;
     // formulation: 0 = Givens / TQ (Engine), 1 = explicit inverses (EngineX, qp_small_x.h), which keeps
     // DENSE copies of A and H in LDS. Measured per shape on the 512-QP hs0xx batch (ms, TQ vs explicit):
     // 5x1 0.14 / 0.16, 8x2 0.045 / 0.051, 8x3 0.25 / 0.21, 12x4 0.49 / 0.42, 16x6 0.73 / 0.55,
     // 23x6 1.26 / 1.01, 37x14 2.57 / 1.51, 69x28 10.8 / 4.1 -- the chains of the TQ form grow with nZ.
-    static const int forcedE = env_int("RSQP_SMALL_ENGINE", -1);
+    const int forcedE = kn.engine;
     // hs071-scale problems: the register-resident tableau kernel (qp_tiny.hip) serves every call shape
-    if (rsqp_small_launch_is_tiny(p, nVmax, nCmax)) return rsqp_launch_tiny_qp(p, nq, nVmax, nCmax, mode, maxWSR, stream);
+    if (rsqp_small_launch_is_tiny(kn, p, nVmax, nCmax)) return rsqp_launch_tiny_qp(kn, p, nq, nVmax, nCmax, mode, maxWSR, stream);
     const int eng = forcedE == 0 || forcedE == 1 ? forcedE : (nVmax > 8 ? 1 : 0);
     if (eng == 1 && mat_bytes_max >= 0) mat_bytes_max = 8LL * ((long long)nVmax * nVmax + (long long)nCmax * nVmax);
     // uniform hs071-scale batches (8 x 2 through the QPhandler formulation; parameter scans of one NLP iterate) run
     // the build with the shape as a compile-time constant and the target vectors in registers (see RegVec)
-    static const int noshape = env_int("RSQP_SMALL_NOSHAPE", 0);
-    static const int forcedL0 = env_int("RSQP_SMALL_LANES", -1);
+    const int noshape = kn.noshape, forcedL0 = kn.lanes;
     const bool shape82 = eng == 0 && p.uniV == 8 && p.uniC == 2 && !noshape && mat_bytes_max >= 0 &&
                          (forcedL0 < 0 || forcedL0 == 8);        // only the 8-lane build has the shape instantiation
     // LDS image of the chosen formulation (the persistent copy in HBM is sized for the larger one)
@@ -1237,7 +1244,7 @@ hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCma
 #if defined(RSQP_SMALL_EXPERIMENT) && RSQP_SMALL_EXPERIMENT == 1
     // tuning build only: the 8-lane shape kernel with the matrices left in global memory (L2) -- a smaller LDS image per problem,
     // more resident waves (RSQP_EXP_MATGLOBAL=1 with RSQP_SMALL_WAVES=3)
-    static const int exp_nomat = env_int("RSQP_EXP_MATGLOBAL", 0);
+    const int exp_nomat = kn.exp_matglobal;
 #else
     constexpr int exp_nomat = 0;
 #endif
@@ -1249,7 +1256,7 @@ hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCma
     // lanes per problem: the vectors of the engine have nV (+ nC) entries, a wave of 64 lanes is
     // mostly idle on hs0xx-scale problems, so 64 / L of them share a wave. Problems in one wave
     // follow their own control flow (exec masking); the LDS capacity bounds the problems in flight.
-    static const int forcedL = env_int("RSQP_SMALL_LANES", -1), forcedW = env_int("RSQP_SMALL_WAVES", -1);
+    const int forcedL = kn.lanes, forcedW = kn.waves;
     const int nmax = nVmax > nCmax ? nVmax : nCmax;
     int L = nmax <= 8 ? 8 : (nmax <= 16 ? 16 : (nmax <= 32 ? 32 : 64));
     if ((forcedL == 8 || forcedL == 16 || forcedL == 32 || forcedL == 64) && forcedL >= L) L = forcedL;   // never fewer lanes than entries
@@ -1257,7 +1264,7 @@ hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCma
     if (!mat_lds && !exp_nomat) L = 64;
     while (L < 64 && (64 / L) * stride > kMaxLds) L *= 2;
     if (L == 64 && stride > kMaxLds) stride = align16(mat_lds ? img + mat_bytes_max : img);
-    static const int forcedWide0 = env_int("RSQP_SMALL_WIDE", -1);
+    const int forcedWide0 = kn.wide;
     const bool wide0 = eng == 1 && mat_lds && L == 64 && (forcedWide0 >= 0 ? forcedWide0 != 0 : nVmax > 32);
     bool wide = false;
     // several waves per problem: four (256 lanes, one wave per SIMD). The kernel keeps ~430 values live per lane
@@ -1265,7 +1272,7 @@ hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCma
     // With one wave per SIMD every wave instruction costs its full 4+ cycles: the four-wave kernel is bound by the
     // instruction count per wave (~350 per 69 x 69 product stage), not by LDS bandwidth or barriers.
 #if defined(RSQP_SMALL_EXPERIMENT) && RSQP_SMALL_EXPERIMENT == 2
-    static const int wideL = env_int("RSQP_SMALL_WIDE_LANES", 256) == 512 ? 512 : 256;
+    const int wideL = kn.wide_lanes;
 #else
     constexpr int wideL = 256;
 #endif
@@ -1276,7 +1283,7 @@ hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCma
     // every vector access of an 8-lane build is a 4-way conflict (measured: 54 % of the LDS-array cycles, LDS busy
     // 73 % of the kernel). The stride is padded to the next such value when that does not cost a resident workgroup.
     if (L < 64) {
-        static const int nospread = env_int("RSQP_SMALL_NOSPREAD", 0);
+        const int nospread = kn.nospread;
         long long s1 = stride;
         while ((s1 & 255) != ((8 * L) & 255)) s1 += 16;
         auto wgs = [&](long long st) { const long long a = (((64 / L) * st) + 511) / 512 * 512; return a > 0 ? kMaxLds / a : 0; };
@@ -1295,7 +1302,7 @@ hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCma
     // ---- batches of mid-size problems (cold starts and hot starts on new vectors): the tableau kernel first (qp_small_g.h: 3 phases
     // per working-set change instead of ~50); members it cannot carry (non-symmetric H, LP, undecidable tests) come back with
     // ret == RET_BAIL and are solved by the null-space kernel launched right behind it, which skips everybody else
-    static const int noK = env_int("RSQP_SMALL_NO_KKT", 0);
+    const int noK = kn.no_kkt;
     // 32 row blocks x 8 column blocks of lanes: up to 72 variables x 32 constraints -- the 69 x 28 class of the hs0xx batch.
     typedef EngineG<3, 1, 9, 4> EK;      // up to 72 variables x 32 constraints
     typedef EngineG<2, 2, 8, 8> EK2;     // up to 64 variables x 64 constraints
@@ -1311,7 +1318,7 @@ hipError_t rsqp_launch_small_qp(const QPPools &p_in, int nq, int nVmax, int nCma
         else if (nVmax <= EK2::MAXV && nCmax <= EK2::MAXC) KK_LAUNCH(2, 2, 8, 8);
 #undef KK_LAUNCH
     }
-    static const int konly = env_int("RSQP_SMALL_KKT_ONLY", 0);     // diagnostics: no second pass (bailed members keep ret = 9, nflips = reason)
+    const int konly = kn.kkt_only;     // diagnostics: no second pass (bailed members keep ret = 9, nflips = reason)
     if (konly && p.only_bailed) return hipGetLastError();
 #define SQ_LAUNCH_U(ENG, LL, ML, W, U)                                                                        \
     do {                                                                                                      \

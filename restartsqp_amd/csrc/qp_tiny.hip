@@ -773,16 +773,15 @@ long long rsqp_tiny_state_bytes(int nCmax) {
     return 8 * (N * N + 48 + 32 + 16) + 4 * 24;
 }
 // 1 if the batch shape is served by this engine
-int rsqp_tiny_fits(int nVmax, int nCmax) {
-    static const int off = getenv("RSQP_SMALL_NO_TINY") ? atoi(getenv("RSQP_SMALL_NO_TINY")) : 0;
-    return !off && nVmax <= MV && nCmax <= 8 && nVmax >= 1;
+int rsqp_tiny_fits(const SmallKnobs &kn, int nVmax, int nCmax) {
+    return !kn.no_tiny && nVmax <= MV && nCmax <= 8 && nVmax >= 1;
 }
-hipError_t rsqp_launch_tiny_qp(const QPPools &p, int nq, int nVmax, int nCmax, int mode, int maxWSR, hipStream_t stream) {
+hipError_t rsqp_launch_tiny_qp(const SmallKnobs &kn, const QPPools &p, int nq, int nVmax, int nCmax, int mode, int maxWSR, hipStream_t stream) {
     if (nq <= 0) return hipSuccess;
-    if (!rsqp_tiny_fits(nVmax, nCmax)) return hipErrorInvalidValue;
+    if (!rsqp_tiny_fits(kn, nVmax, nCmax)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((nq + TG - 1) / TG)), block(TB);
     // RSQP_TINY_LDS=1: the tableau in LDS, three waves per SIMD (tuning: default decided by measurement)
-    static const int glds = getenv("RSQP_TINY_LDS") ? atoi(getenv("RSQP_TINY_LDS")) : 0;
+    const int glds = kn.tiny_lds;
     if (nCmax <= 2 && glds) hipLaunchKernelGGL((tiny_qp_kernel<2, 3, true>), grid, block, 0, stream, p, nq, mode, maxWSR);
     else if (nCmax <= 2) hipLaunchKernelGGL((tiny_qp_kernel<2, 2>), grid, block, 0, stream, p, nq, mode, maxWSR);
     else if (nCmax <= 4) hipLaunchKernelGGL((tiny_qp_kernel<4, 2>), grid, block, 0, stream, p, nq, mode, maxWSR);

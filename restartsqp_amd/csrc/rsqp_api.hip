@@ -308,6 +308,7 @@ struct rsqp_solver {
     bool fits_small = true;
     RsqpLargeEngine *large = nullptr;
     bool large_ready = false, profile_large = false;
+    SmallKnobs kn = rsqp_small_knobs_from_env();   // the environment switches of the LDS-scale kernels as they were when this handle was created
     int state_engine = -1;        // which kernel family wrote the hot-start state of this handle: 1 the register-resident tableau kernel, 0 the
                                   // LDS-resident ones (different layouts in the same block), -1 none yet
     bool h_sym = true;            // H symmetric value by value (or absent): the tableau kernel of qp_tiny.hip may take the handle
@@ -529,7 +530,7 @@ int wait_done(rsqp_solver *s, int val) {
     HIPCHK(hipStreamSynchronize(s->stream));
     return RSQP_OK;
 }
-bool spin_enabled() { static const bool on = getenv("RSQP_NO_SPIN") == nullptr; return on; }
+
 
 bool solved(const rsqp_solver *s) { return s->status_word == QPS_SOLVED; }
 bool infeasible(const rsqp_solver *s) { return s->status_word >= 100 && s->status_word < 200; }
@@ -929,7 +930,7 @@ int solve_large(rsqp_solver *s, int mode, int *nWSR, const double *x0, const dou
 }
 }  // namespace
 
-namespace { void launch_speculative_certificate(rsqp_solver *s, const QPPools &p); bool spec_cert_enabled(); }
+namespace { void launch_speculative_certificate(rsqp_solver *s, const QPPools &p); }
 
 extern "C" int rsqp_solve(rsqp_solver *s, int mode, int *nWSR, const double *x0, const double *y0,
                           const int *guess_b) {
@@ -949,18 +950,18 @@ extern "C" int rsqp_solve(rsqp_solver *s, int mode, int *nWSR, const double *x0,
         if (y0) { HIPCHK(s->d_y0.upload(y0, s->nV + s->nC)); p.y0 = s->d_y0.p; }
         if (guess_b) { HIPCHK(s->d_guess.upload(guess_b, s->nV)); p.guess_b = s->d_guess.p; }
     }
-    if (s->d_done && spin_enabled()) { p.done_flag = s->d_done; p.done_val = ++s->done_seq; }
+    if (s->d_done && !s->kn.no_spin) { p.done_flag = s->d_done; p.done_val = ++s->done_seq; }
     // the hs071-scale tableau kernel forms the certificate QPhandler::solveQP asks for at the end of the SAME launch
-    const bool fused_cert = p.done_flag && p.tiny_ok && rsqp_tiny_fits(s->nV, s->nC) && spec_cert_enabled() && !s->lp_mode &&
-                            s->A.initialised == (s->nC > 0) && getenv("RSQP_SMALL_ENGINE") == nullptr;
+    const bool fused_cert = p.done_flag && p.tiny_ok && rsqp_tiny_fits(s->kn, s->nV, s->nC) && !s->kn.no_spec_cert && !s->lp_mode &&
+                            s->A.initialised == (s->nC > 0) && s->kn.engine < 0;
     if (fused_cert) { p.cert_out = s->d_kkt.p; p.cert_Wb = s->d_Wb.p; p.cert_Wc = s->d_Wc.p; }
     {   // the tableau kernel and the LDS-resident kernels keep different layouts in the same state block: a solve that changes
         // the family (H lost or regained its symmetry between two solves) starts cold instead of restoring the other's bytes
-        const int fam = rsqp_small_launch_is_tiny(p, s->nV, s->nC);
+        const int fam = rsqp_small_launch_is_tiny(s->kn, p, s->nV, s->nC);
         if ((mode == RSQP_MODE_HOT_VECTORS || mode == RSQP_MODE_HOT_MATRICES) && s->state_engine != fam) { mode = RSQP_MODE_COLD; s->last_mode = mode; }
         s->state_engine = fam;
     }
-    hipError_t e = rsqp_launch_small_qp(p, 1, s->nV, s->nC,
+    hipError_t e = rsqp_launch_small_qp(s->kn, p, 1, s->nV, s->nC,
                                         rsqp_mat_lds_bytes(s->nV, s->nC, s->A.initialised ? s->A.nnz : 0, s->H.initialised ? s->H.nnz : 0),
                                         mode, *nWSR, s->stream);
     if (e != hipSuccess) return fail(RSQP_ERR_DEVICE, std::string("QP kernel launch: ") + hipGetErrorString(e));
@@ -1201,11 +1202,11 @@ void fill_kkt_args(rsqp_solver *s, RsqpKktArgs &a) {
     a.Ax = s->d_Ax.p; a.ATy = s->d_ATy.p; a.Hx = s->d_Hx.p;
     a.ws_b = s->d_wsb.p; a.ws_c = s->d_wsc.p; a.W_b = s->d_Wb.p; a.W_c = s->d_Wc.p; a.out = s->d_kkt.p;
 }
-bool spec_cert_enabled() { static const bool on = getenv("RSQP_NO_SPEC_CERT") == nullptr; return on; }
+
 // the fused products + certificate kernel of an LDS-scale QP right behind its solve kernel (same stream), see rsqp_solver::spec_cert
 void launch_speculative_certificate(rsqp_solver *s, const QPPools &p) {
     s->spec_cert = false;
-    if (!spec_cert_enabled() || s->lp_mode || !p.done_flag || !(s->fits_small && s->A.initialised == (s->nC > 0))) return;
+    if (s->kn.no_spec_cert || s->lp_mode || !p.done_flag || !(s->fits_small && s->A.initialised == (s->nC > 0))) return;
     RsqpKktArgs a;
     fill_kkt_args(s, a);
     a.done_flag = s->d_done; a.done_val = ++s->done_seq;
@@ -1243,7 +1244,7 @@ int run_certificate(rsqp_solver *s, rsqp_optimality_status *out, int *W_c, int *
     }
     RsqpKktArgs a;
     fill_kkt_args(s, a);
-    if (s->d_done && spin_enabled()) { a.done_flag = s->d_done; a.done_val = ++s->done_seq; }
+    if (s->d_done && !s->kn.no_spin) { a.done_flag = s->d_done; a.done_val = ++s->done_seq; }
     if (fused) {
         QPPools p = pools_of(s);
         if (rsqp_launch_small_certificate(p, a, 1, s->d_Ax.p, s->d_ATy.p, s->d_Hx.p, s->stream) != hipSuccess)
@@ -1309,6 +1310,7 @@ struct rsqp_batch {
     bool uni_pat = false; int uni_annz = 0, uni_hnnz = 0; long long uni_state = 0;     // (QPPools::uni_pat)
     long long sumV = 0, sumC = 0, sumAnz = 0, sumHnz = 0, mat_bytes_max = 0;
     bool haveH = false;
+    SmallKnobs kn = rsqp_small_knobs_from_env();
     int state_engine = -1;                // kernel family that wrote the members' hot-start states (see rsqp_solver::state_engine)
     bool h_sym = true;                    // every H symmetric value by value (the tableau kernel of qp_tiny.hip may take the batch)
     std::vector<int> h_Hjc, h_Hir;        // host copy of the H patterns (re-examined when the values change), small batches only
@@ -1495,11 +1497,11 @@ extern "C" int rsqp_batch_solve(rsqp_batch *b, int mode, int max_nWSR) {
     QPPools p = pools_of(b);
     if (!b->timing) HIPCHK(hipEventRecord(b->ev0, b->stream));
     {
-        const int fam = rsqp_small_launch_is_tiny(p, b->nVmax, b->nCmax);
+        const int fam = rsqp_small_launch_is_tiny(b->kn, p, b->nVmax, b->nCmax);
         if ((mode == RSQP_MODE_HOT_VECTORS || mode == RSQP_MODE_HOT_MATRICES) && b->state_engine != fam) mode = RSQP_MODE_COLD;
         b->state_engine = fam;
     }
-    hipError_t e = rsqp_launch_small_qp(p, b->nq, b->nVmax, b->nCmax, b->mat_bytes_max, mode, max_nWSR, b->stream);
+    hipError_t e = rsqp_launch_small_qp(b->kn, p, b->nq, b->nVmax, b->nCmax, b->mat_bytes_max, mode, max_nWSR, b->stream);
     if (e != hipSuccess) return fail(RSQP_ERR_DEVICE, std::string("QP kernel launch: ") + hipGetErrorString(e));
     if (!b->timing) HIPCHK(hipEventRecord(b->ev1, b->stream));
     return RSQP_OK;

@@ -33,6 +33,28 @@ struct QPDesc {
     long long offState;   // persistent engine image (doubles) for hot starts
 };
 
+// The RSQP_SMALL_* / RSQP_TINY_* / RSQP_K_* / RSQP_NO_SPIN / RSQP_NO_SPEC_CERT environment switches, read ONCE PER HANDLE (rsqp_create /
+// rsqp_batch_create) and kept with it: a handle's behaviour does not depend on what another handle's first use found in the
+// environment. Table of every switch: INTEGRATION.md 6.
+struct SmallKnobs {
+    int engine = -1;          // RSQP_SMALL_ENGINE      0 / 1: force the Givens-TQ / the explicit-inverse LDS kernel (no tableau kernels)
+    int k_debug_bail = -1;    // RSQP_K_DEBUG_BAIL      test hook: the mid-size tableau kernel bails out of a hot start before its n-th change
+    int noshape = 0;          // RSQP_SMALL_NOSHAPE     no compile-time 8 x 2 shape build
+    int lanes = -1;           // RSQP_SMALL_LANES       lanes per problem (8 / 16 / 32 / 64)
+    int waves = -1;           // RSQP_SMALL_WAVES       waves per SIMD the build is compiled for
+    int wide = -1;            // RSQP_SMALL_WIDE        0 / 1: never / always four waves per problem
+    int wide_lanes = 256;     // RSQP_SMALL_WIDE_LANES  (tuning builds) 512
+    int nospread = 0;         // RSQP_SMALL_NOSPREAD    no bank-spreading pad of the LDS stride
+    int no_kkt = 0;           // RSQP_SMALL_NO_KKT      no mid-size tableau kernel
+    int kkt_only = 0;         // RSQP_SMALL_KKT_ONLY    diagnostics: no second pass for bailed members
+    int no_tiny = 0;          // RSQP_SMALL_NO_TINY     no hs071-scale tableau kernel
+    int tiny_lds = 0;         // RSQP_TINY_LDS          the hs071-scale kernel with its tableau in LDS, three waves per SIMD
+    int exp_matglobal = 0;    // RSQP_EXP_MATGLOBAL     (tuning builds) matrices left in global memory
+    int no_spin = 0;          // RSQP_NO_SPIN           single-QP waits block in hipStreamSynchronize instead of spinning on a mapped word
+    int no_spec_cert = 0;     // RSQP_NO_SPEC_CERT      the certificate of a single LDS-scale QP only on demand
+};
+SmallKnobs rsqp_small_knobs_from_env();      // qp_small.hip
+
 struct QPPools {
     const QPDesc *desc;
     const int *Ajc, *Air; const double *Aval;
@@ -101,14 +123,14 @@ inline void rsqp_allow_full_lds(const void *fn, std::atomic<unsigned long long> 
 }
 
 // launchers (defined in the .hip files)
-hipError_t rsqp_launch_small_qp(const QPPools &p, int nq, int nVmax, int nCmax, long long mat_bytes_max, int mode,
+hipError_t rsqp_launch_small_qp(const SmallKnobs &kn, const QPPools &p, int nq, int nVmax, int nCmax, long long mat_bytes_max, int mode,
                                 int maxWSR, hipStream_t stream);
 long long rsqp_mat_lds_bytes(int nV, int nC, int annz, int hnnz);
 int rsqp_small_qp_fits(int nVmax, int nCmax);
 // qp_tiny.hip: the register-resident tableau kernel for problems of at most 8 variables and 8 constraints
-int rsqp_tiny_fits(int nVmax, int nCmax);
+int rsqp_tiny_fits(const SmallKnobs &kn, int nVmax, int nCmax);
 // 1 when rsqp_launch_small_qp hands this launch to the register-resident tableau kernel (qp_tiny.hip), whose hot-start state has
 // another layout than the LDS-resident kernels': the caller forces a cold start when the answer changes between two solves of a
 // handle or batch
-int rsqp_small_launch_is_tiny(const QPPools &p, int nVmax, int nCmax);
-hipError_t rsqp_launch_tiny_qp(const QPPools &p, int nq, int nVmax, int nCmax, int mode, int maxWSR, hipStream_t stream);
+int rsqp_small_launch_is_tiny(const SmallKnobs &kn, const QPPools &p, int nVmax, int nCmax);
+hipError_t rsqp_launch_tiny_qp(const SmallKnobs &kn, const QPPools &p, int nq, int nVmax, int nCmax, int mode, int maxWSR, hipStream_t stream);
