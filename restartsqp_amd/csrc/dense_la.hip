@@ -96,7 +96,7 @@ __device__ __forceinline__ void store_tile(const double (&r)[GK * T / NTHR], dou
 template <int TM, int TN, int NW, int MINW, int GK>
 __global__ void __launch_bounds__(NW * 64, MINW)
 k_dgemm(int ta, int tb, int m, int n, int kfull, int kc, double alpha, const double *__restrict__ A, long long lda,
-        const double *__restrict__ B, long long ldb, double beta, double *__restrict__ C, long long ldc, int upper) {
+        const double *__restrict__ B, long long ldb, double beta, double *__restrict__ C, long long ldc, int upper, int ktri) {
     extern __shared__ __attribute__((aligned(16))) double gemm_lds[];
     // RSQP_GEMM_DB=1 (tuning build, tools/gemm_pad_variants.sh): two LDS buffers, the tiles of step i + 1 stored while step i is
     // still being multiplied, one barrier per K step instead of two -- measured SLOWER (51.3 vs 53.1 TFLOP/s on 4096^3, QR
@@ -114,7 +114,14 @@ k_dgemm(int ta, int tb, int m, int n, int kfull, int kc, double alpha, const dou
     if (upper && i0 >= j0 + TN) return;
     const bool akc = ta != 0, bkc = tb == 0;   // k-contiguous operands
     // split K: slice blockIdx.z of the inner dimension, partial result into its own m x n slab
-    const int kbeg = blockIdx.z * kc, k = min(kfull, kbeg + kc);
+    int kbeg = blockIdx.z * kc, k = min(kfull, kbeg + kc);
+    // ktri != 0: an operand is TRIANGULAR with exact zeros in its other triangle -- the part of the inner dimension on which this
+    // tile's rows or columns are zero is skipped (the skipped terms are products with 0.0: the result keeps its bits).
+    //   1  C = X X' (upper tiles), X upper triangular: X[i][kk] = 0 for kk < i, so only kk >= j0 contributes
+    //   2  op(A) upper triangular (A not transposed): kk >= i0        3  op(A) = A', A upper triangular: kk < i0 + TM
+    if (ktri == 1) kbeg = max(kbeg, (j0 / GK) * GK);
+    else if (ktri == 2) kbeg = max(kbeg, (i0 / GK) * GK);
+    else if (ktri == 3) k = min(k, i0 + TM);
     C += (long long)blockIdx.z * m * n;
     d4 acc[NJ][MI];
 #pragma unroll
@@ -208,7 +215,7 @@ __global__ void k_splitk_reduce(int m, int n, int splits, const double *__restri
 
 static hipError_t dgemm_ws(bool transA, bool transB, int m, int n, int k, double alpha, const double *A, long long lda,
                            const double *B, long long ldb, double beta, double *C, long long ldc, double *ws,
-                           long long ws_cap, hipStream_t st, int upper = 0) {
+                           long long ws_cap, hipStream_t st, int upper = 0, int ktri = 0) {
     if (m <= 0 || n <= 0) return hipSuccess;
     const int ta = transA ? 1 : 0, tb = transB ? 1 : 0;
     // large tiles when they still give every CU work, small ones otherwise
@@ -245,7 +252,7 @@ static hipError_t dgemm_ws(bool transA, bool transB, int m, int n, int k, double
         static std::atomic<unsigned long long> set_{0};                                                            \
         rsqp_allow_full_lds(reinterpret_cast<const void *>(&k_dgemm<a, b, nw, mw, gk>), set_, (int)lds_);          \
         hipLaunchKernelGGL((k_dgemm<a, b, nw, mw, gk>), grid, dim3(nw * 64), lds_, st, ta, tb, m, n, k, kc, al, A, \
-                           lda, B, ldb, be, Cout, ldo, upper);                                                     \
+                           lda, B, ldb, be, Cout, ldo, upper, ktri);                                               \
     } while (0)
     if (TM == 128 && TN == 128) {
         // measured on 4096^3: 8 waves (4 resident per SIMD, 122 VGPRs) 53.5 TFLOP/s; 4 waves x 2 resident
@@ -267,6 +274,15 @@ static hipError_t dgemm_ws(bool transA, bool transB, int m, int n, int k, double
 hipError_t rsqp_dgemm(bool transA, bool transB, int m, int n, int k, double alpha, const double *A, long long lda,
                       const double *B, long long ldb, double beta, double *C, long long ldc, hipStream_t st) {
     return dgemm_ws(transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, 0, st);
+}
+// an operand triangular with exact zeros in its other triangle (ktri: see k_dgemm): the zero part of the inner dimension is skipped
+hipError_t rsqp_dgemm_tri(bool transA, bool transB, int m, int n, int k, double alpha, const double *A, long long lda,
+                          const double *B, long long ldb, double beta, double *C, long long ldc, int ktri, hipStream_t st) {
+    return dgemm_ws(transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, 0, st, 0, ktri);
+}
+// C (n x n, upper tiles) = X X' for an UPPER TRIANGULAR X (n x n; its strict lower triangle must hold zeros): U^-1 U^-T
+hipError_t rsqp_dtrmmt_upper(int n, double alpha, const double *X, long long ldx, double *C, long long ldc, hipStream_t st) {
+    return dgemm_ws(false, true, n, n, n, alpha, X, ldx, X, ldx, 0.0, C, ldc, nullptr, 0, st, 1, 1);
 }
 // the same for a symmetric n x n result of which only the UPPER triangle is wanted (tiles strictly below the diagonal are skipped)
 hipError_t rsqp_dgemm_upper(bool transA, bool transB, int n, int k, double alpha, const double *A, long long lda,
@@ -1043,11 +1059,11 @@ hipError_t rsqp_dtrtri_upper(int n, const double *R, long long ldr, double *X, l
             // instead keep it simple: tmp' = X22' R12' is not needed; store tmp in the lower block column-major with ld = ldx
             double *tmp = X + a1 + (long long)a0 * ldx;     // s2 x s block (lower triangle), holds (R12 X22)' 
             // (R12 X22)' = X22' R12'  ->  tmp (s2 x s) = X22' (s2 x s2) * R12' (s2 x s)
-            DCHK(rsqp_dgemm(true, true, s2, s, s2, 1.0, X + a1 + (long long)a1 * ldx, ldx, R + a0 + (long long)a1 * ldr, ldr, 0.0,
-                            tmp, ldx, st));
+            DCHK(rsqp_dgemm_tri(true, true, s2, s, s2, 1.0, X + a1 + (long long)a1 * ldx, ldx, R + a0 + (long long)a1 * ldr, ldr, 0.0,
+                                tmp, ldx, 3, st));      // (X22 upper triangular: row i of X22' ends at column i)
             // X12 (s x s2) = -X11 (s x s) * tmp' (s x s2)
-            DCHK(rsqp_dgemm(false, true, s, s2, s, -1.0, X + a0 + (long long)a0 * ldx, ldx, tmp, ldx, 0.0,
-                            X + a0 + (long long)a1 * ldx, ldx, st));
+            DCHK(rsqp_dgemm_tri(false, true, s, s2, s, -1.0, X + a0 + (long long)a0 * ldx, ldx, tmp, ldx, 0.0,
+                                X + a0 + (long long)a1 * ldx, ldx, 2, st));      // (X11 upper triangular: row i starts at column i)
             hipLaunchKernelGGL(k_zero_block, dim3((s2 + 255) / 256, s), dim3(256), 0, st, s2, s, tmp, ldx);
         }
     }
@@ -1164,7 +1180,7 @@ extern "C" int rsqp_dense_chol_inverse(int n, double *G, double *Ginv, double pd
     sw.start();
     hipError_t e = rsqp_dpotrf_upper(n, dG.p, n, pd_rel, pd_abs, &w, nullptr);
     if (e == hipSuccess) e = rsqp_dtrtri_upper(n, dG.p, n, dX.p, n, &w, nullptr);
-    if (e == hipSuccess) e = rsqp_dgemm(false, true, n, n, n, 1.0, dX.p, n, dX.p, n, 0.0, dI.p, n, nullptr);   // U^-1 U^-T
+    if (e == hipSuccess) e = rsqp_dgemm_tri(false, true, n, n, n, 1.0, dX.p, n, dX.p, n, 0.0, dI.p, n, 2, nullptr);   // U^-1 U^-T (both triangles)
     const float t = sw.stop();
     if (ms) *ms = t;
     int flags[4] = {0, 0, 0, 0};

@@ -2803,7 +2803,7 @@ struct RsqpLargeEngine::Impl {
         LCHK(hipStreamSynchronize(st));      // (the host vectors above go out of scope as well)
         if (h_pinned_i[1] != 0) return RET_FALLBACK;
         LCHK(rsqp_dtrtri_upper(n, G, lg, Ui, lg, &dw, st));
-        LCHK(rsqp_dgemm_upper(false, true, n, n, 1.0, Ui, lg, Ui, lg, 0.0, Minv, ldm, st));
+        LCHK(rsqp_dtrmmt_upper(n, 1.0, Ui, lg, Minv, ldm, st));
         if (!dual_sym) LCHK(rsqp_mirror_upper(n, Minv, ldm, st));
         (void)hipEventRecord(se2, st);
         {   // what the matrix cores were asked for (algorithmic: the symmetric results counted once): Gram matrix n^2 m, Cholesky
@@ -3180,7 +3180,7 @@ struct RsqpLargeEngine::Impl {
         if (h_pinned_i[1] != 0) return RET_SETUP_FAILED;   // not positive definite on the null space
         double *Ui = HZ;   // nZ x nZ
         LCHK(rsqp_dtrtri_upper(nZ, G, lg, Ui, lg, &dw, st));
-        LCHK(rsqp_dgemm(false, true, nZ, nZ, nZ, 1.0, Ui, lg, Ui, lg, 0.0, Wz, ld, st));
+        LCHK(rsqp_dgemm_tri(false, true, nZ, nZ, nZ, 1.0, Ui, lg, Ui, lg, 0.0, Wz, ld, 2, st));      // (Ui upper triangular: row i starts at column i; both triangles of the result wanted)
         chk("setup_wz_blocked");
         return RET_OK;
     }

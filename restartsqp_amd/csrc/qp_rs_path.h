@@ -93,7 +93,7 @@ int Impl::rs_build_dense(bool *ok) {
     LCHK(hipStreamSynchronize(st));
     if (h_pinned_i[1] != 0) return RET_OK;
     LCHK(rsqp_dtrtri_upper(nV, G, ld, Ui, ld, &dw, st));
-    LCHK(rsqp_dgemm_upper(false, true, nV, nV, 1.0, Ui, ld, Ui, ld, 0.0, Z, ld, st));
+    LCHK(rsqp_dtrmmt_upper(nV, 1.0, Ui, ld, Z, ld, st));
     LCHK(rsqp_mirror_upper(nV, Z, ld, st));
     *ok = true;
     return RET_OK;
@@ -367,7 +367,7 @@ int Impl::rs_setup_rows(const std::vector<int> &rows, const std::vector<int> &gb
     if (h_pinned_i[1] != 0) return RET_FALLBACK;
     double *Ui = big;
     LCHK(rsqp_dtrtri_upper(n, rs_G, ld, Ui, ld, &dw, st));
-    LCHK(rsqp_dgemm_upper(false, true, n, n, 1.0, Ui, ld, Ui, ld, 0.0, Wz, ld, st));
+    LCHK(rsqp_dtrmmt_upper(n, 1.0, Ui, ld, Wz, ld, st));
     (void)hipEventRecord(se2, st);
     {
         (void)hipEventSynchronize(se2);

@@ -47,6 +47,13 @@ hipError_t rsqp_dorgqr(int m, int n, const double *B, long long ldb, double *Q, 
 hipError_t rsqp_dgemm_upper(bool transA, bool transB, int n, int k, double alpha, const double *A, long long lda,
                             const double *B, long long ldb, double beta, double *C, long long ldc, hipStream_t st);
 hipError_t rsqp_mirror_upper(int n, double *M, long long ld, hipStream_t st);
+// C (n x n, upper tiles only) = alpha X X' for an UPPER TRIANGULAR X whose strict lower triangle holds zeros (U^-1 U^-T behind
+// rsqp_dtrtri_upper): the zero part of the inner dimension is skipped -- a third of the multiply-adds of rsqp_dgemm_upper
+// rsqp_dgemm with a triangular operand (ktri: 2 = op(A) upper triangular, A not transposed; 3 = op(A) = A', A upper triangular;
+// exact zeros in the other triangle): the zero part of the inner dimension is skipped
+hipError_t rsqp_dgemm_tri(bool transA, bool transB, int m, int n, int k, double alpha, const double *A, long long lda,
+                          const double *B, long long ldb, double beta, double *C, long long ldc, int ktri, hipStream_t st);
+hipError_t rsqp_dtrmmt_upper(int n, double alpha, const double *X, long long ldx, double *C, long long ldc, hipStream_t st);
 // X (n x n, ldx) = R^-1 for the upper triangular R (n x n, ldr); X is upper triangular, its strict
 // lower part is zeroed
 hipError_t rsqp_dtrtri_upper(int n, const double *R, long long ldr, double *X, long long ldx, RsqpDenseWork *w,
