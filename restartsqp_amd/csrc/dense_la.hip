@@ -96,7 +96,8 @@ __device__ __forceinline__ void store_tile(const double (&r)[GK * T / NTHR], dou
 template <int TM, int TN, int NW, int MINW, int GK>
 __global__ void __launch_bounds__(NW * 64, MINW)
 k_dgemm(int ta, int tb, int m, int n, int kfull, int kc, double alpha, const double *__restrict__ A, long long lda,
-        const double *__restrict__ B, long long ldb, double beta, double *__restrict__ C, long long ldc, int upper, int ktri) {
+        const double *__restrict__ B, long long ldb, double beta, double *__restrict__ C, long long ldc, int upper, int ktri,
+        long long sA, long long sB, long long sC) {
     extern __shared__ __attribute__((aligned(16))) double gemm_lds[];
     // RSQP_GEMM_DB=1 (tuning build, tools/gemm_pad_variants.sh): two LDS buffers, the tiles of step i + 1 stored while step i is
     // still being multiplied, one barrier per K step instead of two -- measured SLOWER (51.3 vs 53.1 TFLOP/s on 4096^3, QR
@@ -114,7 +115,11 @@ k_dgemm(int ta, int tb, int m, int n, int kfull, int kc, double alpha, const dou
     if (upper && i0 >= j0 + TN) return;
     const bool akc = ta != 0, bkc = tb == 0;   // k-contiguous operands
     // split K: slice blockIdx.z of the inner dimension, partial result into its own m x n slab
-    int kbeg = blockIdx.z * kc, k = min(kfull, kbeg + kc);
+    // sC != 0: blockIdx.z is a BATCH index -- independent products of one shape whose operands lie sA / sB / sC doubles apart (the
+    // pairs of one level of the triangular inverse in ONE launch); otherwise it is the split-K slice
+    const bool batched = sC != 0;
+    if (batched) { A += (long long)blockIdx.z * sA; B += (long long)blockIdx.z * sB; C += (long long)blockIdx.z * sC; }
+    int kbeg = batched ? 0 : blockIdx.z * kc, k = min(kfull, kbeg + kc);
     // ktri != 0: an operand is TRIANGULAR with exact zeros in its other triangle -- the part of the inner dimension on which this
     // tile's rows or columns are zero is skipped (the skipped terms are products with 0.0: the result keeps its bits).
     //   1  C = X X' (upper tiles), X upper triangular: X[i][kk] = 0 for kk < i, so only kk >= j0 contributes
@@ -122,7 +127,7 @@ k_dgemm(int ta, int tb, int m, int n, int kfull, int kc, double alpha, const dou
     if (ktri == 1) kbeg = max(kbeg, (j0 / GK) * GK);
     else if (ktri == 2) kbeg = max(kbeg, (i0 / GK) * GK);
     else if (ktri == 3) k = min(k, i0 + TM);
-    C += (long long)blockIdx.z * m * n;
+    if (!batched) C += (long long)blockIdx.z * m * n;
     d4 acc[NJ][MI];
 #pragma unroll
     for (int a = 0; a < NJ; a++)
@@ -215,15 +220,16 @@ __global__ void k_splitk_reduce(int m, int n, int splits, const double *__restri
 
 static hipError_t dgemm_ws(bool transA, bool transB, int m, int n, int k, double alpha, const double *A, long long lda,
                            const double *B, long long ldb, double beta, double *C, long long ldc, double *ws,
-                           long long ws_cap, hipStream_t st, int upper = 0, int ktri = 0) {
+                           long long ws_cap, hipStream_t st, int upper = 0, int ktri = 0, int batch = 1, long long sA = 0,
+                           long long sB = 0, long long sC = 0) {
     if (m <= 0 || n <= 0) return hipSuccess;
     const int ta = transA ? 1 : 0, tb = transB ? 1 : 0;
     // large tiles when they still give every CU work, small ones otherwise
-    const long long big = (long long)((m + 127) / 128) * ((n + 127) / 128);
+    const long long big = (long long)((m + 127) / 128) * ((n + 127) / 128) * std::max(batch, 1);
     int TM = 128, TN = 128;
     if (big < 512) {
-        TM = m <= 64 || (long long)((m + 63) / 64) * ((n + 127) / 128) < 512 ? 64 : 128;
-        TN = n <= 64 || (long long)((m + TM - 1) / TM) * ((n + 127) / 128) < 512 ? 64 : 128;
+        TM = m <= 64 || (long long)((m + 63) / 64) * ((n + 127) / 128) * std::max(batch, 1) < 512 ? 64 : 128;
+        TN = n <= 64 || (long long)((m + TM - 1) / TM) * ((n + 127) / 128) * std::max(batch, 1) < 512 ? 64 : 128;
     }
     // a block of reflectors against a wide matrix (W = V'C: 256 x n with an inner dimension of thousands): the large tile,
     // and K split so that the chip has work -- 64 x 64 tiles ran these at 29-35 TFLOP/s (RSQP_GEMM_SKINNY=0: as before)
@@ -241,7 +247,8 @@ static hipError_t dgemm_ws(bool transA, bool transB, int m, int n, int k, double
     }
     int kc = k;
     if (splits > 1) { kc = ((k + splits - 1) / splits + 31) / 32 * 32; splits = (k + kc - 1) / kc; }
-    dim3 grid(bx, by, splits);
+    if (batch > 1) splits = 1;
+    dim3 grid(bx, by, batch > 1 ? batch : splits);
     double *Cout = splits > 1 ? ws : C;
     const long long ldo = splits > 1 ? m : ldc;
     const double al = splits > 1 ? 1.0 : alpha, be = splits > 1 ? 0.0 : beta;
@@ -252,7 +259,8 @@ static hipError_t dgemm_ws(bool transA, bool transB, int m, int n, int k, double
         static std::atomic<unsigned long long> set_{0};                                                            \
         rsqp_allow_full_lds(reinterpret_cast<const void *>(&k_dgemm<a, b, nw, mw, gk>), set_, (int)lds_);          \
         hipLaunchKernelGGL((k_dgemm<a, b, nw, mw, gk>), grid, dim3(nw * 64), lds_, st, ta, tb, m, n, k, kc, al, A, \
-                           lda, B, ldb, be, Cout, ldo, upper, ktri);                                               \
+                           lda, B, ldb, be, Cout, ldo, upper, ktri, batch > 1 ? sA : 0LL, batch > 1 ? sB : 0LL,    \
+                           batch > 1 ? sC : 0LL);                                                                  \
     } while (0)
     if (TM == 128 && TN == 128) {
         // measured on 4096^3: 8 waves (4 resident per SIMD, 122 VGPRs) 53.5 TFLOP/s; 4 waves x 2 resident
@@ -847,6 +855,10 @@ __global__ void k_zero_block(int m, int n, double *__restrict__ X, long long ldx
     const int j = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m && j < n) X[i + (long long)j * ldx] = 0.0;
 }
+__global__ void k_zero_block_batched(int m, int n, double *__restrict__ X, long long ldx, long long stride) {
+    const int j = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m && j < n) X[(long long)blockIdx.z * stride + i + (long long)j * ldx] = 0.0;
+}
 
 // unblocked Cholesky (upper, G = U'U) of one NB x NB diagonal block in LDS with the definiteness
 // test of the engine; also returns the inverse of the block's factor in Uinv (upper)
@@ -1051,13 +1063,24 @@ hipError_t rsqp_dtrtri_upper(int n, const double *R, long long ldr, double *X, l
     hipLaunchKernelGGL(k_zero_block, dim3((n + 255) / 256, n), dim3(256), 0, st, n, n, X, ldx);
     hipLaunchKernelGGL(k_trinv_diag, dim3((n + NB - 1) / NB), dim3(64), 0, st, n, R, ldr, X, ldx);
     if (n <= NB) return hipGetLastError();
-    // scratch for R12 X22: the strictly lower triangle of X is free; blocks of it are zeroed again afterwards
+    // scratch for R12 X22: the strictly lower triangle of X is free; blocks of it are zeroed again afterwards.
+    // All pairs of a level that have the full shape s x s run as ONE batched launch per product (round 5: at n = 7 656 the levels
+    // s = 64 .. 512 were 336 launches of 12 us, 3.2 of the 8.3 ms of this routine); a ragged last pair runs on its own.
     for (int s = NB; s < n; s *= 2) {
-        for (int a0 = 0; a0 + s < n; a0 += 2 * s) {
-            const int a1 = a0 + s, a2 = std::min(n, a1 + s), s2 = a2 - a1;
-            // tmp (s x s2) lives in the lower-left block X[a1:a2, a0:a1]' -- use its transpose slot X[a1.., a0..] of shape s2 x s
-            // instead keep it simple: tmp' = X22' R12' is not needed; store tmp in the lower block column-major with ld = ldx
-            double *tmp = X + a1 + (long long)a0 * ldx;     // s2 x s block (lower triangle), holds (R12 X22)' 
+        int nfull = 0;
+        for (int a0 = 0; a0 + 2 * s <= n; a0 += 2 * s) nfull++;
+        if (nfull > 0) {
+            const long long stX = 2LL * s * (ldx + 1), stR = 2LL * s * (ldr + 1);
+            double *tmp = X + s;                                            // pair z: X + (a0 + s) + a0 ldx, a0 = 2 s z
+            DCHK(dgemm_ws(true, true, s, s, s, 1.0, X + s + (long long)s * ldx, ldx, R + (long long)s * ldr, ldr, 0.0, tmp, ldx, nullptr, 0, st, 0, 3,
+                          nfull, stX, stR, stX));
+            DCHK(dgemm_ws(false, true, s, s, s, -1.0, X, ldx, tmp, ldx, 0.0, X + (long long)s * ldx, ldx, nullptr, 0, st, 0, 2, nfull, stX, stX, stX));
+            hipLaunchKernelGGL(k_zero_block_batched, dim3((s + 255) / 256, s, nfull), dim3(256), 0, st, s, s, tmp, ldx, stX);
+        }
+        const int a0 = 2 * s * nfull;
+        if (a0 + s < n) {                                                  // the ragged pair behind them
+            const int a1 = a0 + s, a2 = n, s2 = a2 - a1;
+            double *tmp = X + a1 + (long long)a0 * ldx;     // s2 x s block (lower triangle), holds (R12 X22)'
             // (R12 X22)' = X22' R12'  ->  tmp (s2 x s) = X22' (s2 x s2) * R12' (s2 x s)
             DCHK(rsqp_dgemm_tri(true, true, s2, s, s2, 1.0, X + a1 + (long long)a1 * ldx, ldx, R + a0 + (long long)a1 * ldr, ldr, 0.0,
                                 tmp, ldx, 3, st));      // (X22 upper triangular: row i of X22' ends at column i)
@@ -1075,19 +1098,35 @@ hipError_t rsqp_dpotrf_upper(int n, double *G, long long ldg, double pd_rel, dou
     if (n > w->mmax) return hipErrorInvalidValue;
     double *Uinv = w->dblk;
     hipLaunchKernelGGL(k_get_diag, dim3((n + 255) / 256), dim3(256), 0, st, n, G, ldg, w->norm2);
-    for (int k0 = 0; k0 < n; k0 += NB) {
-        const int jb = std::min(NB, n - k0), nt = n - k0 - jb;
-        double *Gd = G + k0 + (long long)k0 * ldg;
-        static const bool old_potf2 = getenv("RSQP_POTF2_OLD") != nullptr;
-        if (old_potf2) hipLaunchKernelGGL(k_potf2, dim3(1), dim3(64), 0, st, jb, Gd, ldg, w->norm2 + k0, pd_rel, pd_abs, Uinv, w->flag + 1);
-        else hipLaunchKernelGGL(k_potf2_elim, dim3(1), dim3(256), CHOLQR_LDS1, st, jb, Gd, ldg, w->norm2 + k0, pd_rel, pd_abs, Uinv, w->flag + 1);
-        if (nt > 0) {
-            double *G12 = G + k0 + (long long)(k0 + jb) * ldg;
-            // U12 = Ujj^-T G12  (jb x nt): via W, then copied back
-            DCHK(rsqp_dgemm(true, false, jb, nt, jb, 1.0, Uinv, NB, G12, ldg, 0.0, w->W, NB, st));
-            DCHK(hipMemcpy2DAsync(G12, sizeof(double) * ldg, w->W, sizeof(double) * NB, sizeof(double) * jb, nt, hipMemcpyDeviceToDevice, st));
-            // G22 -= U12' U12 (the upper triangle's tiles only: the lower one is scratch and zeroed below)
-            DCHK(rsqp_dgemm_upper(true, false, nt, jb, -1.0, w->W, NB, w->W, NB, 1.0, G + (k0 + jb) + (long long)(k0 + jb) * ldg, ldg, st));
+    // Two levels (round 5). The trailing matrix is updated once per OUTER block of COB = 256 columns, with an inner dimension of
+    // 256: the first version updated it behind every 64-column panel -- 120 passes over the trailing triangle at n = 7 656, each
+    // with an inner dimension of 64 (8 flop per byte: HBM-bound, 2.3 TB/s measured), 12 of the 22 ms of this routine
+    // (profiles/r05_j_kernel_stats_setup_full.csv). Inside an outer block the panels are right-looking on the block ROW only
+    // (COB x remaining columns: a few MB).
+    constexpr int COB = 256;
+    static const bool old_potf2 = getenv("RSQP_POTF2_OLD") != nullptr;
+    for (int K0 = 0; K0 < n; K0 += COB) {
+        const int ob = std::min(COB, n - K0), K1 = K0 + ob;
+        for (int k0 = K0; k0 < K1; k0 += NB) {
+            const int jb = std::min(NB, K1 - k0), nt = n - k0 - jb, mrest = K1 - k0 - jb;
+            double *Gd = G + k0 + (long long)k0 * ldg;
+            if (old_potf2) hipLaunchKernelGGL(k_potf2, dim3(1), dim3(64), 0, st, jb, Gd, ldg, w->norm2 + k0, pd_rel, pd_abs, Uinv, w->flag + 1);
+            else hipLaunchKernelGGL(k_potf2_elim, dim3(1), dim3(256), CHOLQR_LDS1, st, jb, Gd, ldg, w->norm2 + k0, pd_rel, pd_abs, Uinv, w->flag + 1);
+            if (nt > 0) {
+                double *G12 = G + k0 + (long long)(k0 + jb) * ldg;
+                // U12 = Ujj^-T G12  (jb x nt): via W, then copied back
+                DCHK(rsqp_dgemm(true, false, jb, nt, jb, 1.0, Uinv, NB, G12, ldg, 0.0, w->W, NB, st));
+                DCHK(hipMemcpy2DAsync(G12, sizeof(double) * ldg, w->W, sizeof(double) * NB, sizeof(double) * jb, nt, hipMemcpyDeviceToDevice, st));
+                // the rest of this outer block's rows: G[k0+jb .. K1, k0+jb .. n) -= U12[:, 0 .. mrest)' U12   (what lands below the
+                // diagonal of the block is scratch, zeroed at the end)
+                if (mrest > 0) DCHK(rsqp_dgemm(true, false, mrest, nt, jb, -1.0, w->W, NB, w->W, NB, 1.0, G + (k0 + jb) + (long long)(k0 + jb) * ldg, ldg, st));
+            }
+        }
+        // trailing matrix (upper tiles): G22 -= U12' U12 with the whole block row, inner dimension ob
+        const int nt2 = n - K1;
+        if (nt2 > 0) {
+            const double *U12 = G + K0 + (long long)K1 * ldg;
+            DCHK(rsqp_dgemm_upper(true, false, nt2, ob, -1.0, U12, ldg, U12, ldg, 1.0, G + K1 + (long long)K1 * ldg, ldg, st));
         }
     }
     hipLaunchKernelGGL(k_zero_lower, dim3((n + 255) / 256, n), dim3(256), 0, st, n, G, ldg);
@@ -1180,7 +1219,8 @@ extern "C" int rsqp_dense_chol_inverse(int n, double *G, double *Ginv, double pd
     sw.start();
     hipError_t e = rsqp_dpotrf_upper(n, dG.p, n, pd_rel, pd_abs, &w, nullptr);
     if (e == hipSuccess) e = rsqp_dtrtri_upper(n, dG.p, n, dX.p, n, &w, nullptr);
-    if (e == hipSuccess) e = rsqp_dgemm_tri(false, true, n, n, n, 1.0, dX.p, n, dX.p, n, 0.0, dI.p, n, 2, nullptr);   // U^-1 U^-T (both triangles)
+    if (e == hipSuccess) e = rsqp_dtrmmt_upper(n, 1.0, dX.p, n, dI.p, n, nullptr);      // U^-1 U^-T: upper tiles, as the engine forms it
+    if (e == hipSuccess) e = rsqp_mirror_upper(n, dI.p, n, nullptr);
     const float t = sw.stop();
     if (ms) *ms = t;
     int flags[4] = {0, 0, 0, 0};
