@@ -163,7 +163,7 @@ def compact_line(full):
         "hs0xx_batch_64_shard_ms": c.get("hs0xx_batch_64_shard_ms"),
         "roofline_mfma_frac": c.get("roofline_mfma_frac"),
         "roofline_spmv_frac": c.get("roofline_spmv_frac"),
-        "roofline_spmv_in_solver_frac": _dig(full, "roofline_spmv", "in_solver_frac"),
+        "roofline_spmv_in_solver_frac": _dig(full, "large_engine", "in_solver_spmv", "frac"),
     }
     cfg.update({k: _r(v, 5) for k, v in scal.items() if v is not None})
     line["config"] = cfg
@@ -553,6 +553,10 @@ def large_configs(capi, problems, seq_steps=50, ref_rule_steps=10, cpu_seconds=1
         s.optimize_qp()
     prof = s.engine_profile()
     if prof:
+        if "spmv" in prof:      # the product the SOLVER runs (csx_stream_spmv, one matrix, entry order): its own figure, next to the
+            out["in_solver_spmv"] = dict(prof["spmv"], kernel="csx_stream_spmv", note=(     # batched roofline kernel's
+                "every A x / A'y of the HBM engine's homotopy on the sparse 10k x 20k configuration: 2.7 MB per call, launch-bound and "
+                "cache-resident -- NOT the 0.69 of roofline_spmv, which is the batched kernel no solver path calls"))
         out["roofline_large_engine_kernels"] = {
             "workload": "sparse 10 000 x 20 000, one FIXED and one VARIED step of the warm-started sequence", "kernels": prof,
             "note": "achieved = algorithmic bytes (8 B x rows x cols for a product, 16 B for a rank-1 update) / HIP-event time per call"}

@@ -104,7 +104,8 @@ double rsqp_get_structure_seconds(const rsqp_solver *s, int which);
 int rsqp_get_last_mode(const rsqp_solver *s);
 /* which formulation of the HBM-resident engine holds the factors of this handle (the stand-in for qpOASES' TQ / Cholesky factors
  * behind SQProblem::init / hotstart, call sites qpOASESInterface.cpp:155,180-206): 0 = null-space (any Hessian), 1 = range-space,
- * diagonal positive Hessian, 2 = general range-space with a banded H^-1 operator, 3 = the same with the dense inverse;
+ * diagonal positive Hessian, 2 = general range-space with a banded H^-1 operator, 3 = the same with the dense inverse, 4 = 3 plus
+ * the static tableau [I; A] H^-1 [I A'] of small dense problems (nV + nC <= 8192);
  * -1: the handle has no HBM-resident engine (or has not solved yet) */
 int rsqp_get_large_path(const rsqp_solver *s);
 int rsqp_get_nV(const rsqp_solver *s);

@@ -282,7 +282,7 @@ class Solver:
         return lib().rsqp_get_last_mode(self._h)
 
     LARGE_PATHS = {-1: "none", 0: "null-space", 1: "range-space (diagonal H)", 2: "general range-space (banded H^-1)",
-                   3: "general range-space (dense H^-1)"}
+                   3: "general range-space (dense H^-1)", 4: "general range-space (dense H^-1 + static tableau [I; A] H^-1 [I A'])"}
 
     def large_path(self):
         """which formulation of the HBM-resident engine holds this handle's factors (rsqp_get_large_path)"""

@@ -1872,7 +1872,7 @@ struct RsqpLargeEngine::Impl {
     ~Impl() {
         double *dv[] = {Z, Y, Minv, Wz, x, g, lb, ub, gN, lbN, ubN, dx, w1, w2, w3, w4, w5, w6, wz1, wz2, wz3, Ax, lbA, ubA,
                         lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col, c_wY, c_wY2, c_xY, c_xi, c_wZ, py_t, py_v, pm_s, hinv, ps_u, sym_part, wz_part,
-                        rs_p, rs_Ap, ra1, ra2, ra3, ra4, rs_dl, rs_ps_u, rs_G, band_buf};
+                        rs_p, ra1, ra2, ra3, ra4, rs_dl, rs_ps_u, rs_G, band_buf, rs_WW, rs_dA};
         for (double *p : dv) if (p) (void)hipFree(p);
         if (big) (void)hipFree(big);
         rsqp_dense_work_free(&dw);
@@ -1901,7 +1901,7 @@ struct RsqpLargeEngine::Impl {
     }
     void preport() {
         if (!profile) return;
-        const char *nm[10] = {"gemv_n", "gemv_t", "ger", "wz_shrink", "wz_grow", "spmv", "ger_gemv_t", "shrink_gemv", "ger_gemv_n", ""};
+        const char *nm[10] = {"gemv_n", "gemv_t", "ger", "wz_shrink", "wz_grow", "spmv", "ger_gemv_t", "shrink_gemv", "ger_gemv_n", "band_hinv"};
         for (int k = 0; k < 10; k++)
             if (prof[k].calls) fprintf(stderr, "[rsqp profile] %-9s calls %8lld  time %9.3f ms  bytes %10.3f GB  => %7.1f GB/s  (avg %.1f us)\n", nm[k], prof[k].calls, prof[k].ms, prof[k].bytes / 1e9, prof[k].bytes / (prof[k].ms * 1e-3) / 1e9, 1e3 * prof[k].ms / prof[k].calls);
     }
@@ -2096,15 +2096,18 @@ struct RsqpLargeEngine::Impl {
     void A_times(const double *in, double *out) {   // out[nC] = A in
         if (nC <= 0) return;
         if (M.denseA) gemv_n(M.denseA, nC, nC, nV, in, 1.0, 0.0, nullptr, out);
-        else (void)rsqp_launch_spmv(M.blk_r, M.nblk_r, M.Arp, M.Aci, M.Arv, in, out, 1, 0, 0, 0, 0, st);
+        else { pbegin(); (void)rsqp_launch_spmv(M.blk_r, M.nblk_r, M.Arp, M.Aci, M.Arv, in, out, 1, 0, 0, 0, 0, st); pend(5, spmv_bytes(nC, nV)); }
     }
+    // algorithmic bytes of one sparse product with A (12 nnz + 4 (majors + 1) + 8 majors + 8 minors; nnz from the set-up)
+    double nnzA_ = 0.0;
+    double spmv_bytes(int nmajor, int nminor) const { return 12.0 * nnzA_ + 4.0 * (nmajor + 1) + 8.0 * nmajor + 8.0 * nminor; }
     void AT_times(const double *in, double *out) {  // out[nV] = A' in
         if (nC <= 0) fill(out, nV, 0.0);
         // (every vector this is called with lives on the ACTIVE constraints, but reading only those rows through the row-major copy
         //  with k_gemv_n1<.., SKIP0> measured 17.5 us against 8.5 us for the full transposed product at 2048 x 4096: the skipped
         //  loads leave too few in flight; the matrices of that size sit in the 256 MB memory-side cache anyway)
         else if (M.denseA) gemv_t(M.denseA, nC, nC, nV, in, out);
-        else (void)rsqp_launch_spmv(M.blk_c, M.nblk_c, M.Ajc, M.Air, M.Aval, in, out, 1, 0, 0, 0, 0, st);
+        else { pbegin(); (void)rsqp_launch_spmv(M.blk_c, M.nblk_c, M.Ajc, M.Air, M.Aval, in, out, 1, 0, 0, 0, 0, st); pend(5, spmv_bytes(nV, nC)); }
     }
     // A in and (H + hreg I) in of the SAME vector in one launch when both matrices have dense copies (A through its
     // row-major copy: both are transposed products then); otherwise one after the other
@@ -3060,7 +3063,14 @@ struct RsqpLargeEngine::Impl {
     bool rsh_enabled = getenv("RSQP_LARGE_NO_RSH") == nullptr;
     bool rs_force_dense = getenv("RSQP_LARGE_RSH_DENSE") != nullptr;      // (tests: the dense operator on a banded Hessian)
     bool rsh = false;
-    int rs_kind = 0;                 // 1: banded factor (k_band_apply), 2: explicit dense inverse in Z
+    int rs_kind = 0;                 // 1: banded factor (k_band_apply), 2: explicit dense inverse in Z, 3: 2 + the static tableau
+                                     // WW = [I; A] H^-1 [I A'] of small dense problems (nV + nC <= WW_MAX)
+    static constexpr int WW_MAX = 8192, S_WW_AD = 47;
+    bool rs_no_ww = getenv("RSQP_LARGE_NO_TABLEAU") != nullptr;
+    double *rs_WW = nullptr, *rs_dA = nullptr;
+    long long ldw = 0;
+    int rs_cur_id = -1;
+    int rs_build_ww();
     int nR = 0;                      // active rows: (nV - nFR) + nAC
     int *R = nullptr, *posR = nullptr;
     std::vector<int> hR, hposR;
@@ -3358,7 +3368,8 @@ hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
     DA(d_fpos, nV); DA(d_cand, nC); DA(d_freev, nV);
     DA(hinv, nV); DA(dflag, 4); DA(ps_u, P.nAmax + 4);
     DA(sym_part, 2 * (size_t)((P.nAmax + SYT - 1) / SYT + 1) * (size_t)std::max(P.nAmax, 1));
-    DA(rs_p, nV); DA(rs_Ap, std::max(nC, 1)); DA(ra1, nV + 4); DA(ra2, nV + 4); DA(ra3, nV + 4); DA(ra4, nV + 4); DA(rs_dl, nV + 4); DA(rs_ps_u, nV + 4);
+    DA(rs_p, nV + std::max(nC, 1)); P.rs_Ap = P.rs_p + nV;      // ([p; A p] contiguous: one product with the tableau refreshes both)
+    DA(ra1, nV + 4); DA(ra2, nV + 4); DA(ra3, nV + 4); DA(ra4, nV + 4); DA(rs_dl, nV + 4); DA(rs_ps_u, nV + 4);
     DA(wz_part, 2 * (size_t)((nV + SYT - 1) / SYT + 1) * (size_t)nV);
 #undef DA
     if ((e = rsqp_dense_work_alloc(&P.dw, nV)) != hipSuccess) return e;
@@ -3371,7 +3382,7 @@ hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
     return hipSuccess;
 }
 
-void RsqpLargeEngine::set_matrices(const RsqpLargeMatrices &m) { p_->M = m; }
+void RsqpLargeEngine::set_matrices(const RsqpLargeMatrices &m) { p_->M = m; p_->nnzA_ = (double)m.Annz; }
 
 int RsqpLargeEngine::solve(int mode, const double *d_g, const double *d_lb, const double *d_ub, const double *d_lbA,
                            const double *d_ubA, int *nWSR, const double *h_x0, const double *h_y0, const int *h_guess_b) {
@@ -3497,10 +3508,10 @@ int RsqpLargeEngine::status_word() const {
     return p_->infeasible ? 100 + p_->status : (p_->unbounded ? 200 + p_->status : p_->status);
 }
 int RsqpLargeEngine::nflips() const { return p_->nflips; }
-int RsqpLargeEngine::path() const { return p_->rsh ? 1 + p_->rs_kind : (p_->dual ? 1 : 0); }
+int RsqpLargeEngine::path() const { return p_->rsh ? 1 + p_->rs_kind : (p_->dual ? 1 : 0); }      // (4: dense H^-1 + tableau)
 hipError_t RsqpLargeEngine::last_error() const { return p_->err_; }
 const char *RsqpLargeEngine::profile_name(int k) {
-    static const char *nm[PROFILE_CLASSES] = {"gemv_n", "gemv_t", "ger", "wz_shrink", "wz_grow", "spmv", "ger_gemv_t", "shrink_gemv", "ger_gemv_n", ""};
+    static const char *nm[PROFILE_CLASSES] = {"gemv_n", "gemv_t", "ger", "wz_shrink", "wz_grow", "spmv", "ger_gemv_t", "shrink_gemv", "ger_gemv_n", "band_hinv"};
     return k >= 0 && k < PROFILE_CLASSES ? nm[k] : "";
 }
 void RsqpLargeEngine::profile_enable(bool on) { p_->profile = on; }

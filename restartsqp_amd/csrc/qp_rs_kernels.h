@@ -213,6 +213,11 @@ __global__ void __launch_bounds__(64) k_band_apply_mw(BandOp op, const double *_
     for (int i = r0 + lane; i < r1; i += 64) if (!q.Sb || q.Sb[i] == 0) out[i] = v[i - r0] * op.sinv[i];
 }
 
+// (Tried and dropped in round 5, profiles/r05_l_kernel_stats_sparse.csv / r05_m_*: cv = C w over the active rows by one thread per row
+//  instead of a full product with A + a gather -- four dependent memory hops per thread, 13 us against 5.9 + 3.9 us; stage 1 of the
+//  independence test and the carried step's dot product in the tail of the reduction kernel (last-ticket workgroup) -- 24.6 us
+//  against 9.0 + 7.7 us for the two launches: a dependent kernel boundary costs ~1.5 us on this chip, a one-workgroup tail behind a
+//  grid-wide ticket more. Cold start of the sparse configuration 1.99 s with both against 2.01 s without: reverted.)
 // ---- rows of C ----------------------------------------------------------------------------------------------------------------
 // the incoming row as a dense vector: id < nV: e_id, else row id - nV of A (all variables). One workgroup.
 __global__ void __launch_bounds__(NT) k_rs_row(int nV, int id, const int *__restrict__ rp, const int *__restrict__ ci,
@@ -336,6 +341,106 @@ __global__ void __launch_bounds__(NT) k_rs_carry_add(int k, double om, const dou
 __global__ void k_rs_diff(int n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] - b[i];
+}
+
+// ---- small dense problems: the static tableau WW = [I; A] H^-1 [I A']  ((nV + nC)^2, built once per Hessian; rs_kind 3) ----------
+// Column id of WW is [w; A w] for the row with that id (w = H^-1 c'): the products of an incoming row, the step direction and the
+// set-up matrix are GATHERS and one gathered-column GEMV instead of products with A, A' and H^-1 (dense 2048 x 4096: three
+// 32-64 MB products per change less).
+// cv[j] = (C w)[j] = WW[R[j]][id]; scal[so] = c w = WW[id][id]
+__global__ void k_ww_cv(int nR, const int *__restrict__ R, const double *__restrict__ WW, long long ldw, int id, double *__restrict__ cv,
+                        double *__restrict__ scal, int so) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const double *col = WW + (long long)id * ldw;
+    if (j < nR) cv[j] = col[R[j]];
+    if (j == 0) scal[so] = col[id];
+}
+// stage 1 of the independence test from the tableau: |c_FR|^2 from the row itself (dense copy or CSR), c w from scal[so],
+// cv'u over the active rows. One workgroup; published.
+__global__ void __launch_bounds__(NT) k_ww_li_publish(int nV, const int *__restrict__ Sb, int id, const double *__restrict__ denseAT,
+                                                      const int *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ rv,
+                                                      int k, const double *__restrict__ cv, const double *__restrict__ u,
+                                                      double *__restrict__ scal, int so, double *__restrict__ ctl, double seqv) {
+    __shared__ double sh[4];
+    double a2;
+    if (id < nV) a2 = (threadIdx.x == 0 && Sb[id] == 0) ? 1.0 : 0.0;
+    else if (denseAT) {
+        const double *row = denseAT + (long long)(id - nV) * nV;
+        a2 = lane_sum4(nV, [&](int v) { const double x0 = row[v]; return Sb[v] == 0 ? x0 * x0 : 0.0; });
+    } else {
+        const int r = id - nV, k0 = rp[r], n = rp[r + 1] - k0;
+        a2 = lane_sum4(n, [&](int e) { const double x0 = rv[k0 + e]; return Sb[ci[k0 + e]] == 0 ? x0 * x0 : 0.0; });
+    }
+    double cu = lane_sum4(k, [&](int j) { return cv[j] * u[j]; });
+    a2 = block_sum(a2, sh);
+    cu = block_sum(cu, sh);
+    if (threadIdx.x != 0) return;
+    const double ad = scal[so], sp = ad - cu;
+    scal[6] = a2; scal[7] = 0.0; scal[5] = sp; scal[8] = sp != 0.0 ? 1.0 / sp : 0.0;
+    ctl[2] = a2; ctl[3] = 0.0; ctl[4] = sp; ctl[5] = ad;
+    publish(ctl, seqv);
+}
+// the step direction in ONE launch: [dx; A dx] = sum_j dl[j] WW[:, R[j]] - [p; A p]. A workgroup owns 16 consecutive entries (8
+// lanes x 16 bytes) and all active columns, dealt to NTH / 8 column groups whose sums meet in LDS in group order (the scheme of
+// k_gemv_n1). Epilogue: dx on the free variables only (the fixed ones keep the move of their bound), and the two products the
+// homotopy step integrates, A'dl_C and H dx, are never formed -- only their difference A'dl_C - H dx = (gN - g) - dl_B enters
+// the gradient the drift correction derives (g = A'y + y_B - H x), so ATdy := 0 and Hdx := dl_B - (gN - g) carry it (both
+// products are recomputed from the iterate every 8 changes as before).
+template <int NTH>
+__global__ void __launch_bounds__(NTH) k_ww_step(const double *__restrict__ WW, long long ldw, int nV, int nC, int nR,
+                                                 const int *__restrict__ R, const double *__restrict__ dl, const double *__restrict__ pp,
+                                                 const int *__restrict__ Sb, const double *__restrict__ dy, const double *__restrict__ gN,
+                                                 const double *__restrict__ g, double *__restrict__ dx, double *__restrict__ dAx,
+                                                 double *__restrict__ Hdx, double *__restrict__ ATdy) {
+    constexpr int NG = NTH / 8;
+    __shared__ double sh[NG][17];
+    const int rl = threadIdx.x & 7, cg = threadIdx.x >> 3;
+    const int n = nV + nC, r = (blockIdx.x * 8 + rl) * 2;
+    double a0 = 0.0, a1 = 0.0;
+    if (r + 1 < n) {
+        double2 s0 = {0, 0}, s1 = {0, 0}, s2 = {0, 0}, s3 = {0, 0};
+        int c = cg;
+        for (; c + 3 * NG < nR; c += 4 * NG) {
+            const double w0 = dl[c], w1 = dl[c + NG], w2 = dl[c + 2 * NG], w3 = dl[c + 3 * NG];
+            const double2 m0 = *reinterpret_cast<const double2 *>(WW + (long long)R[c] * ldw + r);
+            const double2 m1 = *reinterpret_cast<const double2 *>(WW + (long long)R[c + NG] * ldw + r);
+            const double2 m2 = *reinterpret_cast<const double2 *>(WW + (long long)R[c + 2 * NG] * ldw + r);
+            const double2 m3 = *reinterpret_cast<const double2 *>(WW + (long long)R[c + 3 * NG] * ldw + r);
+            s0.x += m0.x * w0; s0.y += m0.y * w0; s1.x += m1.x * w1; s1.y += m1.y * w1;
+            s2.x += m2.x * w2; s2.y += m2.y * w2; s3.x += m3.x * w3; s3.y += m3.y * w3;
+        }
+        for (; c < nR; c += NG) {
+            const double w0 = dl[c];
+            const double2 m0 = *reinterpret_cast<const double2 *>(WW + (long long)R[c] * ldw + r);
+            s0.x += m0.x * w0; s0.y += m0.y * w0;
+        }
+        a0 = (s0.x + s1.x) + (s2.x + s3.x);
+        a1 = (s0.y + s1.y) + (s2.y + s3.y);
+    } else if (r < n) {
+        for (int c = cg; c < nR; c += NG) a0 += WW[(long long)R[c] * ldw + r] * dl[c];
+    }
+    sh[cg][2 * rl] = a0; sh[cg][2 * rl + 1] = a1;
+    __syncthreads();
+    if ((int)threadIdx.x < 16) {
+        const int i = blockIdx.x * 16 + threadIdx.x;
+        if (i < n) {
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+            for (int q = 0; q < NG; q += 4) { t0 += sh[q][threadIdx.x]; t1 += sh[q + 1][threadIdx.x]; t2 += sh[q + 2][threadIdx.x]; t3 += sh[q + 3][threadIdx.x]; }
+            const double v = ((t0 + t1) + (t2 + t3)) - pp[i];
+            if (i < nV) {
+                const bool fixed = Sb[i] != 0;
+                if (!fixed) dx[i] = v;
+                Hdx[i] = (fixed ? dy[i] : 0.0) - (gN[i] - g[i]);
+                ATdy[i] = 0.0;
+            } else dAx[i - nV] = v;
+        }
+    }
+}
+// S = C H^-1 C' of a guessed working set is a sub-matrix of the tableau: G[i][j] = WW[R[i]][R[j]] (upper triangle)
+__global__ void k_ww_gather_S(int n, const int *__restrict__ R, const double *__restrict__ WW, long long ldw, double *__restrict__ G, long long ldg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (i < n && i <= j) G[i + (long long)j * ldg] = WW[R[i] + (long long)R[j] * ldw];
 }
 
 // ---- one step of iterative refinement on the final KKT system (rs_refine) --------------------------------------------------------

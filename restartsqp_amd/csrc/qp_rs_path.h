@@ -98,6 +98,26 @@ int Impl::rs_build_dense(bool *ok) {
     *ok = true;
     return RET_OK;
 }
+// the static tableau of a small dense problem: WW = [I; A] H^-1 [I A'], (nV + nC)^2, three GEMMs once per Hessian
+int Impl::rs_build_ww() {
+    const int n = nV + nC;
+    ldw = pad16(n);
+    if (!rs_WW) LCHK(hipMalloc(reinterpret_cast<void **>(&rs_WW), sizeof(double) * (size_t)ldw * n));
+    LCHK(hipMemcpy2DAsync(rs_WW, sizeof(double) * ldw, Z, sizeof(double) * ld, sizeof(double) * nV, nV, hipMemcpyDeviceToDevice, st));
+    if (nC <= 0) return RET_OK;
+    const double *dA = M.denseA;
+    if (!dA) {
+        if (!rs_dA) LCHK(hipMalloc(reinterpret_cast<void **>(&rs_dA), sizeof(double) * (size_t)nC * nV));
+        LCHK(rsqp_launch_densify(nC, nV, M.Ajc, M.Air, M.Aval, rs_dA, st));
+        dA = rs_dA;
+    }
+    double *TR = rs_WW + (size_t)nV * ldw, *BL = rs_WW + nV, *BR = rs_WW + nV + (size_t)nV * ldw;
+    LCHK(rsqp_dgemm(false, true, nV, nC, nV, 1.0, Z, ld, dA, nC, 0.0, TR, ldw, st));        // H^-1 A'
+    LCHK(rsqp_dgemm(false, false, nC, nV, nV, 1.0, dA, nC, Z, ld, 0.0, BL, ldw, st));       // A H^-1
+    LCHK(rsqp_dgemm(false, false, nC, nC, nV, 1.0, dA, nC, TR, ldw, 0.0, BR, ldw, st));     // A H^-1 A'
+    chk("rs_build_ww");
+    return RET_OK;
+}
 int Impl::rs_prepare(bool *ok) {
     *ok = false;
     if (!rsh_enabled || !M.haveH || !M.h_Hjc || !M.h_Hir || M.Hnnz <= 0 || nV > BAND_MAX_N) return RET_OK;
@@ -122,7 +142,11 @@ int Impl::rs_prepare(bool *ok) {
     }
     bool built = false;
     if (hb <= 2 && !rs_force_dense) { if (rs_build_band(hv, &built) != RET_OK) return RET_SETUP_FAILED; if (built) rs_kind = 1; }
-    if (!built) { if (rs_build_dense(&built) != RET_OK) return RET_SETUP_FAILED; if (built) rs_kind = 2; }
+    if (!built) {
+        if (rs_build_dense(&built) != RET_OK) return RET_SETUP_FAILED;
+        if (built) rs_kind = 2;
+        if (built && !rs_no_ww && nV + nC <= WW_MAX) { if (rs_build_ww() != RET_OK) return RET_SETUP_FAILED; rs_kind = 3; }
+    }
     *ok = built;
     return RET_OK;
 }
@@ -148,7 +172,7 @@ void Impl::rs_hinv_apply(const double *in, const double *sub, double *out, bool 
     pbegin();
     if (rs_kind == 1) {
         band_launch(1, in, sub, out, 0LL, fix_dx);
-        pend(5, 40.0 * nV);
+        pend(9, 40.0 * nV);
     } else if (fix_dx) {
         hipLaunchKernelGGL(k_rs_q, g1(nV), dim3(NT), 0, st, nV, Sb, ATdy, dy, gN, g, Hdx);
         gemv_n(Z, ld, nV, nV, Hdx, 1.0, 0.0, nullptr, w4, Sb, out);       // (merge epilogue: out = the product on the free variables only)
@@ -200,6 +224,13 @@ void Impl::rs_count(int id, int delta) {       // delta +1: the row joined, -1: 
 // products of the incoming row with the working set: c in w1 (all variables), w = H^-1 c' in w5, cv = C w in ra1, u = Sinv cv in
 // ra2; |c_FR|^2, the pivot s and c w published (stage 1 of the independence test)
 void Impl::rs_products(int id) {
+    rs_cur_id = id;
+    if (rs_kind == 3) {      // everything about the row is a column of the tableau
+        hipLaunchKernelGGL(k_ww_cv, g1(std::max(nR, 1)), dim3(NT), 0, st, nR, R, rs_WW, ldw, id, ra1, scal, S_WW_AD);
+        rs_sinv_times(ra1, ra2);
+        hipLaunchKernelGGL(k_ww_li_publish, dim3(1), dim3(NT), 0, st, nV, Sb, id, M.denseAT, M.Arp, M.Aci, M.Arv, nR, ra1, ra2, scal, S_WW_AD, d_ctl, next_seq());
+        return;
+    }
     hipLaunchKernelGGL(k_rs_row, dim3(1), dim3(NT), 0, st, nV, id, M.Arp, M.Aci, M.Arv, M.denseAT, w1);
     if (rs_kind == 2 && !M.denseAT) hipLaunchKernelGGL(k_rs_hinv_row, g1(nV), dim3(NT), 0, st, nV, id, M.Arp, M.Aci, M.Arv, Z, ld, w5);
     else rs_hinv_apply(w1, nullptr, w5, false);
@@ -220,6 +251,10 @@ int Impl::rs_li_decision(bool *li) {
     double a2n = h_ctl[2], sp = h_ctl[4];
     const double ad = h_ctl[5];
     if (nR < nV && a2n > 0.0 && sp > 1e-6 * ad) { *li = true; return RET_OK; }
+    if (rs_kind == 3) {      // the residual test wants the row and H^-1 of it as vectors: the row from A, the other from the tableau
+        hipLaunchKernelGGL(k_rs_row, dim3(1), dim3(NT), 0, st, nV, rs_cur_id, M.Arp, M.Aci, M.Arv, M.denseAT, w1);
+        copy(rs_WW + (size_t)rs_cur_id * ldw, w5, nV);
+    }
     rs_residual();
     if (wait_ctl() != RET_OK) return wait_failed();
     a2n = h_ctl[2]; sp = h_ctl[4];
@@ -287,6 +322,11 @@ int Impl::rs_change_active_set(int kind, int idx, int side) {
 
 // ---- step direction ----------------------------------------------------------------------------------------------------------------
 void Impl::rs_refresh_p() {
+    if (rs_kind == 3) {      // [p; A p] = WW[:, variables] (gN - g)
+        hipLaunchKernelGGL(k_rs_diff, g1(nV), dim3(NT), 0, st, nV, gN, g, wz3);
+        gemv_n(rs_WW, ldw, nV + nC, nV, wz3, 1.0, 0.0, nullptr, rs_p);
+        return;
+    }
     rs_hinv_apply(gN, g, rs_p, false);
     A_times(rs_p, rs_Ap);
 }
@@ -307,9 +347,15 @@ void Impl::rs_step_direction() {
             carried = 0;
         }
     }
-    AT_times(dy + nV, ATdy);
-    rs_hinv_apply(nullptr, nullptr, dx, true);
-    A_times(dx, dAx);
+    if (rs_kind == 3) {
+        pbegin();
+        hipLaunchKernelGGL((k_ww_step<512>), dim3((nV + nC + 15) / 16), dim3(512), 0, st, rs_WW, ldw, nV, nC, nR, R, rs_dl, rs_p, Sb, dy, gN, g, dx, dAx, Hdx, ATdy);
+        pend(0, 8.0 * (nV + nC) * (double)nR);
+    } else {
+        AT_times(dy + nV, ATdy);
+        rs_hinv_apply(nullptr, nullptr, dx, true);
+        A_times(dx, dAx);
+    }
     carry_pending = carry_ready = false;
     carry_valid = nR > 0;
     chk("rs_step_direction");
@@ -351,14 +397,19 @@ int Impl::rs_setup_rows(const std::vector<int> &rows, const std::vector<int> &gb
     if (!rs_G) LCHK(hipMalloc(reinterpret_cast<void **>(&rs_G), sizeof(double) * (size_t)ld * ld));
     double *Cd = big, *T = big + (size_t)ld * ld;
     LCHK(hipMemcpyAsync(R, rows.data(), sizeof(int) * n, hipMemcpyHostToDevice, st));
-    LCHK(hipMemsetAsync(Cd, 0, sizeof(double) * (size_t)ld * n, st));
-    hipLaunchKernelGGL(k_rs_build_C, dim3(n), dim3(64), 0, st, nV, R, M.Arp, M.Aci, M.Arv, Cd, ld);
+    if (rs_kind != 3) {
+        LCHK(hipMemsetAsync(Cd, 0, sizeof(double) * (size_t)ld * n, st));
+        hipLaunchKernelGGL(k_rs_build_C, dim3(n), dim3(64), 0, st, nV, R, M.Arp, M.Aci, M.Arv, Cd, ld);
+    }
     if (!se0) { (void)hipEventCreate(&se0); (void)hipEventCreate(&se1); (void)hipEventCreate(&se2); }
     setup_stat = SetupStat();
     (void)hipEventRecord(se0, st);
-    if (rs_kind == 1) band_launch(n, Cd, nullptr, T, ld, false);
-    else LCHK(rsqp_dgemm(false, false, nV, n, nV, 1.0, Z, ld, Cd, ld, 0.0, T, ld, st));
-    LCHK(rsqp_dgemm_upper(true, false, n, nV, 1.0, Cd, ld, T, ld, 0.0, rs_G, ld, st));
+    if (rs_kind == 3) hipLaunchKernelGGL(k_ww_gather_S, dim3(g1(n).x, n), dim3(NT), 0, st, n, R, rs_WW, ldw, rs_G, ld);      // S is a sub-matrix of the tableau
+    else {
+        if (rs_kind == 1) band_launch(n, Cd, nullptr, T, ld, false);
+        else LCHK(rsqp_dgemm(false, false, nV, n, nV, 1.0, Z, ld, Cd, ld, 0.0, T, ld, st));
+        LCHK(rsqp_dgemm_upper(true, false, n, nV, 1.0, Cd, ld, T, ld, 0.0, rs_G, ld, st));
+    }
     (void)hipEventRecord(se1, st);
     LCHK(hipMemsetAsync(dw.flag, 0, sizeof(int) * 4, st));
     LCHK(rsqp_dpotrf_upper(n, rs_G, ld, 1e-10, RSQP_EPS_PD_ABS, &dw, st));
@@ -376,7 +427,7 @@ int Impl::rs_setup_rows(const std::vector<int> &rows, const std::vector<int> &gb
         const double dn = n, dm = nV;
         setup_stat.valid = 1; setup_stat.dual = 2; setup_stat.m = nV; setup_stat.n = n; setup_stat.nZ = nV - n;
         setup_stat.ms_tq = ms1; setup_stat.ms_wz = ms2;
-        setup_stat.flops_tq = dn * dn * dm + (rs_kind == 2 ? 2.0 * dm * dm * dn : 0.0); setup_stat.flops_wz = dn * dn * dn;
+        setup_stat.flops_tq = rs_kind == 3 ? 0.0 : dn * dn * dm + (rs_kind == 2 ? 2.0 * dm * dm * dn : 0.0); setup_stat.flops_wz = dn * dn * dn;
     }
     std::fill(hposR.begin(), hposR.end(), -1);
     std::fill(hSb.begin(), hSb.end(), 0); std::fill(hSc.begin(), hSc.end(), 0);

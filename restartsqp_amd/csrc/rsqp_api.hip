@@ -877,6 +877,7 @@ int solve_large(rsqp_solver *s, int mode, int *nWSR, const double *x0, const dou
         m.Ajc = s->A.jc.p; m.Air = s->A.ir.p; m.Aval = s->A.val.p; m.blk_c = s->A.blk_c.p; m.nblk_c = s->A.nblk_c;
         m.Arp = s->A.rp.p; m.Aci = s->A.ci.p; m.Arv = s->A.rval.p; m.blk_r = s->A.blk_r.p; m.nblk_r = s->A.nblk_r;
         m.sparse_rows = 8.0 * (double)s->A.nnz < (double)s->nC * s->nV;
+        m.Annz = s->A.nnz;
     }
     m.hreg = s->hreg;
     if (s->H.initialised && !s->lp_mode) {

@@ -9,7 +9,7 @@ struct RsqpLargeMatrices {
     const int *Ajc = nullptr, *Air = nullptr; const double *Aval = nullptr; const int4 *blk_c = nullptr; int nblk_c = 0;
     const int *Arp = nullptr, *Aci = nullptr; const double *Arv = nullptr; const int4 *blk_r = nullptr; int nblk_r = 0;
     const int *Hjc = nullptr, *Hir = nullptr; const double *Hval = nullptr; const int4 *blk_h = nullptr; int nblk_h = 0;
-    int haveH = 0;
+    int haveH = 0, Annz = 0;
     const int *h_Hjc = nullptr, *h_Hir = nullptr; int Hnnz = 0;   // HOST mirror of H's pattern (full symmetric CSC): the general
                                                                   // range-space path reads the band width from it
     int sparse_rows = 0;             // rows of A are sparse enough (fill < 1/8) for gathered row products
@@ -41,7 +41,7 @@ public:
     const int *d_Sc() const;
     int status_word() const;
     int nflips() const;
-    int path() const;               // 0 null-space, 1 range-space (diagonal H), 2 general range-space (banded H^-1), 3 (dense H^-1)
+    int path() const;               // 0 null-space, 1 range-space (diagonal H), 2 general range-space (banded H^-1), 3 (dense H^-1), 4 (3 + tableau)
     double objective();
     hipError_t last_error() const;
     // per-kernel-class accounting (HIP events around every launch of the class: serialises the stream, so

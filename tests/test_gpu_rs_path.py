@@ -66,20 +66,27 @@ def all_call_shapes(capi, oracle, rng, q, want_path):
     assert ok and st.KKT_error < 1e-9
 
 
-@pytest.mark.parametrize("knob", [None, "RSQP_LARGE_RSH_DENSE", "RSQP_NO_BLOCKED_SETUP", "RSQP_LARGE_BAND_1WG", "RSQP_LARGE_NO_CARRY"])
+@pytest.mark.parametrize("knob", [None, "RSQP_LARGE_RSH_DENSE", "RSQP_LARGE_RSH_DENSE+RSQP_LARGE_NO_TABLEAU", "RSQP_NO_BLOCKED_SETUP", "RSQP_LARGE_BAND_1WG",
+                                  "RSQP_LARGE_NO_CARRY"])
 def test_banded_hessian_all_call_shapes(capi, oracle, monkeypatch, knob):
-    if knob:
-        monkeypatch.setenv(knob, "1")
+    for k in (knob or "").split("+"):
+        if k:
+            monkeypatch.setenv(k, "1")
     rng = np.random.default_rng(501)
-    want = 3 if knob == "RSQP_LARGE_RSH_DENSE" else 2
+    want = {"RSQP_LARGE_RSH_DENSE": 4, "RSQP_LARGE_RSH_DENSE+RSQP_LARGE_NO_TABLEAU": 3}.get(knob, 2)
     for nV, nC, hb, free in ((40, 30, 2, False), (97, 140, 2, False), (150, 90, 1, False), (64, 80, 2, True), (33, 0, 2, False)):
         all_call_shapes(capi, oracle, rng, banded_qp(rng, nV, nC, hb=hb, free=free), want)
 
 
-def test_dense_hessian_all_call_shapes(capi, oracle):
+@pytest.mark.parametrize("tableau", [True, False])
+def test_dense_hessian_all_call_shapes(capi, oracle, monkeypatch, tableau):
+    """dense H^-1; with the static tableau [I; A] H^-1 [I A'] (the default for nV + nC <= 8192: products of a row, step direction
+    and set-up matrix are gathers / one gathered-column product) and without it"""
+    if not tableau:
+        monkeypatch.setenv("RSQP_LARGE_NO_TABLEAU", "1")
     rng = np.random.default_rng(502)
-    for nV, nC in ((30, 25), (90, 60), (50, 130)):
-        all_call_shapes(capi, oracle, rng, problems.random_qp(rng, nV, nC, 0.3), 3)
+    for nV, nC, dens in ((30, 25, 0.3), (90, 60, 0.3), (50, 130, 1.0), (70, 0, 0.3)):
+        all_call_shapes(capi, oracle, rng, problems.random_qp(rng, nV, nC, dens), 4 if tableau else 3)
 
 
 def test_same_path_as_the_null_space_formulation(capi, monkeypatch):

@@ -12,6 +12,10 @@ echo "bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 bench.py --no-build --no-large --cpu-seconds 1 --steps 20 --warmup 3 --stat-launches 20 > gpurun_out/${tag}_bench_under_rocprof.json 2>/dev/null
 # bench.py starts the C++ host program for the single-QP latency leg: one stats file per process, keep the parent's (largest)
 cp "$(find /tmp/prof_bench -name '*kernel_stats.csv' -printf '%s %p\n' | sort -n | tail -1 | cut -d' ' -f2-)" gpurun_out/${tag}_kernel_stats_bench.csv
+# the HEADLINE kernel alone: --no-extras launches nothing but the 65 536-QP batch, so the average of this file
+# IS the kernel_ms of the bench line (the file above mixes batch sizes: the extras launch the same kernel on 16 384 QPs)
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_head -- python3 bench.py --no-build --no-extras --steps 200 --warmup 10 --stat-launches 50 > gpurun_out/${tag}_bench_headline_only.json 2>/dev/null
+cp "$(find /tmp/prof_head -name '*kernel_stats.csv' | head -1)" gpurun_out/${tag}_kernel_stats_headline_only.csv
 echo "stats done"
 bash tools/pmc_hbm.sh gpurun_out/${tag}_pmc_hbm_traffic.json
 echo "pmc hbm done"
