@@ -3392,6 +3392,8 @@ int RsqpLargeEngine::solve(int mode, const double *d_g, const double *d_lb, cons
     P.err_ = hipSuccess;
     const int maxit = *nWSR;
     *nWSR = 0;
+    const bool tstat = P.profile || getenv("RSQP_LARGE_WAITSTAT") != nullptr;
+    const double t_solve0 = Impl::now_s();
     if (mode != RSQP_LMODE_COLD && P.status == QPS_NOTINITIALISED) mode = RSQP_LMODE_COLD;
     // targets, clamped to +-INFTY
     hipLaunchKernelGGL(k_copy, g1(nV), dim3(NT), 0, st, d_g, P.gN, nV);
@@ -3467,6 +3469,7 @@ int RsqpLargeEngine::solve(int mode, const double *d_g, const double *d_lb, cons
             }
         }
         P.nflips = 0;
+        const double t_prep0 = Impl::now_s();
         {
             bool ok = false;
             if (P.dual_prepare(&ok) != RET_OK) return RET_SETUP_FAILED;
@@ -3478,7 +3481,9 @@ int RsqpLargeEngine::solve(int mode, const double *d_g, const double *d_lb, cons
                 P.rsh = ok2;
             }
         }
+        const double t_prep1 = Impl::now_s();
         rc = P.setup_aux(gb, gc);
+        if (tstat) { (void)hipStreamSynchronize(st); fprintf(stderr, "[rsqp profile] solve: data checks + guess %.4f s, H^-1 operator %.4f s, factors of the guess %.4f s\n", t_prep0 - t_solve0, t_prep1 - t_prep0, Impl::now_s() - t_prep1); }
         if (rc != RET_OK && mode != RSQP_LMODE_COLD) {   // fall back to a cold start
             (void)hipMemsetAsync(P.x, 0, 8 * nV, st); (void)hipMemsetAsync(P.y, 0, 8 * (nV + nC), st);
             for (int v = 0; v < nV; v++) gb[v] = hl[v] > -RSQP_INFTY ? -1 : (hu[v] < RSQP_INFTY ? 1 : 0);

@@ -121,24 +121,18 @@ int Impl::rs_build_ww() {
 int Impl::rs_prepare(bool *ok) {
     *ok = false;
     if (!rsh_enabled || !M.haveH || !M.h_Hjc || !M.h_Hir || M.Hnnz <= 0 || nV > BAND_MAX_N) return RET_OK;
-    // symmetry (pattern and values) and band width from the host mirror of the pattern + one copy of the values
-    std::vector<double> hv(M.Hnnz);
-    LCHK(hipMemcpyAsync(hv.data(), M.Hval, sizeof(double) * M.Hnnz, hipMemcpyDeviceToHost, st));
+    // symmetry (pattern and values) and band width: on the device, two words back
+    LCHK(hipMemsetAsync(dflag + 2, 0, 2 * sizeof(int), st));
+    hipLaunchKernelGGL(k_rs_sym_check, dim3(nV), dim3(NT), 0, st, nV, M.Hjc, M.Hir, M.Hval, dflag + 2);
+    LCHK(hipMemcpyAsync(h_pinned_i, dflag + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     LCHK(hipStreamSynchronize(st));
-    int hb = 0;
-    double amax = 0.0;
-    for (int c = 0; c < nV; c++)
-        for (int k = M.h_Hjc[c]; k < M.h_Hjc[c + 1]; k++) { hb = std::max(hb, std::abs(M.h_Hir[k] - c)); amax = std::max(amax, std::fabs(hv[k])); }
-    {   // H(r, c) == H(c, r): every stored entry must find its mirror image (binary search in the sorted column)
-        for (int c = 0; c < nV; c++)
-            for (int k = M.h_Hjc[c]; k < M.h_Hjc[c + 1]; k++) {
-                const int r = M.h_Hir[k];
-                if (r == c) continue;
-                const int *b = M.h_Hir + M.h_Hjc[r], *e = M.h_Hir + M.h_Hjc[r + 1];
-                const int *f = std::lower_bound(b, e, c);
-                if (f == e || *f != c) return RET_OK;
-                if (std::fabs(hv[f - M.h_Hir] - hv[k]) > 1e-12 * amax) return RET_OK;
-            }
+    const int hb = h_pinned_i[0];
+    if (h_pinned_i[1] != 0) return RET_OK;
+    std::vector<double> hv;
+    if (hb <= 2 && !rs_force_dense) {      // the banded factor is built on the host: its few values come over
+        hv.resize(M.Hnnz);
+        LCHK(hipMemcpyAsync(hv.data(), M.Hval, sizeof(double) * M.Hnnz, hipMemcpyDeviceToHost, st));
+        LCHK(hipStreamSynchronize(st));
     }
     bool built = false;
     if (hb <= 2 && !rs_force_dense) { if (rs_build_band(hv, &built) != RET_OK) return RET_SETUP_FAILED; if (built) rs_kind = 1; }
