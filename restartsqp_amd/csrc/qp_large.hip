@@ -1527,6 +1527,18 @@ __global__ void __launch_bounds__(256) k_sym_tile(double *__restrict__ M, long l
     const int ii = threadIdx.x & 63, wv = threadIdx.x >> 6, i = I * SYT + ii;
     const double ui = (UPD && i < n) ? cs * scal[ci] * u[i] : 0.0;
     if (MV && threadIdx.x < SYT) { wI[threadIdx.x] = i < n ? w[i] : 0.0; const int j = J * SYT + (int)threadIdx.x; wJ[threadIdx.x] = j < n ? w[j] : 0.0; }
+    if (!UPD) {
+        // read-only product (the lazy form of round 5): all 16 loads of a lane are issued before the first LDS store -- with the
+        // 4-deep unroll of the updating form a compute unit had ~32 KB in flight and the kernel read at 2.8 TB/s
+        double mm[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const int jj = wv * 16 + c, j = J * SYT + jj;
+            mm[c] = (i < n && j < n && (!diag || ii <= jj)) ? M[(long long)j * ld + i] : 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < 16; c++) S[wv * 16 + c][ii] = mm[c];
+    } else {
 #pragma unroll 4
     for (int c = 0; c < 16; c++) {
         const int jj = wv * 16 + c, j = J * SYT + jj;
@@ -1537,6 +1549,7 @@ __global__ void __launch_bounds__(256) k_sym_tile(double *__restrict__ M, long l
             if (UPD) { m += ui * u[j]; *p = m; }
         }
         if (MV) S[jj][ii] = m;
+    }
     }
     if (!MV) return;
     __syncthreads();
@@ -1837,6 +1850,7 @@ struct RsqpLargeEngine::Impl {
     int wait_failed() {
         status = QPS_NOTINITIALISED;
         pendZ.on = pendW.on = pendY.on = pendM.on = pendS.on = pendR.on = false;
+        lz_n = 0;
         return RET_SETUP_FAILED;
     }
     double *h_pinned = nullptr;  // small pinned read-back buffer
@@ -1872,7 +1886,7 @@ struct RsqpLargeEngine::Impl {
     ~Impl() {
         double *dv[] = {Z, Y, Minv, Wz, x, g, lb, ub, gN, lbN, ubN, dx, w1, w2, w3, w4, w5, w6, wz1, wz2, wz3, Ax, lbA, ubA,
                         lbAN, ubAN, dAx, c1, c2, c3, a1, a2, a3, a4, y, dy, part, scal, pt, res_t, ATy, Hx, Hdx, ATdy, pz_t, pz_v, pw_s, pw_col, c_wY, c_wY2, c_xY, c_xi, c_wZ, py_t, py_v, pm_s, hinv, ps_u, sym_part, wz_part,
-                        rs_p, ra1, ra2, ra3, ra4, rs_dl, rs_ps_u, rs_G, band_buf, rs_WW, rs_dA};
+                        rs_p, ra1, ra2, ra3, ra4, rs_dl, rs_ps_u, rs_G, band_buf, rs_WW, rs_dA, lz_vec, lz_c, lz_d};
         for (double *p : dv) if (p) (void)hipFree(p);
         if (big) (void)hipFree(big);
         rsqp_dense_work_free(&dw);
@@ -2001,7 +2015,15 @@ struct RsqpLargeEngine::Impl {
                            (double *)nullptr, (double *)nullptr);
         pend(2, 8.0 * n * (double)n);
     }
+    bool dual_lazy() const { return lz_enabled && dual_sym; }      // lazy rank-1 terms (qp_rs_kernels.h: LzP) on the triangle storage
     void dual_flush() {
+        if (rsh) return;      // (the pending terms belong to the general path's matrix: rs_flush)
+        if (lz_n > 0 && nAC > 0 && dual_lazy()) {
+            pbegin();
+            hipLaunchKernelGGL(k_sym_tile_lz, dim3(sym_tiles(nAC)), dim3(256), 0, st, Minv, ldm, nAC, lz_p());
+            pend(2, 8.0 * nAC * (double)nAC);
+        }
+        lz_n = 0;
         if (!pendS.on) return;
         pendS.on = false;
         dual_rank1(pendS.n, ps_u, S_KEEP_S, 1.0);
@@ -2012,6 +2034,16 @@ struct RsqpLargeEngine::Impl {
             if (nAC <= 0) return;
             const int nt = (nAC + SYT - 1) / SYT;
             double *P1 = sym_part, *P2 = sym_part + (size_t)nt * nAC;
+            if (dual_lazy()) {      // one read of the triangle; the pending terms in the reduction
+                if (lz_n > 0) hipLaunchKernelGGL(k_lz_dots, dim3(lz_n), dim3(NT), 0, st, lz_p(), nAC, wv, lz_d);
+                pbegin();
+                hipLaunchKernelGGL((k_sym_tile<false, true>), dim3(sym_tiles(nAC)), dim3(256), 0, st, Minv, ldm, nAC, (const double *)nullptr, scal, 0, 0.0,
+                                   wv, P1, P2);
+                pend(0, 4.0 * nAC * (double)nAC);
+                hipLaunchKernelGGL(k_sym_reduce_lz, g1(nAC), dim3(NT), 0, st, nAC, nt, P1, P2, out, (const int *)nullptr, (double *)nullptr, lz_p(), lz_d);
+                chk("dual lazy product");
+                return;
+            }
             pbegin();
             if (pendS.on && nAC == pendS.n + 1) {     // (ps_u is zero behind pendS.n: the update leaves the new border alone)
                 pendS.on = false;
@@ -2731,7 +2763,21 @@ struct RsqpLargeEngine::Impl {
         return RET_OK;
     }
     // Sinv <- [[Sinv + u u'/s, -u/s], [-u'/s, 1/s]]  (u in a2, 1/s in scal[8])
+    void lz_push(int n, const double *v, int src) {      // c v v' with c = scal[src] joins the pending terms
+        if (lz_n >= LZK) dual_flush();
+        hipLaunchKernelGGL(k_lz_push, g1(std::max(n, 1)), dim3(NT), 0, st, n, v, scal, src, lz_vec, lz_stride, lz_n, lz_c);
+        lz_n++;
+    }
     void dual_add_constraint(int r, int side, int yidx = -1, double yval = 0.0) {
+        if (dual_lazy()) {
+            if (lz_n >= LZK) dual_flush();
+            hipLaunchKernelGGL(k_lz_border, g1(nAC + 1), dim3(NT), 0, st, Minv, ldm, nAC, a2, scal, AC, posAC, Sc, r, side, y, yidx, yval, lz_vec, lz_stride, lz_n, lz_c);
+            lz_n++;
+            hAC[nAC] = r; hSc[r] = side;
+            nAC++;
+            nZ = nFR - nAC;
+            return;
+        }
         dual_flush();       // (none is pending here: the products of this row have applied it)
         const bool defer = dual_defer && nAC > 0;
         if (defer) {
@@ -2747,8 +2793,8 @@ struct RsqpLargeEngine::Impl {
     }
     // a variable joins the fixed set: S loses a_v a_v'/d_v, Sinv += u u'/s with the same u and s as a bordering would use
     void dual_add_bound(int v, int side) {
-        dual_flush();
-        dual_rank1(nAC, a2, 8, 1.0);
+        if (dual_lazy()) { if (nAC > 0) lz_push(nAC, a2, 8); }
+        else { dual_flush(); dual_rank1(nAC, a2, 8, 1.0); }
         hipLaunchKernelGGL(k_set_Sb, dim3(1), dim3(1), 0, st, Sb, v, side);
         hSb[v] = side;
         nFR--;
@@ -2756,11 +2802,19 @@ struct RsqpLargeEngine::Impl {
     }
     void dual_remove_constraint(int k, bool carry) {
         const int r = hAC[k];
+        if (dual_lazy()) {
+            if (lz_n >= LZK) dual_flush();
+            hipLaunchKernelGGL(k_lz_colcoef, g1(nAC), dim3(NT), 0, st, Minv, ldm, nAC, k, lz_p(), a3, scal);
+            if (carry) hipLaunchKernelGGL(k_dual_carry_remove, dim3(1), dim3(NT), 0, st, nAC, k, 1.0 - last_tau, a3, c_wY);
+            hipLaunchKernelGGL(k_lz_remove_fix, g1(std::max(nAC, 1)), dim3(NT), 0, st, nAC, k, a3, scal, lz_vec, lz_stride, lz_n, lz_c);
+            lz_n++;
+        } else {
         dual_flush();
         if (dual_sym) hipLaunchKernelGGL(k_dual_colcoef_sym, g1(nAC), dim3(NT), 0, st, Minv, ldm, nAC, k, a3, scal);
         else hipLaunchKernelGGL(k_dual_colcoef, g1(nAC), dim3(NT), 0, st, Minv, ldm, nAC, k, a3, scal);
         if (carry) hipLaunchKernelGGL(k_dual_carry_remove, dim3(1), dim3(NT), 0, st, nAC, k, 1.0 - last_tau, a3, c_wY);
         dual_rank1(nAC, a3, 9, 1.0);
+        }
         if (dual_sym) hipLaunchKernelGGL(k_dual_move_last_sym, g1(std::max(nAC - 1, 1)), dim3(NT), 0, st, Minv, ldm, nAC, k, AC, posAC, Sc, r, y, nV + r);
         else hipLaunchKernelGGL(k_dual_move_last, g1(std::max(nAC - 1, 1)), dim3(NT), 0, st, Minv, ldm, nAC, k, AC, posAC, Sc, r, y, nV + r);
         if (k != nAC - 1) hAC[k] = hAC[nAC - 1];
@@ -2778,7 +2832,7 @@ struct RsqpLargeEngine::Impl {
         hipLaunchKernelGGL(k_col_of_A_active, dim3(4), dim3(NT), 0, st, M.Ajc, M.Air, M.Aval, v, posAC, a4);  // a_v
         dual_sinv_times(a4, a3);                                         // w = Sinv a_v
         hipLaunchKernelGGL(k_dual_free_coef, dim3(1), dim3(NT), 0, st, nAC, a4, a3, M.Hval, M.hreg, v, scal);
-        dual_rank1(nAC, a3, 9, 1.0);
+        if (dual_lazy()) lz_push(nAC, a3, 9); else dual_rank1(nAC, a3, 9, 1.0);
     }
     // factors for a guessed working set: S = B'B with B = D^-1/2 A_cand,FR' (GEMM), Cholesky, inverse. RET_FALLBACK: dependent rows
     // in the guess (or too few candidates): the caller adds them one by one
@@ -3000,12 +3054,13 @@ struct RsqpLargeEngine::Impl {
         status = QPS_PERFORMINGHOMOTOPY;
         dx_ready = false;
         pendZ.on = pendW.on = pendY.on = pendM.on = pendS.on = false;      // (nothing is deferred across solves; a solve that failed half-way leaves nothing behind)
+        lz_n = 0;
         carry_valid = carry_pending = carry_ready = false;
         carried = 0;
         refresh_products();
         hipLaunchKernelGGL(k_rerelax, g1(nV), dim3(NT), 0, st, nV, Sb, x, lbN, ubN, lb, ub);
         if (nC > 0) hipLaunchKernelGGL(k_rerelax, g1(nC), dim3(NT), 0, st, nC, Sc, Ax, lbAN, ubAN, lbA, ubA);
-        if (rsh) { pendR.on = false; rs_refresh_p(); }
+        if (rsh) { pendR.on = false; lz_n = 0; rs_refresh_p(); }
         for (;;) {
             step_direction();
             hipLaunchKernelGGL(k_ratio1, dim3(nblk_ratio), dim3(NT), 0, st, nV, nC, Sb, Sc, x, y, dx, dy, Ax, dAx, lb, ub,
@@ -3081,6 +3136,12 @@ struct RsqpLargeEngine::Impl {
     double band_seq = 0.0;           // tag of the last multi-workgroup product (k_band_apply_mw)
     bool band_mw = getenv("RSQP_LARGE_BAND_1WG") == nullptr;      // (tests / tuning: the one-workgroup kernel for single vectors as well)
     struct { bool on = false; int n = 0; } pendR;
+    // lazy rank-1 terms of Sinv (qp_rs_kernels.h): vectors lz_vec[k] (stride lz_stride), coefficients lz_c[k], dots lz_d[k]
+    bool lz_enabled = getenv("RSQP_LARGE_NO_LAZY") == nullptr;
+    double *lz_vec = nullptr, *lz_c = nullptr, *lz_d = nullptr;
+    long long lz_stride = 0;
+    int lz_n = 0;
+    LzP lz_p() const { LzP q; q.vec = lz_vec; q.stride = lz_stride; q.c = lz_c; q.np = lz_n; return q; }
     int rs_prepare(bool *ok);
     int rs_build_band(const std::vector<double> &hv, bool *ok);
     int rs_build_dense(bool *ok);
@@ -3368,6 +3429,7 @@ hipError_t RsqpLargeEngine::init(int nV, int nC, hipStream_t stream) {
     DA(d_fpos, nV); DA(d_cand, nC); DA(d_freev, nV);
     DA(hinv, nV); DA(dflag, 4); DA(ps_u, P.nAmax + 4);
     DA(sym_part, 2 * (size_t)((P.nAmax + SYT - 1) / SYT + 1) * (size_t)std::max(P.nAmax, 1));
+    P.lz_stride = Impl::pad16(nV + 4); DA(lz_vec, (size_t)LZK * P.lz_stride); DA(lz_c, LZK); DA(lz_d, LZK);
     DA(rs_p, nV + std::max(nC, 1)); P.rs_Ap = P.rs_p + nV;      // ([p; A p] contiguous: one product with the tableau refreshes both)
     DA(ra1, nV + 4); DA(ra2, nV + 4); DA(ra3, nV + 4); DA(ra4, nV + 4); DA(rs_dl, nV + 4); DA(rs_ps_u, nV + 4);
     DA(wz_part, 2 * (size_t)((nV + SYT - 1) / SYT + 1) * (size_t)nV);

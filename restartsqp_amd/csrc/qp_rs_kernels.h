@@ -239,6 +239,127 @@ __global__ void __launch_bounds__(NT) k_rs_sym_check(int nV, const int *__restri
     if ((threadIdx.x & 63) == 0) { if (hb > 0) atomicMax(flag, hb); if (bad) atomicOr(flag + 1, bad); }
 }
 
+// ---- LAZY rank-1 updates of Sinv (round 5) ----------------------------------------------------------------------------------------
+// The effective matrix is  Sinv = M + sum_k c_k p_k p_k'  with up to LZK pending rank-1 terms (the bordering of a row that joined:
+// p = u, c = 1 / s; the elimination of a row that left: p = its column, c = -1 / v_j). A product never writes M -- it reads the
+// triangle once (k_sym_tile<false, true>) and adds sum_k c_k (p_k'w) p_k in the reduction -- and one pass applies all pending
+// terms when the list is full (k_sym_tile_lz). Before: every row that joined or left cost a read + WRITE pass over the triangle
+// (0.2 GB at nR = 5 000); now a row that leaves costs O(nR), one that joins a read-only pass, and the write pass comes every
+// LZK changes.
+constexpr int LZK = 6;
+struct LzP { const double *vec; long long stride; const double *c; int np; };
+__global__ void __launch_bounds__(NT) k_lz_dots(LzP P, int n, const double *__restrict__ w, double *__restrict__ d) {
+    __shared__ double sh[4];
+    const double *p = P.vec + (long long)blockIdx.x * P.stride;
+    double s = lane_sum4(n, [&](int i) { return p[i] * w[i]; });
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) d[blockIdx.x] = s;
+}
+__global__ void k_sym_reduce_lz(int n, int nt, const double *__restrict__ P1, const double *__restrict__ P2, double *__restrict__ y,
+                                const int *__restrict__ R, double *__restrict__ full, LzP P, const double *__restrict__ d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int Ti = i / SYT;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+    int J = Ti;
+    for (; J + 3 < nt; J += 4) {
+        a0 += P1[(long long)J * n + i]; a1 += P1[(long long)(J + 1) * n + i]; a2 += P1[(long long)(J + 2) * n + i]; a3 += P1[(long long)(J + 3) * n + i];
+    }
+    for (; J < nt; J++) a0 += P1[(long long)J * n + i];
+    int I = 0;
+    for (; I + 3 <= Ti; I += 4) {
+        b0 += P2[(long long)I * n + i]; b1 += P2[(long long)(I + 1) * n + i]; b2 += P2[(long long)(I + 2) * n + i]; b3 += P2[(long long)(I + 3) * n + i];
+    }
+    for (; I <= Ti; I++) b0 += P2[(long long)I * n + i];
+    double val = ((a0 + a1) + (a2 + a3)) + ((b0 + b1) + (b2 + b3));
+    for (int k = 0; k < P.np; k++) val += (P.c[k] * d[k]) * P.vec[(long long)k * P.stride + i];
+    y[i] = val;
+    if (R) full[R[i]] = val;
+}
+// M += sum_k c_k p_k p_k' on the upper tiles (the flush)
+__global__ void __launch_bounds__(256) k_sym_tile_lz(double *__restrict__ M, long long ld, int n, LzP P) {
+    __shared__ double pj[LZK][SYT];       // the terms' entries of this tile's columns (every lane needs all 64 of them)
+    int I, J;
+    sym_tile_of((int)blockIdx.x, I, J);
+    const bool diag = I == J;
+    const int ii = threadIdx.x & 63, wv = threadIdx.x >> 6, i = I * SYT + ii;
+    for (int e = threadIdx.x; e < LZK * SYT; e += 256) {
+        const int k = e / SYT, jj = e % SYT, j = J * SYT + jj;
+        pj[k][jj] = (k < P.np && j < n) ? P.vec[(long long)k * P.stride + j] : 0.0;
+    }
+    double pi[LZK];
+#pragma unroll
+    for (int k = 0; k < LZK; k++) pi[k] = (k < P.np && i < n) ? P.c[k] * P.vec[(long long)k * P.stride + i] : 0.0;
+    __syncthreads();
+    double mm[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        const int jj = wv * 16 + c, j = J * SYT + jj;
+        mm[c] = (i < n && j < n && (!diag || ii <= jj)) ? M[(long long)j * ld + i] : 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        const int jj = wv * 16 + c, j = J * SYT + jj;
+        if (i < n && j < n && (!diag || ii <= jj)) {
+            double m = mm[c];
+#pragma unroll
+            for (int k = 0; k < LZK; k++) m += pi[k] * pj[k][jj];
+            M[(long long)j * ld + i] = m;
+        }
+    }
+}
+// column j of the EFFECTIVE matrix and the coefficient of its elimination (scal[9] = -1 / v_j)
+__global__ void k_lz_colcoef(const double *__restrict__ M, long long ld, int n, int j, LzP P, double *__restrict__ v, double *__restrict__ scal) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double val = i <= j ? M[(long long)j * ld + i] : M[(long long)i * ld + j];
+    for (int k = 0; k < P.np; k++) { const double *p = P.vec + (long long)k * P.stride; val += P.c[k] * p[j] * p[i]; }
+    v[i] = val;
+    if (i == j) scal[9] = val != 0.0 ? -1.0 / val : 0.0;
+}
+// a row joined at position n (after the products: u = Sinv cv, 1 / s in scal[8]): column n of M = -u / s, corner 1 / s, working-set
+// entry, multiplier; the rank-1 part u u' / s becomes pending term `slot` (zero behind n), the older terms get a zero at n
+__global__ void k_lz_border(double *M, long long ld, int n, const double *__restrict__ u, const double *__restrict__ scal, int *R, int *posR,
+                            int *Sall, int id, int side, double *y, int yidx, double yval, double *pvec, long long stride, int slot,
+                            double *pc) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > n) return;
+    const double is = scal[8];
+    double *pn = pvec + (long long)slot * stride;
+    if (j == n) {
+        R[n] = id; posR[id] = n; Sall[id] = side;
+        if (yidx >= 0) y[yidx] = yval;
+        M[(long long)n * ld + n] = is;
+        for (int k = 0; k <= slot; k++) { pvec[(long long)k * stride + n] = 0.0; pvec[(long long)k * stride + n + 1] = 0.0; }
+        pc[slot] = is;
+    } else {
+        const double uj = u[j];
+        M[(long long)n * ld + j] = -uj * is;
+        pn[j] = uj;
+    }
+}
+// the row at position j leaves (v = its effective column, scal[9] = -1 / v_j): new pending term `slot` = v with the LAST entry moved
+// into slot j (as the matrix does), the older terms permuted the same way. (k_dual_move_last_sym moves the stored row / column.)
+__global__ void k_lz_remove_fix(int n, int j, const double *__restrict__ v, const double *__restrict__ scal, double *pvec, long long stride,
+                                int slot, double *pc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int last = n - 1;
+    double *pn = pvec + (long long)slot * stride;
+    if (i < last) pn[i] = i == j ? v[last] : v[i];
+    if (i == 0) {
+        pc[slot] = scal[9];
+        if (j != last) for (int k = 0; k < slot; k++) pvec[(long long)k * stride + j] = pvec[(long long)k * stride + last];
+    }
+}
+
+// a rank-1 term c v v' on the current rows joins the pending list (DESIGN 4.4's bound changes: Sherman-Morrison terms)
+__global__ void k_lz_push(int n, const double *__restrict__ v, const double *__restrict__ scal, int src, double *pvec, long long stride, int slot,
+                          double *pc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pvec[(long long)slot * stride + i] = v[i];
+    if (i == 0) pc[slot] = scal[src];
+}
+
 // ---- rows of C ----------------------------------------------------------------------------------------------------------------
 // the incoming row as a dense vector: id < nV: e_id, else row id - nV of A (all variables). One workgroup.
 __global__ void __launch_bounds__(NT) k_rs_row(int nV, int id, const int *__restrict__ rp, const int *__restrict__ ci,

@@ -187,15 +187,33 @@ void Impl::rs_rank1(int n, const double *v, int slot, double cs) {
     pend(2, 8.0 * n * (double)n);
 }
 void Impl::rs_flush() {
+    if (!rsh) return;
+    if (lz_n > 0 && nR > 0) {      // all pending terms in one pass over the triangle
+        pbegin();
+        hipLaunchKernelGGL(k_sym_tile_lz, dim3(sym_tiles(nR)), dim3(256), 0, st, Wz, ld, nR, lz_p());
+        pend(2, 8.0 * nR * (double)nR);
+    }
+    lz_n = 0;
     if (!pendR.on) return;
     pendR.on = false;
     rs_rank1(pendR.n, rs_ps_u, S_KEEP_S, 1.0);
 }
-// out = Sinv w, the deferred rank-1 part of the last bordering applied on the way
+// out = Sinv w. Lazy form: one read of the triangle, the pending terms in the reduction; otherwise the deferred rank-1 part of the
+// last bordering is applied on the way
 void Impl::rs_sinv_times(const double *wv, double *out, bool scatter_dy) {
     if (nR <= 0) return;
     const int nt = (nR + SYT - 1) / SYT;
     double *P1 = wz_part, *P2 = wz_part + (size_t)nt * nR;
+    if (lz_enabled) {
+        if (lz_n > 0) hipLaunchKernelGGL(k_lz_dots, dim3(lz_n), dim3(NT), 0, st, lz_p(), nR, wv, lz_d);
+        pbegin();
+        hipLaunchKernelGGL((k_sym_tile<false, true>), dim3(sym_tiles(nR)), dim3(256), 0, st, Wz, ld, nR, (const double *)nullptr, scal, 0, 0.0, wv, P1, P2);
+        pend(0, 4.0 * nR * (double)nR);
+        hipLaunchKernelGGL(k_sym_reduce_lz, g1(nR), dim3(NT), 0, st, nR, nt, P1, P2, out, scatter_dy ? R : (const int *)nullptr,
+                           scatter_dy ? dy : (double *)nullptr, lz_p(), lz_d);
+        chk("rs lazy product");
+        return;
+    }
     pbegin();
     if (pendR.on && nR == pendR.n + 1) {
         pendR.on = false;
@@ -258,11 +276,18 @@ int Impl::rs_li_decision(bool *li) {
 }
 // Sinv <- [[Sinv + u u'/s, -u/s], [-u'/s, 1/s]]  (u in ra2, 1/s in scal[8]); the rank-1 part rides on the next product
 void Impl::rs_add_row(int id, int side, int yidx, double yval) {
-    rs_flush();
-    const bool defer = nR > 0;
-    if (defer) { pendR.on = true; pendR.n = nR; }
-    hipLaunchKernelGGL(k_dual_border_sym, g1(nR + 1), dim3(NT), 0, st, Wz, ld, nR, ra2, scal, R, posR, Sall, id, side, y, yidx, yval,
-                       defer ? rs_ps_u : (double *)nullptr, S_KEEP_S);
+    if (lz_enabled) {
+        if (lz_n >= LZK) rs_flush();
+        // (nR = 0: no rank-1 part; the term is recorded with an empty vector all the same)
+        hipLaunchKernelGGL(k_lz_border, g1(nR + 1), dim3(NT), 0, st, Wz, ld, nR, ra2, scal, R, posR, Sall, id, side, y, yidx, yval, lz_vec, lz_stride, lz_n, lz_c);
+        lz_n++;
+    } else {
+        rs_flush();
+        const bool defer = nR > 0;
+        if (defer) { pendR.on = true; pendR.n = nR; }
+        hipLaunchKernelGGL(k_dual_border_sym, g1(nR + 1), dim3(NT), 0, st, Wz, ld, nR, ra2, scal, R, posR, Sall, id, side, y, yidx, yval,
+                           defer ? rs_ps_u : (double *)nullptr, S_KEEP_S);
+    }
     hR[nR] = id; hposR[id] = nR;
     if (id < nV) hSb[id] = side; else hSc[id - nV] = side;
     nR++;
@@ -270,10 +295,18 @@ void Impl::rs_add_row(int id, int side, int yidx, double yval) {
 }
 void Impl::rs_remove_row(int k, bool carry) {
     const int id = hR[k];
-    rs_flush();
-    hipLaunchKernelGGL(k_dual_colcoef_sym, g1(nR), dim3(NT), 0, st, Wz, ld, nR, k, ra3, scal);
-    if (carry) hipLaunchKernelGGL(k_dual_carry_remove, dim3(1), dim3(NT), 0, st, nR, k, 1.0 - last_tau, ra3, rs_dl);
-    rs_rank1(nR, ra3, 9, 1.0);
+    if (lz_enabled) {
+        if (lz_n >= LZK) rs_flush();
+        hipLaunchKernelGGL(k_lz_colcoef, g1(nR), dim3(NT), 0, st, Wz, ld, nR, k, lz_p(), ra3, scal);
+        if (carry) hipLaunchKernelGGL(k_dual_carry_remove, dim3(1), dim3(NT), 0, st, nR, k, 1.0 - last_tau, ra3, rs_dl);
+        hipLaunchKernelGGL(k_lz_remove_fix, g1(std::max(nR, 1)), dim3(NT), 0, st, nR, k, ra3, scal, lz_vec, lz_stride, lz_n, lz_c);
+        lz_n++;
+    } else {
+        rs_flush();
+        hipLaunchKernelGGL(k_dual_colcoef_sym, g1(nR), dim3(NT), 0, st, Wz, ld, nR, k, ra3, scal);
+        if (carry) hipLaunchKernelGGL(k_dual_carry_remove, dim3(1), dim3(NT), 0, st, nR, k, 1.0 - last_tau, ra3, rs_dl);
+        rs_rank1(nR, ra3, 9, 1.0);
+    }
     hipLaunchKernelGGL(k_dual_move_last_sym, g1(std::max(nR - 1, 1)), dim3(NT), 0, st, Wz, ld, nR, k, R, posR, Sall, id, y, id);
     if (k != nR - 1) { hR[k] = hR[nR - 1]; hposR[hR[k]] = k; }
     hposR[id] = -1;
@@ -442,6 +475,7 @@ int Impl::rs_setup_rows(const std::vector<int> &rows, const std::vector<int> &gb
 // the factors of a guessed working set (gb: bounds, gc: constraints; Sb already holds gb, Sc is zero, x is set)
 int Impl::rs_setup(const std::vector<int> &gb, const std::vector<int> &gc) {
     pendR.on = false;
+    lz_n = 0;
     A_times(x, Ax);
     std::vector<int> rows, cons;
     for (int v = 0; v < nV; v++) if (gb[v] != 0) rows.push_back(v);

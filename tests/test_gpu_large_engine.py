@@ -176,7 +176,7 @@ def _diag_h_qp(rng, nV, nC, density, hmin=0.5):
                   q.lbA, q.ubA, name="diagH_%dx%d" % (nV, nC))
 
 
-@pytest.mark.parametrize("knob", [None, "RSQP_LARGE_NO_DUAL", "RSQP_LARGE_NO_CARRY", "RSQP_LARGE_NO_FUSE", "RSQP_NO_BLOCKED_SETUP", "RSQP_LARGE_NO_SYM"])
+@pytest.mark.parametrize("knob", [None, "RSQP_LARGE_NO_DUAL", "RSQP_LARGE_NO_CARRY", "RSQP_LARGE_NO_FUSE", "RSQP_NO_BLOCKED_SETUP", "RSQP_LARGE_NO_SYM", "RSQP_LARGE_NO_LAZY"])
 def test_range_space_path_all_call_shapes(capi, oracle, monkeypatch, knob):
     """Diagonal positive Hessian: the HBM-resident engine keeps the explicit inverse of A_AC,FR D^-1 A_AC,FR' instead of the null-space
     factors (qp_large.hip, Impl::dual). Every call shape against the oracle -- cold, hot start on new vectors, hot start with new

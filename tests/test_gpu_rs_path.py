@@ -67,7 +67,7 @@ def all_call_shapes(capi, oracle, rng, q, want_path):
 
 
 @pytest.mark.parametrize("knob", [None, "RSQP_LARGE_RSH_DENSE", "RSQP_LARGE_RSH_DENSE+RSQP_LARGE_NO_TABLEAU", "RSQP_NO_BLOCKED_SETUP", "RSQP_LARGE_BAND_1WG",
-                                  "RSQP_LARGE_NO_CARRY"])
+                                  "RSQP_LARGE_NO_CARRY", "RSQP_LARGE_NO_LAZY"])
 def test_banded_hessian_all_call_shapes(capi, oracle, monkeypatch, knob):
     for k in (knob or "").split("+"):
         if k:
