@@ -1453,19 +1453,36 @@ __global__ void __launch_bounds__(1024) k_dual_li_publish(int nV, const int *__r
 // the multiplier step CARRIED over a plain added constraint (the right-hand sides of the rows that were active before have
 // (1 - tau) of their way left): Sinv_new rhs_new = [om dy - lam u; lam], lam = (rhs_k - om c'dy) / s -- O(nAC) instead of a pass over
 // Sinv; k = the position of the new constraint r, Av = A (D^-1 dg_FR - dx_FX) of the new step. One workgroup.
-__global__ void __launch_bounds__(NT) k_dual_carry_add(int k, double om, const double *__restrict__ c, const double *__restrict__ u,
-                                                       double *__restrict__ dyv, const double *__restrict__ scal, int r,
-                                                       const int *__restrict__ Sc, const double *__restrict__ lbA,
-                                                       const double *__restrict__ ubA, const double *__restrict__ lbAN,
-                                                       const double *__restrict__ ubAN, const double *__restrict__ Av,
-                                                       const int *__restrict__ AC, double *__restrict__ dyC) {
-    // (dyC: the multiplier step by constraint index -- dy + nV, zeroed before -- filled here as well: one launch less)
-    __shared__ double sh[4];
-    double t = lane_sum4(k, [&](int j) { return c[j] * dyv[j]; });
-    t = block_sum(t, sh);
-    const double rk = (Sc[r] == -1 ? delta_of(lbAN[r], lbA[r]) : delta_of(ubAN[r], ubA[r])) + Av[r];
+// 1024 lanes (a dot product over up to 10 000 rows by 256 lanes is 40 dependent loads: 11 us); the ONE entry of A (D^-1 dg_FR - dx_FX)
+// the new row needs is formed here from its sparse row instead of by a full product with A in front of the kernel (round 5: a
+// carried step then runs two sparse products, not three)
+__device__ __forceinline__ double block_sum_w(double v, double *sh16) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh16[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) s += sh16[w];
+    return s;
+}
+__global__ void __launch_bounds__(1024) k_dual_carry_add_w(int k, double om, const double *__restrict__ c, const double *__restrict__ u,
+                                                           double *__restrict__ dyv, const double *__restrict__ scal, int r,
+                                                           const int *__restrict__ Sc, const double *__restrict__ lbA,
+                                                           const double *__restrict__ ubA, const double *__restrict__ lbAN,
+                                                           const double *__restrict__ ubAN, const int *__restrict__ rp,
+                                                           const int *__restrict__ ci, const double *__restrict__ rv,
+                                                           const double *__restrict__ wvec, const int *__restrict__ AC,
+                                                           double *__restrict__ dyC) {
+    __shared__ double sh[16];
+    double t = 0.0, a = 0.0;
+    for (int j = threadIdx.x; j < k; j += 1024) t += c[j] * dyv[j];
+    for (int e = rp[r] + threadIdx.x; e < rp[r + 1]; e += 1024) a += rv[e] * wvec[ci[e]];
+    t = block_sum_w(t, sh);
+    a = block_sum_w(a, sh);
+    const double rk = (Sc[r] == -1 ? delta_of(lbAN[r], lbA[r]) : delta_of(ubAN[r], ubA[r])) + a;
     const double lam = (rk - om * t) * scal[8];
-    for (int j = threadIdx.x; j < k; j += NT) { const double d = om * dyv[j] - lam * u[j]; dyv[j] = d; dyC[AC[j]] = d; }
+    for (int j = threadIdx.x; j < k; j += 1024) { const double d = om * dyv[j] - lam * u[j]; dyv[j] = d; dyC[AC[j]] = d; }
     if (threadIdx.x == 0) { dyv[k] = lam; dyC[r] = lam; }
 }
 // ... and over a plain removed constraint at position j (v = column j of Sinv before the update): om (dy - (dy_j / v_j) v) with
@@ -2890,14 +2907,15 @@ struct RsqpLargeEngine::Impl {
             hipLaunchKernelGGL(k_dual_rhs_vec, g1(nV), dim3(NT), 0, st, nV, Sb, hinv, gN, g, dx, w5);
         }       // (else: k_drift_all has formed dx on the fixed variables and the right-hand-side vector w5 already)
         dx_ready = false;
-        A_times(w5, c3);
+        const bool carried_step = nAC > 0 && carry_valid && (carry_ready || carry_pending);
+        if (!carried_step) A_times(w5, c3);      // (the right-hand side of the exact multiplier step; a carried one needs one entry of it at most)
         bool scattered = false;
         if (nAC > 0) {
             if (carry_ready && carry_valid) {
                 carried++; stat_carried++;                                    // (transformed by dual_remove_constraint already)
             } else if (carry_pending && carry_valid) {
-                hipLaunchKernelGGL(k_dual_carry_add, dim3(1), dim3(NT), 0, st, nAC - 1, 1.0 - last_tau, a1, a2, c_wY, scal, dual_carry_row, Sc,
-                                   lbA, ubA, lbAN, ubAN, c3, AC, dy + nV);
+                hipLaunchKernelGGL(k_dual_carry_add_w, dim3(1), dim3(1024), 0, st, nAC - 1, 1.0 - last_tau, a1, a2, c_wY, scal, dual_carry_row, Sc,
+                                   lbA, ubA, lbAN, ubAN, M.Arp, M.Aci, M.Arv, w5, AC, dy + nV);
                 carried++; stat_carried++;
                 scattered = true;
             } else {

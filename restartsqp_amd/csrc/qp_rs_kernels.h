@@ -462,7 +462,7 @@ __global__ void k_rs_q(int nV, const int *__restrict__ Sb, const double *__restr
 // the multiplier step CARRIED over a row that joined at position k (the right-hand sides of the rows that were active before
 // have (1 - tau) of their way left): Sinv_new rhs_new = [om dl - lam u; lam], lam = (rhs_k - om cv'dl) / s -- O(nR) instead of a
 // pass over Sinv. One workgroup; dy (by row id, zeroed before) is filled as well.
-__global__ void __launch_bounds__(NT) k_rs_carry_add(int k, double om, const double *__restrict__ cv, const double *__restrict__ u,
+__global__ void __launch_bounds__(1024) k_rs_carry_add(int k, double om, const double *__restrict__ cv, const double *__restrict__ u,
                                                      double *__restrict__ dl, const double *__restrict__ scal, int id, int nV,
                                                      const int *__restrict__ Sall, const double *__restrict__ lb,
                                                      const double *__restrict__ ub, const double *__restrict__ lbN,
@@ -470,14 +470,15 @@ __global__ void __launch_bounds__(NT) k_rs_carry_add(int k, double om, const dou
                                                      const double *__restrict__ ubA, const double *__restrict__ lbAN,
                                                      const double *__restrict__ ubAN, const double *__restrict__ p,
                                                      const double *__restrict__ Ap, const int *__restrict__ R, double *__restrict__ dy) {
-    __shared__ double sh[4];
-    double t = lane_sum4(k, [&](int j) { return cv[j] * dl[j]; });
-    t = block_sum(t, sh);
+    __shared__ double sh[16];
+    double t = 0.0;
+    for (int j = threadIdx.x; j < k; j += 1024) t += cv[j] * dl[j];
+    t = block_sum_w(t, sh);
     double rk;
     if (id < nV) rk = (Sall[id] == -1 ? delta_of(lbN[id], lb[id]) : delta_of(ubN[id], ub[id])) + p[id];
     else { const int r = id - nV; rk = (Sall[id] == -1 ? delta_of(lbAN[r], lbA[r]) : delta_of(ubAN[r], ubA[r])) + Ap[r]; }
     const double lam = (rk - om * t) * scal[8];
-    for (int j = threadIdx.x; j < k; j += NT) { const double d = om * dl[j] - lam * u[j]; dl[j] = d; dy[R[j]] = d; }
+    for (int j = threadIdx.x; j < k; j += 1024) { const double d = om * dl[j] - lam * u[j]; dl[j] = d; dy[R[j]] = d; }
     if (threadIdx.x == 0) { dl[k] = lam; dy[id] = lam; }
 }
 __global__ void k_rs_diff(int n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out) {

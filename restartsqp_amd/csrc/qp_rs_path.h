@@ -365,7 +365,7 @@ void Impl::rs_step_direction() {
             hipLaunchKernelGGL(k_rs_scatter, g1(nR), dim3(NT), 0, st, nR, R, rs_dl, dy);
             carried++; stat_carried++;
         } else if (carry_pending && carry_valid) {
-            hipLaunchKernelGGL(k_rs_carry_add, dim3(1), dim3(NT), 0, st, nR - 1, 1.0 - last_tau, ra1, ra2, rs_dl, scal, rs_carry_id, nV, Sall, lb, ub,
+            hipLaunchKernelGGL(k_rs_carry_add, dim3(1), dim3(1024), 0, st, nR - 1, 1.0 - last_tau, ra1, ra2, rs_dl, scal, rs_carry_id, nV, Sall, lb, ub,
                                lbN, ubN, lbA, ubA, lbAN, ubAN, rs_p, rs_Ap, R, dy);
             carried++; stat_carried++;
         } else {
