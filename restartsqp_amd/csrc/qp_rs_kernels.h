@@ -360,6 +360,11 @@ __global__ void k_lz_push(int n, const double *__restrict__ v, const double *__r
     if (i == 0) pc[slot] = scal[src];
 }
 
+__global__ void k_rs_unit_diag(int n, double *__restrict__ X, long long ld) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) X[i + (long long)i * ld] = 1.0;
+}
+
 // ---- rows of C ----------------------------------------------------------------------------------------------------------------
 // the incoming row as a dense vector: id < nV: e_id, else row id - nV of A (all variables). One workgroup.
 __global__ void __launch_bounds__(NT) k_rs_row(int nV, int id, const int *__restrict__ rp, const int *__restrict__ ci,

@@ -77,6 +77,16 @@ int Impl::rs_build_band(const std::vector<double> &hv, bool *ok) {
         LCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_apply<16>), hipFuncAttributeMaxDynamicSharedMemorySize, BAND_MAX_N * 8));
         attr_set = true;
     }
+    // the explicit inverse as well (in Z: n^2 doubles, 0.8 GB at n = 10 000): H^-1 c' of an incoming row -- a unit vector or a few
+    // entries -- is then a combination of a few of its columns (k_rs_hinv_row, every lane busy) instead of a banded product whose
+    // two scans and two cross-workgroup hand-offs take 20 us whatever the vector holds. One banded product per column, all at once.
+    band_hinv = false;
+    if (rs_band_columns) {
+        LCHK(hipMemsetAsync(Z, 0, sizeof(double) * (size_t)ld * nV, st));
+        hipLaunchKernelGGL(k_rs_unit_diag, g1(nV), dim3(NT), 0, st, nV, Z, ld);
+        band_launch(nV, Z, nullptr, Z, ld, false);
+        band_hinv = true;
+    }
     *ok = true;
     return RET_OK;
 }
@@ -244,7 +254,7 @@ void Impl::rs_products(int id) {
         return;
     }
     hipLaunchKernelGGL(k_rs_row, dim3(1), dim3(NT), 0, st, nV, id, M.Arp, M.Aci, M.Arv, M.denseAT, w1);
-    if (rs_kind == 2 && !M.denseAT) hipLaunchKernelGGL(k_rs_hinv_row, g1(nV), dim3(NT), 0, st, nV, id, M.Arp, M.Aci, M.Arv, Z, ld, w5);
+    if ((rs_kind == 2 || (rs_kind == 1 && band_hinv)) && !M.denseAT) hipLaunchKernelGGL(k_rs_hinv_row, g1(nV), dim3(NT), 0, st, nV, id, M.Arp, M.Aci, M.Arv, Z, ld, w5);
     else rs_hinv_apply(w1, nullptr, w5, false);
     A_times(w5, c3);
     if (nR > 0) hipLaunchKernelGGL(k_rs_gather, g1(nR), dim3(NT), 0, st, nR, R, nV, w5, c3, ra1);
