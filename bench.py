@@ -431,6 +431,7 @@ def large_configs(capi, problems, seq_steps=50, ref_rule_steps=10, cpu_seconds=1
     #      QPhandler formulation gives its slack variables -- takes the null-space path. Its numbers, same inputs, path forced by
     #      RSQP_LARGE_NO_DUAL (read when the engine of a handle is created): cold start + one FIXED + one VARIED step
     os.environ["RSQP_LARGE_NO_DUAL"] = "1"
+    os.environ["RSQP_LARGE_NO_RSH"] = "1"        # (round 5: a diagonal Hessian would otherwise take the GENERAL range-space path, as a band of width 0)
     try:
         s2 = load(q)
         t = time.perf_counter(); n2 = s2.optimize_qp(); t_cold2 = time.perf_counter() - t
@@ -444,13 +445,17 @@ def large_configs(capi, problems, seq_steps=50, ref_rule_steps=10, cpu_seconds=1
             nk = s2.optimize_qp()
             okk, _, _, _ = s2.test_optimality()
             steps2.append({"matrices_changed": bool(changed), "seconds": time.perf_counter() - t, "nWSR": nk, "certified": bool(okk)})
+        path2 = s2.large_path()
         s2.close()
         out["sparse_10000x20000_null_space_path"] = {
             "cold_seconds": t_cold2, "cold_nWSR": n2, "steps_reference_rule": steps2,
-            "note": "RSQP_LARGE_NO_DUAL=1: what this configuration costs when its Hessian is not diagonal and positive (the same "
-                    "working-set sequences: the two paths differ in how the KKT systems are solved, not in the decisions)"}
+            "path": capi.Solver.LARGE_PATHS.get(path2, "?"),
+            "note": "RSQP_LARGE_NO_DUAL=1 RSQP_LARGE_NO_RSH=1: what this configuration costs on the NULL-SPACE path -- since round 5 only an "
+                    "indefinite, semidefinite or non-symmetric Hessian takes it (the same working-set sequences: the paths differ in how "
+                    "the KKT systems are solved, not in the decisions)"}
     finally:
         del os.environ["RSQP_LARGE_NO_DUAL"]
+        del os.environ["RSQP_LARGE_NO_RSH"]
 
     # ---- SURVEY 8(d)'s other Hessian for this configuration: "+ optional 5-band SPD" (problems.sparse_qp(band=5)): not diagonal,
     #      so DESIGN 4.4's path does not apply; it takes the GENERAL range-space path (bounds and constraints as rows of C,

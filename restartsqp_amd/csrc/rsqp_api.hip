@@ -945,6 +945,7 @@ extern "C" int rsqp_solve(rsqp_solver *s, int mode, int *nWSR, const double *x0,
     rc = ensure_desc(s);
     if (rc != RSQP_OK) return rc;
     if (s->engine == 2) return solve_large(s, mode, nWSR, x0, y0, guess_b);
+    const int nWSR_in = *nWSR;
     QPPools p = pools_of(s);
     if (mode == RSQP_MODE_WARM_REINIT) {
         if (x0) { HIPCHK(s->d_x0.upload(x0, s->nV)); p.x0 = s->d_x0.p; }
@@ -974,6 +975,27 @@ extern "C" int rsqp_solve(rsqp_solver *s, int mode, int *nWSR, const double *x0,
     else HIPCHK(hipStreamSynchronize(s->stream));
     rc = fetch_results(s);
     if (rc != RSQP_OK) return rc;
+    if (s->state_engine == 1 && s->last_ret == RET_SETUP_FAILED) {
+        // the register-resident tableau kernel gave up on a pivot in its rounding band (it has no hand-over of its own: the mid-size
+        // tableau kernel bails to the null-space kernel inside the launcher): the LDS-resident Givens / TQ kernel takes the
+        // same call over -- from scratch where the call wanted the tableau kernel's stored state
+        SmallKnobs k2 = s->kn;
+        k2.no_tiny = 1;
+        int mode2 = (mode == RSQP_MODE_HOT_VECTORS || mode == RSQP_MODE_HOT_MATRICES) ? RSQP_MODE_COLD : mode;
+        p.cert_out = nullptr; p.cert_Wb = nullptr; p.cert_Wc = nullptr;
+        if (p.done_flag) p.done_val = ++s->done_seq;
+        s->spec_cert = false; s->cert_pending = false;
+        s->state_engine = 0;
+        s->last_mode = mode2;
+        int n2 = nWSR_in;
+        e = rsqp_launch_small_qp(k2, p, 1, s->nV, s->nC,
+                                 rsqp_mat_lds_bytes(s->nV, s->nC, s->A.initialised ? s->A.nnz : 0, s->H.initialised ? s->H.nnz : 0), mode2, n2, s->stream);
+        if (e != hipSuccess) return fail(RSQP_ERR_DEVICE, std::string("QP kernel launch: ") + hipGetErrorString(e));
+        if (p.done_flag) { if ((rc = wait_done(s, p.done_val)) != RSQP_OK) return rc; }
+        else HIPCHK(hipStreamSynchronize(s->stream));
+        rc = fetch_results(s);
+        if (rc != RSQP_OK) return rc;
+    }
     HIPCHK(s->d_nwsr.download(nWSR, 1));
     return RSQP_OK;
 }

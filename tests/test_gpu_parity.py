@@ -706,6 +706,35 @@ def test_degenerate_sweep_mismatch_rate_is_bounded(capi, oracle, keep_state):
     b.close()
 
 
+def test_single_qp_handles_on_degenerate_hs071_scale_inputs(capi, oracle):
+    """the hs071-scale tableau kernel serves every single-QP handle of <= 8 x 8 and has no hand-over of its own; where it
+    gives up on a rounding-band pivot (numerical failure), rsqp_solve lets the LDS-resident Givens / TQ kernel take the call over.
+    400 seeded degenerate QPs of <= 8 variables / <= 8 constraints, one handle each: the status is the oracle's, every solved one
+    is a certified KKT point with the oracle's objective, and at most 2 % end in another working set (exact ties)."""
+    rng = np.random.default_rng(20260106)
+    probs = []
+    while len(probs) < 400:
+        q = problems.degenerate_qp(rng, len(probs) % 5)
+        if q.nV <= 8 and q.nC <= 8:
+            probs.append(q)
+    differ = 0
+    for q in probs:
+        s = capi.Solver(q.nV, q.nC)
+        s.set_A_csc(q.A_jc, q.A_ir, q.A_val); s.set_H_csc(q.H_jc, q.H_ir, q.H_val)
+        for w, v in zip(range(5), (q.g, q.lb, q.ub, q.lbA, q.ubA)):
+            s.set_vector(w, v)
+        n = s.solve(capi.MODE_COLD, 2000)
+        qp, rc, n_or = oracle_cold(oracle, q, 2000)
+        assert s.status == qp.exitflag(), (q.name, q.nV, q.nC, s.status, qp.exitflag())
+        if s.status == 20:
+            ok, st, _, _ = s.test_optimality()
+            assert ok and abs(s.objective - qp.objective) <= 1e-7 * max(1.0, abs(qp.objective)), (q.name, s.objective, qp.objective)
+            wb, wc = s.working_set_raw()
+            differ += not (np.array_equal(wb, qp.ws_bounds) and np.array_equal(wc, qp.ws_constraints))
+        s.close()
+    assert differ <= 8, differ
+
+
 @pytest.mark.gpu
 def test_packed_waves_match_one_problem_per_wave():
     """64/L problems share a wave in the LDS engine (L = 16 / 32 lanes per problem). Every packing
