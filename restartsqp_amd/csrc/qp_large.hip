@@ -1475,6 +1475,8 @@ __global__ void __launch_bounds__(1024) k_dual_carry_add_w(int k, double om, con
                                                            const double *__restrict__ wvec, const int *__restrict__ AC,
                                                            double *__restrict__ dyC) {
     __shared__ double sh[16];
+    // (tried: everything the update loop reads fetched into registers before the two reductions -- 17.7 us against 11.5 us,
+    //  profiles/r05_s_kernel_stats_large_sparse.csv: reverted)
     double t = 0.0, a = 0.0;
     for (int j = threadIdx.x; j < k; j += 1024) t += c[j] * dyv[j];
     for (int e = rp[r] + threadIdx.x; e < rp[r + 1]; e += 1024) a += rv[e] * wvec[ci[e]];

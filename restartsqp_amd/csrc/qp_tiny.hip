@@ -726,7 +726,7 @@ __global__ void __launch_bounds__(TB, W) tiny_qp_kernel(QPPools P, int nq, int m
         pr[80 + l * 2] = E.dV; pr[80 + l * 2 + 1] = E.dC;
         si[l] = E.sv; si[8 + l] = E.sc;
         if (l == 0) { si[16] = E.status; si[17] = (E.fmask & 0xff) | ((E.amask & 0xff) << 8); si[18] = TINY_MAGIC; si[19] = pivots; }
-    } else if (l == 0) { si[16] = QPS_NOTINITIALISED; si[18] = TINY_MAGIC; }
+    } else if (l == 0 && !P.skip_mark) { si[16] = QPS_NOTINITIALISED; si[18] = TINY_MAGIC; }
     TSTAMP(4);
     if (P.cert_out) {
         // the reference's certificate (qpOASESInterface::test_optimality, src/qpOASESInterface.cpp:498-684) on the answer just

@@ -1523,6 +1523,8 @@ extern "C" int rsqp_batch_solve(rsqp_batch *b, int mode, int max_nWSR) {
         const int fam = rsqp_small_launch_is_tiny(b->kn, p, b->nVmax, b->nCmax);
         if ((mode == RSQP_MODE_HOT_VECTORS || mode == RSQP_MODE_HOT_MATRICES) && b->state_engine != fam) mode = RSQP_MODE_COLD;
         b->state_engine = fam;
+        // a cold-start-only batch on the tableau kernel keeps no state and leaves no mark: the handle remembers it instead
+        if (fam == 1 && !b->keep_state) { p.skip_mark = 1; b->state_engine = -1; }
     }
     hipError_t e = rsqp_launch_small_qp(b->kn, p, b->nq, b->nVmax, b->nCmax, b->mat_bytes_max, mode, max_nWSR, b->stream);
     if (e != hipSuccess) return fail(RSQP_ERR_DEVICE, std::string("QP kernel launch: ") + hipGetErrorString(e));

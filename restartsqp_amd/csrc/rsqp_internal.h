@@ -81,6 +81,9 @@ struct QPPools {
     long long uni_state; double uni_hreg; //    needs no descriptor load, and it reads the PATTERN arrays of member 0 (cache-resident for the
                       //    whole launch) instead of its own copy: two dependent HBM round trips less in front of every solve
                       //    (single-QP handles are the batch of one: set as well; uni_hreg = the LP regularisation, 0 in batches)
+    int skip_mark;    // 1 (batches with keep_state = 0 on the hs071-scale tableau kernel): the HOST remembers that no state was kept
+                      //    (rsqp_batch::state_engine = -1: the next hot start runs cold), so the kernel does not touch the state block at
+                      //    all -- the "not initialised" mark was one scattered 64-byte line per QP
     int keep_state;   // 1: write the hot-start part of the engine image back to HBM at the end of a solve (what the
                       //    SQProblem object keeps between calls); 0: cold-start-only batches skip that write --
                       //    the image is marked "not initialised", a later hot start falls back to a cold start
