@@ -427,7 +427,8 @@ int upload_matrix(DevMatrix &M, const Compressed &c, bool want_csr, bool zero_co
         M.nblk_r = (int)blr.size();
         HIPCHK(M.blk_r.from(blr));
         if (M.pin) { for (int k = 0; k < M.nnz; k++) M.rval.host[k] = M.val.host[r.perm[k]]; }
-        else if (rsqp_launch_gather(M.nnz, M.perm.p, M.val.p, M.rval.p, nullptr) != hipSuccess)
+        else if (((long long)M.nnz == (long long)M.nrow * M.ncol ? rsqp_launch_gather_dense(M.nrow, M.ncol, M.val.p, M.rval.p, nullptr)
+                                                                 : rsqp_launch_gather(M.nnz, M.perm.p, M.val.p, M.rval.p, nullptr)) != hipSuccess)
             return fail(RSQP_ERR_DEVICE, "gather launch failed");
     }
     M.initialised = true;
@@ -772,7 +773,8 @@ int set_csc(rsqp_solver *s, DevMatrix &M, int nrow, int ncol, const int *jc, con
         if (M.pin && s->cert_pending) { HIPCHK(hipStreamSynchronize(s->stream)); s->cert_pending = false; }
         HIPCHK(M.val.upload(val, nnz));
         if (M.pin) { if (M.have_csr) for (int k = 0; k < M.nnz; k++) M.rval.host[k] = val[M.h_perm[k]]; }
-        else if (M.have_csr && rsqp_launch_gather(M.nnz, M.perm.p, M.val.p, M.rval.p, s->stream) != hipSuccess)
+        else if (M.have_csr && ((long long)M.nnz == (long long)M.nrow * M.ncol ? rsqp_launch_gather_dense(M.nrow, M.ncol, M.val.p, M.rval.p, s->stream)
+                                                                                : rsqp_launch_gather(M.nnz, M.perm.p, M.val.p, M.rval.p, s->stream)) != hipSuccess)
             return fail(RSQP_ERR_DEVICE, "gather launch failed");
         return RSQP_OK;
     }

@@ -40,6 +40,8 @@ hipError_t rsqp_launch_spmv_segscan(int nminor, const int4 *chunks, int nchunks,
 hipError_t rsqp_launch_scatter(int n, const int *order, const int *tmap, const double *tv, double *val,
                                hipStream_t stream);
 hipError_t rsqp_launch_gather(int n, const int *perm, const double *src, double *dst, hipStream_t stream);
+// the same for a matrix that stores every entry (CSC = column-major, CSR = row-major): a tiled transpose
+hipError_t rsqp_launch_gather_dense(int nrow, int ncol, const double *src, double *dst, hipStream_t stream);
 hipError_t rsqp_launch_scatter_csc_csr(int n, const int *order, const int *rorder, const double *tv, double *val, double *rval,
                                        hipStream_t stream);
 hipError_t rsqp_launch_densify(int nrow, int ncol, const int *jc, const int *ir, const double *val, double *dense,

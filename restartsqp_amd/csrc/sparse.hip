@@ -933,6 +933,28 @@ hipError_t rsqp_launch_scatter_csc_csr(int n, const int *order, const int *rorde
     return hipGetLastError();
 }
 
+namespace {
+// the CSR values of a FULLY dense matrix are the transpose of its CSC values: 32 x 32 tiles through LDS instead of a gather through
+// the permutation (whose reads are nrow * 8 bytes apart: 28 ms for the 8.4 M entries of the dense 2048 x 4096 configuration)
+__global__ void dense_values_transpose(int nrow, int ncol, const double *__restrict__ src, double *__restrict__ dst) {
+    __shared__ double tile[32][33];
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    for (int k = threadIdx.y; k < 32; k += 8) {
+        const int r = r0 + threadIdx.x, c = c0 + k;
+        tile[k][threadIdx.x] = (r < nrow && c < ncol) ? src[(long long)c * nrow + r] : 0.0;      // tile[c][r]
+    }
+    __syncthreads();
+    for (int k = threadIdx.y; k < 32; k += 8) {
+        const int c = c0 + threadIdx.x, r = r0 + k;
+        if (r < nrow && c < ncol) dst[(long long)r * ncol + c] = tile[threadIdx.x][k];
+    }
+}
+}  // namespace
+hipError_t rsqp_launch_gather_dense(int nrow, int ncol, const double *src, double *dst, hipStream_t stream) {
+    if (nrow <= 0 || ncol <= 0) return hipSuccess;
+    hipLaunchKernelGGL(dense_values_transpose, dim3((nrow + 31) / 32, (ncol + 31) / 32), dim3(32, 8), 0, stream, nrow, ncol, src, dst);
+    return hipGetLastError();
+}
 hipError_t rsqp_launch_gather(int n, const int *perm, const double *src, double *dst, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(gather_values, dim3((n + 255) / 256), dim3(256), 0, stream, n, perm, src, dst);
