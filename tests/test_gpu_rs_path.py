@@ -178,3 +178,37 @@ def test_band5_sequence_reference_rule_matches_oracle_at_2500(capi):
         assert np.abs(s.y - y).max() <= 1e-9 * max(1.0, np.abs(y).max())
         ok, st, _, _ = s.test_optimality()
         assert ok
+
+
+def test_infeasible_qp_is_reported_infeasible_on_every_path(capi, oracle, monkeypatch):
+    """A 142 x 208 QP whose perturbed limits are inconsistent (found by tests/checks/fuzz_large_vs_oracle.py 14: HiGHS confirms the
+    infeasibility): on the way to the vertex where the homotopy stops, the multipliers grow without bound and the explicit inverse
+    of a range-space path loses its pivots -- the engine then lets the null-space path take the solve over (RsqpLargeEngine::
+    solve) and must end with the oracle's verdict, 22, from a hot start and from a cold start, whatever formulation began."""
+    rng = np.random.default_rng(14)
+    for k in range(11):
+        nV = int(rng.integers(50, 160)); nC = int(rng.integers(30, 220))
+        q = problems.random_qp(rng, nV, nC, density=float(rng.choice([0.05, 0.3, 1.0])))
+        q2 = problems.perturb(rng, q, 0.03)
+        if k < 10:
+            rng.normal(size=q2.A_val.shape); problems.perturb(rng, q2, 0.03)
+    assert (q.nV, q.nC) == (142, 208)
+    qp = oracle.OracleQP(q.nV, q.nC); qp.set_A_csc(q.A_jc, q.A_ir, q.A_val); qp.set_H_csc(q.H_jc, q.H_ir, q.H_val)
+    qp.init(q.g, q.lb, q.ub, q.lbA, q.ubA, 100000)
+    qp.hotstart(q2.g, q2.lb, q2.ub, q2.lbA, q2.ubA, 100000)
+    assert qp.exitflag() == 22
+    for knob in (None, "RSQP_LARGE_NO_TABLEAU", "RSQP_LARGE_NO_LAZY", "RSQP_LARGE_NO_RSH"):
+        if knob:
+            monkeypatch.setenv(knob, "1")
+        s = load(capi, q)
+        s.solve(capi.MODE_COLD, 100000)
+        assert s.status == 20
+        for w, v in zip(range(5), (q2.g, q2.lb, q2.ub, q2.lbA, q2.ubA)):
+            s.set_vector(w, v)
+        s.solve(capi.MODE_HOT_VECTORS, 100000)
+        assert s.status == 22, (knob, s.status)
+        t = load(capi, q2)
+        t.solve(capi.MODE_COLD, 100000)
+        assert t.status == 22, (knob, t.status)
+        if knob:
+            monkeypatch.delenv(knob)
