@@ -121,6 +121,23 @@ def random_qp(rng, nV, nC, density=0.5, name=""):
     return QPData(nV, nC, *dense_to_csc(H), *dense_to_csc(A), g, lb, ub, lbA, ubA, name=name)
 
 
+def banded_qp(rng, nV, nC, density=0.3, hb=2, free=False, name="banded"):
+    """random convex QP with a (2 hb + 1)-band strictly diagonally dominant Hessian (the general range-space path's banded operator)"""
+    H = np.diag(1.0 + np.abs(rng.normal(size=nV)))
+    for off in range(1, hb + 1):
+        o = 0.3 * rng.normal(size=nV - off)
+        H += np.diag(o, off) + np.diag(o, -off)
+    H += np.diag(np.abs(H - np.diag(np.diag(H))).sum(axis=1))
+    A = rng.normal(size=(nC, nV)) * (rng.random((nC, nV)) < density)
+    g = 3.0 * rng.normal(size=nV)
+    xh = rng.normal(size=nV)
+    lb = xh - np.abs(rng.normal(size=nV)); ub = xh + np.abs(rng.normal(size=nV))
+    if free:
+        lb[::3] = -np.inf; ub[1::3] = np.inf
+    lbA = A @ xh - np.abs(rng.normal(size=nC)); ubA = A @ xh + np.abs(rng.normal(size=nC))
+    return QPData(nV, nC, *dense_to_csc(H), *dense_to_csc(A), g, lb, ub, lbA, ubA, name=name)
+
+
 def perturb(rng, q, rel=0.01):
     """Seeded perturbation of g and of the bounds (keeps lb <= ub)."""
     def pb(lo, hi):

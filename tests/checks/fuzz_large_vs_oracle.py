@@ -1,6 +1,7 @@
 """Randomised check of the HBM-resident engine against the CPU oracle: dense and sparse problems of
 50-160 variables, cold start, hot start on vectors, hot start with new matrices (blocked QR /
-Cholesky set-up), warm re-initialisation. Usage (GPU box): python tests/checks/fuzz_large_vs_oracle.py [seed] [count]"""
+Cholesky set-up), warm re-initialisation. Usage (GPU box): python tests/checks/fuzz_large_vs_oracle.py [seed] [count] [band]
+(band: any third argument -> 5-band Hessians, i.e. the banded H^-1 operator of the general range-space path, some with free variables)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,6 +11,7 @@ import oracle as O
 O.build()
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+band = len(sys.argv) > 3
 rng = np.random.default_rng(seed)
 
 
@@ -33,7 +35,8 @@ def same(s, n, qp, n_or, what, q):
 bad = 0
 for k in range(count):
     nV = int(rng.integers(50, 160)); nC = int(rng.integers(30, 220))
-    q = problems.random_qp(rng, nV, nC, density=float(rng.choice([0.05, 0.3, 1.0])))
+    dens = float(rng.choice([0.05, 0.3, 1.0]))
+    q = problems.banded_qp(rng, nV, nC, density=dens, hb=int(rng.integers(1, 3)), free=bool(k % 3 == 0)) if band else problems.random_qp(rng, nV, nC, density=dens)
     s = capi.Solver(q.nV, q.nC); s.set_engine(2); s.set_options(100000, 100)
     s.set_A_csc(q.A_jc, q.A_ir, q.A_val); s.set_H_csc(q.H_jc, q.H_ir, q.H_val)
     for w, v in zip(range(5), (q.g, q.lb, q.ub, q.lbA, q.ubA)):
