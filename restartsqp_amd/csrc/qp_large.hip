@@ -3154,6 +3154,7 @@ struct RsqpLargeEngine::Impl {
     double *rs_G = nullptr;          // ld x ld scratch of the blocked set-up (allocated on first use)
     double *band_buf = nullptr;      // the nine arrays of the banded operator
     BandOp band{};
+    bool band_attr_set = false;
     bool band_hinv = false;          // Z holds the explicit inverse of the banded H as well (products of incoming rows)
     bool rs_band_columns = getenv("RSQP_LARGE_BAND_NO_COLUMNS") == nullptr;
     double band_seq = 0.0;           // tag of the last multi-workgroup product (k_band_apply_mw)

@@ -68,14 +68,13 @@ int Impl::rs_build_band(const std::vector<double> &hv, bool *ok) {
     band.err = dflag + 1;
     band_seq = 0.0;
     LCHK(hipMemsetAsync(dflag + 1, 0, sizeof(int), st));
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!band_attr_set) {      // (per handle: a function attribute belongs to the device the handle lives on)
         LCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_apply<4>), hipFuncAttributeMaxDynamicSharedMemorySize, BAND_MAX_N * 8));
         LCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_apply<8>), hipFuncAttributeMaxDynamicSharedMemorySize, BAND_MAX_N * 8));
         LCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_apply<10>), hipFuncAttributeMaxDynamicSharedMemorySize, BAND_MAX_N * 8));
         LCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_apply<12>), hipFuncAttributeMaxDynamicSharedMemorySize, BAND_MAX_N * 8));
         LCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_band_apply<16>), hipFuncAttributeMaxDynamicSharedMemorySize, BAND_MAX_N * 8));
-        attr_set = true;
+        band_attr_set = true;
     }
     // the explicit inverse as well (in Z: n^2 doubles, 0.8 GB at n = 10 000): H^-1 c' of an incoming row -- a unit vector or a few
     // entries -- is then a combination of a few of its columns (k_rs_hinv_row, every lane busy) instead of a banded product whose
