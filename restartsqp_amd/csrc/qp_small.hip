@@ -1209,6 +1209,7 @@ SmallKnobs rsqp_small_knobs_from_env() {
     k.wide_lanes = env_int("RSQP_SMALL_WIDE_LANES", 256) == 512 ? 512 : 256; k.nospread = env_int("RSQP_SMALL_NOSPREAD", 0);
     k.no_kkt = env_int("RSQP_SMALL_NO_KKT", 0); k.kkt_only = env_int("RSQP_SMALL_KKT_ONLY", 0); k.no_tiny = env_int("RSQP_SMALL_NO_TINY", 0);
     k.tiny_lds = env_int("RSQP_TINY_LDS", 0); k.exp_matglobal = env_int("RSQP_EXP_MATGLOBAL", 0);
+    k.arena_mapped = env_int("RSQP_ARENA_MAPPED", -1);
     k.no_spin = getenv("RSQP_NO_SPIN") != nullptr; k.no_spec_cert = getenv("RSQP_NO_SPEC_CERT") != nullptr;
     return k;
 }

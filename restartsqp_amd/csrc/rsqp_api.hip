@@ -224,13 +224,24 @@ struct DevMatrix {
     // copy instead of 17 hipMalloc + 15 blocking hipMemcpy + 2 hipHostMalloc (365 -> ~90 us for the first iteration of hs071)
     char *arena_dev = nullptr, *arena_stage = nullptr;
     size_t arena_cap = 0, arena_used = 0;
-    hipError_t reserve(int nrow_, int ncol_) {
+    bool arena_mapped = false;             // the arena IS its staging mirror (host-mapped memory): no copy at all -- the kernels read the few
+                                           // dozen pattern words of an hs071-scale matrix over the link, as they read its values already
+    hipError_t reserve(int nrow_, int ncol_, bool mapped = false) {
         const size_t cap = (size_t)nrow_ * (size_t)ncol_ + 2 * (size_t)(nrow_ + ncol_) + 8;      // dense + an identity block or two
         arena_cap = 64 * cap + 64 * (size_t)(nrow_ + ncol_) + 4096;
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&arena_dev), arena_cap);
+        hipError_t e;
+        arena_mapped = mapped;
+        if (mapped) {
+            e = hipHostMalloc(reinterpret_cast<void **>(&arena_stage), arena_cap, hipHostMallocMapped);
+            if (e != hipSuccess) { arena_stage = nullptr; arena_cap = 0; return e; }
+            e = hipHostGetDevicePointer(reinterpret_cast<void **>(&arena_dev), arena_stage, 0);
+            if (e != hipSuccess) { arena_dev = nullptr; return e; }
+        } else {
+        e = hipMalloc(reinterpret_cast<void **>(&arena_dev), arena_cap);
         if (e != hipSuccess) { arena_dev = nullptr; arena_cap = 0; return e; }
         e = hipHostMalloc(reinterpret_cast<void **>(&arena_stage), arena_cap, hipHostMallocDefault);
         if (e != hipSuccess) { arena_stage = nullptr; return e; }
+        }
         std::memset(arena_stage, 0, arena_cap);
         e = hipHostMalloc(&pin, 2 * (cap + 2) * sizeof(double), hipHostMallocMapped);
         if (e != hipSuccess) { pin = nullptr; return e; }
@@ -240,7 +251,8 @@ struct DevMatrix {
     }
     void release_arena() {     // undo a partial reserve(): without an arena every array is allocated on its own
         if (pin) { (void)hipHostFree(pin); pin = nullptr; pin_cap = 0; }
-        if (arena_dev) { (void)hipFree(arena_dev); arena_dev = nullptr; }
+        if (arena_dev && !arena_mapped) (void)hipFree(arena_dev);
+        arena_dev = nullptr;
         if (arena_stage) { (void)hipHostFree(arena_stage); arena_stage = nullptr; }
         arena_cap = arena_used = 0;
     }
@@ -258,7 +270,7 @@ struct DevMatrix {
     }
     ~DevMatrix() {
         if (pin) { val.release(); rval.release(); (void)hipHostFree(pin); }
-        if (arena_dev) { drop_slices(); (void)hipFree(arena_dev); }
+        if (arena_dev) { drop_slices(); if (!arena_mapped) (void)hipFree(arena_dev); }
         if (arena_stage) (void)hipHostFree(arena_stage);
     }
 };
@@ -369,7 +381,7 @@ int upload_matrix_arena(DevMatrix &M, const Compressed &c, bool want_csr, hipStr
         M.h_rorder = ro; M.h_perm = r.perm;
         for (int k = 0; k < M.nnz; k++) M.rval.host[k] = M.val.host[r.perm[k]];
     }
-    HIPCHK(hipMemcpyAsync(M.arena_dev, M.arena_stage, M.arena_used, hipMemcpyHostToDevice, stream));
+    if (!M.arena_mapped) HIPCHK(hipMemcpyAsync(M.arena_dev, M.arena_stage, M.arena_used, hipMemcpyHostToDevice, stream));
     M.initialised = true;
     return RSQP_OK;
 }
@@ -378,13 +390,16 @@ int upload_matrix(DevMatrix &M, const Compressed &c, bool want_csr, bool zero_co
     M.nrow = c.nrow; M.ncol = c.ncol; M.nnz = c.nnz();
     M.h_jc = c.jc; M.h_ir = c.ir; M.h_order = c.order; M.h_tmap = c.tmap;
     if (zero_copy && M.arena_dev && M.pin && (size_t)M.nnz + 2 <= M.pin_cap) {
-        (void)hipStreamSynchronize(stream);        // (an earlier copy of the staging mirror may still be on its way)
+        // (an earlier copy of the staging mirror may still be on its way -- or, mapped arena, a kernel may still be reading the old
+        //  structure; nothing can be when the matrix is set for the first time)
+        if (!(M.arena_mapped && !M.initialised)) (void)hipStreamSynchronize(stream);
         const int rc = upload_matrix_arena(M, c, want_csr, stream);
         if (rc == RSQP_OK) return rc;
         if (rc < 0) return rc;
         // the arena is too small for this matrix (rc == 1): the allocating path below, and the arena is not used again
         M.drop_slices(); M.val.release(); M.rval.release();
-        (void)hipFree(M.arena_dev); M.arena_dev = nullptr; M.arena_cap = 0;
+        if (!M.arena_mapped) (void)hipFree(M.arena_dev);
+        M.arena_dev = nullptr; M.arena_cap = 0;
     }
     if (M.pin) { M.val.release(); M.rval.release(); (void)hipHostFree(M.pin); M.pin = nullptr; M.pin_cap = 0; }
     HIPCHK(M.jc.from(c.jc));
@@ -596,8 +611,11 @@ extern "C" int rsqp_create(int nV, int nC, int device, rsqp_solver **out) {
         s->d_desc.map(reinterpret_cast<QPDesc *>(static_cast<char *>(dev) + bytes_io),
                       reinterpret_cast<QPDesc *>(static_cast<char *>(s->io_host) + bytes_io), 1);
         // (a failed reservation is "no arena": set_A / set_H then allocate per array as the HBM-scale handles do -- ADVICE r4)
-        if (nC > 0 && s->A.reserve(nC, nV) != hipSuccess) { s->A.release_arena(); (void)hipGetLastError(); }
-        if (s->H.reserve(nV, nV) != hipSuccess) { s->H.release_arena(); (void)hipGetLastError(); }
+        // (hs071-scale handles keep the arena in host-mapped memory: set_A / set_H then cost a store each instead of a stream wait and a
+        //  copy -- 78 -> 37 us on the first QP of an SQP run, later QPs unchanged; RSQP_ARENA_MAPPED=0 / 1 forces either form)
+        const bool am = s->kn.arena_mapped >= 0 ? s->kn.arena_mapped != 0 : rsqp_tiny_fits(s->kn, nV, nC) != 0;
+        if (nC > 0 && s->A.reserve(nC, nV, am) != hipSuccess) { s->A.release_arena(); (void)hipGetLastError(); }
+        if (s->H.reserve(nV, nV, am) != hipSuccess) { s->H.release_arena(); (void)hipGetLastError(); }
     } else {
         for (int k = 0; k < 5; k++) HIPCHK(s->d_vec[k].alloc((k <= RSQP_VEC_UB) ? nV : nC));
         HIPCHK(s->d_x.alloc(nV)); HIPCHK(s->d_y.alloc(nV + nC)); HIPCHK(s->d_obj.alloc(1));

@@ -50,6 +50,7 @@ struct SmallKnobs {
     int no_tiny = 0;          // RSQP_SMALL_NO_TINY     no hs071-scale tableau kernel
     int tiny_lds = 0;         // RSQP_TINY_LDS          the hs071-scale kernel with its tableau in LDS, three waves per SIMD
     int exp_matglobal = 0;    // RSQP_EXP_MATGLOBAL     (tuning builds) matrices left in global memory
+    int arena_mapped = -1;    // RSQP_ARENA_MAPPED      single-QP handles: patterns / plans in host-mapped memory, no upload at set_A / set_H (-1: hs071 scale only)
     int no_spin = 0;          // RSQP_NO_SPIN           single-QP waits block in hipStreamSynchronize instead of spinning on a mapped word
     int no_spec_cert = 0;     // RSQP_NO_SPEC_CERT      the certificate of a single LDS-scale QP only on demand
 };

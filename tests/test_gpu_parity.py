@@ -282,9 +282,12 @@ def test_assembly_from_triplets(capi, oracle):
         assert np.array_equal(s.get_H_csc()[2], oracle.sphb_set_matval_sym(hr + 1, hc + 1, True, ooo, nv, ov.copy()))
 
 
-def test_structure_upload_of_small_handles_arena_and_fallback(capi, oracle):
-    """LDS-scale handles take their pattern arrays from an arena allocated by rsqp_create (one copy per set_A / set_H). A triplet
-    list with so many DUPLICATE entries that it exceeds the arena must fall back to the allocating path with the same result."""
+@pytest.mark.parametrize("arena_mapped", ["0", "1"])
+def test_structure_upload_of_small_handles_arena_and_fallback(capi, oracle, arena_mapped, monkeypatch):
+    """LDS-scale handles take their pattern arrays from an arena allocated by rsqp_create (one copy per set_A / set_H, or none at
+    all when the arena is host-mapped -- the default at hs071 scale). A triplet list with so many DUPLICATE entries that it exceeds
+    the arena must fall back to the allocating path with the same result."""
+    monkeypatch.setenv("RSQP_ARENA_MAPPED", arena_mapped)          # (read per handle, at rsqp_create)
     rng = np.random.default_rng(91)
     n, m = 4, 2
     for ndup in (1, 30):                                       # 8 entries / 240 entries (the arena holds a dense 2 x 4 + slack)
