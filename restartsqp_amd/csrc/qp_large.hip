@@ -3592,7 +3592,7 @@ int RsqpLargeEngine::solve(int mode, const double *d_g, const double *d_lb, cons
     if (rc == RET_SETUP_FAILED && (P.rsh || P.dual) && !P.force_null_space && P.err_ == hipSuccess) {
         // A range-space path gave up on a pivot: the explicit inverse of C H^-1 C' squares the conditioning of the active rows, and on
         // the way to a vertex of an INFEASIBLE QP (multipliers growing without bound) that is where it ends -- seen on a 142 x 208
-        // member of the randomised large-engine check, whose null-space run reports "infeasible" like the oracle. The null-space path
+        // member of the randomised large-engine check, whose null-space run reports "infeasible", as the CPU restatement of qpOASES does. The null-space path
         // takes the solve over from a cold start; the changes of both attempts are counted.
         P.force_null_space = true;
         int n2 = maxit;
