@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB = os.path.join(LIB_DIR, "librsqp_hip.so")
-SOURCES = ["rsqp_api.hip", "qp_small.hip", "qp_tiny.hip", "qp_large.hip", "sparse.hip", "dense_la.hip", "qp_dump.cpp", "rsqp_rccl.cpp"]
+SOURCES = ["rsqp_api.hip", "qp_small.hip", "qp_tiny.hip", "qp_lane.hip", "qp_large.hip", "sparse.hip", "dense_la.hip", "qp_dump.cpp", "rsqp_rccl.cpp"]
 STAMP = "build_stamp.cpp"
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 LINK_LIBS = []          # librccl is bound at run time (dlopen in rsqp_rccl.cpp): a single-GPU host needs no RCCL

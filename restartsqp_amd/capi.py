@@ -87,6 +87,7 @@ SYMBOLS = {
     "rsqp_batch_solve": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rsqp_batch_sync": (C.c_int, [C.c_void_p]),
     "rsqp_batch_set_keep_state": (C.c_int, [C.c_void_p, C.c_int]),
+    "rsqp_batch_get_last_kernel": (C.c_int, [C.c_void_p]),
     "rsqp_batch_last_solve_ms": (C.c_float, [C.c_void_p]),
     "rsqp_batch_timer_start": (C.c_int, [C.c_void_p]),
     "rsqp_batch_timer_stop_ms": (C.c_float, [C.c_void_p]),
@@ -462,6 +463,10 @@ class Batch:
 
     def set_keep_state(self, keep):
         check(lib().rsqp_batch_set_keep_state(self._h, int(bool(keep))))
+
+    def last_kernel(self):
+        """0 LDS null-space kernels, 1 tableau kernel with 8 lanes per problem, 2 lane-per-problem kernel (rsqp_batch_get_last_kernel)"""
+        return lib().rsqp_batch_get_last_kernel(self._h)
 
     def last_solve_ms(self):
         return lib().rsqp_batch_last_solve_ms(self._h)

@@ -1208,7 +1208,7 @@ SmallKnobs rsqp_small_knobs_from_env() {
     k.lanes = env_int("RSQP_SMALL_LANES", -1); k.waves = env_int("RSQP_SMALL_WAVES", -1); k.wide = env_int("RSQP_SMALL_WIDE", -1);
     k.wide_lanes = env_int("RSQP_SMALL_WIDE_LANES", 256) == 512 ? 512 : 256; k.nospread = env_int("RSQP_SMALL_NOSPREAD", 0);
     k.no_kkt = env_int("RSQP_SMALL_NO_KKT", 0); k.kkt_only = env_int("RSQP_SMALL_KKT_ONLY", 0); k.no_tiny = env_int("RSQP_SMALL_NO_TINY", 0);
-    k.tiny_lds = env_int("RSQP_TINY_LDS", 0); k.exp_matglobal = env_int("RSQP_EXP_MATGLOBAL", 0);
+    k.tiny_lds = env_int("RSQP_TINY_LDS", 0); k.lane = env_int("RSQP_LANE", -1); k.exp_matglobal = env_int("RSQP_EXP_MATGLOBAL", 0);
     k.arena_mapped = env_int("RSQP_ARENA_MAPPED", -1);
     k.no_spin = getenv("RSQP_NO_SPIN") != nullptr; k.no_spec_cert = getenv("RSQP_NO_SPEC_CERT") != nullptr;
     return k;
@@ -1229,6 +1229,7 @@ hipError_t rsqp_launch_small_qp(const SmallKnobs &kn, const QPPools &p_in, int n
     // 23x6 1.26 / 1.01, 37x14 2.57 / 1.51, 69x28 10.8 / 4.1 -- the chains of the TQ form grow with nZ.
     const int forcedE = kn.engine;
     // hs071-scale problems: the register-resident tableau kernel (qp_tiny.hip) serves every call shape
+    if (rsqp_small_launch_is_tiny(kn, p, nVmax, nCmax) && rsqp_lane_fits(kn, p, nq, nVmax, nCmax, mode)) return rsqp_launch_lane_qp(p, nq, maxWSR, stream);
     if (rsqp_small_launch_is_tiny(kn, p, nVmax, nCmax)) return rsqp_launch_tiny_qp(kn, p, nq, nVmax, nCmax, mode, maxWSR, stream);
     const int eng = forcedE == 0 || forcedE == 1 ? forcedE : (nVmax > 8 ? 1 : 0);
     if (eng == 1 && mat_bytes_max >= 0) mat_bytes_max = 8LL * ((long long)nVmax * nVmax + (long long)nCmax * nVmax);

@@ -1355,6 +1355,7 @@ struct rsqp_batch {
     bool haveH = false;
     SmallKnobs kn = rsqp_small_knobs_from_env();
     int state_engine = -1;                // kernel family that wrote the members' hot-start states (see rsqp_solver::state_engine)
+    int last_kernel = -1;                 // rsqp_batch_get_last_kernel
     bool h_sym = true;                    // every H symmetric value by value (the tableau kernel of qp_tiny.hip may take the batch)
     std::vector<int> h_Hjc, h_Hir;        // host copy of the H patterns (re-examined when the values change), small batches only
     std::vector<QPDesc> desc;
@@ -1545,12 +1546,15 @@ extern "C" int rsqp_batch_solve(rsqp_batch *b, int mode, int max_nWSR) {
         b->state_engine = fam;
         // a cold-start-only batch on the tableau kernel keeps no state and leaves no mark: the handle remembers it instead
         if (fam == 1 && !b->keep_state) { p.skip_mark = 1; b->state_engine = -1; }
+        b->last_kernel = fam == 1 ? (rsqp_lane_fits(b->kn, p, b->nq, b->nVmax, b->nCmax, mode) ? 2 : 1) : 0;
     }
     hipError_t e = rsqp_launch_small_qp(b->kn, p, b->nq, b->nVmax, b->nCmax, b->mat_bytes_max, mode, max_nWSR, b->stream);
     if (e != hipSuccess) return fail(RSQP_ERR_DEVICE, std::string("QP kernel launch: ") + hipGetErrorString(e));
     if (!b->timing) HIPCHK(hipEventRecord(b->ev1, b->stream));
     return RSQP_OK;
 }
+
+extern "C" int rsqp_batch_get_last_kernel(const rsqp_batch *b) { return b ? b->last_kernel : -1; }
 
 extern "C" int rsqp_batch_set_keep_state(rsqp_batch *b, int keep) {
     if (!b) return fail(RSQP_ERR_ARG, "null batch");

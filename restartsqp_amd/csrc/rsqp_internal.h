@@ -48,6 +48,7 @@ struct SmallKnobs {
     int no_kkt = 0;           // RSQP_SMALL_NO_KKT      no mid-size tableau kernel
     int kkt_only = 0;         // RSQP_SMALL_KKT_ONLY    diagnostics: no second pass for bailed members
     int no_tiny = 0;          // RSQP_SMALL_NO_TINY     no hs071-scale tableau kernel
+    int lane = -1;            // RSQP_LANE              0: never the lane-per-problem kernel (qp_lane.hip); n > 0: from n members on (default 16 384)
     int tiny_lds = 0;         // RSQP_TINY_LDS          the hs071-scale kernel with its tableau in LDS, three waves per SIMD
     int exp_matglobal = 0;    // RSQP_EXP_MATGLOBAL     (tuning builds) matrices left in global memory
     int arena_mapped = -1;    // RSQP_ARENA_MAPPED      single-QP handles: patterns / plans in host-mapped memory, no upload at set_A / set_H (-1: hs071 scale only)
@@ -133,6 +134,9 @@ long long rsqp_mat_lds_bytes(int nV, int nC, int annz, int hnnz);
 int rsqp_small_qp_fits(int nVmax, int nCmax);
 // qp_tiny.hip: the register-resident tableau kernel for problems of at most 8 variables and 8 constraints
 int rsqp_tiny_fits(const SmallKnobs &kn, int nVmax, int nCmax);
+// qp_lane.hip: one lane per problem, for cold starts of large one-pattern batches of at most 8 x 2 that keep no state
+int rsqp_lane_fits(const SmallKnobs &kn, const QPPools &p, int nq, int nVmax, int nCmax, int mode);
+hipError_t rsqp_launch_lane_qp(const QPPools &p, int nq, int maxWSR, hipStream_t stream);
 // 1 when rsqp_launch_small_qp hands this launch to the register-resident tableau kernel (qp_tiny.hip), whose hot-start state has
 // another layout than the LDS-resident kernels': the caller forces a cold start when the answer changes between two solves of a
 // handle or batch
