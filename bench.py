@@ -292,7 +292,15 @@ def value_refresh_roofline(capi, problems):
                     "gather_values are the two separate kernels of rounds 1-3 (the gather still refreshes the CSR copy on the CSC setter)"}
 
 
-HEADLINE_PMC_KEY = "tiny_qp_kernel<2"     # substring of the headline kernel's name in the committed PMC files
+# the headline batch's kernel by rsqp_batch_get_last_kernel: (name, substring of it in the committed PMC files, description, note)
+HEADLINE_KERNELS = {
+    1: ("tiny_qp_kernel<2,2>", "tiny_qp_kernel<2",
+        "tiny_qp_kernel<2,2> (qp_tiny.hip: register-resident tableau G = -SWEEP_S(K) of the 10 x 10 KKT matrix, 8 lanes per QP = 8 QPs per wave, dense K staged in LDS)",
+        "instruction-issue-bound kernel (2 waves per SIMD, ~46k cycles per wave of 8 QPs): the HBM fraction is not its limiter; see roofline_lds / DESIGN.md 6"),
+    2: ("lane_qp_kernel<2>", "lane_qp_kernel<2",
+        "lane_qp_kernel<2> (qp_lane.hip: ONE LANE PER QP, 64 QPs per wave, the upper triangle of the tableau G = -SWEEP_S(K) + dense A in LDS [entry][lane], solver state in registers, one wave per SIMD)",
+        "instruction-issue-bound kernel (one wave per SIMD, ~105k cycles per wave of 64 QPs, of which ~30k wait for the inputs / drain the results): the HBM fraction is not its limiter; see roofline_lds / DESIGN.md 6"),
+}
 MFMA_F64_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: dense f64 matrix (v_mfma_f64_16x16x4_f64) peak
 
 
@@ -1073,17 +1081,18 @@ def main():
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9
         fcal, fcal_note = pmc_fetch_calibration()
         ffac = 2.0 if (fcal is not None and fcal > 1.5) else 1.0     # (the guide's x2 or nothing: the calibration decides which)
-        traffic, tfile = pmc_traffic(HEADLINE_PMC_KEY, ffac) if B == 65536 else (None, None)
+        kname, kkey, kdesc, knote = HEADLINE_KERNELS.get(batch.last_kernel(), HEADLINE_KERNELS[1])
+        traffic, tfile = pmc_traffic(kkey, ffac) if B == 65536 else (None, None)
         line = {
             "metric": "QP-subproblem solves/sec", "value": total / elapsed, "unit": "QP solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "hs071-scale QP batch (derived hs071 first QP + seeded 1 %% perturbations, "
                                    "nV=8 x nC=2 via QPhandler [J I -I]), cold start, %d QPs/GPU per step" % B,
-                       "qps_per_gpu": B, "engine": "tiny_qp_kernel<2,2> (qp_tiny.hip: register-resident tableau G = -SWEEP_S(K) of the 10 x 10 KKT matrix, 8 lanes per QP = 8 QPs per wave, dense K staged in LDS)",
+                       "qps_per_gpu": B, "engine": kdesc,
                        "keep_state": bool(args.keep_state),
                        "mean_nWSR": float(np.mean([r["nWSR"] for r in res])), "unsolved_or_kkt_fail": n_bad},
-            "roofline": {"kernel": "tiny_qp_kernel<2,2>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tfile,
                          "traffic_note": "from the committed rocprofv3 --pmc passes of this command, not measured in this run: "
                                          "FETCH_SIZE x %.0f + WRITE_SIZE. The x2 of MI355X_MICROARCH.md (FETCH_SIZE tallies 128-B requests at "
@@ -1092,10 +1101,10 @@ def main():
                                          "known byte count: %s" % (ffac, fcal_note or "no calibration entry found: FETCH_SIZE taken as is"),
                          "fetch_size_factor": ffac,
                          "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_launch,
-                         "note": "instruction-issue-bound kernel (2 waves per SIMD, ~46k cycles per wave of 8 QPs): the HBM fraction is not its limiter; see roofline_lds / DESIGN.md 6"},
+                         "note": knote},
             "kernel_ms_stats": quartiles(per_launch),
         }
-        issue = pmc_issue_roofline(HEADLINE_PMC_KEY) if B == 65536 else None
+        issue = pmc_issue_roofline(kkey) if B == 65536 else None
         if issue:
             line["roofline_lds"] = issue
         if gather is not None:

@@ -153,44 +153,117 @@ struct LaneT {
         store_row(q, w);
     }
 
-    // ------------------------------------------------------------------ staging: CSC of the batch's one pattern -> K in LDS, vectors
-    __device__ __forceinline__ void stage(const QPPools &P, int q) {
+    // ------------------------------------------------------------------ staging: the wave's 64 problems, HBM -> LDS -> registers
+    // In HBM a problem's values are consecutive (member-major pools, the layout every kernel of the library shares), so the block
+    // of the wave's 64 problems is one contiguous run per array: lane j loads elements j, j + 64, ... (512 consecutive bytes per
+    // instruction) and drops each one into the LDS slot of the lane that owns its problem, [entry][owner]; a lane then finds its
+    // own values at compile-time offsets. (One lane gathering its own problem touches 64 cache lines per instruction to use 8
+    // bytes of each: 4 waves per CU staging that way spent 21 k cycles here, a fifth of the kernel.)
+    // T: the wave's LDS block from lane 0's point of view (G = T + lane); nqw: problems of this wave (64, less in the last one)
+    template <int CH> __device__ __forceinline__ void load_block(const double *src, int n, int t0, int cnt, int lane, double (&w)[CH]) const {
+        // elements m = (t0 + t) * 64 + lane of the block, t < CH (beyond the block: its last element, dropped by drop_block)
+        SFOR(t, CH, const int m = (t0 + t) * WL + lane; w[t] = src[m < cnt ? m : cnt - 1];);
+    }
+    template <int CH> __device__ __forceinline__ void drop_block(ldouble *T, int s0, int n, int t0, int cnt, int lane, const double (&w)[CH]) const {
+        const float rn = 1.0f / (float)n;
+        SFOR(t, CH, if (t0 + t < n) {
+                 const int m = (t0 + t) * WL + lane;
+                 const int qq = (int)(((float)m + 0.5f) * rn), e = m - qq * n;      // (m < 64 * 64: the quotient is exact)
+                 if (m < cnt) T[(s0 + e) * WL + qq] = w[t];
+             });
+    }
+    // the reverse for results: every lane has put its n values into slots s0 .. s0 + n - 1 of its own column; lane j stores
+    // elements j, j + 64, ... of the wave's contiguous block (64-bit values, or 32-bit ones kept in the low halves of the slots)
+    template <int CH, class TV> __device__ __forceinline__ void put_block(TV *dst, int n, int cnt, int lane, const ldouble *T, int s0) const {
+        const float rn = 1.0f / (float)n;
+        SFOR(t, CH, if (t < n) {
+                 const int m = t * WL + lane;
+                 const int qq = (int)(((float)m + 0.5f) * rn), e = m - qq * n;
+                 if (m < cnt) {
+                     if constexpr (sizeof(TV) == 8) dst[m] = T[(s0 + e) * WL + qq];
+                     else dst[m] = ((const __attribute__((address_space(3))) int *)(T + (s0 + e) * WL + qq))[0];
+                 }
+             });
+    }
+    __device__ __forceinline__ void wave_sync() const {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __device__ __forceinline__ void stage(const QPPools &P, long long q0, int lane, int nqw, ldouble *T) {
         const int annz = P.uni_annz, hnnz = P.uni_haveH ? P.uni_hnnz : 0;
-        const double *gA = P.Aval + (long long)q * annz, *gH = P.Hval + (long long)q * hnnz;
-        const long long oV = (long long)q * nV, oC = (long long)q * nC;
-        // my vectors: independent loads (slots beyond the sizes read slot 0 and drop it: no branch splits the batch of loads),
-        // all in flight together with the first values of the matrices
-        double lb_[MV], ub_[MV], la_[MC], ua_[MC];
-        SFOR(l, MV, const bool v = l < nV; const long long o = oV + (v ? l : 0);
-             const double a0 = P.g[o], a1 = P.lb[o], a2 = P.ub[o];
-             gN[l] = v ? a0 : 0.0; lb_[l] = v ? a1 : 0.0; ub_[l] = v ? a2 : 0.0;);
-        SFOR(i, MC, const bool c = i < nC; const long long o = nC > 0 ? oC + (c ? i : 0) : 0;
-             const double a0 = nC > 0 ? P.lbA[o] : 0.0, a1 = nC > 0 ? P.ubA[o] : 0.0;
-             la_[i] = c ? a0 : -RSQP_INFTY; ua_[i] = c ? a1 : RSQP_INFTY;);
-        SFOR(e, NA, K[e * WL] = 0.0;);
-        SFOR(e, NH, G[e * WL] = 0.0;);          // (H is staged through the tableau's space, not yet in use)
+        constexpr int SV = 0, SC = 3 * MV, SA = 3 * MV + 2 * MC, SH = NH, HC = 16;      // slots of the passes (SA + NA <= NT, SH + HC <= NT)
+        static_assert(SA + NA <= NT && SH + HC <= NT, "staging slots");
+        const int cV = nqw * nV, cC = nqw * nC, cA = nqw * annz, cH = nqw * hnnz;
+        // lanes beyond the batch (last wave) take the LAST problem's values: they run the same path beside it, store nothing, and
+        // stay for the joint work of the wave (staging here, the stores of the results at the end)
+        const ldouble *S = T + (lane < nqw ? lane : nqw - 1);
+        // ---- every load of the first round before anything waits: vectors, the entries of A, the first 16 entries of H
+        double wg[MV], wl[MV], wu[MV], wla[MC], wua[MC], wa[NA], wh[HC];
+        load_block<MV>(P.g + q0 * nV, nV, 0, cV, lane, wg);
+        load_block<MV>(P.lb + q0 * nV, nV, 0, cV, lane, wl);
+        load_block<MV>(P.ub + q0 * nV, nV, 0, cV, lane, wu);
+        if (nC > 0) { load_block<MC>(P.lbA + q0 * nC, nC, 0, cC, lane, wla); load_block<MC>(P.ubA + q0 * nC, nC, 0, cC, lane, wua); }
+        if (annz > 0) load_block<NA>(P.Aval + q0 * annz, annz, 0, cA, lane, wa);
+        if (hnnz > 0 && hnnz <= HC) load_block<HC>(P.Hval + q0 * hnnz, hnnz, 0, cH, lane, wh);
         // the pattern is the batch's (member 0's arrays, wave-uniform): column pointers in scalars, a column by counting them
         int ajc[MV + 1], hjc[MV + 1];
         SFOR(j, (MV) + 1, ajc[j] = j <= nV ? P.Ajc[j] : 0x7fffffff; hjc[j] = (j <= nV && hnnz > 0) ? P.Hjc[j] : 0x7fffffff;);
-        for (int e0 = 0; e0 < annz; e0 += 8) {
-            double w[8];
-            SFOR(t, 8, w[t] = gA[e0 + t < annz ? e0 + t : annz - 1];);
-            SFOR(t, 8, if (e0 + t < annz) {
-                    const int e = e0 + t, r = P.Air[e];
-                    int c = 0;
-                    SFOR1(j, MV, c += e >= ajc[j] ? 1 : 0;);
-                    K[(r * MV + c) * WL] = w[t];
-                });
+        drop_block<MV>(T, SV, nV, 0, cV, lane, wg);
+        drop_block<MV>(T, SV + MV, nV, 0, cV, lane, wl);
+        drop_block<MV>(T, SV + 2 * MV, nV, 0, cV, lane, wu);
+        if (nC > 0) { drop_block<MC>(T, SC, nC, 0, cC, lane, wla); drop_block<MC>(T, SC + MC, nC, 0, cC, lane, wua); }
+        if (annz > 0) drop_block<NA>(T, SA, annz, 0, cA, lane, wa);
+        SFOR(e, NA, K[e * WL] = 0.0;);
+        wave_sync();
+        // ---- my vectors (slots beyond the sizes: neutral values); my entries of A to their places in the dense copy
+        double lb_[MV], ub_[MV], la_[MC], ua_[MC];
+        SFOR(l, MV, const bool v = l < nV;
+             const double a0 = S[(SV + l) * WL], a1 = S[(SV + MV + l) * WL], a2 = S[(SV + 2 * MV + l) * WL];
+             gN[l] = v ? a0 : 0.0; lb_[l] = v ? a1 : 0.0; ub_[l] = v ? a2 : 0.0;);
+        SFOR(i, MC, const bool c = i < nC;
+             const double a0 = S[(SC + i) * WL], a1 = S[(SC + MC + i) * WL];
+             la_[i] = c ? a0 : -RSQP_INFTY; ua_[i] = c ? a1 : RSQP_INFTY;);
+        for (int e0 = 0; e0 < annz; e0 += 4) {
+            double w[4];
+            SFOR(t, 4, w[t] = S[(SA + (e0 + t < annz ? e0 + t : annz - 1)) * WL];);
+            SFOR(t, 4, if (e0 + t < annz) {
+                     const int e = e0 + t, r = P.Air[e];
+                     int c = 0;
+                     SFOR1(j, MV, c += e >= ajc[j] ? 1 : 0;);
+                     K[(r * MV + c) * WL] = w[t];
+                 });
         }
-        for (int e0 = 0; e0 < hnnz; e0 += 8) {
-            double w[8];
-            SFOR(t, 8, w[t] = gH[e0 + t < hnnz ? e0 + t : hnnz - 1];);
-            SFOR(t, 8, if (e0 + t < hnnz) {
-                    const int e = e0 + t, r = P.Hir[e];
-                    int c = 0;
-                    SFOR1(j, MV, c += e >= hjc[j] ? 1 : 0;);
-                    if (r <= c) G[(((c * (c + 1)) >> 1) + r) * WL] = w[t];         // (H arrives with both triangles: the upper one is kept)
-                });
+        wave_sync();           // (every lane has read its slots: the space is the tableau's / H's from here on)
+        // ---- H: the upper triangle is collected in slots 0 .. NH - 1. Up to 16 entries per problem (the headline's H has 11) pass
+        // through slots SH.. like everything else; a fuller H is gathered by its owner (a round of 16 load instructions covers ALL
+        // entries of 1024 / hnnz problems, not 16 entries of each: the slots of a whole H do not fit beside the triangle)
+        SFOR(e, NH, G[e * WL] = 0.0;);
+        if (hnnz > 0 && hnnz <= HC) {
+            drop_block<HC>(T, SH, hnnz, 0, cH, lane, wh);
+            wave_sync();
+            for (int e0 = 0; e0 < hnnz; e0 += 4) {
+                double w[4];
+                SFOR(t, 4, w[t] = S[(SH + (e0 + t < hnnz ? e0 + t : hnnz - 1)) * WL];);
+                SFOR(t, 4, if (e0 + t < hnnz) {
+                         const int e = e0 + t, r = P.Hir[e];
+                         int c = 0;
+                         SFOR1(j, MV, c += e >= hjc[j] ? 1 : 0;);
+                         if (r <= c) G[(((c * (c + 1)) >> 1) + r) * WL] = w[t];         // (H arrives with both triangles: the upper one is kept)
+                     });
+            }
+        } else if (hnnz > HC) {
+            const double *gH = P.Hval + (q0 + (lane < nqw ? lane : nqw - 1)) * hnnz;
+            for (int e0 = 0; e0 < hnnz; e0 += 8) {
+                double w[8];
+                SFOR(t, 8, w[t] = gH[e0 + t < hnnz ? e0 + t : hnnz - 1];);
+                SFOR(t, 8, if (e0 + t < hnnz) {
+                         const int e = e0 + t, r = P.Hir[e];
+                         int c = 0;
+                         SFOR1(j, MV, c += e >= hjc[j] ? 1 : 0;);
+                         if (r <= c) G[(((c * (c + 1)) >> 1) + r) * WL] = w[t];
+                     });
+            }
         }
         SFOR(e, NH, Hr[e] = G[e * WL];);
         if (hreg != 0.0) {
@@ -526,8 +599,8 @@ __global__ void __launch_bounds__(WL) lane_qp_kernel(QPPools P, int nq, int maxW
     constexpr int N = ENG::N;
     __shared__ __attribute__((aligned(16))) double lds[(ENG::NT + ENG::NA) * WL];
     const int lane = (int)threadIdx.x;
-    const int q = (int)blockIdx.x * WL + lane;
-    if (q >= nq) return;        // (nothing crosses lanes: idle lanes may leave)
+    const int q0 = (int)blockIdx.x * WL, q = q0 + lane;
+    const int nqw = nq - q0 < WL ? nq - q0 : WL;
     ENG E;
     E.G = (ldouble *)lds + lane; E.K = E.G + ENG::NT * WL;
     E.nV = P.uniV; E.nC = P.uniC; E.hreg = P.uni_hreg;
@@ -537,7 +610,7 @@ __global__ void __launch_bounds__(WL) lane_qp_kernel(QPPools P, int nq, int maxW
     E.tlast = clock64();
     long long &tlast = E.tlast;
 #endif
-    E.stage(P, q);
+    E.stage(P, q0, lane, nqw, (ldouble *)lds);
     LSTAMP(0);
     int rcode = RET_OK, nWSR = 0, setup_pivots = 0;
     if (E.bounds_inconsistent()) {
@@ -558,13 +631,28 @@ __global__ void __launch_bounds__(WL) lane_qp_kernel(QPPools P, int nq, int maxW
     // (the refinement step repairs what the update-only tableau accumulates: with at most 4 pivots there is nothing to repair yet)
     const double obj = E.finish(rcode == RET_OK && setup_pivots + nWSR > 4);
     LSTAMP(3);
-    // ---- results (x, y = [bounds; constraints], working set, status / nWSR / objective)
-    const long long oV = (long long)q * nV, oC = (long long)q * nC, oY = (long long)q * (nV + nC);
-    SFOR(l, MV, if (l < nV) { P.x[oV + l] = E.xv[l]; P.ws_b[oV + l] = E.sv[l]; P.y[oY + l] = E.yv[l]; });
-    SFOR(i, MC, if (i < nC) { P.y[oY + nV + i] = E.yc[i]; P.ws_c[oC + i] = E.sc[i]; });
-    const int st = E.status;
-    P.status[q] = E.infeasible ? 100 + st : (E.unbounded ? 200 + st : st);
-    P.ret[q] = rcode; P.nwsr[q] = nWSR; P.nflips[q] = E.nflips; P.obj[q] = obj;
+    // ---- results (x, y = [bounds; constraints], working set, status / nWSR / objective): the member-major vectors leave through the
+    // wave's LDS block like the inputs came (a lane storing its own problem's 8-byte pieces touched 64 lines per instruction)
+    {
+        ldouble *T = (ldouble *)lds;
+        typedef __attribute__((address_space(3))) int lint;
+        constexpr int SX = 0, SY = MV, SB = 2 * MV + MC, SW = 3 * MV + MC;          // slots: x | y | ws_b | ws_c (<= 3 MV + 2 MC <= NT)
+        E.wave_sync();
+        SFOR(l, MV, E.G[(SX + l) * WL] = E.xv[l]; ((lint *)(E.G + (SB + l) * WL))[0] = E.sv[l];);
+        // y of a problem = [nV bound multipliers; nC constraint multipliers]: its slots follow the problem's own nV
+        SFOR(l, MV, if (l < nV) E.G[(SY + l) * WL] = E.yv[l];);
+        SFOR(i, MC, if (i < nC) E.G[(SY + nV + i) * WL] = E.yc[i]; ((lint *)(E.G + (SW + i) * WL))[0] = E.sc[i];);
+        E.wave_sync();
+        E.template put_block<MV>(P.x + (long long)q0 * nV, nV, nqw * nV, lane, T, SX);
+        E.template put_block<MV + MC>(P.y + (long long)q0 * (nV + nC), nV + nC, nqw * (nV + nC), lane, T, SY);
+        E.template put_block<MV>(P.ws_b + (long long)q0 * nV, nV, nqw * nV, lane, T, SB);
+        if (nC > 0) E.template put_block<MC>(P.ws_c + (long long)q0 * nC, nC, nqw * nC, lane, T, SW);
+    }
+    if (q < nq) {
+        const int st = E.status;
+        P.status[q] = E.infeasible ? 100 + st : (E.unbounded ? 200 + st : st);
+        P.ret[q] = rcode; P.nwsr[q] = nWSR; P.nflips[q] = E.nflips; P.obj[q] = obj;
+    }
     LSTAMP(4);
     (void)N;
 }
