@@ -190,33 +190,57 @@ struct LaneT {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    // drop_block for a matrix: entry e of a problem goes to the slot the wave's table names for it (tab[e]: a slot, or -1 = skip)
+    template <int CH> __device__ __forceinline__ void drop_entries(ldouble *T, const __attribute__((address_space(3))) int *tab, int n, int cnt,
+                                                                   int lane, const double (&w)[CH]) const {
+        const float rn = 1.0f / (float)n;
+        SFOR(t, CH, if (t < n) {
+                 const int m = t * WL + lane;
+                 const int qq = (int)(((float)m + 0.5f) * rn), e = m - qq * n;
+                 const int d = tab[e < CH ? e : 0];
+                 if (m < cnt && d >= 0) T[d * WL + qq] = w[t];
+             });
+    }
     __device__ __forceinline__ void stage(const QPPools &P, long long q0, int lane, int nqw, ldouble *T) {
+        typedef __attribute__((address_space(3))) int lint;
         const int annz = P.uni_annz, hnnz = P.uni_haveH ? P.uni_hnnz : 0;
-        constexpr int SV = 0, SC = 3 * MV, SA = 3 * MV + 2 * MC, SH = NH, HC = 16;      // slots of the passes (SA + NA <= NT, SH + HC <= NT)
-        static_assert(SA + NA <= NT && SH + HC <= NT, "staging slots");
+        constexpr int SV = 0, SC = 3 * MV, HC = 16;          // slots of the vectors' pass; H passes through the table when it has <= 16 entries
+        static_assert(3 * MV + 2 * MC <= NT && NA <= HC, "staging slots");
         const int cV = nqw * nV, cC = nqw * nC, cA = nqw * annz, cH = nqw * hnnz;
+        const bool hfast = hnnz > 0 && hnnz <= HC;
         // lanes beyond the batch (last wave) take the LAST problem's values: they run the same path beside it, store nothing, and
         // stay for the joint work of the wave (staging here, the stores of the results at the end)
         const ldouble *S = T + (lane < nqw ? lane : nqw - 1);
-        // ---- every load of the first round before anything waits: vectors, the entries of A, the first 16 entries of H
+        lint *tab = (lint *)(T + (NT + NA) * WL);            // 2 x 16 destination slots (A, H), behind the tableau and A
+        // ---- every load before anything waits: vectors, the entries of A, up to 16 entries of H, and the batch's one pattern
+        // (member 0's arrays): lane e < 16 takes entry e of A, lane 16 + e entry e of H -- its row index, its column by counting
+        // the column pointers it has passed (wave-uniform scalars)
         double wg[MV], wl[MV], wu[MV], wla[MC], wua[MC], wa[NA], wh[HC];
         load_block<MV>(P.g + q0 * nV, nV, 0, cV, lane, wg);
         load_block<MV>(P.lb + q0 * nV, nV, 0, cV, lane, wl);
         load_block<MV>(P.ub + q0 * nV, nV, 0, cV, lane, wu);
         if (nC > 0) { load_block<MC>(P.lbA + q0 * nC, nC, 0, cC, lane, wla); load_block<MC>(P.ubA + q0 * nC, nC, 0, cC, lane, wua); }
         if (annz > 0) load_block<NA>(P.Aval + q0 * annz, annz, 0, cA, lane, wa);
-        if (hnnz > 0 && hnnz <= HC) load_block<HC>(P.Hval + q0 * hnnz, hnnz, 0, cH, lane, wh);
-        // the pattern is the batch's (member 0's arrays, wave-uniform): column pointers in scalars, a column by counting them
-        int ajc[MV + 1], hjc[MV + 1];
-        SFOR(j, (MV) + 1, ajc[j] = j <= nV ? P.Ajc[j] : 0x7fffffff; hjc[j] = (j <= nV && hnnz > 0) ? P.Hjc[j] : 0x7fffffff;);
+        if (hfast) load_block<HC>(P.Hval + q0 * hnnz, hnnz, 0, cH, lane, wh);
+        const bool forH = lane >= HC;
+        const int pe = forH ? lane - HC : lane, pn = forH ? (hfast ? hnnz : 0) : annz;
+        int prow = 0;
+        if (pe < pn) prow = forH ? P.Hir[pe] : P.Air[pe];
+        int pcol = 0;
+        SFOR1(j, MV, const int ja = P.Ajc[j <= nV ? j : nV], jh = hfast ? P.Hjc[j <= nV ? j : nV] : 0;
+              const int jj = forH ? jh : ja; pcol += (j <= nV && pe >= jj) ? 1 : 0;);
+        LSTAMP(10);
+        if (lane < 2 * HC) tab[lane] = pe < pn ? (forH ? (prow <= pcol ? ((pcol * (pcol + 1)) >> 1) + prow : -1) : NT + prow * MV + pcol) : -1;
+        SFOR(e, NA, K[e * WL] = 0.0;);
+        wave_sync();
         drop_block<MV>(T, SV, nV, 0, cV, lane, wg);
         drop_block<MV>(T, SV + MV, nV, 0, cV, lane, wl);
         drop_block<MV>(T, SV + 2 * MV, nV, 0, cV, lane, wu);
         if (nC > 0) { drop_block<MC>(T, SC, nC, 0, cC, lane, wla); drop_block<MC>(T, SC + MC, nC, 0, cC, lane, wua); }
-        if (annz > 0) drop_block<NA>(T, SA, annz, 0, cA, lane, wa);
-        SFOR(e, NA, K[e * WL] = 0.0;);
+        if (annz > 0) drop_entries<NA>(T, tab, annz, cA, lane, wa);          // (straight to their places in the dense copy)
         wave_sync();
-        // ---- my vectors (slots beyond the sizes: neutral values); my entries of A to their places in the dense copy
+        LSTAMP(11);
+        // ---- my vectors (slots beyond the sizes: neutral values)
         double lb_[MV], ub_[MV], la_[MC], ua_[MC];
         SFOR(l, MV, const bool v = l < nV;
              const double a0 = S[(SV + l) * WL], a1 = S[(SV + MV + l) * WL], a2 = S[(SV + 2 * MV + l) * WL];
@@ -224,35 +248,25 @@ struct LaneT {
         SFOR(i, MC, const bool c = i < nC;
              const double a0 = S[(SC + i) * WL], a1 = S[(SC + MC + i) * WL];
              la_[i] = c ? a0 : -RSQP_INFTY; ua_[i] = c ? a1 : RSQP_INFTY;);
-        for (int e0 = 0; e0 < annz; e0 += 4) {
-            double w[4];
-            SFOR(t, 4, w[t] = S[(SA + (e0 + t < annz ? e0 + t : annz - 1)) * WL];);
-            SFOR(t, 4, if (e0 + t < annz) {
-                     const int e = e0 + t, r = P.Air[e];
-                     int c = 0;
-                     SFOR1(j, MV, c += e >= ajc[j] ? 1 : 0;);
-                     K[(r * MV + c) * WL] = w[t];
-                 });
+        if (lane >= nqw) {        // (a lane beyond the batch: its own column of A is the last problem's as well)
+            SFOR(e, NA, K[e * WL] = S[(NT + e) * WL];);
         }
         wave_sync();           // (every lane has read its slots: the space is the tableau's / H's from here on)
-        // ---- H: the upper triangle is collected in slots 0 .. NH - 1. Up to 16 entries per problem (the headline's H has 11) pass
-        // through slots SH.. like everything else; a fuller H is gathered by its owner (a round of 16 load instructions covers ALL
-        // entries of 1024 / hnnz problems, not 16 entries of each: the slots of a whole H do not fit beside the triangle)
+        LSTAMP(12);
+        // ---- H: the upper triangle is collected in slots 0 .. NH - 1 (H arrives with both triangles: the table skips the lower one).
+        // Up to 16 entries per problem (the headline's H has 11) come through the table like A; a fuller H is gathered by its owner
+        // (a round of 16 load instructions covers ALL entries of 1024 / hnnz problems, not 16 entries of each)
         SFOR(e, NH, G[e * WL] = 0.0;);
-        if (hnnz > 0 && hnnz <= HC) {
-            drop_block<HC>(T, SH, hnnz, 0, cH, lane, wh);
+        wave_sync();
+        if (hfast) {
+            drop_entries<HC>(T, tab + HC, hnnz, cH, lane, wh);
             wave_sync();
-            for (int e0 = 0; e0 < hnnz; e0 += 4) {
-                double w[4];
-                SFOR(t, 4, w[t] = S[(SH + (e0 + t < hnnz ? e0 + t : hnnz - 1)) * WL];);
-                SFOR(t, 4, if (e0 + t < hnnz) {
-                         const int e = e0 + t, r = P.Hir[e];
-                         int c = 0;
-                         SFOR1(j, MV, c += e >= hjc[j] ? 1 : 0;);
-                         if (r <= c) G[(((c * (c + 1)) >> 1) + r) * WL] = w[t];         // (H arrives with both triangles: the upper one is kept)
-                     });
+            if (lane >= nqw) {
+                SFOR(e, NH, G[e * WL] = S[e * WL];);
             }
         } else if (hnnz > HC) {
+            int hjc[MV + 1];
+            SFOR(j, (MV) + 1, hjc[j] = P.Hjc[j <= nV ? j : nV]; if (j > nV) hjc[j] = 0x7fffffff;);
             const double *gH = P.Hval + (q0 + (lane < nqw ? lane : nqw - 1)) * hnnz;
             for (int e0 = 0; e0 < hnnz; e0 += 8) {
                 double w[8];
@@ -265,13 +279,13 @@ struct LaneT {
                      });
             }
         }
-        SFOR(e, NH, Hr[e] = G[e * WL];);
-        if (hreg != 0.0) {
-            SFOR(l, MV, if (l < nV) Hr[tri(l, l)] += hreg;);
-        }
+        // (H + hreg I: the LP regularisation; hscale = the largest diagonal entry)
         hscale = 0.0;
+        SFOR(k, MV, SFOR(j, k + 1, double w = G[tri(j, k) * WL];
+                         if (j == k) { w = (k < nV) ? w + hreg : w; hscale = fmax(hscale, k < nV ? fabs(w) : 0.0); }
+                         Hr[tri(j, k)] = w;););
+        LSTAMP(13);
         SFOR(l, MV, const bool v = l < nV;
-             hscale = fmax(hscale, v ? fabs(Hs(l, l)) : 0.0);
              loN[l] = v ? clampinf(lb_[l]) : 0.0; upN[l] = v ? clampinf(ub_[l]) : 0.0;);
         SFOR(i, MC, const bool c = i < nC;
              cloN[i] = c ? clampinf(la_[i]) : -RSQP_INFTY; cupN[i] = c ? clampinf(ua_[i]) : RSQP_INFTY;);
@@ -397,18 +411,20 @@ struct LaneT {
                      const double xu = ss * u[MV + i];
                      xic[i] = on ? xu : 0.0;
                      const double num = wl ? yc[i] : -yc[i], den = wl ? xic[i] : -xic[i];
-                     const bool live = on & (den > RSQP_EPS_DEN);
-                     const double t = (num > 0.0 ? num : 0.0) / (live ? den : 1.0);
-                     const bool better = live & ((t < bt) | ((t == bt) & (i < bid)));
-                     bt = better ? t : bt; bid = better ? i : bid;);
+                     if (on & (den > RSQP_EPS_DEN)) {
+                         const double t = (num > 0.0 ? num : 0.0) / den;
+                         const bool better = (t < bt) | ((t == bt) & (i < bid));
+                         bt = better ? t : bt; bid = better ? i : bid;
+                     });
                 SFOR(l, MV, const bool on = (l < nV) & (sv[l] != 0), wl = sv[l] == -1;
                      const double xu = ss * u[l];
                      xiv[l] = on ? xu : 0.0;
                      const double num = wl ? yv[l] : -yv[l], den = wl ? xiv[l] : -xiv[l];
-                     const bool live = on & (den > RSQP_EPS_DEN);
-                     const double t = (num > 0.0 ? num : 0.0) / (live ? den : 1.0);
-                     const bool better = live & ((t < bt) | ((t == bt) & (nC + l < bid)));
-                     bt = better ? t : bt; bid = better ? nC + l : bid;);
+                     if (on & (den > RSQP_EPS_DEN)) {
+                         const double t = (num > 0.0 ? num : 0.0) / den;
+                         const bool better = (t < bt) | ((t == bt) & (nC + l < bid));
+                         bt = better ? t : bt; bid = better ? nC + l : bid;
+                     });
                 if (bid == 0x7fffffff) {
                     // no partner: infeasible beyond this point of the homotopy -- unless that point IS its end to rounding
                     if (tau >= 1.0 - 1e-9) { treat_done = true; return RET_OK; }
@@ -487,11 +503,15 @@ struct LaneT {
             double dxv[MV], dyv[MV], hd[MV], dax[MC], dyc[MC];
             double bt = 1.0;
             int bid = 0x7fffffff;
+            // (one branch per candidate, around its division: perturbations of one QP agree on which candidates are dead -- half
+            //  of them on the headline batch --, and the wave skips those)
             auto cand = [&](double num, double den, int id, bool ok) {
                 const bool live = ok & (den >= RSQP_EPS_DEN);
-                const double t = (num > 0.0 ? num : 0.0) / (live ? den : 1.0);
-                const bool better = live & ((t < bt) | ((t == bt) & (id < bid)));
-                bt = better ? t : bt; bid = better ? id : bid;
+                if (live) {
+                    const double t = (num > 0.0 ? num : 0.0) / den;
+                    const bool better = (t < bt) | ((t == bt) & (id < bid));
+                    bt = better ? t : bt; bid = better ? id : bid;
+                }
             };
             SFOR(i, MC, const double oc = o[MV + i], noc = -oc;
                  const bool act = sc[i] != 0, wl = sc[i] == -1;
@@ -597,7 +617,7 @@ template <int MC>
 __global__ void __launch_bounds__(WL) lane_qp_kernel(QPPools P, int nq, int maxWSR) {
     typedef LaneT<MC> ENG;
     constexpr int N = ENG::N;
-    __shared__ __attribute__((aligned(16))) double lds[(ENG::NT + ENG::NA) * WL];
+    __shared__ __attribute__((aligned(16))) double lds[(ENG::NT + ENG::NA) * WL + 16];      // (+ the staging table: 32 ints)
     const int lane = (int)threadIdx.x;
     const int q0 = (int)blockIdx.x * WL, q = q0 + lane;
     const int nqw = nq - q0 < WL ? nq - q0 : WL;
@@ -660,13 +680,15 @@ __global__ void __launch_bounds__(WL) lane_qp_kernel(QPPools P, int nq, int maxW
 }  // namespace
 
 // 1 if this launch is served by the lane-per-problem kernel: a cold start of a one-pattern batch that keeps no state (the host
-// remembers that: QPPools::skip_mark), no certificate / doorbell of a single-QP handle, at most 8 x 2, and enough members to fill
-// the chip better than 8 lanes per problem do
+// remembers that: QPPools::skip_mark), no certificate / doorbell of a single-QP handle, at most 8 x 2, and enough members (40 960)
+// to fill the chip better than 8 lanes per problem do
 int rsqp_lane_fits(const SmallKnobs &kn, const QPPools &p, int nq, int nVmax, int nCmax, int mode) {
     if (kn.lane == 0) return 0;
     if (!(p.uni_pat && p.uniV >= 1 && p.uniV <= MV && p.uniC >= 0 && p.uniC <= 2 && nVmax <= MV && nCmax <= 2)) return 0;
     if (mode != 0 || p.keep_state || !p.skip_mark || p.cert_out || p.done_flag || !p.tiny_ok) return 0;
-    return nq >= (kn.lane > 0 ? kn.lane : 16384) ? 1 : 0;
+    // (measured, tools/lane_vs_tiny_sweep.py: a wave of 64 problems takes ~44 us whatever the batch size, the 8-lane kernel 20 us up to
+    //  8 192 problems and 47 us at 32 768: 0.051 / 0.047 ms at 32 768, 0.058 / 0.068 at 49 152, 0.063 / 0.089 at 65 536)
+    return nq >= (kn.lane > 0 ? kn.lane : 40960) ? 1 : 0;
 }
 hipError_t rsqp_launch_lane_qp(const QPPools &p, int nq, int maxWSR, hipStream_t stream) {
     if (nq <= 0) return hipSuccess;

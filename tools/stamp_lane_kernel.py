@@ -21,7 +21,8 @@ reps = 5
 for _ in range(reps):
     b.solve(capi.MODE_COLD, 1000)
 L.rsqp_debug_lane_stamps(buf, 0)
-names = {0: "staging (CSC -> K in LDS, vectors)", 1: "set-up (auxiliary QP)", 2: "homotopy: tail of the last pass",
+names = {10: "staging: loads issued, pattern pointers", 11: "staging: loads arrived, dropped into LDS", 12: "staging: own vectors, A scattered",
+         13: "staging: H scattered and read", 0: "staging: rest", 1: "set-up (auxiliary QP)", 2: "homotopy: tail of the last pass",
          5: "homotopy: x on bounds, refresh, drift, input", 6: "homotopy: out = G in", 7: "homotopy: dx / dy, candidates (divisions)",
          8: "homotopy: decode, step", 9: "homotopy: change (row fetch, tests, pivot, working set)",
          3: "refinement step + exact products + objective", 4: "results to HBM"}
