@@ -44,7 +44,11 @@ extern "C" void rsqp_debug_lane_stamps(unsigned long long *out, int reset) {
     }
 }
 #else
-#define LSTAMP(k) do { } while (0)
+// the phase boundaries stay fences for the instruction scheduler in the product build: without them it hoists the loads and
+// row fetches of a phase far up into the one before, and the 234 registers of persistent state (of the 256 the vector ALU can
+// name) leave no room for that -- 0.0566 ms per launch of the headline batch without, 0.0433 ms with them (the build with the
+// time stamps had been the faster one). Finer fences (per slot, inside the pivots) measured no better (0.0442 ms)
+#define LSTAMP(k) __builtin_amdgcn_sched_barrier(0)
 #endif
 
 namespace {
@@ -680,15 +684,16 @@ __global__ void __launch_bounds__(WL) lane_qp_kernel(QPPools P, int nq, int maxW
 }  // namespace
 
 // 1 if this launch is served by the lane-per-problem kernel: a cold start of a one-pattern batch that keeps no state (the host
-// remembers that: QPPools::skip_mark), no certificate / doorbell of a single-QP handle, at most 8 x 2, and enough members (40 960)
-// to fill the chip better than 8 lanes per problem do
+// remembers that: QPPools::skip_mark), no certificate / doorbell of a single-QP handle, at most 8 x 2, and more members (16 384)
+// than 8 lanes per problem hold at a time
 int rsqp_lane_fits(const SmallKnobs &kn, const QPPools &p, int nq, int nVmax, int nCmax, int mode) {
     if (kn.lane == 0) return 0;
     if (!(p.uni_pat && p.uniV >= 1 && p.uniV <= MV && p.uniC >= 0 && p.uniC <= 2 && nVmax <= MV && nCmax <= 2)) return 0;
     if (mode != 0 || p.keep_state || !p.skip_mark || p.cert_out || p.done_flag || !p.tiny_ok) return 0;
-    // (measured, tools/lane_vs_tiny_sweep.py: a wave of 64 problems takes ~44 us whatever the batch size, the 8-lane kernel 20 us up to
-    //  8 192 problems and 47 us at 32 768: 0.051 / 0.047 ms at 32 768, 0.058 / 0.068 at 49 152, 0.063 / 0.089 at 65 536)
-    return nq >= (kn.lane > 0 ? kn.lane : 40960) ? 1 : 0;
+    // (measured, tools/lane_vs_tiny_sweep.py: a launch of this kernel takes 36 us up to 16 384 problems and 43 us at 65 536 -- one
+    //  round of waves either way; the 8-lane kernel holds 16 384 problems at a time: 21 us up to 8 192, 26 us at 16 384, 40 us at
+    //  20 480 (second round), 47 us at 32 768, 90 us at 65 536)
+    return nq >= (kn.lane > 0 ? kn.lane : 16385) ? 1 : 0;
 }
 hipError_t rsqp_launch_lane_qp(const QPPools &p, int nq, int maxWSR, hipStream_t stream) {
     if (nq <= 0) return hipSuccess;

@@ -48,7 +48,7 @@ struct SmallKnobs {
     int no_kkt = 0;           // RSQP_SMALL_NO_KKT      no mid-size tableau kernel
     int kkt_only = 0;         // RSQP_SMALL_KKT_ONLY    diagnostics: no second pass for bailed members
     int no_tiny = 0;          // RSQP_SMALL_NO_TINY     no hs071-scale tableau kernel
-    int lane = -1;            // RSQP_LANE              0: never the lane-per-problem kernel (qp_lane.hip); n > 0: from n members on (default 40 960)
+    int lane = -1;            // RSQP_LANE              0: never the lane-per-problem kernel (qp_lane.hip); n > 0: from n members on (default 16 385)
     int tiny_lds = 0;         // RSQP_TINY_LDS          the hs071-scale kernel with its tableau in LDS, three waves per SIMD
     int exp_matglobal = 0;    // RSQP_EXP_MATGLOBAL     (tuning builds) matrices left in global memory
     int arena_mapped = -1;    // RSQP_ARENA_MAPPED      single-QP handles: patterns / plans in host-mapped memory, no upload at set_A / set_H (-1: hs071 scale only)

@@ -1,7 +1,7 @@
 """The lane-per-problem kernel (csrc/qp_lane.hip) against the CPU oracle and against the 8-lanes-per-problem kernel it relieves.
 
 It serves cold starts of one-pattern batches of at most 8 x 2 that keep no hot-start state (bench.py's headline workload); by default
-only from 40 960 members on -- RSQP_LANE=1 (read per batch) sends every eligible batch to it. Bar as everywhere: working sets,
+only for more than 16 384 members -- RSQP_LANE=1 (read per batch) sends every eligible batch to it. Bar as everywhere: working sets,
 statuses and iteration counts exact, x / y / objective within 1e-9 relative."""
 import numpy as np
 import pytest
@@ -88,7 +88,7 @@ def test_infeasible_unbounded_and_inconsistent_members(capi, oracle, monkeypatch
 
 
 def test_default_threshold_and_the_calls_the_lane_kernel_does_not_take(capi, oracle, monkeypatch):
-    """Default: batches below 40 960 members, batches that keep their state and hot starts stay on the 8-lane kernel -- and a hot
+    """Default: batches of at most 16 384 members, batches that keep their state and hot starts stay on the 8-lane kernel -- and a hot
     start that follows a cold start of the lane kernel (which kept nothing) runs cold, as the handle promises."""
     monkeypatch.setenv("RSQP_LANE", "1")
     rng = np.random.default_rng(9)

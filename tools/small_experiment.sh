@@ -9,5 +9,5 @@ mkdir -p $OBJ
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -x hip ${EXPDEF:--DRSQP_SMALL_EXPERIMENT=1} "$@" \
     -c restartsqp_amd/csrc/qp_small.hip -o $OBJ/qp_small_exp.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o restartsqp_amd/lib/librsqp_exp.so \
-    $OBJ/qp_small_exp.o $OBJ/qp_tiny.o $OBJ/rsqp_api.o $OBJ/qp_large.o $OBJ/sparse.o $OBJ/dense_la.o $OBJ/qp_dump.o $OBJ/rsqp_rccl.o $OBJ/build_stamp.o
+    $OBJ/qp_small_exp.o $OBJ/qp_tiny.o $OBJ/qp_lane.o $OBJ/rsqp_api.o $OBJ/qp_large.o $OBJ/sparse.o $OBJ/dense_la.o $OBJ/qp_dump.o $OBJ/rsqp_rccl.o $OBJ/build_stamp.o
 echo built restartsqp_amd/lib/librsqp_exp.so
