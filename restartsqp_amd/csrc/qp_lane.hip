@@ -63,6 +63,10 @@ template <int I, int E, class F> __device__ __forceinline__ void sfor_(F &&f) {
 #define SFOR(var, n, ...) sfor_<0, (n)>([&](auto var##_c) { constexpr int var = decltype(var##_c)::value; (void)var; __VA_ARGS__ })
 #define SFOR1(var, n, ...) sfor_<1, (n) + 1>([&](auto var##_c) { constexpr int var = decltype(var##_c)::value; (void)var; __VA_ARGS__ })
 
+// a status word the compiler must not look through: the slot passes of homotopy() each start from a fresh copy, so the lane masks
+// derived from it (free / at lower / at upper) are re-formed per pass (one compare) instead of kept in scalar registers across the
+// whole iteration, from where they were spilled to lanes of vector registers and read back (2-3 % of the kernel)
+__device__ __forceinline__ int opq(int v) { asm volatile("" : "+v"(v)); return v; }
 __host__ __device__ constexpr int tri(int j, int k) { return j <= k ? k * (k + 1) / 2 + j : j * (j + 1) / 2 + k; }
 
 __device__ __forceinline__ double clampinf(double v) { return v > RSQP_INFTY ? RSQP_INFTY : (v < -RSQP_INFTY ? -RSQP_INFTY : v); }
@@ -149,7 +153,8 @@ struct LaneT {
             b[k] = hq ? sq : (hp ? 0.0 : uq[k]);
             cp[k] = fma(w11, a[k], w12 * b[k]);
             cq[k] = fma(w12, a[k], w22 * b[k]););
-            SFOR(k, N, SFOR(j, (k) + 1, G[tri(j, k) * WL] = fma(-a[j], cp[k], fma(-b[j], cq[k], G[tri(j, k) * WL]));););
+            // (one pass; as two passes of one rank-1 term each -- 20 instead of 40 doubles of vectors live -- 0.0449 against 0.0433 ms)
+        SFOR(k, N, SFOR(j, (k) + 1, G[tri(j, k) * WL] = fma(-a[j], cp[k], fma(-b[j], cq[k], G[tri(j, k) * WL]));););
         double w[N];
         SFOR(k, N, w[k] = -sp * cp[k];);
         store_row(p, w);
@@ -482,7 +487,7 @@ struct LaneT {
              loA[i] = c1 ? l1 : loA[i]; upA[i] = c2 ? u1 : upA[i];);
         for (;;) {
             // ---- x exactly on its active bounds; (exact products); drift correction + input of the product
-            SFOR(l, MV, const double xb = sv[l] == -1 ? lo[l] : up[l]; xv[l] = sv[l] != 0 ? xb : xv[l];);
+            SFOR(l, MV, const int s_ = opq(sv[l]); const double xb = s_ == -1 ? lo[l] : up[l]; xv[l] = s_ != 0 ? xb : xv[l];);
             if (since_refresh >= REFRESH) {
                 double gyx[MV], axx[MC], hxx[MV];
                 exact_products(gyx, axx, hxx);
@@ -491,15 +496,15 @@ struct LaneT {
                 since_refresh = 0;
             }
             double in[N], o[N];
-            SFOR(l, MV, const double gl = gy[l] + yv[l]; g[l] = gl;
+            SFOR(l, MV, const int s_ = opq(sv[l]); const double gl = gy[l] + yv[l]; g[l] = gl;
                  const double a0 = -(gN[l] - gl), a1 = loN[l] - lo[l], a2 = upN[l] - up[l];
-                 const double a12 = sv[l] == -1 ? a1 : a2;
-                 in[l] = sv[l] == 0 ? a0 : a12;);              // (slots beyond nV: fixed at 0 = lo = loN)
-            SFOR(i, MC, const bool wl = sc[i] == -1, wu = sc[i] == 1;
+                 const double a12 = s_ == -1 ? a1 : a2;
+                 in[l] = s_ == 0 ? a0 : a12;);              // (slots beyond nV: fixed at 0 = lo = loN)
+            SFOR(i, MC, const int s_ = opq(sc[i]); const bool wl = s_ == -1, wu = s_ == 1;
                  loA[i] = wl ? ax[i] : loA[i]; upA[i] = wu ? ax[i] : upA[i];
                  const double a1 = cloN[i] - loA[i], a2 = cupN[i] - upA[i];
                  const double a12 = wl ? a1 : a2;
-                 in[MV + i] = sc[i] == 0 ? 0.0 : a12;);
+                 in[MV + i] = s_ == 0 ? 0.0 : a12;);
             LSTAMP(5);
             // ---- out = G in; dx / dy / A dx and the ratio test over my slots (ties go to the lowest id)
             g_times(in, o);
@@ -517,8 +522,8 @@ struct LaneT {
                     bt = better ? t : bt; bid = better ? id : bid;
                 }
             };
-            SFOR(i, MC, const double oc = o[MV + i], noc = -oc;
-                 const bool act = sc[i] != 0, wl = sc[i] == -1;
+            SFOR(i, MC, const int s_ = opq(sc[i]); const double oc = o[MV + i], noc = -oc;
+                 const bool act = s_ != 0, wl = s_ == -1;
                  dax[i] = act ? in[MV + i] : noc; dyc[i] = act ? noc : 0.0;
                  const double nA = wl ? yc[i] : -yc[i], nI = ax[i] - loA[i];
                  const double dA = wl ? -dyc[i] : dyc[i], dI = (cloN[i] - loA[i]) - dax[i];
@@ -526,8 +531,8 @@ struct LaneT {
                  const int id1 = act ? i : nC + nV + i;
                  cand(num1, den1, id1, (i < nC) & (act | (cloN[i] > -RSQP_INFTY)));
                  cand(upA[i] - ax[i], dax[i] - (cupN[i] - upA[i]), 2 * nC + nV + i, (i < nC) & !act & (cupN[i] < RSQP_INFTY)););
-            SFOR(l, MV, const double ov = o[l], dg = gN[l] - g[l], nov = -ov, dgo = dg - ov, ndg = -dg;
-                 const bool fr = sv[l] == 0, wl = sv[l] == -1;
+            SFOR(l, MV, const int s_ = opq(sv[l]); const double ov = o[l], dg = gN[l] - g[l], nov = -ov, dgo = dg - ov, ndg = -dg;
+                 const bool fr = s_ == 0, wl = s_ == -1;
                  dxv[l] = fr ? ov : in[l]; dyv[l] = fr ? 0.0 : dgo; hd[l] = fr ? ndg : nov;
                  const double nA = wl ? yv[l] : -yv[l], nI = xv[l] - lo[l];
                  const double dA = wl ? -dyv[l] : dyv[l], dI = (loN[l] - lo[l]) - dxv[l];
@@ -551,12 +556,12 @@ struct LaneT {
             const bool cap = iter >= maxit;
             const bool go = !done & !cap;
             // ---- homotopy step on my slots
-            SFOR(l, MV, yv[l] += tau * dyv[l];
+            SFOR(l, MV, const int s_ = opq(sv[l]); yv[l] += tau * dyv[l];
                  const double xn = xv[l] + tau * dxv[l];
                  const double l1 = lo[l] + tau * (loN[l] - lo[l]), u1 = up[l] + tau * (upN[l] - up[l]);
                  const double gn = g[l] + tau * (gN[l] - g[l]);
                  const bool hit = go & (kind == 4) & (l == idx);
-                 const double xe1 = sv[l] == 1 ? upN[l] : xn, xe = sv[l] == -1 ? loN[l] : xe1;
+                 const double xe1 = s_ == 1 ? upN[l] : xn, xe = s_ == -1 ? loN[l] : xe1;
                  xv[l] = done ? xe : xn;
                  g[l] = done ? gN[l] : gn;
                  gy[l] -= tau * hd[l];
