@@ -122,3 +122,28 @@ def test_default_threshold_and_the_calls_the_lane_kernel_does_not_take(capi, ora
     b.solve(capi.MODE_COLD, 1000)
     assert b.last_kernel() == 1                       # 70 members: below the default threshold
     b.close()
+
+
+def test_members_that_take_different_paths(capi, oracle, monkeypatch):
+    """The QPs of the hs071 SQP trajectory that share one sparsity pattern (tests/golden/sqp_traces.json: 5 of its 6 iterates), each
+    with seeded perturbations, interleaved: neighbouring lanes of a wave take different paths of 5 changes each (entering and leaving
+    bounds and constraints, exchanges) -- the wave executes their union, every lane must still end where the oracle does."""
+    import json, os
+    from collections import Counter
+    from conftest import GOLDEN
+    tr = json.load(open(os.path.join(GOLDEN, "sqp_traces.json")))["hs071"]["qps"]
+    base = [problems.handler_qp(problems.hs071_nlp(np.array(g["x"]), np.array(g["lam"])), delta=g["delta"], rho=g["rho"]) for g in tr]
+    key = lambda q: (tuple(q.A_jc), tuple(q.A_ir), tuple(q.H_jc), tuple(q.H_ir))
+    best = Counter(key(q) for q in base).most_common(1)[0][0]
+    base = [q for q in base if key(q) == best]
+    assert len(base) >= 3
+    rng = np.random.default_rng(20260104)
+    probs = [problems.perturb(rng, base[k % len(base)]) for k in range(640)]
+    res, ok, kkt = solve_cold(capi, probs, "1", monkeypatch)
+    paths = set()
+    for q, r, o in zip(probs, res, ok):
+        qp, rc, n = oracle_cold(oracle, q)
+        assert_same_solution(qp, r, n)
+        assert rc == 0 and o == 1
+        paths.add((r["nWSR"], tuple(r["ws_b"]), tuple(r["ws_c"])))
+    assert len(paths) >= 2
