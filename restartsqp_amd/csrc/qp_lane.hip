@@ -181,6 +181,69 @@ struct LaneT {
                  if (m < cnt) T[(s0 + e) * WL + qq] = w[t];
              });
     }
+    // ---- the state blocks of the wave's problems (QPPools::keep_state: what the next hot start continues from), LDS -> HBM. A
+    // problem's block is N N + 96 doubles + 20 ints, consecutive, blocks `stride` doubles apart (the layout of qp_tiny.hip, see
+    // LANE_TINY_MAGIC). A lane storing its own block piece by piece touches 64 lines per instruction for 8 bytes of each -- 0.17 ms
+    // instead of 0.04 for the headline launch with its state kept; instead lane j handles pairs j, j + 64, ... of the wave's run
+    // of blocks (two doubles of one problem per instruction, consecutive lanes consecutive pairs): 0.075 ms.
+    // The tableau part: both triangles in HBM (what the 8-lane kernel holds), from the upper one in the LDS slots
+    __device__ __forceinline__ void state_put_tableau(double *sbase, long long stride, int nqw, int lane, const ldouble *T) const {
+        static_assert((N & 1) == 0, "pairs of a row");
+        constexpr int PAIRS = N * N / 2;
+        // (a run-time loop: nothing here indexes a register array, and 50 unrolled trips were hoisted in front of each other until
+        //  1 493 registers spilled)
+#pragma unroll 5
+        for (int t = 0; t < PAIRS; t++) {
+            const int m = t * WL + lane;
+            const int qq = m / PAIRS, e = (m - qq * PAIRS) * 2, r = e / N, k = e - r * N;            // entries (r, k), (r, k + 1)
+            const int hi0 = r > k ? r : k, lo0 = r > k ? k : r, hi1 = r > k + 1 ? r : k + 1, lo1 = r > k + 1 ? k + 1 : r;
+            double2 v;
+            v.x = T[(((hi0 * (hi0 + 1)) >> 1) + lo0) * WL + qq]; v.y = T[(((hi1 * (hi1 + 1)) >> 1) + lo1) * WL + qq];
+            if (qq < nqw) *reinterpret_cast<double2 *>(sbase + (long long)qq * stride + e) = v;
+        }
+    }
+    // the slot state + status words behind it: TAILD doubles (the ints as pairs), staged in LDS slots 0 .. in two halves
+    static constexpr int TAILD = 96 + 10, THALF = TAILD / 2;
+    static_assert(THALF <= NT, "the halves of the slot state pass through the tableau's slots");
+    __device__ __forceinline__ void state_put_tail_half(double *sbase, long long stride, int nqw, int lane, const ldouble *T, int half) const {
+#pragma unroll 4
+        for (int t = 0; t < THALF; t++) {
+            const int m = t * WL + lane;
+            const int qq = m / THALF, f = m - qq * THALF;
+            if (qq < nqw) sbase[(long long)qq * stride + N * N + half * THALF + f] = T[f * WL + qq];
+        }
+    }
+    // my slot state as the TAILD doubles behind the tableau: f < 48 variable slot f / 6, field f % 6 (x g lo up gy y); f < 80 constraint
+    // slot (f - 48) / 4 (A x, loA, upA, y; slots beyond MC: zero); f < 96 the tableau's diagonal (G_ll, G_{8+l,8+l}: the 8-lane kernel
+    // tracks them apart); then the status words two by two: sv (8), sc (8), status, masks, magic, pivots since G was built from the data
+    template <int W> __device__ __forceinline__ int state_word(int pivots) const {
+        if constexpr (W < 8) return sv[W];
+        else if constexpr (W < 16) { if constexpr (W - 8 < MC) return sc[W - 8]; else return 0; }
+        else if constexpr (W == 16) return status;
+        else if constexpr (W == 17) return (fmask & 0xff) | ((amask & 0xff) << 8);
+        else if constexpr (W == 18) return 0x7a11e;
+        else return pivots;
+    }
+    template <int F> __device__ __forceinline__ double tail_value(const double (&dg)[N], int pivots) const {
+        if constexpr (F < 48) {
+            constexpr int l = F / 6, c = F % 6;
+            if constexpr (c == 0) return xv[l]; else if constexpr (c == 1) return g[l]; else if constexpr (c == 2) return lo[l];
+            else if constexpr (c == 3) return up[l]; else if constexpr (c == 4) return gy[l]; else return yv[l];
+        } else if constexpr (F < 80) {
+            constexpr int l = (F - 48) / 4, c = (F - 48) % 4;
+            if constexpr (l >= MC) return 0.0;
+            else if constexpr (c == 0) return ax[l]; else if constexpr (c == 1) return loA[l]; else if constexpr (c == 2) return upA[l]; else return yc[l];
+        } else if constexpr (F < 96) {
+            constexpr int l = (F - 80) / 2, c = (F - 80) % 2;
+            if constexpr (c == 0) return dg[l]; else if constexpr (l < MC) return dg[MV + l]; else return 0.0;
+        } else {
+            constexpr int w = (F - 96) * 2;
+            return __hiloint2double(state_word<w + 1>(pivots), state_word<w>(pivots));
+        }
+    }
+    template <int HALF> __device__ __forceinline__ void tail_put_half(ldouble *Gm, const double (&dg)[N], int pivots) const {
+        SFOR(fl, THALF, Gm[fl * WL] = tail_value<HALF * THALF + fl>(dg, pivots););
+    }
     // the reverse for results: every lane has put its n values into slots s0 .. s0 + n - 1 of its own column; lane j stores
     // elements j, j + 64, ... of the wave's contiguous block (64-bit values, or 32-bit ones kept in the low halves of the slots)
     template <int CH, class TV> __device__ __forceinline__ void put_block(TV *dst, int n, int cnt, int lane, const ldouble *T, int s0) const {
@@ -622,16 +685,28 @@ struct LaneT {
     }
 };
 
-template <int MC>
+// persistent state of a problem between solves (hot starts): the layout qp_tiny.hip keeps in the problem's state block. This
+// kernel only WRITES it (KEEP): every hot start of a batch -- new vectors, new matrices, warm re-initialisation -- runs on the 8-lane
+// kernel, which continues from what either kernel left:
+// [N x N tableau by slot, both triangles][6 doubles per variable slot: x g lo up gy y][4 per constraint slot (8 of them): A x, loA,
+// upA, y][G_ll, G_{8+l,8+l} per l][ints: sv (8), sc (8), status, masks, magic, pivots since the tableau was built from the data]
+// (Hot starts were built for this mapping as well -- state block -> LDS -> registers, the guess of a hot start with new matrices
+// turned into a tableau by single and 2 x 2 pivots -- and matched the oracle's hotstart sequences in every test; they were 2-3 x
+// SLOWER than the 8-lane kernel (0.23 / 0.25 ms against 0.097 / 0.13 ms for 65 536 members): 1.6 KB of state per problem each way
+// with one wave per SIMD to hide the round trips, 100-144 KB of code, 340-960 registers spilled to scratch. Removed.)
+constexpr int LANE_TINY_MAGIC = 0x7a11e;
+
+template <int MC, bool KEEP>
 __global__ void __launch_bounds__(WL) lane_qp_kernel(QPPools P, int nq, int maxWSR) {
     typedef LaneT<MC> ENG;
     constexpr int N = ENG::N;
     __shared__ __attribute__((aligned(16))) double lds[(ENG::NT + ENG::NA) * WL + 16];      // (+ the staging table: 32 ints)
+    ldouble *T = (ldouble *)lds;
     const int lane = (int)threadIdx.x;
     const int q0 = (int)blockIdx.x * WL, q = q0 + lane;
     const int nqw = nq - q0 < WL ? nq - q0 : WL;
     ENG E;
-    E.G = (ldouble *)lds + lane; E.K = E.G + ENG::NT * WL;
+    E.G = T + lane; E.K = E.G + ENG::NT * WL;
     E.nV = P.uniV; E.nC = P.uniC; E.hreg = P.uni_hreg;
     E.nflips = 0; E.infeasible = E.unbounded = 0; E.status = QPS_NOTINITIALISED; E.fmask = E.amask = 0; E.since_refresh = 0;
     const int nV = E.nV, nC = E.nC;
@@ -639,7 +714,7 @@ __global__ void __launch_bounds__(WL) lane_qp_kernel(QPPools P, int nq, int maxW
     E.tlast = clock64();
     long long &tlast = E.tlast;
 #endif
-    E.stage(P, q0, lane, nqw, (ldouble *)lds);
+    E.stage(P, q0, lane, nqw, T);
     LSTAMP(0);
     int rcode = RET_OK, nWSR = 0, setup_pivots = 0;
     if (E.bounds_inconsistent()) {
@@ -658,12 +733,29 @@ __global__ void __launch_bounds__(WL) lane_qp_kernel(QPPools P, int nq, int maxW
         LSTAMP(2);
     }
     // (the refinement step repairs what the update-only tableau accumulates: with at most 4 pivots there is nothing to repair yet)
-    const double obj = E.finish(rcode == RET_OK && setup_pivots + nWSR > 4);
+    const int pivots = setup_pivots + nWSR;
+    const double obj = E.finish(rcode == RET_OK && pivots > 4);
     LSTAMP(3);
+    if constexpr (KEEP) {
+        // ---- the state first (its tableau part IS the LDS slots the rest is about to pass through)
+        double *sbase = P.state + (long long)q0 * P.uni_state;
+        double dg[N];
+        SFOR(k, N, dg[k] = E.G[tri(k, k) * WL];);
+        E.wave_sync();
+        E.state_put_tableau(sbase, P.uni_state, nqw, lane, T);
+        E.wave_sync();
+        E.template tail_put_half<0>(E.G, dg, pivots);
+        E.wave_sync();
+        E.state_put_tail_half(sbase, P.uni_state, nqw, lane, T, 0);
+        E.wave_sync();
+        E.template tail_put_half<1>(E.G, dg, pivots);
+        E.wave_sync();
+        E.state_put_tail_half(sbase, P.uni_state, nqw, lane, T, 1);
+        LSTAMP(15);
+    }
     // ---- results (x, y = [bounds; constraints], working set, status / nWSR / objective): the member-major vectors leave through the
     // wave's LDS block like the inputs came (a lane storing its own problem's 8-byte pieces touched 64 lines per instruction)
     {
-        ldouble *T = (ldouble *)lds;
         typedef __attribute__((address_space(3))) int lint;
         constexpr int SX = 0, SY = MV, SB = 2 * MV + MC, SW = 3 * MV + MC;          // slots: x | y | ws_b | ws_c (<= 3 MV + 2 MC <= NT)
         E.wave_sync();
@@ -683,26 +775,27 @@ __global__ void __launch_bounds__(WL) lane_qp_kernel(QPPools P, int nq, int maxW
         P.ret[q] = rcode; P.nwsr[q] = nWSR; P.nflips[q] = E.nflips; P.obj[q] = obj;
     }
     LSTAMP(4);
-    (void)N;
 }
 
 }  // namespace
 
-// 1 if this launch is served by the lane-per-problem kernel: a cold start of a one-pattern batch that keeps no state (the host
-// remembers that: QPPools::skip_mark), no certificate / doorbell of a single-QP handle, at most 8 x 2, and more members (16 384)
-// than 8 lanes per problem hold at a time
+// 1 if this launch is served by the lane-per-problem kernel: a cold start of a one-pattern batch of at most 8 x 2 with more members
+// (16 384) than 8 lanes per problem hold at a time; no certificate / doorbell of a single-QP handle, no warm re-initialisation
+// inputs. A batch that keeps its state gets it written in the 8-lane kernel's layout; one that does not leaves no mark either
+// (the handle remembers: QPPools::skip_mark)
 int rsqp_lane_fits(const SmallKnobs &kn, const QPPools &p, int nq, int nVmax, int nCmax, int mode) {
     if (kn.lane == 0) return 0;
     if (!(p.uni_pat && p.uniV >= 1 && p.uniV <= MV && p.uniC >= 0 && p.uniC <= 2 && nVmax <= MV && nCmax <= 2)) return 0;
-    if (mode != 0 || p.keep_state || !p.skip_mark || p.cert_out || p.done_flag || !p.tiny_ok) return 0;
+    if (mode != 0 || (!p.keep_state && !p.skip_mark) || p.cert_out || p.done_flag || !p.tiny_ok || p.x0 || p.y0 || p.guess_b) return 0;
     // (measured, tools/lane_vs_tiny_sweep.py: a launch of this kernel takes 36 us up to 16 384 problems and 43 us at 65 536 -- one
     //  round of waves either way; the 8-lane kernel holds 16 384 problems at a time: 21 us up to 8 192, 26 us at 16 384, 40 us at
-    //  20 480 (second round), 47 us at 32 768, 90 us at 65 536)
+    //  20 480 (second round), 47 us at 32 768, 90 us at 65 536. With the state kept, 65 536 members: 0.075 against 0.132 ms)
     return nq >= (kn.lane > 0 ? kn.lane : 16385) ? 1 : 0;
 }
 hipError_t rsqp_launch_lane_qp(const QPPools &p, int nq, int maxWSR, hipStream_t stream) {
     if (nq <= 0) return hipSuccess;
     const dim3 grid((unsigned)((nq + WL - 1) / WL)), block(WL);
-    hipLaunchKernelGGL((lane_qp_kernel<2>), grid, block, 0, stream, p, nq, maxWSR);
+    if (p.keep_state) hipLaunchKernelGGL((lane_qp_kernel<2, true>), grid, block, 0, stream, p, nq, maxWSR);
+    else hipLaunchKernelGGL((lane_qp_kernel<2, false>), grid, block, 0, stream, p, nq, maxWSR);
     return hipGetLastError();
 }

@@ -1,6 +1,6 @@
 """The lane-per-problem kernel (csrc/qp_lane.hip) against the CPU oracle and against the 8-lanes-per-problem kernel it relieves.
 
-It serves cold starts of one-pattern batches of at most 8 x 2 that keep no hot-start state (bench.py's headline workload); by default
+It serves cold starts of one-pattern batches of at most 8 x 2 (bench.py's headline workload), with or without the state written back; by default
 only for more than 16 384 members -- RSQP_LANE=1 (read per batch) sends every eligible batch to it. Bar as everywhere: working sets,
 statuses and iteration counts exact, x / y / objective within 1e-9 relative."""
 import numpy as np
@@ -88,8 +88,8 @@ def test_infeasible_unbounded_and_inconsistent_members(capi, oracle, monkeypatch
 
 
 def test_default_threshold_and_the_calls_the_lane_kernel_does_not_take(capi, oracle, monkeypatch):
-    """Default: batches of at most 16 384 members, batches that keep their state and hot starts stay on the 8-lane kernel -- and a hot
-    start that follows a cold start of the lane kernel (which kept nothing) runs cold, as the handle promises."""
+    """Default: batches of at most 16 384 members stay on the 8-lane kernel; a hot start that follows a cold start which kept nothing
+    runs cold, as the handle promises; a warm re-initialisation from (x0, y0) goes to the 8-lane kernel."""
     monkeypatch.setenv("RSQP_LANE", "1")
     rng = np.random.default_rng(9)
     probs = one_pattern_batch(rng, 8, 2, 70)
@@ -104,17 +104,6 @@ def test_default_threshold_and_the_calls_the_lane_kernel_does_not_take(capi, ora
     for q, r in zip(p2, b.results()):
         qp, rc, n = oracle_cold(oracle, q)
         assert_same_solution(qp, r, n)
-    b.set_keep_state(True)
-    b.solve(capi.MODE_COLD, 1000)                     # keeps its state: the 8-lane kernel
-    assert b.last_kernel() == 1
-    p3 = [problems.perturb(rng, q, 0.05) for q in p2]
-    orcs = [oracle_cold(oracle, q)[0] for q in p2]
-    b.set_vectors_from(p3)
-    b.solve(capi.MODE_HOT_VECTORS, 1000)
-    assert b.last_kernel() == 1
-    for q, qp, r in zip(p3, orcs, b.results()):
-        rc, n = qp.hotstart(q.g, q.lb, q.ub, q.lbA, q.ubA, 1000)
-        assert_same_solution(qp, r, n)
     b.close()
     monkeypatch.delenv("RSQP_LANE")
     b = capi.Batch(probs)
@@ -122,6 +111,75 @@ def test_default_threshold_and_the_calls_the_lane_kernel_does_not_take(capi, ora
     b.solve(capi.MODE_COLD, 1000)
     assert b.last_kernel() == 1                       # 70 members: below the default threshold
     b.close()
+
+
+@pytest.mark.parametrize("shape", [(8, 2), (6, 1), (4, 2), (8, 0)])
+def test_hot_starts_continue_from_the_state_the_lane_kernel_wrote(capi, oracle, monkeypatch, shape):
+    """A batch that keeps its state: the cold start runs on the lane kernel, which writes every member's state block in the layout of
+    the 8-lane kernel; the hot starts that follow (new vectors, new matrices, new vectors) run on the 8-lane kernel FROM that state.
+    Every member against the oracle's init / hotstart / hotstart(H, g, A, ...) sequence: working sets, statuses and nWSR exact --
+    a hot start from a wrong tableau or slot state would take another path."""
+    monkeypatch.setenv("RSQP_LANE", "1")
+    nV, nC = shape
+    rng = np.random.default_rng(300 + 10 * nV + nC)
+    probs = one_pattern_batch(rng, nV, nC, 150, free=(nV == 6))
+    b = capi.Batch(probs)
+    b.solve(capi.MODE_COLD, 1000)
+    assert b.last_kernel() == 2
+    orcs = []
+    for q, r in zip(probs, b.results()):
+        qp, rc, n = oracle_cold(oracle, q)
+        assert_same_solution(qp, r, n)
+        orcs.append(qp)
+    cur = probs
+    hot_changes = 0
+    for step in range(3):
+        nxt = [problems.perturb(rng, q, 0.3) for q in cur]
+        new_matrices = step == 1
+        if new_matrices:
+            for q in nxt:
+                q.A_val = q.A_val * (1.0 + 0.02 * rng.normal(size=q.A_val.shape))
+        b.set_vectors_from(nxt)
+        if new_matrices:
+            b.set_matrix_values(np.concatenate([q.A_val for q in nxt]), np.concatenate([q.H_val for q in nxt]))
+        b.solve(capi.MODE_HOT_MATRICES if new_matrices else capi.MODE_HOT_VECTORS, 1000)
+        assert b.last_kernel() == 1
+        for q, qp, r in zip(nxt, orcs, b.results()):
+            if new_matrices:
+                qp.set_A_csc(q.A_jc, q.A_ir, q.A_val); qp.set_H_csc(q.H_jc, q.H_ir, q.H_val)
+                rc, n = qp.hotstart_matrices(q.g, q.lb, q.ub, q.lbA, q.ubA, 1000)
+            else:
+                rc, n = qp.hotstart(q.g, q.lb, q.ub, q.lbA, q.ubA, 1000)
+            assert_same_solution(qp, r, n)
+            hot_changes += r["nWSR"]
+        cur = nxt
+    assert hot_changes > 0
+    b.close()
+
+
+def test_a_sequence_of_calls_gives_the_same_answers_with_and_without_the_lane_kernel(capi, oracle, monkeypatch):
+    """cold start (state kept), hot start on new vectors, hot start with new matrices: the same answers, state-dependent results
+    included (nWSR of every hot start), whether the cold start ran on the lane kernel or on the 8-lane kernel."""
+    rng = np.random.default_rng(77)
+    probs = one_pattern_batch(rng, 8, 2, 90)
+    p2 = [problems.perturb(rng, q, 0.3) for q in probs]
+    p3 = [problems.perturb(rng, q, 0.3) for q in p2]
+    out = {}
+    for lane in ("0", "1"):
+        monkeypatch.setenv("RSQP_LANE", lane)
+        b = capi.Batch(probs)
+        b.solve(capi.MODE_COLD, 1000)
+        assert b.last_kernel() == (2 if lane == "1" else 1)
+        seq = [b.results()]
+        b.set_vectors_from(p2); b.solve(capi.MODE_HOT_VECTORS, 1000); seq.append(b.results())
+        b.set_vectors_from(p3); b.solve(capi.MODE_HOT_MATRICES, 1000); seq.append(b.results())
+        assert b.last_kernel() == 1
+        out[lane] = seq
+        b.close()
+    for ra, rb in zip(out["0"], out["1"]):
+        for a, c in zip(ra, rb):
+            assert a["status"] == c["status"] and a["nWSR"] == c["nWSR"] and np.array_equal(a["ws_b"], c["ws_b"]) and np.array_equal(a["ws_c"], c["ws_c"])
+            assert np.abs(a["x"] - c["x"]).max() <= 1e-9 * max(1.0, np.abs(a["x"]).max())
 
 
 def test_members_that_take_different_paths(capi, oracle, monkeypatch):
