@@ -691,7 +691,7 @@ struct LaneT {
 // [N x N tableau by slot, both triangles][6 doubles per variable slot: x g lo up gy y][4 per constraint slot (8 of them): A x, loA,
 // upA, y][G_ll, G_{8+l,8+l} per l][ints: sv (8), sc (8), status, masks, magic, pivots since the tableau was built from the data]
 // (Hot starts were built for this mapping as well -- state block -> LDS -> registers, the guess of a hot start with new matrices
-// turned into a tableau by single and 2 x 2 pivots -- and matched the oracle's hotstart sequences in every test; they were 2-3 x
+// turned into a tableau by single and 2 x 2 pivots -- and matched the CPU restatement's hot-start sequences in every test; they were 2-3 x
 // SLOWER than the 8-lane kernel (0.23 / 0.25 ms against 0.097 / 0.13 ms for 65 536 members): 1.6 KB of state per problem each way
 // with one wave per SIMD to hide the round trips, 100-144 KB of code, 340-960 registers spilled to scratch. Removed.)
 constexpr int LANE_TINY_MAGIC = 0x7a11e;
