@@ -707,7 +707,9 @@ def native_rccl_gather(capi, torch, dist, batch, B, rank, world, local_rank, kst
 
 
 def trajectory_batch(capi, problems, nq=16384, reps=20):
-    """The headline kernel on a REPRESENTATIVE mix: the QPs of a whole hs071 SQP run (tests/golden/sqp_traces.json: the
+    """The hs071-scale batch path on a REPRESENTATIVE mix (two sparsity patterns among the members: the 8-lanes-per-problem kernel; the
+    members that share one pattern, 65 536 of them, on the lane-per-problem kernel: tools/lane_mix_check.py): the QPs of a whole
+    hs071 SQP run (tests/golden/sqp_traces.json: the
     iterates, multipliers, radii and penalties of the trajectory that tests/sqp_driver.py walks to the optimum), each with
     seeded 1 % perturbations, cold start -- not only the first QP of the run, whose two working-set changes make it the
     easiest one."""
@@ -731,6 +733,7 @@ def trajectory_batch(capi, problems, nq=16384, reps=20):
     out = {"qps": nq, "distinct_trajectory_qps": len(base), "ms_per_batch": st["median"], "qp_solves_per_s": nq / (st["median"] * 1e-3),
            "mean_nWSR": float(np.mean([r["nWSR"] for r in res])), "max_nWSR": int(max(r["nWSR"] for r in res)),
            "solved_and_certified": int(sum(1 for r, o in zip(res, ok) if r["status"] == 20 and o == 1)),
+           "kernel": {0: "LDS null-space kernels", 1: "tiny_qp_kernel (8 lanes per QP)", 2: "lane_qp_kernel (one lane per QP)"}.get(b.last_kernel()),
            "note": "cold starts of the %d QPs of the hs071 trajectory (x_k, lambda_k, delta_k of every SQP iteration) +- 1 %%" % len(base)}
     b.close()
     return out
