@@ -249,7 +249,7 @@ int rsqp_batch_sync(rsqp_batch *b);
 int rsqp_batch_set_keep_state(rsqp_batch *b, int keep);
 /* which kernel the last rsqp_batch_solve launched (diagnostics; all of them stand in for the SQProblem::init / hotstart calls of
  * qpOASESInterface.cpp:155,180-206): 0 = the LDS-resident null-space kernels (+ the mid-size tableau kernel), 1 = the hs071-scale
- * tableau kernel with 8 lanes per problem, 2 = the lane-per-problem kernel (cold starts of one-pattern batches of at most 8 x 2
+ * tableau kernel with 8 lanes per problem, 2 = the lane-per-problem kernel (cold starts of one-shape batches of at most 8 x 2
  * with more than 16 384 members; RSQP_LANE); -1 before the first solve */
 int rsqp_batch_get_last_kernel(const rsqp_batch *b);
 /* device time of the last rsqp_batch_solve in milliseconds (HIP events on its stream) */

@@ -1,7 +1,7 @@
-// qp_lane.hip -- hs071-scale QPs of a ONE-PATTERN batch, cold start, ONE LANE PER PROBLEM (round 5).
+// qp_lane.hip -- hs071-scale QPs of a ONE-SHAPE batch, cold start, ONE LANE PER PROBLEM (round 5).
 //
-// Replaces, for large batches of one shape and one sparsity pattern (parameter scans, perturbations of one QP: bench.py's
-// headline workload, 65 536 x the hs071 QP through the QPhandler formulation), the qpOASES 3.2.1 SQProblem::init call made
+// Replaces, for large batches of one shape (one sparsity pattern -- parameter scans, perturbations of one QP: bench.py's
+// headline workload, 65 536 x the hs071 QP through the QPhandler formulation -- or patterns of their own), the qpOASES 3.2.1 SQProblem::init call made
 // at reference src/qpOASESInterface.cpp:155,180. Same algorithm as qp_tiny.hip -- the symmetric tableau
 //      G = - SWEEP_S(K),  K = [H A'; A 0],  S = free variables + active constraints,  N = 8 + MC fixed slots
 // with one product per step direction, one principal pivot per working-set change (2 x 2 block for an exchange), exact
@@ -273,9 +273,31 @@ struct LaneT {
                  if (m < cnt && d >= 0) T[d * WL + qq] = w[t];
              });
     }
-    __device__ __forceinline__ void stage(const QPPools &P, long long q0, int lane, int nqw, ldouble *T) {
+    // the entries of MY problem's A (into the dense copy) or H (upper triangle into slots 0 ..) from its own CSC arrays: column
+    // pointers first, then the entries four at a time (index and value loads of a round in flight together), a column by counting
+    // the pointers an entry has passed. Lanes differ in their counts: the loop runs to the longest of the wave
+    template <bool ISH> __device__ __forceinline__ void own_entries(const int *jc, const int *ir_pool, const double *val_pool, int off) {
+        int cp[MV + 1];
+        SFOR(j, (MV) + 1, cp[j] = jc[j <= nV ? j : nV];);
+        const int cnt = cp[MV] - cp[0];                       // (cp[j] = cp[nV] beyond nV)
+        const int *ir = ir_pool + off; const double *val = val_pool + off;
+        for (int e0 = 0; e0 < cnt; e0 += 4) {
+            int r[4]; double w[4];
+            SFOR(t, 4, const int e = e0 + t < cnt ? e0 + t : cnt - 1; r[t] = ir[e]; w[t] = val[e];);
+            SFOR(t, 4, if (e0 + t < cnt) {
+                     const int e = cp[0] + e0 + t;
+                     int c = 0;
+                     SFOR1(j, MV, c += (j <= nV && e >= cp[j]) ? 1 : 0;);
+                     if constexpr (ISH) { if (r[t] <= c) G[(((c * (c + 1)) >> 1) + r[t]) * WL] = w[t]; }
+                     else K[(r[t] * MV + c) * WL] = w[t];
+                 });
+        }
+    }
+    // UNI: the batch has ONE sparsity pattern (QPPools::uni_pat). Otherwise -- one SHAPE, patterns of their own -- the vectors still
+    // come through the wave's block, but every lane walks the CSC arrays of its own problem (own_entries)
+    template <bool UNI> __device__ __forceinline__ void stage(const QPPools &P, long long q0, int lane, int nqw, ldouble *T) {
         typedef __attribute__((address_space(3))) int lint;
-        const int annz = P.uni_annz, hnnz = P.uni_haveH ? P.uni_hnnz : 0;
+        const int annz = UNI ? P.uni_annz : 0, hnnz = (UNI && P.uni_haveH) ? P.uni_hnnz : 0;       // (entries that travel through the block)
         constexpr int SV = 0, SC = 3 * MV, HC = 16;          // slots of the vectors' pass; H passes through the table when it has <= 16 entries
         static_assert(3 * MV + 2 * MC <= NT && NA <= HC, "staging slots");
         const int cV = nqw * nV, cC = nqw * nC, cA = nqw * annz, cH = nqw * hnnz;
@@ -294,6 +316,7 @@ struct LaneT {
         if (nC > 0) { load_block<MC>(P.lbA + q0 * nC, nC, 0, cC, lane, wla); load_block<MC>(P.ubA + q0 * nC, nC, 0, cC, lane, wua); }
         if (annz > 0) load_block<NA>(P.Aval + q0 * annz, annz, 0, cA, lane, wa);
         if (hfast) load_block<HC>(P.Hval + q0 * hnnz, hnnz, 0, cH, lane, wh);
+        if constexpr (UNI) {
         const bool forH = lane >= HC;
         const int pe = forH ? lane - HC : lane, pn = forH ? (hfast ? hnnz : 0) : annz;
         int prow = 0;
@@ -303,6 +326,7 @@ struct LaneT {
               const int jj = forH ? jh : ja; pcol += (j <= nV && pe >= jj) ? 1 : 0;);
         LSTAMP(10);
         if (lane < 2 * HC) tab[lane] = pe < pn ? (forH ? (prow <= pcol ? ((pcol * (pcol + 1)) >> 1) + prow : -1) : NT + prow * MV + pcol) : -1;
+        }
         SFOR(e, NA, K[e * WL] = 0.0;);
         wave_sync();
         drop_block<MV>(T, SV, nV, 0, cV, lane, wg);
@@ -320,9 +344,11 @@ struct LaneT {
         SFOR(i, MC, const bool c = i < nC;
              const double a0 = S[(SC + i) * WL], a1 = S[(SC + MC + i) * WL];
              la_[i] = c ? a0 : -RSQP_INFTY; ua_[i] = c ? a1 : RSQP_INFTY;);
-        if (lane >= nqw) {        // (a lane beyond the batch: its own column of A is the last problem's as well)
+        if (UNI && lane >= nqw) {        // (a lane beyond the batch: its own column of A is the last problem's as well)
             SFOR(e, NA, K[e * WL] = S[(NT + e) * WL];);
         }
+        const long long qown = q0 + (lane < nqw ? lane : nqw - 1);
+        if constexpr (!UNI) own_entries<false>(P.Ajc + qown * (nV + 1), P.Air, P.Aval, P.desc[qown].offAnz);
         wave_sync();           // (every lane has read its slots: the space is the tableau's / H's from here on)
         LSTAMP(12);
         // ---- H: the upper triangle is collected in slots 0 .. NH - 1 (H arrives with both triangles: the table skips the lower one).
@@ -336,6 +362,8 @@ struct LaneT {
             if (lane >= nqw) {
                 SFOR(e, NH, G[e * WL] = S[e * WL];);
             }
+        } else if (!UNI) {
+            if (P.uni_haveH) own_entries<true>(P.Hjc + qown * (nV + 1), P.Hir, P.Hval, P.desc[qown].offHnz);
         } else if (hnnz > HC) {
             int hjc[MV + 1];
             SFOR(j, (MV) + 1, hjc[j] = P.Hjc[j <= nV ? j : nV]; if (j > nV) hjc[j] = 0x7fffffff;);
@@ -696,7 +724,7 @@ struct LaneT {
 // with one wave per SIMD to hide the round trips, 100-144 KB of code, 340-960 registers spilled to scratch. Removed.)
 constexpr int LANE_TINY_MAGIC = 0x7a11e;
 
-template <int MC, bool KEEP>
+template <int MC, bool KEEP, bool UNI>
 __global__ void __launch_bounds__(WL) lane_qp_kernel(QPPools P, int nq, int maxWSR) {
     typedef LaneT<MC> ENG;
     constexpr int N = ENG::N;
@@ -714,7 +742,7 @@ __global__ void __launch_bounds__(WL) lane_qp_kernel(QPPools P, int nq, int maxW
     E.tlast = clock64();
     long long &tlast = E.tlast;
 #endif
-    E.stage(P, q0, lane, nqw, T);
+    E.template stage<UNI>(P, q0, lane, nqw, T);
     LSTAMP(0);
     int rcode = RET_OK, nWSR = 0, setup_pivots = 0;
     if (E.bounds_inconsistent()) {
@@ -779,13 +807,14 @@ __global__ void __launch_bounds__(WL) lane_qp_kernel(QPPools P, int nq, int maxW
 
 }  // namespace
 
-// 1 if this launch is served by the lane-per-problem kernel: a cold start of a one-pattern batch of at most 8 x 2 with more members
+// 1 if this launch is served by the lane-per-problem kernel: a cold start of a one-shape batch of at most 8 x 2 with more members
 // (16 384) than 8 lanes per problem hold at a time; no certificate / doorbell of a single-QP handle, no warm re-initialisation
 // inputs. A batch that keeps its state gets it written in the 8-lane kernel's layout; one that does not leaves no mark either
 // (the handle remembers: QPPools::skip_mark)
 int rsqp_lane_fits(const SmallKnobs &kn, const QPPools &p, int nq, int nVmax, int nCmax, int mode) {
     if (kn.lane == 0) return 0;
-    if (!(p.uni_pat && p.uniV >= 1 && p.uniV <= MV && p.uniC >= 0 && p.uniC <= 2 && nVmax <= MV && nCmax <= 2)) return 0;
+    // one shape (every member nV x nC); one sparsity pattern (member 0's arrays serve all) or patterns of their own (each lane walks its own)
+    if (!(p.uniV >= 1 && p.uniV <= MV && p.uniC >= 0 && p.uniC <= 2 && nVmax <= MV && nCmax <= 2 && (p.uni_pat || p.desc))) return 0;
     if (mode != 0 || (!p.keep_state && !p.skip_mark) || p.cert_out || p.done_flag || !p.tiny_ok || p.x0 || p.y0 || p.guess_b) return 0;
     // (measured, tools/lane_vs_tiny_sweep.py: a launch of this kernel takes 36 us up to 16 384 problems and 43 us at 65 536 -- one
     //  round of waves either way; the 8-lane kernel holds 16 384 problems at a time: 21 us up to 8 192, 26 us at 16 384, 40 us at
@@ -795,7 +824,12 @@ int rsqp_lane_fits(const SmallKnobs &kn, const QPPools &p, int nq, int nVmax, in
 hipError_t rsqp_launch_lane_qp(const QPPools &p, int nq, int maxWSR, hipStream_t stream) {
     if (nq <= 0) return hipSuccess;
     const dim3 grid((unsigned)((nq + WL - 1) / WL)), block(WL);
-    if (p.keep_state) hipLaunchKernelGGL((lane_qp_kernel<2, true>), grid, block, 0, stream, p, nq, maxWSR);
-    else hipLaunchKernelGGL((lane_qp_kernel<2, false>), grid, block, 0, stream, p, nq, maxWSR);
+    if (p.uni_pat) {
+        if (p.keep_state) hipLaunchKernelGGL((lane_qp_kernel<2, true, true>), grid, block, 0, stream, p, nq, maxWSR);
+        else hipLaunchKernelGGL((lane_qp_kernel<2, false, true>), grid, block, 0, stream, p, nq, maxWSR);
+    } else {
+        if (p.keep_state) hipLaunchKernelGGL((lane_qp_kernel<2, true, false>), grid, block, 0, stream, p, nq, maxWSR);
+        else hipLaunchKernelGGL((lane_qp_kernel<2, false, false>), grid, block, 0, stream, p, nq, maxWSR);
+    }
     return hipGetLastError();
 }

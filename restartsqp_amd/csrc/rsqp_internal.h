@@ -134,7 +134,7 @@ long long rsqp_mat_lds_bytes(int nV, int nC, int annz, int hnnz);
 int rsqp_small_qp_fits(int nVmax, int nCmax);
 // qp_tiny.hip: the register-resident tableau kernel for problems of at most 8 variables and 8 constraints
 int rsqp_tiny_fits(const SmallKnobs &kn, int nVmax, int nCmax);
-// qp_lane.hip: one lane per problem, for cold starts of large one-pattern batches of at most 8 x 2
+// qp_lane.hip: one lane per problem, for cold starts of large one-shape batches of at most 8 x 2
 int rsqp_lane_fits(const SmallKnobs &kn, const QPPools &p, int nq, int nVmax, int nCmax, int mode);
 hipError_t rsqp_launch_lane_qp(const QPPools &p, int nq, int maxWSR, hipStream_t stream);
 // 1 when rsqp_launch_small_qp hands this launch to the register-resident tableau kernel (qp_tiny.hip), whose hot-start state has

@@ -182,6 +182,47 @@ def test_a_sequence_of_calls_gives_the_same_answers_with_and_without_the_lane_ke
             assert np.abs(a["x"] - c["x"]).max() <= 1e-9 * max(1.0, np.abs(a["x"]).max())
 
 
+@pytest.mark.parametrize("shape", [(8, 2), (5, 1), (7, 0)])
+def test_one_shape_with_patterns_of_their_own(capi, oracle, monkeypatch, shape):
+    """Members of one SHAPE whose sparsity patterns differ (three base problems of different density, interleaved member by member;
+    entry counts differ as well): the vectors still travel through the wave's block, every lane walks the CSC arrays of its own
+    problem. Cold start with the state kept, then a hot start on new vectors (8-lane kernel, from that state): the oracle's sequence."""
+    monkeypatch.setenv("RSQP_LANE", "1")
+    nV, nC = shape
+    rng = np.random.default_rng(900 + 10 * nV + nC)
+    bases = [problems.random_qp(rng, nV, nC, density=d) for d in (0.3, 0.6, 1.0)]
+    # different Hessian patterns too: thin out the off-diagonal part of the first two (symmetrically)
+    for k, b0 in enumerate(bases[:2]):
+        H = b0.dense_H()
+        M = np.triu(rng.random((nV, nV)) < (0.3 + 0.3 * k), 1)
+        H = H * (M | M.T | np.eye(nV, dtype=bool))
+        H += np.diag(np.abs(H).sum(axis=1))                      # (stays positive definite)
+        from restartsqp_amd.qpdump import dense_to_csc
+        b0.H_jc, b0.H_ir, b0.H_val = dense_to_csc(H)
+    probs = []
+    for k in range(201):
+        q = problems.perturb(rng, bases[k % 3], 0.05)
+        q.A_val = q.A_val * (1.0 + 0.05 * rng.normal(size=q.A_val.shape))
+        probs.append(q)
+    assert len({(len(q.A_val), len(q.H_val)) for q in probs}) >= 2
+    b = capi.Batch(probs)
+    b.solve(capi.MODE_COLD, 1000)
+    assert b.last_kernel() == 2
+    orcs = []
+    for q, r in zip(probs, b.results()):
+        qp, rc, n = oracle_cold(oracle, q)
+        assert_same_solution(qp, r, n)
+        orcs.append(qp)
+    nxt = [problems.perturb(rng, q, 0.3) for q in probs]
+    b.set_vectors_from(nxt)
+    b.solve(capi.MODE_HOT_VECTORS, 1000)
+    assert b.last_kernel() == 1
+    for q, qp, r in zip(nxt, orcs, b.results()):
+        rc, n = qp.hotstart(q.g, q.lb, q.ub, q.lbA, q.ubA, 1000)
+        assert_same_solution(qp, r, n)
+    b.close()
+
+
 def test_members_that_take_different_paths(capi, oracle, monkeypatch):
     """The QPs of the hs071 SQP trajectory that share one sparsity pattern (tests/golden/sqp_traces.json: 5 of its 6 iterates), each
     with seeded perturbations, interleaved: neighbouring lanes of a wave take different paths of 5 changes each (entering and leaving

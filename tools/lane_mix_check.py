@@ -10,12 +10,14 @@ nq = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 tr = json.load(open(os.path.join(ROOT, "tests", "golden", "sqp_traces.json")))["hs071"]["qps"]
 base = [problems.handler_qp(problems.hs071_nlp(np.array(g["x"]), np.array(g["lam"])), delta=g["delta"], rho=g["rho"]) for g in tr]
 print("distinct QPs", len(base), "entry counts (A, H):", sorted(set((len(q.A_val), len(q.H_val)) for q in base)))
-# the lane-per-problem kernel serves batches of ONE sparsity pattern: keep the QPs that share the most common one
-key = lambda q: (tuple(q.A_jc), tuple(q.A_ir), tuple(q.H_jc), tuple(q.H_ir))
-from collections import Counter
-best = Counter(key(q) for q in base).most_common(1)[0][0]
-base = [q for q in base if key(q) == best]
-print("QPs of the most common pattern:", len(base), "H entries", len(base[0].H_val))
+# (two sparsity patterns among the six: H has 11 or 16 entries -- the lane-per-problem kernel then lets every lane walk the CSC arrays
+#  of its own problem; ONE_PATTERN=1 keeps the QPs of the most common pattern only: everything through the wave's block)
+if os.environ.get("ONE_PATTERN") == "1":
+    key = lambda q: (tuple(q.A_jc), tuple(q.A_ir), tuple(q.H_jc), tuple(q.H_ir))
+    from collections import Counter
+    best = Counter(key(q) for q in base).most_common(1)[0][0]
+    base = [q for q in base if key(q) == best]
+    print("QPs of the most common pattern:", len(base), "H entries", len(base[0].H_val))
 rng = np.random.default_rng(20260104)
 for label, pick in (("trajectory mix, member k = QP k mod %d" % len(base), lambda k: base[k % len(base)]),
                     ("trajectory mix, blocks of 64 equal QPs", lambda k: base[(k // 64) % len(base)])):

@@ -1,5 +1,5 @@
 """Randomised parity beyond the test suite: the lane-per-problem kernel (qp_lane.hip) against the 8-lanes-per-problem kernel
-(qp_tiny.hip) AND the CPU oracle on many one-pattern batches -- random shapes 1..8 x 0..2, random patterns (sparse to dense H and A),
+(qp_tiny.hip) AND the CPU oracle on many one-shape batches (two in three of one sparsity pattern, one in three of up to three patterns) -- random shapes 1..8 x 0..2, random patterns (sparse to dense H and A),
 free / one-sided / boxed variables, degenerate members (duplicate rows, zero rows, integer data), infeasible members.
     python tools/lane_random_sweep.py [patterns] [members per pattern] [seed]
 Prints one line per disagreement and a summary; exit code 1 when a member differs from the ORACLE in status, working set or nWSR
@@ -56,8 +56,18 @@ bad_oracle = bad_tiny = deg_diff = members = lane_batches = 0
 for ip in range(npat):
     kind = int(rng.integers(0, 6))
     base = base_problem(kind)
+    # every third batch: one SHAPE, three patterns of their own (the lanes walk their own CSC arrays)
+    bases = [base]
+    if ip % 3 == 2:
+        for _ in range(40):
+            if len(bases) == 3:
+                break
+            other = base_problem(kind)
+            if (other.nV, other.nC) == (base.nV, base.nC):
+                bases.append(other)
     probs = []
-    for _ in range(nmem):
+    for im_ in range(nmem):
+        base = bases[im_ % len(bases)]
         q = problems.perturb(rng, base, 0.05 if kind != 3 else 0.0)
         if kind != 3:
             q.A_val = q.A_val * (1.0 + 0.05 * rng.normal(size=q.A_val.shape))
