@@ -706,9 +706,9 @@ def native_rccl_gather(capi, torch, dist, batch, B, rank, world, local_rank, kst
             "bytes_gathered_per_rank": 8 * world * B * stride}
 
 
-def trajectory_batch(capi, problems, nq=16384, reps=20):
-    """The hs071-scale batch path on a REPRESENTATIVE mix (two sparsity patterns among the members: the 8-lanes-per-problem kernel; the
-    members that share one pattern, 65 536 of them, on the lane-per-problem kernel: tools/lane_mix_check.py): the QPs of a whole
+def trajectory_batch(capi, problems, nq=65536, reps=20):
+    """The hs071-scale batch path on a REPRESENTATIVE mix, at the headline's batch size (rounds 3-4 ran 16 384 members of it on the
+    8-lanes-per-problem kernel: 0.0416 ms = 394 M solves/s; 65 536 members take that kernel 0.138 ms): the QPs of a whole
     hs071 SQP run (tests/golden/sqp_traces.json: the
     iterates, multipliers, radii and penalties of the trajectory that tests/sqp_driver.py walks to the optimum), each with
     seeded 1 % perturbations, cold start -- not only the first QP of the run, whose two working-set changes make it the
