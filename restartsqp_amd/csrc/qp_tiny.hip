@@ -783,7 +783,12 @@ hipError_t rsqp_launch_tiny_qp(const SmallKnobs &kn, const QPPools &p, int nq, i
     // RSQP_TINY_LDS=1: the tableau in LDS, three waves per SIMD (tuning: default decided by measurement)
     const int glds = kn.tiny_lds;
     if (nCmax <= 2 && glds) hipLaunchKernelGGL((tiny_qp_kernel<2, 3, true>), grid, block, 0, stream, p, nq, mode, maxWSR);
+    // (launches of at most one workgroup per CU -- the single QP of an SQP iteration above all -- get the builds for ONE wave per SIMD:
+    //  268 instead of 256 registers, none spilled to scratch, whose round trips sit in the chain of a lone wave: cold solve of the hs071 QP 30.5 ->
+    //  28.8 us through the Python loop, the solveQP replay 23.0 -> 22.6 us through the C++ boundary, batches of up to 8 192 QPs 3 % faster)
+    else if (nCmax <= 2 && nq <= 32 * 256) hipLaunchKernelGGL((tiny_qp_kernel<2, 1>), grid, block, 0, stream, p, nq, mode, maxWSR);
     else if (nCmax <= 2) hipLaunchKernelGGL((tiny_qp_kernel<2, 2>), grid, block, 0, stream, p, nq, mode, maxWSR);
+    else if (nCmax <= 4 && nq <= 32 * 256) hipLaunchKernelGGL((tiny_qp_kernel<4, 1>), grid, block, 0, stream, p, nq, mode, maxWSR);
     else if (nCmax <= 4) hipLaunchKernelGGL((tiny_qp_kernel<4, 2>), grid, block, 0, stream, p, nq, mode, maxWSR);
     else hipLaunchKernelGGL((tiny_qp_kernel<8, 1>), grid, block, 0, stream, p, nq, mode, maxWSR);
     return hipGetLastError();
