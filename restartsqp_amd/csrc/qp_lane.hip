@@ -213,9 +213,9 @@ struct LaneT {
             if (qq < nqw) sbase[(long long)qq * stride + N * N + half * THALF + f] = T[f * WL + qq];
         }
     }
-    // my slot state as the TAILD doubles behind the tableau: f < 48 variable slot f / 6, field f % 6 (x g lo up gy y); f < 80 constraint
-    // slot (f - 48) / 4 (A x, loA, upA, y; slots beyond MC: zero); f < 96 the tableau's diagonal (G_ll, G_{8+l,8+l}: the 8-lane kernel
-    // tracks them apart); then the status words two by two: sv (8), sc (8), status, masks, magic, pivots since G was built from the data
+    // my slot state as the TAILD doubles behind the tableau: f < 48 field f / 8 (x g lo up gy y) of variable slot f % 8; f < 80 field
+    // (f - 48) / 8 (A x, loA, upA, y) of constraint slot (f - 48) % 8 (slots beyond MC: zero); f < 96 the tableau's diagonal (G_ll of the
+    // 8 variable slots, then G_{8+l,8+l}: the 8-lane kernel tracks them apart); then the status words two by two: sv (8), sc (8), status, masks, magic, pivots since G was built from the data
     template <int W> __device__ __forceinline__ int state_word(int pivots) const {
         if constexpr (W < 8) return sv[W];
         else if constexpr (W < 16) { if constexpr (W - 8 < MC) return sc[W - 8]; else return 0; }
@@ -226,15 +226,15 @@ struct LaneT {
     }
     template <int F> __device__ __forceinline__ double tail_value(const double (&dg)[N], int pivots) const {
         if constexpr (F < 48) {
-            constexpr int l = F / 6, c = F % 6;
+            constexpr int c = F / 8, l = F % 8;
             if constexpr (c == 0) return xv[l]; else if constexpr (c == 1) return g[l]; else if constexpr (c == 2) return lo[l];
             else if constexpr (c == 3) return up[l]; else if constexpr (c == 4) return gy[l]; else return yv[l];
         } else if constexpr (F < 80) {
-            constexpr int l = (F - 48) / 4, c = (F - 48) % 4;
+            constexpr int c = (F - 48) / 8, l = (F - 48) % 8;
             if constexpr (l >= MC) return 0.0;
             else if constexpr (c == 0) return ax[l]; else if constexpr (c == 1) return loA[l]; else if constexpr (c == 2) return upA[l]; else return yc[l];
         } else if constexpr (F < 96) {
-            constexpr int l = (F - 80) / 2, c = (F - 80) % 2;
+            constexpr int c = (F - 80) / 8, l = (F - 80) % 8;
             if constexpr (c == 0) return dg[l]; else if constexpr (l < MC) return dg[MV + l]; else return 0.0;
         } else {
             constexpr int w = (F - 96) * 2;
@@ -716,8 +716,8 @@ struct LaneT {
 // persistent state of a problem between solves (hot starts): the layout qp_tiny.hip keeps in the problem's state block. This
 // kernel only WRITES it (KEEP): every hot start of a batch -- new vectors, new matrices, warm re-initialisation -- runs on the 8-lane
 // kernel, which continues from what either kernel left:
-// [N x N tableau by slot, both triangles][6 doubles per variable slot: x g lo up gy y][4 per constraint slot (8 of them): A x, loA,
-// upA, y][G_ll, G_{8+l,8+l} per l][ints: sv (8), sc (8), status, masks, magic, pivots since the tableau was built from the data]
+// [N x N tableau, both triangles][6 fields x 8 variable slots: x g lo up gy y][4 fields x 8 constraint slots: A x, loA, upA, y][G_ll (8)]
+// [G_{8+l,8+l} (8)][ints: sv (8), sc (8), status, masks, magic, pivots since the tableau was built from the data]
 // (Hot starts were built for this mapping as well -- state block -> LDS -> registers, the guess of a hot start with new matrices
 // turned into a tableau by single and 2 x 2 pivots -- and matched the CPU restatement's hot-start sequences in every test; they were 2-3 x
 // SLOWER than the 8-lane kernel (0.23 / 0.25 ms against 0.097 / 0.13 ms for 65 536 members): 1.6 KB of state per problem each way

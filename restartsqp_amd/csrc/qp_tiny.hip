@@ -618,8 +618,12 @@ struct EngineT {
     }
 };
 
-// persistent state of one problem (hot starts), in the problem's state block: [N*N tableau by slot][10 doubles per variable
-// lane][7 per constraint lane][ints: sv, sc per lane, status, masks, magic]
+// persistent state of one problem (hot starts), in the problem's state block, every piece LANE-CONTIGUOUS (the 8 lanes of a problem
+// store 8 consecutive doubles per instruction; the first layout -- a row of the tableau and the fields of a slot consecutive PER LANE --
+// made every store of a wave 64 separate 8-byte pieces): [N x N tableau, entry k of every slot's row together: position k N + slot; the
+// matrix is symmetric, so this is its transpose up to rounding][6 fields x 8 variable slots: x g lo up gy y][4 fields x 8 constraint
+// slots: A x, loA, upA, y][G_ll of the 8 variable slots][G_{8+l,8+l} of the 8 constraint slots][ints: sv (8), sc (8), status, masks, magic,
+// pivots]
 template <int MC> __device__ __forceinline__ long long tiny_state_doubles() { return (long long)(MV + MC) * (MV + MC) + 8LL * 6 + 8LL * 4 + 8LL * 2; }
 constexpr int TINY_MAGIC = 0x7a11e;
 
@@ -662,15 +666,15 @@ __global__ void __launch_bounds__(TB, W) tiny_qp_kernel(QPPools P, int nq, int m
         if (si[18] != TINY_MAGIC || si[16] == QPS_NOTINITIALISED) mode = 0;
         else {
             double *pr = sd + N * N;
-            px = pr[l * 6 + 0]; pyv = pr[l * 6 + 5]; pyc = pr[48 + l * 4 + 3]; psv = si[l]; psc = si[8 + l];
+            px = pr[0 * 8 + l]; pyv = pr[5 * 8 + l]; pyc = pr[48 + 3 * 8 + l]; psv = si[l]; psc = si[8 + l];
             if (mode == 1) {
 #pragma unroll
-                for (int k = 0; k < N; k++) { E.set_gv(k, sd[l * N + k]); E.set_gc(k, l < MC ? sd[(MV + (l < MC ? l : 0)) * N + k] : 0.0); }
+                for (int k = 0; k < N; k++) { E.set_gv(k, sd[k * N + l]); E.set_gc(k, l < MC ? sd[k * N + MV + (l < MC ? l : 0)] : 0.0); }
                 if constexpr (GL) TSYNC();
-                E.xv = px; E.g = pr[l * 6 + 1]; E.lo = pr[l * 6 + 2]; E.up = pr[l * 6 + 3]; E.gy = pr[l * 6 + 4]; E.yv = pyv;
-                E.ax = pr[48 + l * 4 + 0]; E.loA = pr[48 + l * 4 + 1]; E.upA = pr[48 + l * 4 + 2]; E.yc = pyc;
+                E.xv = px; E.g = pr[1 * 8 + l]; E.lo = pr[2 * 8 + l]; E.up = pr[3 * 8 + l]; E.gy = pr[4 * 8 + l]; E.yv = pyv;
+                E.ax = pr[48 + 0 * 8 + l]; E.loA = pr[48 + 1 * 8 + l]; E.upA = pr[48 + 2 * 8 + l]; E.yc = pyc;
                 E.sv = psv; E.sc = psc; E.status = si[16]; E.fmask = si[17] & 0xff; E.amask = (si[17] >> 8) & 0xff;
-                E.dV = pr[80 + l * 2]; E.dC = pr[80 + l * 2 + 1];
+                E.dV = pr[80 + l]; E.dC = pr[88 + l];
             }
         }
     }
@@ -719,11 +723,11 @@ __global__ void __launch_bounds__(TB, W) tiny_qp_kernel(QPPools P, int nq, int m
     }
     if (P.keep_state) {
 #pragma unroll
-        for (int k = 0; k < N; k++) { sd[l * N + k] = E.gv(k); if (l < MC) sd[(MV + l) * N + k] = E.gc(k); }
+        for (int k = 0; k < N; k++) { sd[k * N + l] = E.gv(k); if (l < MC) sd[k * N + MV + l] = E.gc(k); }
         double *pr = sd + N * N;
-        pr[l * 6 + 0] = E.xv; pr[l * 6 + 1] = E.g; pr[l * 6 + 2] = E.lo; pr[l * 6 + 3] = E.up; pr[l * 6 + 4] = E.gy; pr[l * 6 + 5] = E.yv;
-        pr[48 + l * 4 + 0] = E.ax; pr[48 + l * 4 + 1] = E.loA; pr[48 + l * 4 + 2] = E.upA; pr[48 + l * 4 + 3] = E.yc;
-        pr[80 + l * 2] = E.dV; pr[80 + l * 2 + 1] = E.dC;
+        pr[0 * 8 + l] = E.xv; pr[1 * 8 + l] = E.g; pr[2 * 8 + l] = E.lo; pr[3 * 8 + l] = E.up; pr[4 * 8 + l] = E.gy; pr[5 * 8 + l] = E.yv;
+        pr[48 + 0 * 8 + l] = E.ax; pr[48 + 1 * 8 + l] = E.loA; pr[48 + 2 * 8 + l] = E.upA; pr[48 + 3 * 8 + l] = E.yc;
+        pr[80 + l] = E.dV; pr[88 + l] = E.dC;
         si[l] = E.sv; si[8 + l] = E.sc;
         if (l == 0) { si[16] = E.status; si[17] = (E.fmask & 0xff) | ((E.amask & 0xff) << 8); si[18] = TINY_MAGIC; si[19] = pivots; }
     } else if (l == 0 && !P.skip_mark) { si[16] = QPS_NOTINITIALISED; si[18] = TINY_MAGIC; }
