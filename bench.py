@@ -297,8 +297,8 @@ HEADLINE_KERNELS = {
     1: ("tiny_qp_kernel<2,2>", "tiny_qp_kernel<2",
         "tiny_qp_kernel<2,2> (qp_tiny.hip: register-resident tableau G = -SWEEP_S(K) of the 10 x 10 KKT matrix, 8 lanes per QP = 8 QPs per wave, dense K staged in LDS)",
         "instruction-issue-bound kernel (2 waves per SIMD, ~46k cycles per wave of 8 QPs): the HBM fraction is not its limiter; see roofline_lds / DESIGN.md 6"),
-    2: ("lane_qp_kernel<2, false>", "lane_qp_kernel<2",
-        "lane_qp_kernel<2, false> (qp_lane.hip: ONE LANE PER QP, 64 QPs per wave, the upper triangle of the tableau G = -SWEEP_S(K) + dense A in LDS [entry][lane], solver state in registers, one wave per SIMD)",
+    2: ("lane_qp_kernel<2, false, true>", "lane_qp_kernel<2, false, true>",
+        "lane_qp_kernel<2, false, true> (qp_lane.hip: ONE LANE PER QP, 64 QPs per wave, the upper triangle of the tableau G = -SWEEP_S(K) + dense A in LDS [entry][lane], solver state in registers, one wave per SIMD)",
         "instruction-issue-bound kernel (one wave per SIMD, ~105k cycles per wave of 64 QPs, of which ~30k wait for the inputs / drain the results): the HBM fraction is not its limiter; see roofline_lds / DESIGN.md 6"),
 }
 MFMA_F64_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: dense f64 matrix (v_mfma_f64_16x16x4_f64) peak
@@ -1085,6 +1085,8 @@ def main():
         fcal, fcal_note = pmc_fetch_calibration()
         ffac = 2.0 if (fcal is not None and fcal > 1.5) else 1.0     # (the guide's x2 or nothing: the calibration decides which)
         kname, kkey, kdesc, knote = HEADLINE_KERNELS.get(batch.last_kernel(), HEADLINE_KERNELS[1])
+        if batch.last_kernel() == 2 and args.keep_state:      # (the build that writes the state blocks back)
+            kname = kkey = "lane_qp_kernel<2, true, true>"
         traffic, tfile = pmc_traffic(kkey, ffac) if B == 65536 else (None, None)
         line = {
             "metric": "QP-subproblem solves/sec", "value": total / elapsed, "unit": "QP solves/s",

@@ -722,8 +722,12 @@ __global__ void __launch_bounds__(TB, W) tiny_qp_kernel(QPPools P, int nq, int m
         P.ret[q] = rcode; P.nwsr[q] = nWSR; P.nflips[q] = E.nflips; P.obj[q] = obj;
     }
     if (P.keep_state) {
+        // (a hot start on new vectors that changed nothing in the working set found the tableau in the block and leaves it there:
+        //  half of the block's bytes -- the late iterations of an SQP run)
+        if (!(mode == 1 && nWSR == 0)) {
 #pragma unroll
-        for (int k = 0; k < N; k++) { sd[k * N + l] = E.gv(k); if (l < MC) sd[k * N + MV + l] = E.gc(k); }
+            for (int k = 0; k < N; k++) { sd[k * N + l] = E.gv(k); if (l < MC) sd[k * N + MV + l] = E.gc(k); }
+        }
         double *pr = sd + N * N;
         pr[0 * 8 + l] = E.xv; pr[1 * 8 + l] = E.g; pr[2 * 8 + l] = E.lo; pr[3 * 8 + l] = E.up; pr[4 * 8 + l] = E.gy; pr[5 * 8 + l] = E.yv;
         pr[48 + 0 * 8 + l] = E.ax; pr[48 + 1 * 8 + l] = E.loA; pr[48 + 2 * 8 + l] = E.upA; pr[48 + 3 * 8 + l] = E.yc;
