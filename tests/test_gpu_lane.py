@@ -246,3 +246,29 @@ def test_members_that_take_different_paths(capi, oracle, monkeypatch):
         assert rc == 0 and o == 1
         paths.add((r["nWSR"], tuple(r["ws_b"]), tuple(r["ws_c"])))
     assert len(paths) >= 2
+
+
+@pytest.mark.parametrize("limit", [0, 1, 2])
+def test_iteration_limit(capi, oracle, monkeypatch, limit):
+    """nWSR limits below / at what the members need (the hs071 QP takes 2 changes): status, return code and the iterate where the
+    homotopy was stopped as the oracle has them; the 8-lane kernel agrees."""
+    monkeypatch.setenv("RSQP_LANE", "1")
+    probs = problems.hs071_scale_batch(100)
+    b = capi.Batch(probs)
+    b.set_keep_state(False)
+    b.solve(capi.MODE_COLD, limit)
+    assert b.last_kernel() == 2
+    lane = b.results()
+    b.close()
+    monkeypatch.setenv("RSQP_LANE", "0")
+    b = capi.Batch(probs)
+    b.set_keep_state(False)
+    b.solve(capi.MODE_COLD, limit)
+    tiny = b.results()
+    b.close()
+    for q, r, t in zip(probs, lane, tiny):
+        qp, rc, n = oracle_cold(oracle, q, nWSR=limit)
+        assert r["status"] == qp.exitflag() == t["status"] and r["nWSR"] == n == t["nWSR"]
+        assert (r["status"] == 20) == (limit >= 2)
+        assert np.array_equal(qp.ws_bounds, r["ws_b"]) and np.array_equal(qp.ws_constraints, r["ws_c"])
+        assert np.abs(qp.x - r["x"]).max() <= 1e-9 * max(1.0, np.abs(qp.x).max())
