@@ -1547,8 +1547,26 @@ __global__ void __launch_bounds__(256) k_sym_tile(double *__restrict__ M, long l
     const double ui = (UPD && i < n) ? cs * scal[ci] * u[i] : 0.0;
     if (MV && threadIdx.x < SYT) { wI[threadIdx.x] = i < n ? w[i] : 0.0; const int j = J * SYT + (int)threadIdx.x; wJ[threadIdx.x] = j < n ? w[j] : 0.0; }
     if (!UPD) {
-        // read-only product (the lazy form of round 5): all 16 loads of a lane are issued before the first LDS store -- with the
-        // 4-deep unroll of the updating form a compute unit had ~32 KB in flight and the kernel read at 2.8 TB/s
+        // read-only product (the lazy form of round 5): all loads of a lane are issued before the first LDS store -- with the
+        // 4-deep unroll of the updating form a compute unit had ~32 KB in flight and the kernel read at 2.8 TB/s. 16 bytes per lane
+        // (two rows of a column; 8-byte loads reach 0.54-0.70 of the 16-byte rate on this part, MI355X_MICROARCH.md): lane pair-of-
+        // rows r2 = t & 31 of column 8 c + (t >> 5); the tile arrives in LDS as before, so the sums keep their order bit for bit
+        if ((ld & 1) == 0 && (reinterpret_cast<unsigned long long>(M) & 15) == 0) {
+            const int r2 = threadIdx.x & 31, cg = threadIdx.x >> 5, i0 = I * SYT + 2 * r2;
+            double2 m2[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int j = J * SYT + c * 8 + cg;
+                m2[c] = (i0 < n && j < n) ? *reinterpret_cast<const double2 *>(M + (long long)j * ld + i0) : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const int jj = c * 8 + cg, j = J * SYT + jj;
+                const bool cj = j < n;
+                S[jj][2 * r2] = (cj && i0 < n && (!diag || 2 * r2 <= jj)) ? m2[c].x : 0.0;
+                S[jj][2 * r2 + 1] = (cj && i0 + 1 < n && (!diag || 2 * r2 + 1 <= jj)) ? m2[c].y : 0.0;
+            }
+        } else {
         double mm[16];
 #pragma unroll
         for (int c = 0; c < 16; c++) {
@@ -1557,6 +1575,7 @@ __global__ void __launch_bounds__(256) k_sym_tile(double *__restrict__ M, long l
         }
 #pragma unroll
         for (int c = 0; c < 16; c++) S[wv * 16 + c][ii] = mm[c];
+        }
     } else {
 #pragma unroll 4
     for (int c = 0; c < 16; c++) {

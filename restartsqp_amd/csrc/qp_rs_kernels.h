@@ -287,6 +287,36 @@ __global__ void __launch_bounds__(256) k_sym_tile_lz(double *__restrict__ M, lon
         const int k = e / SYT, jj = e % SYT, j = J * SYT + jj;
         pj[k][jj] = (k < P.np && j < n) ? P.vec[(long long)k * P.stride + j] : 0.0;
     }
+    if ((ld & 1) == 0 && (reinterpret_cast<unsigned long long>(M) & 15) == 0) {
+        // 16 bytes per lane (two rows of a column, as k_sym_tile's read-only product): lane pair-of-rows r2 of column 8 c + (t >> 5).
+        // An entry outside the triangle (below the diagonal of a diagonal tile, behind row n) is written back as it was read
+        const int r2 = threadIdx.x & 31, cg = threadIdx.x >> 5, i0 = I * SYT + 2 * r2;
+        double p0[LZK], p1[LZK];
+#pragma unroll
+        for (int k = 0; k < LZK; k++) {
+            p0[k] = (k < P.np && i0 < n) ? P.c[k] * P.vec[(long long)k * P.stride + i0] : 0.0;
+            p1[k] = (k < P.np && i0 + 1 < n) ? P.c[k] * P.vec[(long long)k * P.stride + i0 + 1] : 0.0;
+        }
+        __syncthreads();
+        double2 m2[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int j = J * SYT + c * 8 + cg;
+            m2[c] = (i0 < n && j < n) ? *reinterpret_cast<const double2 *>(M + (long long)j * ld + i0) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const int jj = c * 8 + cg, j = J * SYT + jj;
+            if (i0 < n && j < n && (!diag || 2 * r2 <= jj)) {
+                double2 m = m2[c];
+                const bool v1 = i0 + 1 < n && (!diag || 2 * r2 + 1 <= jj);
+#pragma unroll
+                for (int k = 0; k < LZK; k++) { m.x += p0[k] * pj[k][jj]; m.y = v1 ? m.y + p1[k] * pj[k][jj] : m.y; }
+                *reinterpret_cast<double2 *>(M + (long long)j * ld + i0) = m;
+            }
+        }
+        return;
+    }
     double pi[LZK];
 #pragma unroll
     for (int k = 0; k < LZK; k++) pi[k] = (k < P.np && i < n) ? P.c[k] * P.vec[(long long)k * P.stride + i] : 0.0;
