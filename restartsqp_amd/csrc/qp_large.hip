@@ -2948,8 +2948,17 @@ struct RsqpLargeEngine::Impl {
         }
         carry_pending = carry_ready = false;
         carry_valid = true;
-        AT_times(dy + nV, ATdy);
-        hipLaunchKernelGGL(k_dual_dx, g1(nV), dim3(NT), 0, st, nV, Sb, hinv, M.Hval, M.hreg, ATdy, gN, g, dx, Hdx);
+        if (fuse_passes && nC > 0 && !M.denseA) {
+            // (sparse A: the dx kernel rides behind the product, in the thread that has just formed the entry -- same bits, a launch less)
+            RsqpSpmvDualDx e;
+            e.Sb = Sb; e.hinv = hinv; e.Hval = M.Hval; e.hreg = M.hreg; e.gN = gN; e.g = g; e.dx = dx; e.Hdx = Hdx;
+            pbegin();
+            (void)rsqp_launch_spmv_dualdx(M.blk_c, M.nblk_c, M.Ajc, M.Air, M.Aval, dy + nV, ATdy, e, st);
+            pend(5, spmv_bytes(nV, nC));
+        } else {
+            AT_times(dy + nV, ATdy);
+            hipLaunchKernelGGL(k_dual_dx, g1(nV), dim3(NT), 0, st, nV, Sb, hinv, M.Hval, M.hreg, ATdy, gN, g, dx, Hdx);
+        }
         A_times(dx, dAx);
         chk("dual_step_direction");
     }

@@ -22,6 +22,14 @@ struct RsqpKktArgs {
 // entries per block (a longer single major gets a block of its own)
 int rsqp_spmv_chunk(void);
 
+// epilogue of the single-matrix product out = A'dy_C on the diagonal range-space path of the HBM-resident engine (qp_large.hip: what
+// was the kernel k_dual_dx): dx on the free variables from stationarity, D dx + dg = A'dy_C; H dx of every variable
+struct RsqpSpmvDualDx {
+    const int *Sb = nullptr; const double *hinv = nullptr, *Hval = nullptr, *gN = nullptr, *g = nullptr; double hreg = 0.0;
+    double *dx = nullptr, *Hdx = nullptr;
+};
+hipError_t rsqp_launch_spmv_dualdx(const int4 *blkinfo, int nblk, const int *ptr, const int *idx, const double *val, const double *in,
+                                   double *out, const RsqpSpmvDualDx &epi, hipStream_t stream);
 hipError_t rsqp_launch_spmv(const int4 *blkinfo, int nblk, const int *ptr, const int *idx, const double *val,
                             const double *in, double *out, int nbatch, long long ptr_stride,
                             long long nnz_stride, long long in_stride, long long out_stride,

@@ -27,11 +27,23 @@ constexpr int SPMV_ITERS = SPMV_CHUNK / (2 * SPMV_NT);
 // all blocks of one batch member carry the same (blockIdx.x % 8): workgroups are dealt
 // round-robin over the 8 XCDs, so a member's gathered input vector is pulled into ONE L2
 // instead of eight (placement only affects speed, never results).
+// EPI: the diagonal range-space path's step direction rides behind A'dy_C (RsqpSpmvDualDx, rsqp_sparse.h): the thread that has
+// formed entry v of the product applies what was the kernel k_dual_dx to it -- one launch less per working-set change
+template <bool EPI>
+__device__ __forceinline__ void spmv_out(double *__restrict__ out, int r, double s, const RsqpSpmvDualDx &e) {
+    out[r] = s;
+    if constexpr (EPI) {
+        double d = e.dx[r];
+        if (e.Sb[r] == 0) { d = e.hinv[r] * (s - (e.gN[r] - e.g[r])); e.dx[r] = d; }
+        e.Hdx[r] = (e.Hval[r] + e.hreg) * d;
+    }
+}
+template <bool EPI>
 __global__ void __launch_bounds__(SPMV_NT)
 csx_stream_spmv(const int4 *__restrict__ blkinfo, int nblk, int nbatch, int xcd_map,
                 const int *__restrict__ ptr, const int *__restrict__ idx, const double *__restrict__ val,
                 const double *__restrict__ in, double *__restrict__ out, long long ptr_stride,
-                long long nnz_stride, long long in_stride, long long out_stride) {
+                long long nnz_stride, long long in_stride, long long out_stride, RsqpSpmvDualDx epi) {
     __shared__ __attribute__((aligned(16))) double prod[SPMV_CHUNK + 2];
     int m, b;
     if (xcd_map) {
@@ -80,13 +92,13 @@ csx_stream_spmv(const int4 *__restrict__ blkinfo, int nblk, int nbatch, int xcd_
         if (myr < r1) {
             double s = 0.0;
             for (int k = pa - ka; k < pb - ka; k++) s += prod[k];
-            out[myr] = s;
+            spmv_out<EPI>(out, myr, s, epi);
         }
         for (int r = myr + SPMV_NT; r < r1; r += SPMV_NT) {
             double s = 0.0;
             const int a = ptr[r] - ka, e = ptr[r + 1] - ka;
             for (int k = a; k < e; k++) s += prod[k];
-            out[r] = s;
+            spmv_out<EPI>(out, r, s, epi);
         }
     } else {
         // a single long segment (the block builder never mixes it with others):
@@ -99,7 +111,7 @@ csx_stream_spmv(const int4 *__restrict__ blkinfo, int nblk, int nbatch, int xcd_
             if (tid < o) prod[tid] += prod[tid + o];
             __syncthreads();
         }
-        if (tid == 0) out[r0] = prod[0];
+        if (tid == 0) spmv_out<EPI>(out, r0, prod[0], epi);
     }
 }
 
@@ -773,8 +785,15 @@ hipError_t rsqp_launch_spmv(const int4 *blkinfo, int nblk, const int *ptr, const
     if (nblk <= 0 || nbatch <= 0) return hipSuccess;
     const int xcd_map = nbatch >= 8;
     const long long grid = xcd_map ? (long long)((nbatch + 7) / 8) * 8 * nblk : (long long)nbatch * nblk;
-    hipLaunchKernelGGL(csx_stream_spmv, dim3((unsigned)grid), dim3(SPMV_NT), 0, stream, blkinfo, nblk, nbatch, xcd_map,
-                       ptr, idx, val, in, out, ptr_stride, nnz_stride, in_stride, out_stride);
+    hipLaunchKernelGGL(csx_stream_spmv<false>, dim3((unsigned)grid), dim3(SPMV_NT), 0, stream, blkinfo, nblk, nbatch, xcd_map,
+                       ptr, idx, val, in, out, ptr_stride, nnz_stride, in_stride, out_stride, RsqpSpmvDualDx());
+    return hipGetLastError();
+}
+hipError_t rsqp_launch_spmv_dualdx(const int4 *blkinfo, int nblk, const int *ptr, const int *idx, const double *val, const double *in,
+                                   double *out, const RsqpSpmvDualDx &epi, hipStream_t stream) {
+    if (nblk <= 0) return hipSuccess;
+    hipLaunchKernelGGL(csx_stream_spmv<true>, dim3((unsigned)nblk), dim3(SPMV_NT), 0, stream, blkinfo, nblk, 1, 0, ptr, idx, val, in, out, 0LL, 0LL,
+                       0LL, 0LL, epi);
     return hipGetLastError();
 }
 
